@@ -1,0 +1,77 @@
+/* C ABI of libw2x.so - the FFI boundary for the hot path.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to /root/reference/src/tensorrt/):
+ *   w2x_create / w2x_destroy      trt::Img2Img::Img2Img / ~Img2Img            img2img.h:16-17, img2img_base.cpp:4-10
+ *   w2x_set_message_callback      trt::Img2Img::setMessageCallback            img2img.h:21, logger.h:20
+ *   w2x_set_progress_callback     trt::Img2Img::setProgressCallback           img2img.h:22, logger.h:21
+ *   w2x_build                     trt::Img2Img::build(path, BuildConfig)      img2img.h:18, img2img_build.cpp:54-173
+ *   w2x_load                      trt::Img2Img::load(path, RenderConfig)      img2img.h:19, img2img_load.cpp:117-291
+ *   w2x_render                    trt::Img2Img::render(cv::Mat, cv::Mat&)     img2img.h:20, img2img_render.cpp:224-352
+ *   w2x_infer                     trt::Img2Img::infer (private)               img2img.h:25, img2img_infer.cpp:41-93
+ *   w2x_calculate_tiles           calculateTiles (file-static)                img2img_render.cpp:7-66
+ *   w2x_tile_weights              createTileWeights (file-static)             img2img_load.cpp:29-52
+ * Return convention: 1 = true, 0 = false (after the message callback received the error text), like the reference's
+ * bool returns.  Plain pointers and sizes only.
+ */
+#ifndef W2X_C_API_H
+#define W2X_C_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct w2x_engine w2x_engine;
+
+enum { W2X_PRECISION_TF32 = 0, W2X_PRECISION_FP16 = 1 };  /* config.h:7-10; CLI map main.cpp:76-84 */
+
+typedef struct w2x_build_config {   /* trt::BuildConfig, config.h:12-31 */
+    int deviceId, precision;
+    int minBatchSize, optBatchSize, maxBatchSize;
+    int minChannels, optChannels, maxChannels;
+    int minWidth, optWidth, maxWidth;
+    int minHeight, optHeight, maxHeight;
+} w2x_build_config;
+
+typedef struct w2x_render_config {  /* trt::RenderConfig, config.h:33-43 */
+    int deviceId, precision, batchSize, channels, height, width, scaling;
+    double overlapX, overlapY;
+    int tta;
+    int ttaBugCompat;               /* extension, see include/w2x/config.h */
+} w2x_render_config;
+
+typedef void (*w2x_message_fn)(int severity, const char* message, void* user);        /* logger.h:20 */
+typedef void (*w2x_progress_fn)(int current, int total, double speed, void* user);    /* logger.h:21 */
+
+w2x_engine* w2x_create(void);
+void w2x_destroy(w2x_engine* e);
+void w2x_set_message_callback(w2x_engine* e, w2x_message_fn fn, void* user);
+void w2x_set_progress_callback(w2x_engine* e, w2x_progress_fn fn, void* user);
+int w2x_build(w2x_engine* e, const char* onnx_path, const w2x_build_config* cfg);
+int w2x_load(w2x_engine* e, const char* onnx_path, const w2x_render_config* cfg);
+/* src/dst: interleaved 8-bit BGR, `step` bytes per row; dst must be rows*scaling x cols*scaling. */
+int w2x_render(w2x_engine* e, const uint8_t* src, int rows, int cols, size_t src_step, uint8_t* dst, size_t dst_step);
+int w2x_infer(w2x_engine* e, const float* input_nchw, float* output_nchw);
+int w2x_output_tile_size(w2x_engine* e);
+double w2x_plan_flops(w2x_engine* e);
+float w2x_last_render_ms(w2x_engine* e);
+float w2x_bench_resident(w2x_engine* e, int iters);
+
+/* Host-only helpers (no GPU needed). */
+/* rects: 4 ints (x,y,w,h) per tile, column-major tile order; returns tile count (or -1 if cap is too small). */
+int w2x_calculate_tiles(int in_w, int in_h, int out_w, int out_h, int tile_in, int tile_out, int scaling,
+                        double overlap_x, double overlap_y, int* in_rects, int* out_rects, int cap);
+/* which: 0 top, 1 right, 2 bottom, 3 left (weights[] index, img2img_load.cpp:30-51); out: size*size floats. */
+int w2x_tile_weights(int which, int overlap_x, int overlap_y, int size, float* out);
+/* Lower an ONNX file at [batch,3,tile,tile] and write a textual description of the plan (ops, FLOPs) into buf. */
+int w2x_describe_plan(const char* onnx_path, int batch, int tile, char* buf, size_t cap);
+/* sha256 hex digest (names engine files; utilities/sha256.h:39-94). out: 65 bytes. */
+void w2x_sha256_hex(const void* data, size_t len, char* out);
+const char* w2x_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,60 @@
+// The engine interface: drop-in for trt::Img2Img (/root/reference/src/tensorrt/img2img.h:14-50) with the same five
+// public methods, the same bool + callback error convention (function-try-blocks that log "[func@line] msg" at
+// severity `error` and return false: logger.h:8, logger.cpp:19-22), one instance = one GPU = one compute stream.
+// cv::Mat is replaced by a (pointer, rows, cols, step) view of interleaved 8-bit BGR pixels.
+#ifndef W2X_IMG2IMG_H
+#define W2X_IMG2IMG_H
+
+#include <cstddef>
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <string>
+
+#include "config.h"
+
+namespace w2x {
+
+enum Severity { critical, error, warn, info, debug, trace };             // logger.h:11-18
+using MessageCallback = std::function<void(Severity, const std::string&)>;  // logger.h:20
+using ProgressCallback = std::function<void(int, int, double)>;             // logger.h:21  (current, total, it/s)
+
+struct Image {          // stand-in for cv::Mat of type CV_8UC3
+    uint8_t* data = nullptr;
+    int rows = 0, cols = 0;
+    size_t step = 0;    // bytes per row
+};
+
+class Img2Img {
+public:
+    Img2Img();
+    virtual ~Img2Img();
+    // img2img.h:18 - ONNX path in; writes <stem>_<sha256(cfg)[:16]>.{w2x,json} next to it (img2img_build.cpp:151-161)
+    bool build(const std::string& path, const BuildConfig& config);
+    // img2img.h:19 - the ONNX path again; the engine is found by scanning its directory (img2img_load.cpp:79-114)
+    bool load(const std::string& path, const RenderConfig& config);
+    // img2img.h:20 - dst must be rows*scaling x cols*scaling (caller pre-sizes it, main.cpp:234-235)
+    bool render(const Image& src, Image& dst);
+    void setMessageCallback(MessageCallback callback);   // img2img.h:21
+    void setProgressCallback(ProgressCallback callback); // img2img.h:22
+
+    // Test hook mirroring the private trt::Img2Img::infer (img2img.h:25, img2img_infer.cpp:41-93):
+    // host NCHW f32 blob [B,3,T,T] in [0,1] -> [B,3,T',T'] f32.
+    bool infer(const float* input, float* output);
+    int outputTileSize() const;
+    int scaling() const;   // RenderConfig::scaling of the loaded configuration (0 before load)
+    double planFlops() const;
+    // Steady-state device timing of the last render() (ms), HIP events on the compute stream.
+    float lastRenderMs() const;
+    // Re-run the device part of the last render() (gather, network, compose; no H2D/D2H) `iters` times and return the
+    // average milliseconds per frame - inputs already resident in HBM (bench.py's timed region).
+    float benchResident(int iters);
+
+    struct Impl;
+private:
+    std::unique_ptr<Impl> impl;
+};
+
+}  // namespace w2x
+
+#endif

@@ -1,0 +1,105 @@
+// Flat C ABI over w2x::Img2Img (declared in include/w2x/c_api.h, which cites the reference interfaces).
+#include "../../include/w2x/c_api.h"
+
+#include <cstring>
+#include <string>
+
+#include "../../include/w2x/img2img.h"
+#include "lower.h"
+#include "sha256.h"
+#include "tiles.h"
+
+struct w2x_engine {
+    w2x::Img2Img engine;
+    w2x_message_fn msg = nullptr; void* msg_user = nullptr;
+    w2x_progress_fn prog = nullptr; void* prog_user = nullptr;
+};
+
+extern "C" {
+
+w2x_engine* w2x_create(void) { try { return new w2x_engine; } catch (...) { return nullptr; } }
+void w2x_destroy(w2x_engine* e) { delete e; }
+
+void w2x_set_message_callback(w2x_engine* e, w2x_message_fn fn, void* user) {
+    if (!e) return;
+    e->msg = fn; e->msg_user = user;
+    if (fn) e->engine.setMessageCallback([e](w2x::Severity s, const std::string& m) { if (e->msg) e->msg((int)s, m.c_str(), e->msg_user); });
+    else e->engine.setMessageCallback(nullptr);
+}
+void w2x_set_progress_callback(w2x_engine* e, w2x_progress_fn fn, void* user) {
+    if (!e) return;
+    e->prog = fn; e->prog_user = user;
+    if (fn) e->engine.setProgressCallback([e](int c, int t, double s) { if (e->prog) e->prog(c, t, s, e->prog_user); });
+    else e->engine.setProgressCallback(nullptr);
+}
+
+int w2x_build(w2x_engine* e, const char* onnx_path, const w2x_build_config* c) {
+    if (!e || !onnx_path || !c) return 0;
+    w2x::BuildConfig b;
+    b.deviceId = c->deviceId; b.precision = c->precision == W2X_PRECISION_FP16 ? w2x::Precision::FP16 : w2x::Precision::TF32;
+    b.minBatchSize = c->minBatchSize; b.optBatchSize = c->optBatchSize; b.maxBatchSize = c->maxBatchSize;
+    b.minChannels = c->minChannels; b.optChannels = c->optChannels; b.maxChannels = c->maxChannels;
+    b.minWidth = c->minWidth; b.optWidth = c->optWidth; b.maxWidth = c->maxWidth;
+    b.minHeight = c->minHeight; b.optHeight = c->optHeight; b.maxHeight = c->maxHeight;
+    return e->engine.build(onnx_path, b) ? 1 : 0;
+}
+
+int w2x_load(w2x_engine* e, const char* onnx_path, const w2x_render_config* c) {
+    if (!e || !onnx_path || !c) return 0;
+    w2x::RenderConfig r;
+    r.deviceId = c->deviceId; r.precision = c->precision == W2X_PRECISION_FP16 ? w2x::Precision::FP16 : w2x::Precision::TF32;
+    r.batchSize = c->batchSize; r.channels = c->channels; r.height = c->height; r.width = c->width; r.scaling = c->scaling;
+    r.overlapX = c->overlapX; r.overlapY = c->overlapY; r.tta = c->tta != 0; r.ttaBugCompat = c->ttaBugCompat != 0;
+    return e->engine.load(onnx_path, r) ? 1 : 0;
+}
+
+int w2x_render(w2x_engine* e, const uint8_t* src, int rows, int cols, size_t src_step, uint8_t* dst, size_t dst_step) {
+    if (!e) return 0;
+    w2x::Image s; s.data = const_cast<uint8_t*>(src); s.rows = rows; s.cols = cols; s.step = src_step;
+    // the caller pre-sizes dst to size*scale (main.cpp:234-235); the scale is the engine's
+    w2x::Image d; d.data = dst; d.step = dst_step;
+    const int sc = e->engine.scaling();
+    d.rows = rows * sc; d.cols = cols * sc;
+    return e->engine.render(s, d) ? 1 : 0;
+}
+
+int w2x_infer(w2x_engine* e, const float* in, float* out) { return e && e->engine.infer(in, out) ? 1 : 0; }
+int w2x_output_tile_size(w2x_engine* e) { return e ? e->engine.outputTileSize() : 0; }
+double w2x_plan_flops(w2x_engine* e) { return e ? e->engine.planFlops() : 0.0; }
+float w2x_last_render_ms(w2x_engine* e) { return e ? e->engine.lastRenderMs() : -1.f; }
+float w2x_bench_resident(w2x_engine* e, int iters) { return e ? e->engine.benchResident(iters) : -1.f; }
+
+int w2x_calculate_tiles(int in_w, int in_h, int out_w, int out_h, int tile_in, int tile_out, int scaling,
+                        double overlap_x, double overlap_y, int* in_rects, int* out_rects, int cap) {
+    w2x::TileGrid g = w2x::calculate_tiles(in_w, in_h, out_w, out_h, tile_in, tile_in, tile_out, tile_out, scaling, overlap_x, overlap_y);
+    if (g.count > cap) return -1;
+    for (int i = 0; i < g.count; ++i) {
+        if (in_rects) { in_rects[4 * i] = g.in[i].x; in_rects[4 * i + 1] = g.in[i].y; in_rects[4 * i + 2] = g.in[i].w; in_rects[4 * i + 3] = g.in[i].h; }
+        if (out_rects) { out_rects[4 * i] = g.out[i].x; out_rects[4 * i + 1] = g.out[i].y; out_rects[4 * i + 2] = g.out[i].w; out_rects[4 * i + 3] = g.out[i].h; }
+    }
+    return g.count;
+}
+
+int w2x_tile_weights(int which, int overlap_x, int overlap_y, int size, float* out) {
+    if (which < 0 || which > 3 || size <= 0 || !out) return 0;
+    auto m = w2x::tile_weight_mask(which, overlap_x, overlap_y, size);
+    memcpy(out, m.data(), m.size() * sizeof(float));
+    return 1;
+}
+
+int w2x_describe_plan(const char* onnx_path, int batch, int tile, char* buf, size_t cap) {
+    std::string s; int ok = 1;
+    try { s = w2x::build_plan(onnx_path, batch, 3, tile, tile).describe(); }
+    catch (const std::exception& e) { s = std::string("ERROR: ") + e.what(); ok = 0; }
+    if (buf && cap) { size_t n = s.size() < cap - 1 ? s.size() : cap - 1; memcpy(buf, s.data(), n); buf[n] = 0; }
+    return ok;
+}
+
+void w2x_sha256_hex(const void* data, size_t len, char* out) {
+    std::string h = w2x::sha256_hex(data, len);
+    memcpy(out, h.c_str(), 65);
+}
+
+const char* w2x_version(void) { return "w2x-hip 0.1 (gfx950)"; }
+
+}  // extern "C"

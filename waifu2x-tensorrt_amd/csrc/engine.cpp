@@ -1,0 +1,517 @@
+// w2x::Img2Img - the MI355X engine behind the reference's trt::Img2Img interface
+// (/root/reference/src/tensorrt/img2img.h:14-50).  build(): ONNX -> plan file; load(): plan -> HBM; render(): frame ->
+// tiles -> fused HIP kernels -> blended frame.  Everything on the device is HIP; there is no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <filesystem>
+#include <fstream>
+#include <sstream>
+
+#include "../../include/w2x/img2img.h"
+#include "common.h"
+#include "kernels.h"
+#include "lower.h"
+#include "plan.h"
+#include "sha256.h"
+#include "tiles.h"
+
+#define W2X_LOG(sev, message) impl->log(sev, message, __FUNCTION__, __LINE__)
+
+namespace w2x {
+
+namespace {
+
+// helper.h:13-17 (cudaAssert): a failed runtime call becomes an exception carrying the runtime's message
+inline void hipAssert(hipError_t e) {
+    if (e != hipSuccess) throw std::runtime_error(hipGetErrorString(e));
+}
+
+// helper.h:27-46
+std::string hipGetDeviceName(int deviceId) {
+    hipDeviceProp_t prop{};
+    hipAssert(hipGetDeviceProperties(&prop, deviceId));
+    return prop.name;
+}
+
+std::string precision_name(Precision p) { return p == Precision::FP16 ? "FP16" : "TF32"; }
+
+// img2img_build.cpp:8-27
+std::string getConfigHash(const BuildConfig& c, std::string deviceName) {
+    deviceName.erase(std::remove_if(deviceName.begin(), deviceName.end(), ::isspace), deviceName.end());
+    std::ostringstream oss;
+    oss << deviceName << "." << precision_name(c.precision) << "."
+        << c.minBatchSize << "." << c.optBatchSize << "." << c.maxBatchSize << "."
+        << c.minChannels << "." << c.optChannels << "." << c.maxChannels << "."
+        << c.minWidth << "." << c.optWidth << "." << c.maxWidth << "."
+        << c.minHeight << "." << c.optHeight << "." << c.maxHeight;
+    std::string s = oss.str();
+    return sha256_hex(s.data(), s.size());
+}
+
+// img2img_build.cpp:29-50 - same keys, same order, 4-space indent
+void serializeConfig(const std::string& path, const BuildConfig& c, const std::string& deviceName) {
+    std::ofstream f(path);
+    if (!f.is_open()) throw std::runtime_error("could not open config \"" + path + "\"");
+    auto esc = [](const std::string& s) { std::string o; for (char ch : s) { if (ch == '"' || ch == '\\') o.push_back('\\'); o.push_back(ch); } return o; };
+    f << "{\n"
+      << "    \"deviceName\": \"" << esc(deviceName) << "\",\n"
+      << "    \"precision\": \"" << precision_name(c.precision) << "\",\n"
+      << "    \"minBatchSize\": " << c.minBatchSize << ",\n    \"optBatchSize\": " << c.optBatchSize << ",\n    \"maxBatchSize\": " << c.maxBatchSize << ",\n"
+      << "    \"minChannels\": " << c.minChannels << ",\n    \"optChannels\": " << c.optChannels << ",\n    \"maxChannels\": " << c.maxChannels << ",\n"
+      << "    \"minWidth\": " << c.minWidth << ",\n    \"optWidth\": " << c.optWidth << ",\n    \"maxWidth\": " << c.maxWidth << ",\n"
+      << "    \"minHeight\": " << c.minHeight << ",\n    \"optHeight\": " << c.optHeight << ",\n    \"maxHeight\": " << c.maxHeight << "\n}";
+}
+
+// img2img_load.cpp:54-77 (flat object of strings and integers)
+void deserializeConfig(const std::string& path, BuildConfig& c, std::string& deviceName) {
+    std::ifstream f(path);
+    if (!f.is_open()) throw std::runtime_error("could not open config \"" + path + "\"");
+    std::stringstream ss; ss << f.rdbuf();
+    const std::string j = ss.str();
+    auto find_value = [&](const std::string& key) -> size_t {
+        size_t k = j.find("\"" + key + "\"");
+        if (k == std::string::npos) throw std::runtime_error("config key \"" + key + "\" missing");
+        size_t c2 = j.find(':', k);
+        if (c2 == std::string::npos) throw std::runtime_error("config malformed");
+        ++c2; while (c2 < j.size() && isspace((unsigned char)j[c2])) ++c2;
+        return c2;
+    };
+    auto get_str = [&](const std::string& key) {
+        size_t p = find_value(key);
+        if (j[p] != '"') throw std::runtime_error("config value of \"" + key + "\" is not a string");
+        std::string o; ++p;
+        while (p < j.size() && j[p] != '"') { if (j[p] == '\\' && p + 1 < j.size()) ++p; o.push_back(j[p++]); }
+        return o;
+    };
+    auto get_int = [&](const std::string& key) { return (int)std::strtol(j.c_str() + find_value(key), nullptr, 10); };
+    deviceName = get_str("deviceName");
+    c.precision = get_str("precision") == "FP16" ? Precision::FP16 : Precision::TF32;
+    c.minBatchSize = get_int("minBatchSize"); c.optBatchSize = get_int("optBatchSize"); c.maxBatchSize = get_int("maxBatchSize");
+    c.minChannels = get_int("minChannels"); c.optChannels = get_int("optChannels"); c.maxChannels = get_int("maxChannels");
+    c.minWidth = get_int("minWidth"); c.optWidth = get_int("optWidth"); c.maxWidth = get_int("maxWidth");
+    c.minHeight = get_int("minHeight"); c.optHeight = get_int("optHeight"); c.maxHeight = get_int("maxHeight");
+}
+
+// img2img_load.cpp:9-20; quirk Q12 fixed: the device is compared by name, not by the index of the first device with that name
+bool isCompatible(const RenderConfig& r, const BuildConfig& b, const std::string& builtOn, const std::string& runningOn) {
+    return builtOn == runningOn && r.precision == b.precision &&
+           r.batchSize >= b.minBatchSize && r.batchSize <= b.maxBatchSize &&
+           r.channels >= b.minChannels && r.channels <= b.maxChannels &&
+           r.width >= b.minWidth && r.width <= b.maxWidth && r.height >= b.minHeight && r.height <= b.maxHeight;
+}
+// img2img_load.cpp:22-27
+bool isOptimized(const RenderConfig& r, const BuildConfig& b) {
+    return r.batchSize == b.optBatchSize && r.channels == b.optChannels && r.width == b.optWidth && r.height == b.optHeight;
+}
+
+constexpr const char* kEngineExt = ".w2x";
+
+}  // namespace
+
+struct Img2Img::Impl {
+    MessageCallback messageCallback{};
+    ProgressCallback progressCallback{};
+
+    // logger.cpp:14-22
+    void log(Severity s, const std::string& m) { if (messageCallback) messageCallback(s, m); }
+    void log(Severity s, const std::string& m, const std::string& fn, int line) { if (messageCallback) messageCallback(s, "[" + fn + "@" + std::to_string(line) + "] " + m); }
+    void log(int current, int total, double speed) { if (progressCallback) progressCallback(current, total, speed); }
+
+    bool loaded = false;
+    Plan plan;
+    RenderConfig cfg;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<void*> tensors, blobs;
+    std::vector<GemmParams> gemm;      // per op (kind == OP_GEMM)
+    std::vector<int> pool_tensors;
+    int final_op = -1;
+
+    // frame-level buffers (grown on demand, reused across frames like the reference's input/output GpuMats, img2img.h:37-38)
+    uint8_t* d_frame = nullptr; size_t frame_cap = 0;
+    uint8_t* d_out = nullptr; size_t out_cap = 0;
+    void* d_slab = nullptr; size_t slab_cap = 0;
+    TileSlot* d_slots = nullptr; size_t slots_cap = 0;
+    float *d_rampx = nullptr, *d_rampy = nullptr;
+    int ovx = 0, ovy = 0;
+    float* d_blob_in = nullptr; float* d_blob_out = nullptr;
+    std::vector<TileSlot> h_slots;
+
+    // last frame (for benchResident)
+    int last_rows = 0, last_cols = 0, last_batches = 0;
+    TileGrid last_grid;
+    float last_ms = 0.f;
+
+    ~Impl() { release(); }
+
+    void release() {
+        // img2img_base.cpp:6-10 frees the IO buffers; here everything the engine owns
+        for (void* p : tensors) if (p) hipFree(p);
+        for (void* p : blobs) if (p) hipFree(p);
+        tensors.clear(); blobs.clear(); gemm.clear(); pool_tensors.clear();
+        for (void** p : {(void**)&d_frame, (void**)&d_out, &d_slab, (void**)&d_slots, (void**)&d_rampx, (void**)&d_rampy, (void**)&d_blob_in, (void**)&d_blob_out})
+            if (*p) { hipFree(*p); *p = nullptr; }
+        frame_cap = out_cap = slab_cap = slots_cap = 0;
+        if (ev0) { hipEventDestroy(ev0); ev0 = nullptr; }
+        if (ev1) { hipEventDestroy(ev1); ev1 = nullptr; }
+        if (stream) { hipStreamDestroy(stream); stream = nullptr; }
+        loaded = false;
+    }
+
+    TView tview(const View& v) const {
+        TView t;
+        if (v.t < 0) return t;
+        const TensorDesc& d = plan.tensors[v.t];
+        t.p = tensors[v.t]; t.Hs = d.H; t.Ws = d.W; t.Cs = d.C; t.y0 = v.y0; t.x0 = v.x0;
+        return t;
+    }
+
+    void upload_plan() {
+        tensors.assign(plan.tensors.size(), nullptr);
+        for (size_t i = 0; i < plan.tensors.size(); ++i) {
+            size_t bytes = (size_t)plan.tensors[i].bytes();
+            hipAssert(hipMalloc(&tensors[i], bytes));
+            hipAssert(hipMemsetAsync(tensors[i], 0, bytes, stream));
+        }
+        blobs.assign(plan.blobs.size(), nullptr);
+        for (size_t i = 0; i < plan.blobs.size(); ++i) {
+            const auto& d = plan.blobs[i].data;
+            hipAssert(hipMalloc(&blobs[i], std::max<size_t>(d.size(), 16)));
+            hipAssert(hipMemcpy(blobs[i], d.data(), d.size(), hipMemcpyHostToDevice));
+        }
+        gemm.assign(plan.ops.size(), GemmParams{});
+        for (size_t i = 0; i < plan.ops.size(); ++i) {
+            const Op& op = plan.ops[i];
+            if (op.kind != OP_GEMM) continue;
+            const GemmOp& g = op.g;
+            GemmParams& p = gemm[i];
+            p.a = tview(g.a); p.amode = g.amode; p.kh = g.kh; p.kw = g.kw; p.stride = g.stride;
+            p.B = plan.B; p.Mrows = g.Mrows; p.aW = g.aW;
+            p.win_table = g.win_table >= 0 ? (const int*)blobs[g.win_table] : nullptr;
+            p.K = g.K; p.N = g.N; p.Kw = round_up(g.K, 8);
+            p.wt = blobs[g.w]; p.bias = (const float*)blobs[g.bias];
+            p.ln = g.ln; p.csum = g.csum >= 0 ? (const float*)blobs[g.csum] : nullptr;
+            p.stats_in = g.stats_in >= 0 ? (const float*)tensors[g.stats_in] : nullptr;
+            p.act = g.act; p.alpha = g.alpha; p.has_clip = g.has_clip; p.clip_lo = g.clip_lo; p.clip_hi = g.clip_hi;
+            p.res = tview(g.res); p.res2 = tview(g.res2); p.out = tview(g.out);
+            p.omode = g.omode; p.r = g.r; p.Cout = g.Cout;
+            p.stats_out = g.stats_out >= 0 ? (float*)tensors[g.stats_out] : nullptr; p.ln_eps = g.ln_eps;
+            p.pool_out = g.pool_out >= 0 ? (float*)tensors[g.pool_out] : nullptr;
+            if (g.pool_out >= 0) pool_tensors.push_back(g.pool_out);
+            if (g.out.t == plan.out_tensor) final_op = (int)i;
+            // shape checks the kernels rely on (a wrong shape would fault on the device)
+            if (p.ln && (!p.stats_in || !p.csum)) throw std::runtime_error("plan: LayerNorm op without statistics");
+            if (p.stats_out && p.Cout != p.out.Cs) throw std::runtime_error("plan: statistics over padded rows");
+            if (p.pool_out && p.omode != O_ROWS) throw std::runtime_error("plan: pooling on a scattered output");
+            if (p.omode == O_PIXSHUF && p.N != p.r * p.r * p.out.Cs) throw std::runtime_error("plan: pixel-shuffle width mismatch");
+            if (p.omode != O_PIXSHUF && p.N != p.out.Cs) throw std::runtime_error("plan: output width mismatch");
+            if ((p.amode == A_WIN || p.omode == O_WIN) && !p.win_table) throw std::runtime_error("plan: missing window table");
+            if (p.a.Cs != 4 && (p.a.Cs % 8)) throw std::runtime_error("plan: unaligned input channels");
+        }
+        if (final_op < 0) throw std::runtime_error("plan: the output tensor is not produced by a fused op");
+        hipAssert(hipStreamSynchronize(stream));
+    }
+
+    // one pass of the network over the tiles currently in plan.in_tensor; the last op writes to `out_override`
+    void run_network(void* out_override) {
+        for (int t : pool_tensors) hipAssert(hipMemsetAsync(tensors[t], 0, (size_t)plan.tensors[t].bytes(), stream));
+        for (size_t i = 0; i < plan.ops.size(); ++i) {
+            const Op& op = plan.ops[i];
+            switch (op.kind) {
+                case OP_GEMM: {
+                    GemmParams p = gemm[i];
+                    if ((int)i == final_op && out_override) p.out.p = out_override;
+                    hipAssert(launch_gemm(p, stream));
+                    break;
+                }
+                case OP_ATTN: {
+                    const AttnOp& a = op.at;
+                    AttnParams p;
+                    p.qkv = tensors[a.qkv]; p.out = tensors[a.out]; p.B = plan.B; p.nwin = a.nwin; p.heads = a.heads; p.hd = a.hd;
+                    p.ntok = a.ws * a.ws; p.scale = a.scale; p.bias = blobs[a.bias]; p.maskid = (const int*)blobs[a.maskid];
+                    hipAssert(launch_attn(p, stream));
+                    break;
+                }
+                case OP_SE: {
+                    const SeOp& s = op.se;
+                    SeParams p;
+                    p.pool = (const float*)tensors[s.pool]; p.scale = (float*)tensors[s.scale]; p.B = plan.B; p.C = s.C;
+                    p.Cs = plan.tensors[s.pool].C; p.Cmid = s.Cmid; p.inv_count = s.inv_count;
+                    p.w1 = (const float*)blobs[s.w1]; p.b1 = (const float*)blobs[s.b1]; p.w2 = (const float*)blobs[s.w2]; p.b2 = (const float*)blobs[s.b2];
+                    hipAssert(launch_se(p, stream));
+                    break;
+                }
+                case OP_SCALE_ADD: {
+                    const TensorDesc& d = plan.tensors[op.se.pool];
+                    hipAssert(launch_scale(tensors[op.se.pool], (const float*)tensors[op.se.scale], d.B, d.H * d.W, d.C, stream));
+                    break;
+                }
+                default: throw std::runtime_error("plan: unknown op kind");
+            }
+        }
+    }
+
+    template <class T> void ensure(T*& p, size_t& cap, size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) hipAssert(hipFree(p));
+        p = nullptr; cap = 0;
+        hipAssert(hipMalloc((void**)&p, bytes));
+        cap = bytes;
+    }
+
+    // device part of one frame: gather -> network per batch -> compose.  Frame must already be in d_frame.
+    void run_frame(int rows, int cols, const TileGrid& grid, bool report) {
+        const int B = plan.B, T = plan.T, To = plan.Tout;
+        const int steps = cfg.tta ? 8 : 1;
+        const int batchCount = (int)std::lround(std::ceil((double)(grid.count * steps) / B));   // img2img_render.cpp:249
+        const size_t slot_bytes = (size_t)To * To * 4 * sizeof(uint16_t);
+        for (int bi = 0; bi < batchCount; ++bi) {
+            const auto t0 = std::chrono::steady_clock::now();
+            GatherParams gp;
+            gp.frame = d_frame; gp.rows = rows; gp.cols = cols; gp.step = (size_t)cols * 3;
+            gp.out = tensors[plan.in_tensor]; gp.slots = d_slots + (size_t)bi * B; gp.B = B; gp.T = T;
+            hipAssert(launch_gather(gp, stream));
+            run_network((uint8_t*)d_slab + (size_t)bi * B * slot_bytes);
+            if (report) {
+                const auto t1 = std::chrono::steady_clock::now();
+                const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+                log(bi + 1, batchCount, 1000.0 / std::max(ms, 1e-6));                           // :336-338
+            }
+        }
+        ComposeParams cp;
+        cp.tiles = d_slab; cp.dst = d_out; cp.dst_step = (size_t)cols * cfg.scaling * 3;
+        cp.outW = cols * cfg.scaling; cp.outH = rows * cfg.scaling; cp.To = To;
+        cp.nx = grid.nx; cp.ny = grid.ny; cp.stride_x = To - grid.outOvX; cp.stride_y = To - grid.outOvY;
+        const bool overlapping = cfg.overlapX != 0 || cfg.overlapY != 0;                      // :244
+        cp.ovx = overlapping ? ovx : 0; cp.ovy = overlapping ? ovy : 0;
+        cp.ramp_x = d_rampx; cp.ramp_y = d_rampy; cp.tta = cfg.tta ? 1 : 0; cp.tta_bug_compat = cfg.ttaBugCompat ? 1 : 0;
+        hipAssert(launch_compose(cp, stream));
+        last_batches = batchCount;
+    }
+};
+
+Img2Img::Img2Img() : impl(new Impl) {}
+Img2Img::~Img2Img() = default;
+
+void Img2Img::setMessageCallback(MessageCallback callback) { impl->messageCallback = std::move(callback); }
+void Img2Img::setProgressCallback(ProgressCallback callback) { impl->progressCallback = std::move(callback); }
+
+bool Img2Img::build(const std::string& onnxModelPath, const BuildConfig& config) try {
+    // img2img_build.cpp:56-64
+    try {
+        hipAssert(hipSetDevice(config.deviceId));
+    } catch (const std::exception& e) {
+        W2X_LOG(error, "Failed to set hip device to device id " + std::to_string(config.deviceId) + ": " + std::string(e.what()) + ".");
+        return false;
+    }
+    // :123-135 - precision support check
+    if (config.precision == Precision::TF32) {
+        W2X_LOG(error, "Failed to set precision: platform does not support TF32");
+        return false;
+    }
+    // :81-88 parse ; :102-116 one profile - the plan is specialised for the opt shape, channels come from the model
+    Plan plan;
+    try {
+        plan = build_plan(onnxModelPath, config.optBatchSize, config.optChannels, config.optHeight, config.optWidth);
+    } catch (const std::exception& e) {
+        W2X_LOG(error, "Failed to parse ONNX model: " + std::string(e.what()) + ".");
+        return false;
+    }
+    W2X_LOG(info, "Lowered \"" + onnxModelPath + "\": " + std::to_string(plan.ops.size()) + " fused ops, " +
+                      std::to_string((long long)plan.flops) + " algorithmic FLOP per batch, output tile " + std::to_string(plan.Tout) + ".");
+    // :151-161
+    const std::string deviceName = hipGetDeviceName(config.deviceId);
+    const auto basePath = std::filesystem::path(onnxModelPath).replace_extension("").string() + "_" + getConfigHash(config, deviceName).substr(0, 16);
+    serializeConfig(basePath + ".json", config, deviceName);
+    try {
+        const auto bytes = plan.serialize();
+        std::ofstream engineFile(basePath + kEngineExt, std::ios::binary);
+        if (!engineFile.is_open()) throw std::runtime_error("could not open \"" + basePath + kEngineExt + "\"");
+        engineFile.write((const char*)bytes.data(), (std::streamsize)bytes.size());
+    } catch (const std::exception& e) {
+        W2X_LOG(error, "Failed to serialize network to disk: " + std::string(e.what()) + ".");
+        return false;
+    }
+    return true;
+} catch (const std::exception& e) {
+    W2X_LOG(error, "Engine build failed unexpectedly: " + std::string(e.what()) + ".");
+    return false;
+}
+
+bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try {
+    namespace fs = std::filesystem;
+    // img2img_load.cpp:127-135
+    try {
+        hipAssert(hipSetDevice(config.deviceId));
+    } catch (const std::exception& e) {
+        W2X_LOG(error, "Failed to set hip device to device id " + std::to_string(config.deviceId) + ": " + std::string(e.what()) + ".");
+        return false;
+    }
+    // :79-114 getEnginePath
+    std::string enginePath;
+    try {
+        if (!fs::exists(modelPath)) throw std::runtime_error("model file does not exist");
+        const std::string runningOn = hipGetDeviceName(config.deviceId);
+        const std::string engineName = fs::path(modelPath).stem().string();
+        fs::path dir = fs::path(modelPath).parent_path();
+        if (dir.empty()) dir = ".";
+        std::vector<fs::path> entries;
+        for (const auto& entry : fs::directory_iterator(dir)) if (entry.is_regular_file()) entries.push_back(entry.path());
+        std::sort(entries.begin(), entries.end());
+        for (const auto& path : entries) {
+            if (path.filename().string().rfind(engineName, 0) != 0 || path.extension().string() != kEngineExt) continue;
+            const std::string configPath = fs::path(path).replace_extension("").string() + ".json";
+            if (!fs::exists(configPath)) continue;
+            BuildConfig bc; std::string builtOn;
+            deserializeConfig(configPath, bc, builtOn);
+            // the plan is specialised for the opt shape, so only an optimized match can run
+            if (isCompatible(config, bc, builtOn, runningOn) && isOptimized(config, bc)) { enginePath = path.string(); break; }
+        }
+        if (enginePath.empty()) throw std::runtime_error("could not satisfy render configuration");
+    } catch (const std::exception& e) {
+        W2X_LOG(error, "Failed to find engine file for model \"" + modelPath + "\": " + std::string(e.what()) + ".");
+        return false;
+    }
+    // :137-147
+    std::ifstream file(enginePath, std::ios::binary | std::ios::ate);
+    if (!file.is_open()) { W2X_LOG(error, "Failed to open engine file \"" + enginePath + "\"."); return false; }
+    std::streamsize fileSize = file.tellg();
+    std::vector<char> engineBuffer((size_t)fileSize);
+    file.seekg(0, std::ios::beg);
+    file.read(engineBuffer.data(), fileSize);
+
+    impl->release();   // :149-154, :209-222
+    try {
+        impl->plan = Plan::deserialize((const uint8_t*)engineBuffer.data(), engineBuffer.size());
+    } catch (const std::exception& e) {
+        W2X_LOG(error, "Failed to deserialize engine from buffer: " + std::string(e.what()) + ".");
+        return false;
+    }
+    const Plan& plan = impl->plan;
+    // :197-203 - the input shape must be the one the plan was specialised for; T' is read from the plan
+    if (plan.B != config.batchSize || plan.Cin != config.channels || plan.T != config.height || plan.T != config.width) {
+        W2X_LOG(error, "Failed to set input tensor shape.");
+        return false;
+    }
+    hipAssert(hipStreamCreateWithFlags(&impl->stream, hipStreamNonBlocking));   // :206
+    hipAssert(hipEventCreate(&impl->ev0));
+    hipAssert(hipEventCreate(&impl->ev1));
+    try {
+        impl->upload_plan();                                                      // :225-248
+    } catch (const std::exception& e) {
+        W2X_LOG(error, "Failed to allocate resources: " + std::string(e.what()) + ".");
+        impl->release();
+        return false;
+    }
+    impl->cfg = config;
+    // :262-269 blend ramps
+    impl->ovx = (int)std::lround(plan.T * config.scaling * config.overlapX);
+    impl->ovy = (int)std::lround(plan.T * config.scaling * config.overlapY);
+    if (config.overlapX != 0 || config.overlapY != 0) {
+        auto rx = blend_ramp(impl->ovx), ry = blend_ramp(impl->ovy);
+        hipAssert(hipMalloc((void**)&impl->d_rampx, std::max<size_t>(rx.size(), 1) * sizeof(float)));
+        hipAssert(hipMalloc((void**)&impl->d_rampy, std::max<size_t>(ry.size(), 1) * sizeof(float)));
+        hipAssert(hipMemcpy(impl->d_rampx, rx.data(), rx.size() * sizeof(float), hipMemcpyHostToDevice));
+        hipAssert(hipMemcpy(impl->d_rampy, ry.data(), ry.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    impl->loaded = true;
+    return true;
+} catch (const std::exception& e) {
+    W2X_LOG(error, "Engine load failed unexpectedly: " + std::string(e.what()) + ".");
+    impl->release();
+    return false;
+}
+
+bool Img2Img::render(const Image& src, Image& dst) try {
+    if (!impl->loaded) { W2X_LOG(error, "Render called before a successful load."); return false; }
+    const RenderConfig& cfg = impl->cfg;
+    const Plan& plan = impl->plan;
+    const int rows = src.rows, cols = src.cols, s = cfg.scaling;
+    if (!src.data || rows <= 0 || cols <= 0 || src.step < (size_t)cols * 3) { W2X_LOG(error, "Input image is empty or has an invalid step."); return false; }
+    if (!dst.data || dst.rows != rows * s || dst.cols != cols * s || dst.step < (size_t)dst.cols * 3) {
+        W2X_LOG(error, "Output image has invalid size: expected " + std::to_string(cols * s) + "x" + std::to_string(rows * s) + ".");
+        return false;
+    }
+    hipStream_t stream = impl->stream;
+    // img2img_render.cpp:226 upload
+    impl->ensure(impl->d_frame, impl->frame_cap, (size_t)rows * cols * 3);
+    impl->ensure(impl->d_out, impl->out_cap, (size_t)rows * s * cols * s * 3);
+    hipAssert(hipMemcpy2DAsync(impl->d_frame, (size_t)cols * 3, src.data, src.step, (size_t)cols * 3, rows, hipMemcpyHostToDevice, stream));
+    // :232-240
+    TileGrid grid = calculate_tiles(cols, rows, cols * s, rows * s, plan.T, plan.T, plan.Tout, plan.Tout, s, cfg.overlapX, cfg.overlapY);
+    if (grid.count <= 0) { W2X_LOG(error, "Tile grid is empty."); return false; }
+    for (const Rect& r : grid.out) if (r.w <= 0 || r.h <= 0) { W2X_LOG(error, "Tile grid does not fit the output (scaling does not match the model)."); return false; }
+    // :246-267 step schedule: slot = step index, tile = step / stepsPerTile, aug = step % stepsPerTile, zero pad slots at the end
+    const int steps = cfg.tta ? 8 : 1, B = plan.B;
+    const int batchCount = (int)std::lround(std::ceil((double)(grid.count * steps) / B));
+    const int stepCount = batchCount * B;
+    impl->h_slots.resize(stepCount);
+    for (int st = 0; st < stepCount; ++st) {
+        int ti = st / steps, aug = st % steps;
+        TileSlot sl{0, 0, aug, 0};
+        if (ti < grid.count) { sl.x = grid.in[ti].x; sl.y = grid.in[ti].y; sl.valid = 1; }
+        impl->h_slots[st] = sl;
+    }
+    impl->ensure(impl->d_slots, impl->slots_cap, (size_t)stepCount * sizeof(TileSlot));
+    hipAssert(hipMemcpyAsync(impl->d_slots, impl->h_slots.data(), (size_t)stepCount * sizeof(TileSlot), hipMemcpyHostToDevice, stream));
+    impl->ensure(impl->d_slab, impl->slab_cap, (size_t)stepCount * plan.Tout * plan.Tout * 4 * sizeof(uint16_t));
+
+    hipAssert(hipEventRecord(impl->ev0, stream));
+    impl->run_frame(rows, cols, grid, true);
+    hipAssert(hipEventRecord(impl->ev1, stream));
+    // :344 download ; the reference leaves the sync commented out (:345, quirk Q10) - we wait before handing dst back
+    hipAssert(hipMemcpy2DAsync(dst.data, dst.step, impl->d_out, (size_t)dst.cols * 3, (size_t)dst.cols * 3, dst.rows, hipMemcpyDeviceToHost, stream));
+    hipAssert(hipStreamSynchronize(stream));
+    hipAssert(hipEventElapsedTime(&impl->last_ms, impl->ev0, impl->ev1));
+    impl->last_rows = rows; impl->last_cols = cols; impl->last_grid = grid;
+    return true;
+} catch (const std::exception& e) {
+    W2X_LOG(error, "Render failed unexpectedly: " + std::string(e.what()) + ".");
+    return false;
+}
+
+bool Img2Img::infer(const float* input, float* output) try {
+    if (!impl->loaded) { W2X_LOG(error, "Infer called before a successful load."); return false; }
+    const Plan& plan = impl->plan;
+    const size_t in_elems = (size_t)plan.B * 3 * plan.T * plan.T, out_elems = (size_t)plan.B * 3 * plan.Tout * plan.Tout;
+    if (!impl->d_blob_in) {
+        hipAssert(hipMalloc((void**)&impl->d_blob_in, in_elems * sizeof(float)));      // img2img_load.cpp:228-232: f32 IO buffers
+        hipAssert(hipMalloc((void**)&impl->d_blob_out, out_elems * sizeof(float)));
+    }
+    hipStream_t stream = impl->stream;
+    hipAssert(hipMemcpyAsync(impl->d_blob_in, input, in_elems * sizeof(float), hipMemcpyHostToDevice, stream));
+    hipAssert(launch_blob_to_nhwc(impl->d_blob_in, impl->tensors[plan.in_tensor], plan.B, plan.T, stream));
+    impl->run_network(nullptr);                                                        // img2img_infer.cpp:80
+    hipAssert(launch_nhwc_to_blob(impl->tensors[plan.out_tensor], impl->d_blob_out, plan.B, plan.Tout, stream));
+    hipAssert(hipMemcpyAsync(output, impl->d_blob_out, out_elems * sizeof(float), hipMemcpyDeviceToHost, stream));
+    hipAssert(hipStreamSynchronize(stream));
+    return true;
+} catch (const std::exception& e) {
+    W2X_LOG(error, "Engine inference failed unexpectedly: " + std::string(e.what()) + ".");
+    return false;
+}
+
+int Img2Img::outputTileSize() const { return impl->loaded ? impl->plan.Tout : 0; }
+int Img2Img::scaling() const { return impl->loaded ? impl->cfg.scaling : 0; }
+double Img2Img::planFlops() const { return impl->loaded ? impl->plan.flops : 0.0; }
+float Img2Img::lastRenderMs() const { return impl->last_ms; }
+
+float Img2Img::benchResident(int iters) try {
+    if (!impl->loaded || impl->last_rows == 0 || iters <= 0) return -1.f;
+    hipStream_t stream = impl->stream;
+    hipAssert(hipEventRecord(impl->ev0, stream));
+    for (int i = 0; i < iters; ++i) impl->run_frame(impl->last_rows, impl->last_cols, impl->last_grid, false);
+    hipAssert(hipEventRecord(impl->ev1, stream));
+    hipAssert(hipStreamSynchronize(stream));
+    float ms = 0.f;
+    hipAssert(hipEventElapsedTime(&ms, impl->ev0, impl->ev1));
+    return ms / iters;
+} catch (const std::exception& e) {
+    W2X_LOG(error, "Bench failed unexpectedly: " + std::string(e.what()) + ".");
+    return -1.f;
+}
+
+}  // namespace w2x

@@ -1,0 +1,217 @@
+// Pre/post kernels of the tile pipeline (HBM-bound byte/fp32 work, bit-exact against the oracle):
+//   gather  : frame u8 BGR -> network input tiles fp16 [B][T][T][4] (RGB, x*fl32(1/255)), replicate padding and the
+//             TTA dihedral transform folded into the source index.   Replaces cv::cuda::cvtColor(BGR2RGB)
+//             (img2img_render.cpp:227), padRoi (:68-105), applyAugmentation (:134-177), blobFromImages
+//             (img2img_infer.cpp:5-21) and the D2D copy (:76-77).
+//   compose : network output tiles fp16 -> frame u8 BGR.  Per output pixel, the covering tiles are visited in
+//             ascending tile index, TTA de-augmentation + fp32 sum in aug order + *0.125f, ramp weights multiplied
+//             in the order left, top, right, bottom, fp32 overlap-add, *255 -> rint -> saturate -> BGR.  Replaces
+//             imagesFromBlob (img2img_infer.cpp:23-39), reverseAugmentation/TTA accumulate (:179-222,:305-318),
+//             applyWeights (:107-121), the canvas add (:329-330) and the final convertTo/cvtColor (:342-343).
+//   se/scale: cunet squeeze-excite gate and channel scaling.
+#include "kernels.h"
+
+namespace w2x {
+namespace {
+
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// source coordinate inside the un-augmented tile for pixel (y,x) of the augmented tile (applyAugmentation)
+__device__ __forceinline__ void aug_src(int k, int n, int y, int x, int& sy, int& sx) {
+    switch (k) {
+        default: sy = y; sx = x; break;
+        case 1: sy = n - y; sx = x; break;          // flip code 0
+        case 2: sy = y; sx = n - x; break;          // flip code 1
+        case 3: sy = x; sx = n - y; break;          // rot90
+        case 4: sy = n - y; sx = n - x; break;      // rot180
+        case 5: sy = n - x; sx = y; break;          // rot270
+        case 6: sy = n - x; sx = n - y; break;      // flip0 then rot90
+        case 7: sy = x; sx = y; break;              // flip1 then rot90
+    }
+}
+// source coordinate inside the network output for pixel (y,x) of the de-augmented tile (reverseAugmentation)
+__device__ __forceinline__ void deaug_src(int k, int n, int y, int x, int& sy, int& sx) {
+    switch (k) {
+        default: sy = y; sx = x; break;
+        case 1: sy = n - y; sx = x; break;
+        case 2: sy = y; sx = n - x; break;
+        case 3: sy = n - x; sx = y; break;          // rot270
+        case 4: sy = n - y; sx = n - x; break;
+        case 5: sy = x; sx = n - y; break;          // rot90
+        case 6: sy = n - x; sx = n - y; break;      // rot270 then flip0
+        case 7: sy = x; sx = y; break;              // rot270 then flip1
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(const GatherParams p) {
+    const int T = p.T;
+    const long total = (long)p.B * T * T;
+    const float inv255 = (float)(1.0 / 255.0);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int b = (int)(i / ((long)T * T));
+        int rem = (int)(i - (long)b * T * T);
+        int y = rem / T, x = rem - y * T;
+        TileSlot sl = p.slots[b];
+        half4 v = (half4){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        if (sl.valid) {
+            int sy, sx;
+            aug_src(sl.aug, T - 1, y, x, sy, sx);
+            int fy = min(max(sl.y + sy, 0), p.rows - 1);
+            int fx = min(max(sl.x + sx, 0), p.cols - 1);
+            const uint8_t* px = p.frame + (size_t)fy * p.step + (size_t)fx * 3;
+            v[0] = (_Float16)((float)px[2] * inv255);
+            v[1] = (_Float16)((float)px[1] * inv255);
+            v[2] = (_Float16)((float)px[0] * inv255);
+        }
+        *((half4*)p.out + i) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void compose_kernel(const ComposeParams p) {
+    const long total = (long)p.outW * p.outH;
+    const int To = p.To, n = To - 1;
+    const int steps = p.tta ? 8 : 1;
+    const half4* tiles = (const half4*)p.tiles;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int Y = (int)(i / p.outW), X = (int)(i - (long)Y * p.outW);
+        // candidate tile columns/rows: origin = idx*stride, extent To (clipped to the canvas)
+        int i0 = X - To + 1; i0 = i0 <= 0 ? 0 : (i0 + p.stride_x - 1) / p.stride_x;
+        int i1 = min(p.nx - 1, X / p.stride_x);
+        int j0 = Y - To + 1; j0 = j0 <= 0 ? 0 : (j0 + p.stride_y - 1) / p.stride_y;
+        int j1 = min(p.ny - 1, Y / p.stride_y);
+        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+        for (int ti = i0; ti <= i1; ++ti) {
+            const int ox = ti * p.stride_x, lx = X - ox;
+            const int rw = ox + To > p.outW ? p.outW - ox : To;
+            for (int tj = j0; tj <= j1; ++tj) {
+                const int oy = tj * p.stride_y, ly = Y - oy;
+                const int rh = oy + To > p.outH ? p.outH - oy : To;
+                const long tile = (long)ti * p.ny + tj;
+                const half4* tp = tiles + tile * steps * (long)To * To;
+                float v0, v1, v2;
+                if (!p.tta) {
+                    half4 h = tp[(long)ly * To + lx];
+                    v0 = (float)h[0]; v1 = (float)h[1]; v2 = (float)h[2];
+                } else {
+                    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+                    half4 h;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        int sy, sx;
+                        deaug_src(k, n, ly, lx, sy, sx);
+                        h = tp[(long)k * To * To + (long)sy * To + sx];
+                        s0 += (float)h[0]; s1 += (float)h[1]; s2 += (float)h[2];
+                    }
+                    if (p.tta_bug_compat) { v0 = (float)h[0]; v1 = (float)h[1]; v2 = (float)h[2]; }
+                    else { v0 = s0 * 0.125f; v1 = s1 * 0.125f; v2 = s2 * 0.125f; }
+                }
+                if (p.ovx || p.ovy) {
+                    if (ox > 0 && lx < p.ovx) { float w = p.ramp_x[lx]; v0 *= w; v1 *= w; v2 *= w; }
+                    if (oy > 0 && ly < p.ovy) { float w = p.ramp_y[ly]; v0 *= w; v1 *= w; v2 *= w; }
+                    if (ox + rw < p.outW && n - lx < p.ovx) { float w = p.ramp_x[n - lx]; v0 *= w; v1 *= w; v2 *= w; }
+                    if (oy + rh < p.outH && n - ly < p.ovy) { float w = p.ramp_y[n - ly]; v0 *= w; v1 *= w; v2 *= w; }
+                }
+                acc0 += v0; acc1 += v1; acc2 += v2;
+            }
+        }
+        uint8_t* d = p.dst + (size_t)Y * p.dst_step + (size_t)X * 3;
+        d[0] = (uint8_t)min(max(__float2int_rn(acc2 * 255.f), 0), 255);
+        d[1] = (uint8_t)min(max(__float2int_rn(acc1 * 255.f), 0), 255);
+        d[2] = (uint8_t)min(max(__float2int_rn(acc0 * 255.f), 0), 255);
+    }
+}
+
+__global__ void se_kernel(const SeParams p) {
+    // one block per batch item; tiny (C <= 256)
+    extern __shared__ float sm[];
+    float* mean = sm;            // [C]
+    float* mid = sm + p.C;       // [Cmid]
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < p.C; c += blockDim.x) mean[c] = p.pool[b * p.Cs + c] * p.inv_count;
+    __syncthreads();
+    for (int m = threadIdx.x; m < p.Cmid; m += blockDim.x) {
+        float a = p.b1[m];
+        for (int c = 0; c < p.C; ++c) a += p.w1[m * p.C + c] * mean[c];
+        mid[m] = a > 0.f ? a : 0.f;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.Cs; c += blockDim.x) {
+        float s = 0.f;
+        if (c < p.C) {
+            float a = p.b2[c];
+            for (int m = 0; m < p.Cmid; ++m) a += p.w2[c * p.Cmid + m] * mid[m];
+            s = 1.f / (1.f + __expf(-a));
+        }
+        p.scale[b * p.Cs + c] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(_Float16* x, const float* scale, int B, long HW, int Cs) {
+    const int pc = Cs / 8;
+    const long total = (long)B * HW * pc;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int cp = (int)(i % pc);
+        long pix = i / pc;
+        int b = (int)(pix / HW);
+        half8 v = *((half8*)x + i);
+        const float* sc = scale + b * Cs + cp * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (_Float16)((float)v[e] * sc[e]);
+        *((half8*)x + i) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void blob_to_nhwc_kernel(const float* nchw, _Float16* out, int B, int T) {
+    const long total = (long)B * T * T;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int b = (int)(i / ((long)T * T));
+        long rem = i - (long)b * T * T;
+        const float* s = nchw + (long)b * 3 * T * T + rem;
+        half4 v;
+        v[0] = (_Float16)s[0]; v[1] = (_Float16)s[(long)T * T]; v[2] = (_Float16)s[2L * T * T]; v[3] = (_Float16)0.f;
+        *((half4*)out + i) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_blob_kernel(const _Float16* in, float* nchw, int B, int T) {
+    const long total = (long)B * T * T;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int b = (int)(i / ((long)T * T));
+        long rem = i - (long)b * T * T;
+        half4 v = *((const half4*)in + i);
+        float* d = nchw + (long)b * 3 * T * T + rem;
+        d[0] = (float)v[0]; d[(long)T * T] = (float)v[1]; d[2L * T * T] = (float)v[2];
+    }
+}
+
+inline unsigned grid_for(long total) { long g = (total + 255) / 256; return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
+
+}  // namespace
+
+hipError_t launch_gather(const GatherParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(gather_kernel, dim3(grid_for((long)p.B * p.T * p.T)), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+hipError_t launch_compose(const ComposeParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(compose_kernel, dim3(grid_for((long)p.outW * p.outH)), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+hipError_t launch_se(const SeParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(se_kernel, dim3(p.B), dim3(256), (p.C + p.Cmid) * sizeof(float), s, p);
+    return hipGetLastError();
+}
+hipError_t launch_scale(void* x, const float* scale, int B, int HW, int Cs, hipStream_t s) {
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for((long)B * HW * (Cs / 8))), dim3(256), 0, s, (_Float16*)x, scale, B, (long)HW, Cs);
+    return hipGetLastError();
+}
+hipError_t launch_blob_to_nhwc(const float* nchw, void* out, int B, int T, hipStream_t s) {
+    hipLaunchKernelGGL(blob_to_nhwc_kernel, dim3(grid_for((long)B * T * T)), dim3(256), 0, s, nchw, (_Float16*)out, B, T);
+    return hipGetLastError();
+}
+hipError_t launch_nhwc_to_blob(const void* in, float* nchw, int B, int T, hipStream_t s) {
+    hipLaunchKernelGGL(nhwc_to_blob_kernel, dim3(grid_for((long)B * T * T)), dim3(256), 0, s, (const _Float16*)in, nchw, B, T);
+    return hipGetLastError();
+}
+
+}  // namespace w2x

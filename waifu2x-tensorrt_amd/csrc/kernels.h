@@ -1,0 +1,81 @@
+// Launch interface of the HIP kernels (gfx950).  Plain C structs, no torch types.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace w2x {
+
+struct TView {           // device view of a channel-last tensor
+    void* p = nullptr;
+    int Hs = 0, Ws = 0, Cs = 0;  // stored dims
+    int y0 = 0, x0 = 0;          // origin of the logical window
+};
+
+struct GemmParams {
+    TView a;
+    int amode = 0, kh = 1, kw = 1, stride = 1;
+    int B = 0, Mrows = 0, aW = 0;
+    const int* win_table = nullptr;
+    int K = 0, N = 0, Kw = 0;       // Kw: row stride of wt (K rounded up to 8, zero padded)
+    const void* wt = nullptr;       // fp16 [N][Kw]
+    const float* bias = nullptr;    // [N]
+    const float* csum = nullptr;    // [N] (ln)
+    const float* stats_in = nullptr;  // [pixels of a][2]
+    int ln = 0;
+    int act = 0; float alpha = 0.f;
+    int has_clip = 0; float clip_lo = 0.f, clip_hi = 0.f;
+    TView res, res2;                // p == nullptr: none
+    TView out;
+    int omode = 0, r = 1, Cout = 0;
+    float* stats_out = nullptr; float ln_eps = 1e-5f;
+    float* pool_out = nullptr;      // [B][out.Cs]
+};
+
+struct AttnParams {
+    const void* qkv = nullptr; void* out = nullptr;
+    int B = 0, nwin = 0, heads = 0, hd = 0, ntok = 0;
+    float scale = 1.f;
+    const void* bias = nullptr;     // fp16 [nmask][heads][ntok][ntok]
+    const int* maskid = nullptr;    // [nwin]
+};
+
+struct SeParams {
+    const float* pool = nullptr; float* scale = nullptr;
+    int B = 0, C = 0, Cs = 0, Cmid = 0; float inv_count = 0.f;
+    const float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+};
+
+struct TileSlot { int x, y, aug, valid; };   // input rect origin (may be negative), augmentation 0..7, 0 = zero-pad slot
+
+struct GatherParams {
+    const uint8_t* frame = nullptr; int rows = 0, cols = 0; size_t step = 0;  // u8 BGR interleaved
+    void* out = nullptr;            // fp16 [B][T][T][4]
+    const TileSlot* slots = nullptr;
+    int B = 0, T = 0;
+};
+
+struct ComposeParams {
+    const void* tiles = nullptr;    // fp16 [slots][To][To][4], slot = tile*steps + aug
+    uint8_t* dst = nullptr; size_t dst_step = 0;    // u8 BGR
+    int outW = 0, outH = 0;
+    int To = 0;
+    int nx = 0, ny = 0;
+    int stride_x = 0, stride_y = 0;   // To - outOverlap
+    int ovx = 0, ovy = 0;             // blend ramp lengths (0: no blending)
+    const float* ramp_x = nullptr;    // [ovx] left ramp, fl32(double(i+1)/(ovx+1))
+    const float* ramp_y = nullptr;
+    int tta = 0;
+    int tta_bug_compat = 0;
+};
+
+hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
+hipError_t launch_attn(const AttnParams& p, hipStream_t s);
+hipError_t launch_se(const SeParams& p, hipStream_t s);
+hipError_t launch_scale(void* x, const float* scale, int B, int HW, int Cs, hipStream_t s);
+hipError_t launch_gather(const GatherParams& p, hipStream_t s);
+hipError_t launch_compose(const ComposeParams& p, hipStream_t s);
+// debug/test helpers used by w2x_infer (mirrors blobFromImages / imagesFromBlob, img2img_infer.cpp:5-39)
+hipError_t launch_blob_to_nhwc(const float* nchw, void* out_nhwc4, int B, int T, hipStream_t s);
+hipError_t launch_nhwc_to_blob(const void* in_nhwc4, float* nchw, int B, int T, hipStream_t s);
+
+}  // namespace w2x

@@ -1,0 +1,66 @@
+#include "tiles.h"
+
+#include <cmath>
+
+namespace w2x {
+
+TileGrid calculate_tiles(int inW, int inH, int outW, int outH, int tileInW, int tileInH, int tileOutW, int tileOutH,
+                         int scaling, double overlapX, double overlapY) {
+    TileGrid g;
+    // img2img_render.cpp:11-14 - the width is used for both dimensions
+    const int sOutW = tileInW * scaling, sOutH = tileInW * scaling;
+    // :16-19
+    const int sInW = (int)std::lround((double)tileOutW / sOutW * tileInW);
+    const int sInH = (int)std::lround((double)tileOutH / sOutH * tileInH);
+    // :21-24
+    g.inOvX = (int)std::lround(tileInW * overlapX);
+    g.inOvY = (int)std::lround(tileInH * overlapY);
+    // :26-29
+    g.outOvX = (int)std::lround(sOutW * overlapX);
+    g.outOvY = (int)std::lround(sOutH * overlapY);
+    // :31-34
+    g.nx = (int)std::lround(std::ceil((double)(inW - g.inOvX) / (sInW - g.inOvX)));
+    g.ny = (int)std::lround(std::ceil((double)(inH - g.inOvY) / (sInH - g.inOvY)));
+    g.count = g.nx * g.ny;
+    g.scaledInW = sInW; g.scaledInH = sInH;
+    g.in.reserve(g.count > 0 ? g.count : 0); g.out.reserve(g.count > 0 ? g.count : 0);
+    for (int i = 0; i < g.nx; ++i) {
+        for (int j = 0; j < g.ny; ++j) {
+            // :46-51
+            g.in.push_back(Rect{-((tileInW - sInW) / 2) + i * sInW - i * g.inOvX,
+                                -((tileInH - sInH) / 2) + j * sInH - j * g.inOvY, tileInW, tileInH});
+            // :54-61
+            const int x = i * tileOutW - i * g.outOvX;
+            const int y = j * tileOutH - j * g.outOvY;
+            g.out.push_back(Rect{x, y, x + tileOutW > outW ? outW - x : tileOutW, y + tileOutH > outH ? outH - y : tileOutH});
+        }
+    }
+    return g;
+}
+
+std::vector<float> blend_ramp(int ov) {
+    std::vector<float> r(ov > 0 ? ov : 0);
+    const int d = ov + 1;
+    for (int i = 1; i < d; ++i) r[i - 1] = (float)((double)i / d);
+    return r;
+}
+
+std::vector<float> tile_weight_mask(int which, int ovx, int ovy, int size) {
+    std::vector<float> m((size_t)size * size, 1.f);
+    if (which == 0 || which == 2) {
+        auto r = blend_ramp(ovy);
+        for (int i = 0; i < ovy && i < size; ++i) {
+            int row = which == 0 ? i : size - 1 - i;
+            for (int x = 0; x < size; ++x) m[(size_t)row * size + x] = r[i];
+        }
+    } else {
+        auto r = blend_ramp(ovx);
+        for (int i = 0; i < ovx && i < size; ++i) {
+            int col = which == 3 ? i : size - 1 - i;
+            for (int y = 0; y < size; ++y) m[(size_t)y * size + col] = r[i];
+        }
+    }
+    return m;
+}
+
+}  // namespace w2x

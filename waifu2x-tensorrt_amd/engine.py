@@ -1,0 +1,261 @@
+"""ctypes binding of libw2x.so mirroring trt::Img2Img (/root/reference/src/tensorrt/img2img.h:14-50):
+same five methods (build, load, render, setMessageCallback, setProgressCallback), same config
+structs (config.h:12-43) and the same bool-return + message-callback error convention."""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+lib_path = os.path.join(_HERE, "libw2x.so")
+
+
+class W2xError(RuntimeError):
+    pass
+
+
+class Precision(enum.IntEnum):      # config.h:7-10
+    TF32 = 0
+    FP16 = 1
+
+
+class Severity(enum.IntEnum):       # logger.h:11-18
+    critical = 0
+    error = 1
+    warn = 2
+    info = 3
+    debug = 4
+    trace = 5
+
+
+class _BuildConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "deviceId", "precision", "minBatchSize", "optBatchSize", "maxBatchSize", "minChannels", "optChannels",
+        "maxChannels", "minWidth", "optWidth", "maxWidth", "minHeight", "optHeight", "maxHeight")]
+
+
+class _RenderConfig(C.Structure):
+    _fields_ = [("deviceId", C.c_int), ("precision", C.c_int), ("batchSize", C.c_int), ("channels", C.c_int),
+                ("height", C.c_int), ("width", C.c_int), ("scaling", C.c_int), ("overlapX", C.c_double),
+                ("overlapY", C.c_double), ("tta", C.c_int), ("ttaBugCompat", C.c_int)]
+
+
+@dataclass
+class BuildConfig:                  # defaults of config.h:12-31
+    deviceId: int = 0
+    precision: Precision = Precision.FP16
+    minBatchSize: int = 1
+    optBatchSize: int = 1
+    maxBatchSize: int = 4
+    minChannels: int = 3
+    optChannels: int = 3
+    maxChannels: int = 3
+    minWidth: int = 64
+    optWidth: int = 256
+    maxWidth: int = 640
+    minHeight: int = 64
+    optHeight: int = 256
+    maxHeight: int = 640
+
+    @staticmethod
+    def fixed(batch: int, tile: int, device: int = 0, precision: Precision = Precision.FP16) -> "BuildConfig":
+        """min = opt = max, the way the CLI fills it (main.cpp:276-291)."""
+        return BuildConfig(device, precision, batch, batch, batch, 3, 3, 3, tile, tile, tile, tile, tile, tile)
+
+
+@dataclass
+class RenderConfig:                 # defaults of config.h:33-43
+    deviceId: int = 0
+    precision: Precision = Precision.FP16
+    batchSize: int = 1
+    channels: int = 3
+    height: int = 256
+    width: int = 256
+    scaling: int = 4
+    overlap: tuple = (0.0625, 0.0625)
+    tta: bool = False
+    ttaBugCompat: bool = False
+
+
+_MSG_FN = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_void_p)
+_PROG_FN = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_double, C.c_void_p)
+_lib = None
+
+
+def lib():
+    """Load libw2x.so and declare every symbol of include/w2x/c_api.h.  Fails loudly if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(lib_path):
+        raise W2xError(f"{lib_path} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "or `make -C waifu2x-tensorrt_amd` (there is no CPU fallback)")
+    L = C.CDLL(lib_path)
+    vp = C.c_void_p
+    L.w2x_create.restype = vp
+    L.w2x_destroy.argtypes = [vp]
+    L.w2x_set_message_callback.argtypes = [vp, _MSG_FN, vp]
+    L.w2x_set_progress_callback.argtypes = [vp, _PROG_FN, vp]
+    L.w2x_build.argtypes = [vp, C.c_char_p, C.POINTER(_BuildConfig)]; L.w2x_build.restype = C.c_int
+    L.w2x_load.argtypes = [vp, C.c_char_p, C.POINTER(_RenderConfig)]; L.w2x_load.restype = C.c_int
+    L.w2x_render.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t]; L.w2x_render.restype = C.c_int
+    L.w2x_infer.argtypes = [vp, vp, vp]; L.w2x_infer.restype = C.c_int
+    L.w2x_output_tile_size.argtypes = [vp]; L.w2x_output_tile_size.restype = C.c_int
+    L.w2x_plan_flops.argtypes = [vp]; L.w2x_plan_flops.restype = C.c_double
+    L.w2x_last_render_ms.argtypes = [vp]; L.w2x_last_render_ms.restype = C.c_float
+    L.w2x_bench_resident.argtypes = [vp, C.c_int]; L.w2x_bench_resident.restype = C.c_float
+    L.w2x_calculate_tiles.argtypes = [C.c_int] * 7 + [C.c_double, C.c_double, vp, vp, C.c_int]; L.w2x_calculate_tiles.restype = C.c_int
+    L.w2x_tile_weights.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp]; L.w2x_tile_weights.restype = C.c_int
+    L.w2x_describe_plan.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]; L.w2x_describe_plan.restype = C.c_int
+    L.w2x_sha256_hex.argtypes = [vp, C.c_size_t, C.c_char_p]
+    L.w2x_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "w2x_create", "w2x_destroy", "w2x_set_message_callback", "w2x_set_progress_callback", "w2x_build", "w2x_load",
+    "w2x_render", "w2x_infer", "w2x_output_tile_size", "w2x_plan_flops", "w2x_last_render_ms", "w2x_bench_resident",
+    "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_sha256_hex", "w2x_version"]
+
+
+class Img2Img:
+    """trt::Img2Img mirror.  cv::Mat <-> numpy uint8 [rows, cols, 3] BGR."""
+
+    def __init__(self):
+        self._L = lib()
+        self._h = self._L.w2x_create()
+        if not self._h:
+            raise W2xError("w2x_create failed")
+        self.messages: list[tuple[int, str]] = []
+        self._user_msg = None
+        self._user_prog = None
+        self._msg_cb = _MSG_FN(self._on_msg)
+        self._prog_cb = _PROG_FN(self._on_prog)
+        self._L.w2x_set_message_callback(self._h, self._msg_cb, None)
+        self._L.w2x_set_progress_callback(self._h, self._prog_cb, None)
+
+    def _on_msg(self, sev, msg, _):
+        m = msg.decode(errors="replace")
+        self.messages.append((sev, m))
+        if self._user_msg:
+            self._user_msg(Severity(sev), m)
+
+    def _on_prog(self, cur, total, speed, _):
+        if self._user_prog:
+            self._user_prog(cur, total, speed)
+
+    def close(self):
+        if self._h:
+            self._L.w2x_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def setMessageCallback(self, cb):
+        self._user_msg = cb
+
+    def setProgressCallback(self, cb):
+        self._user_prog = cb
+
+    def last_error(self) -> str:
+        errs = [m for s, m in self.messages if s <= Severity.error]
+        return errs[-1] if errs else ""
+
+    def build(self, path: str, config: BuildConfig) -> bool:
+        c = _BuildConfig(*[int(getattr(config, f[0])) for f in _BuildConfig._fields_])
+        return bool(self._L.w2x_build(self._h, os.fsencode(path), C.byref(c)))
+
+    def load(self, path: str, config: RenderConfig) -> bool:
+        c = _RenderConfig(config.deviceId, int(config.precision), config.batchSize, config.channels, config.height,
+                          config.width, config.scaling, float(config.overlap[0]), float(config.overlap[1]),
+                          int(config.tta), int(config.ttaBugCompat))
+        ok = bool(self._L.w2x_load(self._h, os.fsencode(path), C.byref(c)))
+        self._scaling = config.scaling if ok else 0
+        return ok
+
+    def render(self, src: np.ndarray, dst: np.ndarray | None = None):
+        """render(src, dst) -> bool like the reference; render(src) -> dst array or raises."""
+        if src.dtype != np.uint8 or src.ndim != 3 or src.shape[2] != 3 or src.strides[2] != 1 or src.strides[1] != 3:
+            raise ValueError("src must be a uint8 [rows, cols, 3] BGR array with packed pixels")
+        ret_array = dst is None
+        if dst is None:
+            s = getattr(self, "_scaling", 0)
+            dst = np.empty((src.shape[0] * s, src.shape[1] * s, 3), np.uint8)
+        ok = bool(self._L.w2x_render(self._h, src.ctypes.data, src.shape[0], src.shape[1], src.strides[0],
+                                     dst.ctypes.data, dst.strides[0]))
+        if ret_array:
+            if not ok:
+                raise W2xError(self.last_error() or "render failed")
+            return dst
+        return ok
+
+    def infer(self, x: np.ndarray) -> np.ndarray:
+        """Private trt::Img2Img::infer (img2img_infer.cpp:41-93) as a test hook: [B,3,T,T] f32 -> [B,3,T',T'] f32."""
+        x = np.ascontiguousarray(x, np.float32)
+        to = self.output_tile_size
+        y = np.empty((x.shape[0], 3, to, to), np.float32)
+        if not self._L.w2x_infer(self._h, x.ctypes.data, y.ctypes.data):
+            raise W2xError(self.last_error() or "infer failed")
+        return y
+
+    @property
+    def output_tile_size(self) -> int:
+        return self._L.w2x_output_tile_size(self._h)
+
+    @property
+    def plan_flops(self) -> float:
+        return self._L.w2x_plan_flops(self._h)
+
+    @property
+    def last_render_ms(self) -> float:
+        return self._L.w2x_last_render_ms(self._h)
+
+    def bench_resident(self, iters: int) -> float:
+        return self._L.w2x_bench_resident(self._h, iters)
+
+
+def calculate_tiles(in_w, in_h, out_w, out_h, tile_in, tile_out, scaling, overlap):
+    """calculateTiles (img2img_render.cpp:7-66) through the C ABI -> (count, in_rects[N,4], out_rects[N,4])."""
+    L = lib()
+    cap = 1 << 16
+    a = np.zeros((cap, 4), np.int32)
+    b = np.zeros((cap, 4), np.int32)
+    n = L.w2x_calculate_tiles(in_w, in_h, out_w, out_h, tile_in, tile_out, scaling, float(overlap[0]), float(overlap[1]),
+                              a.ctypes.data, b.ctypes.data, cap)
+    if n < 0:
+        raise W2xError("tile capacity exceeded")
+    return n, a[:n].copy(), b[:n].copy()
+
+
+def tile_weights(which, ovx, ovy, size):
+    L = lib()
+    out = np.empty((size, size), np.float32)
+    if not L.w2x_tile_weights(which, ovx, ovy, size, out.ctypes.data):
+        raise W2xError("bad arguments")
+    return out
+
+
+def describe_plan(onnx_path, batch, tile) -> str:
+    L = lib()
+    buf = C.create_string_buffer(1 << 20)
+    ok = L.w2x_describe_plan(os.fsencode(onnx_path), batch, tile, buf, len(buf))
+    s = buf.value.decode(errors="replace")
+    if not ok:
+        raise W2xError(s)
+    return s
+
+
+def sha256_hex(data: bytes) -> str:
+    L = lib()
+    out = C.create_string_buffer(65)
+    L.w2x_sha256_hex(data, len(data), out)
+    return out.value.decode()
