@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Headline benchmark: output MPix/s (and frames/s) of 1080p -> 4K upscaling, swin_unet/art scale4 noise3 fp16,
+batch 4, tile 256, blend 1/16 (BASELINE.json configs[2]) on N MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one pass of the hot path (gather -> network on every tile batch -> blend/compose) over one synthetic
+1920x1080 frame that is already resident in HBM; frames are independent, so ranks shard frames with no data-path
+collective (weak scaling: every rank renders K frames).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+MODEL, SCALE, NOISE, BATCH, TILE, BLEND = "swin_unet/art", 4, 3, 4, 256, 0.0625
+FRAME_W, FRAME_H = 1920, 1080
+MFMA_F16_PEAK_TFLOPS = 2500.0        # dense, /opt/skills/guides/MI355X_MICROARCH.md
+OUT_MPIX = FRAME_W * SCALE * FRAME_H * SCALE / 1e6
+
+
+def synthetic_frame(seed: int) -> np.ndarray:
+    """u8 BGR 1080p frame: seeded low-frequency sinusoids + +-4 LSB noise."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:FRAME_H, 0:FRAME_W].astype(np.float32)
+    img = np.full((FRAME_H, FRAME_W, 3), 127.0, np.float32)
+    for k in range(8):
+        fx, fy, ph = rng.uniform(0.002, 0.03), rng.uniform(0.002, 0.03), rng.uniform(0, 6.28, 3)
+        img += 14.0 * np.sin(xx[..., None] * fx + yy[..., None] * fy + ph)
+    img += rng.integers(-4, 5, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def cpu_baseline(path: str, threads: int) -> dict:
+    """The oracle (CPU port of the path: fp32 ONNX executor + numpy tile pipeline) timed on this box's host cores on a
+    bounded sample: one batch of 4 tiles through the network plus the per-tile pre/post work, extrapolated to the 45
+    tiles of a frame."""
+    import torch
+    from oracle import onnx_exec, onnx_reader, pipeline
+    torch.set_num_threads(threads)
+    g = onnx_reader.load(path)
+    ex = onnx_exec.Executor(g)
+    frame = synthetic_frame(0)
+    n, ins, outs = pipeline.calculate_tiles(FRAME_W, FRAME_H, FRAME_W * SCALE, FRAME_H * SCALE, (TILE, TILE), (960, 960), SCALE, (BLEND, BLEND))
+    picks = [0, n // 2, 1, n - 1][:BATCH]
+    t0 = time.perf_counter()
+    tiles = [np.ascontiguousarray(pipeline.pad_roi(frame[..., ::-1], ins[k])) for k in picks]
+    y = ex.run(pipeline.blob_from_tiles(tiles))
+    w = pipeline.create_tile_weights((64, 64), (960, 960))
+    for b, k in enumerate(picks):
+        o = np.ascontiguousarray(y[b].transpose(1, 2, 0))
+        o = pipeline.apply_weights(o, outs[k], FRAME_W * SCALE, FRAME_H * SCALE, w)
+        pipeline.to_u8(o)
+    dt = time.perf_counter() - t0
+    per_tile = dt / BATCH          # the executor processed a full batch of 4 tiles
+    frame_s = per_tile * n
+    return {"value": round(OUT_MPIX / frame_s, 4), "unit": "MPix/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (torch-CPU fp32 ONNX executor + numpy pipeline) on 1 batch of {BATCH} tiles T={TILE} ({dt:.1f} s), "
+                      f"extrapolated to {n} tiles/frame ({frame_s:.0f} s/frame)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--work", default=os.environ.get("W2X_BENCH_WORK", "/tmp/w2x_bench"))
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import __graft_entry__ as g
+    import synth_models as sm
+    pkg = g.package()
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    work = os.path.join(a.work, f"rank{rank}")
+    path = sm.model_path(work, MODEL, SCALE, NOISE)
+    if not os.path.exists(path):
+        sm.export_onnx(sm.make_model(MODEL, SCALE, seed=1234 + NOISE), path, BATCH, TILE)
+    eng = pkg.Img2Img()
+    bc = pkg.BuildConfig.fixed(BATCH, TILE, device=local_rank)
+    if not eng.build(path, bc):
+        raise SystemExit("build failed: " + eng.last_error())
+    rc = pkg.RenderConfig(deviceId=local_rank, batchSize=BATCH, height=TILE, width=TILE, scaling=SCALE, overlap=(BLEND, BLEND))
+    if not eng.load(path, rc):
+        raise SystemExit("load failed: " + eng.last_error())
+
+    frame = synthetic_frame(rank)
+    out = np.empty((FRAME_H * SCALE, FRAME_W * SCALE, 3), np.uint8)
+    if not eng.render(frame, out):           # uploads the frame; it stays resident for the timed steps
+        raise SystemExit("render failed: " + eng.last_error())
+    pcie_ms_one = None
+    t0 = time.perf_counter(); eng.render(frame, out); pcie_ms_one = (time.perf_counter() - t0) * 1e3
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    eng.bench_resident(max(a.warmup, 1))
+    sync_all()
+    t0 = time.perf_counter()
+    ms = eng.bench_resident(a.steps)          # K frames, HIP events on the compute stream + stream sync inside
+    sync_all()
+    wall = time.perf_counter() - t0
+    if ms <= 0:
+        raise SystemExit("bench failed: " + eng.last_error())
+    t = torch.tensor([wall], dtype=torch.float64)
+    if dist is not None:
+        t = t.cuda(); dist.all_reduce(t, op=dist.ReduceOp.MAX); t = t.cpu()
+    wall_max = float(t[0])
+
+    prof = eng.profile_frame()
+    if rank == 0:
+        fps = a.steps * world / wall_max
+        gemm_ms, gemm_n, gemm_flop = prof["gemm"]
+        achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        line = {
+            "metric": "upscaled MPix/s, 1080p->4K swin_unet/art fp16",
+            "value": round(fps * OUT_MPIX, 2), "unit": "MPix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(wall_max * 1e3 / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "configs[2]: swin_unet/art scale4 noise3 batch4 tile256 fp16, 1920x1080 frame, blend=0.0625 "
+                                   "(45 tiles, 12 batches); synthetic-weight graph of that architecture, frame resident in HBM",
+                       "frames_per_s": round(fps, 3), "device_ms_per_frame": round(ms, 3), "frames_per_rank": a.steps,
+                       "parallelism": f"frame-sharded x{world}, no collectives",
+                       "pcie_inclusive_ms_per_frame": round(pcie_ms_one, 2),
+                       "algorithmic_tflop_per_frame": round(eng.plan_flops * 12 / 1e12, 4)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 5), "traffic": None,
+                         "kernel": "gemm_kernel (fused implicit-GEMM conv/linear)", "launches_per_frame": gemm_n,
+                         "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_n, 1), 2),
+                         "families_ms_per_frame": {k: round(v[0], 3) for k, v in prof.items() if k != "frame_ms"}},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(path, threads=os.cpu_count() or 1)
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -49,6 +49,8 @@ public:
     // Re-run the device part of the last render() (gather, network, compose; no H2D/D2H) `iters` times and return the
     // average milliseconds per frame - inputs already resident in HBM (bench.py's timed region).
     float benchResident(int iters);
+    // Per-kernel-family HIP-event timing of one resident frame (layout documented at the definition).
+    bool profileFrame(double* out, int cap);
 
     struct Impl;
 private:

@@ -1,0 +1,52 @@
+"""End-to-end golden vectors (tests/golden/e2e_*.npz, produced by tests/golden/make_golden.py with the oracle).
+CPU: the oracle still reproduces them bit for bit.  GPU: the HIP engine matches them within the fp16 tolerance."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import synth_models as sm
+from oracle import onnx_exec, pipeline
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FILES = sorted(glob.glob(os.path.join(HERE, "golden", "e2e_*.npz")))
+
+
+def _load(f):
+    z = np.load(f)
+    scale, noise, small, batch, tile, tta = [int(v) for v in z["meta"]]
+    return dict(frame=z["frame"], expected=z["expected"], scale=scale, noise=noise, small=bool(small), batch=batch,
+                tile=tile, tta=bool(tta), ov=float(z["overlap"][0]), model=str(z["model"]))
+
+
+def psnr(a, b):
+    mse = float(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2))
+    return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+
+
+@pytest.mark.parametrize("f", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_oracle_reproduces_golden(f, onnx_model):
+    c = _load(f)
+    path = onnx_model(c["model"], c["scale"], c["batch"], c["tile"], noise=c["noise"], small=c["small"])
+    out = pipeline.render(c["frame"], onnx_exec.Executor(path).run, batch=c["batch"], tile=c["tile"], scaling=c["scale"],
+                          overlap=(c["ov"], c["ov"]), tta=c["tta"], net_dtype=np.float16)
+    # fp32 CPU kernels may differ in the last ulp between machines; the u8 image must agree to 1 LSB, almost everywhere exactly
+    d = np.abs(out.astype(int) - c["expected"].astype(int))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("f", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_hip_engine_matches_golden(f, onnx_model, pkg):
+    c = _load(f)
+    path = onnx_model(c["model"], c["scale"], c["batch"], c["tile"], noise=c["noise"], small=c["small"])
+    eng = pkg.Img2Img()
+    assert eng.build(path, pkg.BuildConfig.fixed(c["batch"], c["tile"])), eng.last_error()
+    assert eng.load(path, pkg.RenderConfig(batchSize=c["batch"], height=c["tile"], width=c["tile"], scaling=c["scale"],
+                                           overlap=(c["ov"], c["ov"]), tta=c["tta"])), eng.last_error()
+    out = eng.render(c["frame"])
+    d = np.abs(out.astype(int) - c["expected"].astype(int))
+    # tolerance: north_star asks PSNR > 50 dB against the reference-semantics output; fp16 network => <= 2 LSB per pixel
+    assert psnr(out, c["expected"]) > 50.0 and d.max() <= 2, (psnr(out, c["expected"]), d.max())
+    eng.close()

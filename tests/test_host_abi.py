@@ -1,0 +1,89 @@
+"""CPU-side checks of the product library: it loads, exports every symbol of include/w2x/c_api.h, and its host
+logic (tile grid, ramps, hash, ONNX lowering, error convention) agrees with the oracle.  No compute calls."""
+import ctypes
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import onnx_exec, pipeline as P
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    hdr = open(os.path.join(ROOT, "include", "w2x", "c_api.h")).read()
+    body = hdr[hdr.index('extern "C"'):]
+    declared = set(re.findall(r"\b(w2x_[a-z0-9_]+)\s*\(", body))
+    declared -= {"w2x_message_fn", "w2x_progress_fn"}
+    assert len(declared) >= 15
+    L = ctypes.CDLL(pkg.lib_path)
+    for name in sorted(declared):
+        assert hasattr(L, name), f"libw2x.so does not export {name}"
+    from importlib import import_module
+    eng = import_module("waifu2x-tensorrt_amd.engine")
+    assert declared == set(eng.EXPORTED_SYMBOLS)
+
+
+@pytest.mark.parametrize("W,H", [(1920, 1080), (256, 256), (300, 200), (64, 64), (3840, 2160), (17, 999)])
+@pytest.mark.parametrize("T,s,Tout", [(64, 2, 56), (256, 2, 440), (256, 4, 960), (400, 4, 1536), (640, 4, 2496), (128, 1, 72), (64, 1, 48)])
+@pytest.mark.parametrize("ov", [0.125, 0.0625, 0.03125, 0.0])
+def test_tile_grid_matches_oracle(pkg, W, H, T, s, Tout, ov):
+    n, ins, outs = pkg.calculate_tiles(W, H, W * s, H * s, T, Tout, s, (ov, ov))
+    n2, ins2, outs2 = P.calculate_tiles(W, H, W * s, H * s, (T, T), (Tout, Tout), s, (ov, ov))
+    assert n == n2
+    assert np.array_equal(ins, np.array([r.astuple() for r in ins2], np.int32).reshape(-1, 4))
+    assert np.array_equal(outs, np.array([r.astuple() for r in outs2], np.int32).reshape(-1, 4))
+
+
+@pytest.mark.parametrize("ov,size", [(64, 960), (32, 440), (8, 56), (100, 1536), (0, 48)])
+def test_tile_weights_bit_exact(pkg, ov, size):
+    ref = P.create_tile_weights((ov, ov), (size, size))
+    for which in range(4):
+        got = pkg.tile_weights(which, ov, ov, size)
+        assert np.array_equal(got.view(np.uint32), ref[which].view(np.uint32))
+
+
+def test_sha256(pkg):
+    for msg in (b"", b"abc", b"AMDInstinctMI355X.FP16.4.4.4.3.3.3.256.256.256.256.256.256", os.urandom(1000)):
+        assert pkg.sha256_hex(msg) == hashlib.sha256(msg).hexdigest()
+
+
+@pytest.mark.parametrize("model,scale,tile,small", [("cunet/art", 2, 64, False), ("swin_unet/art", 4, 64, True), ("swin_unet/art", 2, 40, True)])
+def test_lowering_covers_graph_and_counts_flops(pkg, onnx_model, model, scale, tile, small):
+    path = onnx_model(model, scale, 2, tile, small=small)
+    d = pkg.describe_plan(path, 2, tile)
+    flops = int(re.search(r"flops=(\d+)", d).group(1))
+    assert flops == onnx_exec.count_flops(path, (2, 3, tile, tile))["total"]
+    import synth_models as sm
+    to = sm.output_tile_size(model, scale, tile)
+    assert f"out=[2,3,{to},{to}]" in d
+
+
+def test_lowering_rejects_wrong_shape_and_garbage(pkg, onnx_model, tmp_path):
+    path = onnx_model("cunet/art", 2, 2, 64)
+    with pytest.raises(pkg.W2xError):
+        pkg.describe_plan(path, 3, 64)          # static batch 2 in the file
+    bad = tmp_path / "bad.onnx"
+    bad.write_bytes(b"\x00\x01garbage")
+    with pytest.raises(pkg.W2xError):
+        pkg.describe_plan(str(bad), 1, 64)
+    with pytest.raises(pkg.W2xError):
+        pkg.describe_plan(str(tmp_path / "missing.onnx"), 1, 64)
+
+
+def test_error_convention_without_gpu_or_engine(pkg, onnx_model, tmp_path):
+    """bool return + "[function@line] message" through the message callback (logger.h:8, logger.cpp:19-22)."""
+    eng = pkg.Img2Img()
+    seen = []
+    eng.setMessageCallback(lambda sev, msg: seen.append((sev, msg)))
+    frame = np.zeros((8, 8, 3), np.uint8)
+    out = np.zeros((32, 32, 3), np.uint8)
+    assert eng.render(frame, out) is False            # render before load
+    assert seen and seen[-1][0] == pkg.Severity.error and re.match(r"\[render@\d+\] ", seen[-1][1])
+    cfg = pkg.RenderConfig(batchSize=1, height=64, width=64, scaling=2)
+    assert eng.load(str(tmp_path / "nope.onnx"), cfg) is False
+    assert re.match(r"\[load@\d+\] ", seen[-1][1])
+    eng.close()

@@ -140,6 +140,19 @@ struct Img2Img::Impl {
     float* d_blob_in = nullptr; float* d_blob_out = nullptr;
     std::vector<TileSlot> h_slots;
 
+    // per-launch HIP-event profiling (profileFrame): events recorded on the compute stream around every launch
+    bool profiling = false;
+    struct Stamp { int kind; hipEvent_t a, b; double flops; };
+    std::vector<Stamp> stamps;
+    void stamp_begin(int kind, double flops) {
+        if (!profiling) return;
+        Stamp st{kind, nullptr, nullptr, flops};
+        hipAssert(hipEventCreate(&st.a)); hipAssert(hipEventCreate(&st.b));
+        hipAssert(hipEventRecord(st.a, stream));
+        stamps.push_back(st);
+    }
+    void stamp_end() { if (profiling) hipAssert(hipEventRecord(stamps.back().b, stream)); }
+
     // last frame (for benchResident)
     int last_rows = 0, last_cols = 0, last_batches = 0;
     TileGrid last_grid;
@@ -224,7 +237,9 @@ struct Img2Img::Impl {
                 case OP_GEMM: {
                     GemmParams p = gemm[i];
                     if ((int)i == final_op && out_override) p.out.p = out_override;
+                    stamp_begin(0, op.flops);
                     hipAssert(launch_gemm(p, stream));
+                    stamp_end();
                     break;
                 }
                 case OP_ATTN: {
@@ -232,7 +247,9 @@ struct Img2Img::Impl {
                     AttnParams p;
                     p.qkv = tensors[a.qkv]; p.out = tensors[a.out]; p.B = plan.B; p.nwin = a.nwin; p.heads = a.heads; p.hd = a.hd;
                     p.ntok = a.ws * a.ws; p.scale = a.scale; p.bias = blobs[a.bias]; p.maskid = (const int*)blobs[a.maskid];
+                    stamp_begin(1, op.flops);
                     hipAssert(launch_attn(p, stream));
+                    stamp_end();
                     break;
                 }
                 case OP_SE: {
@@ -241,12 +258,16 @@ struct Img2Img::Impl {
                     p.pool = (const float*)tensors[s.pool]; p.scale = (float*)tensors[s.scale]; p.B = plan.B; p.C = s.C;
                     p.Cs = plan.tensors[s.pool].C; p.Cmid = s.Cmid; p.inv_count = s.inv_count;
                     p.w1 = (const float*)blobs[s.w1]; p.b1 = (const float*)blobs[s.b1]; p.w2 = (const float*)blobs[s.w2]; p.b2 = (const float*)blobs[s.b2];
+                    stamp_begin(2, 0);
                     hipAssert(launch_se(p, stream));
+                    stamp_end();
                     break;
                 }
                 case OP_SCALE_ADD: {
                     const TensorDesc& d = plan.tensors[op.se.pool];
+                    stamp_begin(2, 0);
                     hipAssert(launch_scale(tensors[op.se.pool], (const float*)tensors[op.se.scale], d.B, d.H * d.W, d.C, stream));
+                    stamp_end();
                     break;
                 }
                 default: throw std::runtime_error("plan: unknown op kind");
@@ -273,7 +294,9 @@ struct Img2Img::Impl {
             GatherParams gp;
             gp.frame = d_frame; gp.rows = rows; gp.cols = cols; gp.step = (size_t)cols * 3;
             gp.out = tensors[plan.in_tensor]; gp.slots = d_slots + (size_t)bi * B; gp.B = B; gp.T = T;
+            stamp_begin(3, 0);
             hipAssert(launch_gather(gp, stream));
+            stamp_end();
             run_network((uint8_t*)d_slab + (size_t)bi * B * slot_bytes);
             if (report) {
                 const auto t1 = std::chrono::steady_clock::now();
@@ -288,7 +311,9 @@ struct Img2Img::Impl {
         const bool overlapping = cfg.overlapX != 0 || cfg.overlapY != 0;                      // :244
         cp.ovx = overlapping ? ovx : 0; cp.ovy = overlapping ? ovy : 0;
         cp.ramp_x = d_rampx; cp.ramp_y = d_rampy; cp.tta = cfg.tta ? 1 : 0; cp.tta_bug_compat = cfg.ttaBugCompat ? 1 : 0;
+        stamp_begin(4, 0);
         hipAssert(launch_compose(cp, stream));
+        stamp_end();
         last_batches = batchCount;
     }
 };
@@ -512,6 +537,31 @@ float Img2Img::benchResident(int iters) try {
 } catch (const std::exception& e) {
     W2X_LOG(error, "Bench failed unexpectedly: " + std::string(e.what()) + ".");
     return -1.f;
+}
+
+// Per-kernel-family device time of one resident frame, measured with HIP events on the compute stream.
+// out[5*k + {0,1,2}] = {milliseconds, launches, algorithmic FLOP} for k = 0 gemm, 1 attention, 2 se/scale, 3 gather,
+// 4 compose; out[25] = wall ms of the whole frame (first launch start to last launch end).
+bool Img2Img::profileFrame(double* out, int cap) try {
+    if (!impl->loaded || impl->last_rows == 0 || cap < 26) return false;
+    for (int i = 0; i < 26; ++i) out[i] = 0;
+    impl->profiling = true; impl->stamps.clear();
+    impl->run_frame(impl->last_rows, impl->last_cols, impl->last_grid, false);
+    impl->profiling = false;
+    hipAssert(hipStreamSynchronize(impl->stream));
+    for (auto& st : impl->stamps) {
+        float ms = 0.f;
+        hipAssert(hipEventElapsedTime(&ms, st.a, st.b));
+        out[5 * st.kind] += ms; out[5 * st.kind + 1] += 1; out[5 * st.kind + 2] += st.flops;
+    }
+    if (!impl->stamps.empty()) { float ms = 0.f; hipAssert(hipEventElapsedTime(&ms, impl->stamps.front().a, impl->stamps.back().b)); out[25] = ms; }
+    for (auto& st : impl->stamps) { hipEventDestroy(st.a); hipEventDestroy(st.b); }
+    impl->stamps.clear();
+    return true;
+} catch (const std::exception& e) {
+    impl->profiling = false;
+    W2X_LOG(error, "Profile failed unexpectedly: " + std::string(e.what()) + ".");
+    return false;
 }
 
 }  // namespace w2x
