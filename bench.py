@@ -41,31 +41,33 @@ def synthetic_frame(seed: int) -> np.ndarray:
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
-def cpu_baseline(path: str, threads: int) -> dict:
-    """The oracle (CPU port of the path: fp32 ONNX executor + numpy tile pipeline) timed on this box's host cores on a
-    bounded sample: one batch of 4 tiles through the network plus the per-tile pre/post work, extrapolated to the 45
-    tiles of a frame."""
+def cpu_baseline(work: str, threads: int) -> dict:
+    """The oracle (CPU port of the path: fp32 ONNX executor on torch-CPU kernels + numpy tile pipeline) timed on this
+    box's host cores on a bounded sample: 10 tiles of the same workload (same graph exported at batch 1) through the
+    network plus its pre/post work, extrapolated to the 45 tiles of a frame."""
     import torch
-    from oracle import onnx_exec, onnx_reader, pipeline
+    import synth_models as sm
+    from oracle import onnx_exec, pipeline
     torch.set_num_threads(threads)
-    g = onnx_reader.load(path)
-    ex = onnx_exec.Executor(g)
+    path = sm.model_path(os.path.join(work, "cpu_b1"), MODEL, SCALE, NOISE)
+    if not os.path.exists(path):
+        sm.export_onnx(sm.make_model(MODEL, SCALE, seed=1234 + NOISE), path, 1, TILE)
+    ex = onnx_exec.Executor(path)
     frame = synthetic_frame(0)
     n, ins, outs = pipeline.calculate_tiles(FRAME_W, FRAME_H, FRAME_W * SCALE, FRAME_H * SCALE, (TILE, TILE), (960, 960), SCALE, (BLEND, BLEND))
-    picks = [0, n // 2, 1, n - 1][:BATCH]
-    t0 = time.perf_counter()
-    tiles = [np.ascontiguousarray(pipeline.pad_roi(frame[..., ::-1], ins[k])) for k in picks]
-    y = ex.run(pipeline.blob_from_tiles(tiles))
+    picks = list(range(0, n, max(1, n // 10)))[:10]
     w = pipeline.create_tile_weights((64, 64), (960, 960))
-    for b, k in enumerate(picks):
-        o = np.ascontiguousarray(y[b].transpose(1, 2, 0))
-        o = pipeline.apply_weights(o, outs[k], FRAME_W * SCALE, FRAME_H * SCALE, w)
+    ex.run(np.zeros((1, 3, TILE, TILE), np.float32))      # warm-up (thread pool, allocator)
+    t0 = time.perf_counter()
+    for k in picks:
+        tile = np.ascontiguousarray(pipeline.pad_roi(frame[..., ::-1], ins[k]))
+        y = ex.run(pipeline.blob_from_tiles([tile]))
+        o = pipeline.apply_weights(np.ascontiguousarray(y[0].transpose(1, 2, 0)), outs[k], FRAME_W * SCALE, FRAME_H * SCALE, w)
         pipeline.to_u8(o)
     dt = time.perf_counter() - t0
-    per_tile = dt / BATCH          # the executor processed a full batch of 4 tiles
-    frame_s = per_tile * n
+    frame_s = dt / len(picks) * n
     return {"value": round(OUT_MPIX / frame_s, 4), "unit": "MPix/s", "cores": threads, "kind": "port",
-            "sample": f"oracle (torch-CPU fp32 ONNX executor + numpy pipeline) on 1 batch of {BATCH} tiles T={TILE} ({dt:.1f} s), "
+            "sample": f"oracle (torch-CPU fp32 ONNX executor + numpy pipeline) on {len(picks)} tiles T={TILE} ({dt:.1f} s), "
                       f"extrapolated to {n} tiles/frame ({frame_s:.0f} s/frame)"}
 
 
@@ -75,6 +77,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--op-times", action="store_true", help="print HIP-event time per plan op (one frame) to stderr")
     ap.add_argument("--work", default=os.environ.get("W2X_BENCH_WORK", "/tmp/w2x_bench"))
     a = ap.parse_args()
 
@@ -133,6 +136,10 @@ def main():
     wall_max = float(t[0])
 
     prof = eng.profile_frame()
+    if a.op_times and rank == 0:
+        desc = pkg.describe_plan(path, BATCH, TILE).splitlines()[2:]
+        for line, op_ms in zip(desc, eng.op_times()):
+            print(f"{op_ms:8.3f} ms  {line[:150]}", file=sys.stderr)
     if rank == 0:
         fps = a.steps * world / wall_max
         gemm_ms, gemm_n, gemm_flop = prof["gemm"]
@@ -155,7 +162,7 @@ def main():
                          "families_ms_per_frame": {k: round(v[0], 3) for k, v in prof.items() if k != "frame_ms"}},
         }
         if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(path, threads=os.cpu_count() or 1)
+            line["cpu_baseline"] = cpu_baseline(a.work, threads=min(os.cpu_count() or 1, 32))
         print(json.dumps(line), flush=True)
     eng.close()
     if dist is not None:

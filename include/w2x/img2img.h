@@ -51,6 +51,7 @@ public:
     float benchResident(int iters);
     // Per-kernel-family HIP-event timing of one resident frame (layout documented at the definition).
     bool profileFrame(double* out, int cap);
+    int opTimes(double* out, int cap) const;   // ms per plan op of the last profileFrame(); returns the op count
 
     struct Impl;
 private:

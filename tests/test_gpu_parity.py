@@ -63,7 +63,7 @@ def test_network_matches_oracle(pkg, onnx_model, model, scale, batch, tile, smal
     ("swin_unet/art", 2, 3, 64, True, 0.125, True, (70, 50)),
     ("swin_unet/art", 4, 8, 64, True, 0.03125, True, (64, 64)),
     ("cunet/art", 2, 4, 64, False, 0.0625, False, (100, 77)),
-    ("cunet/art", 1, 2, 64, False, 0.125, False, (40, 40)),
+    ("cunet/art", 1, 2, 96, False, 0.125, False, (70, 50)),
     ("cunet/art", 2, 1, 64, False, 0.0625, True, (30, 34)),
 ])
 def test_render_matches_oracle(pkg, onnx_model, model, scale, batch, tile, small, ov, tta, shape):

@@ -68,6 +68,7 @@ int w2x_output_tile_size(w2x_engine* e) { return e ? e->engine.outputTileSize() 
 double w2x_plan_flops(w2x_engine* e) { return e ? e->engine.planFlops() : 0.0; }
 float w2x_last_render_ms(w2x_engine* e) { return e ? e->engine.lastRenderMs() : -1.f; }
 int w2x_profile_frame(w2x_engine* e, double* out, int cap) { return e && e->engine.profileFrame(out, cap) ? 1 : 0; }
+int w2x_op_times(w2x_engine* e, double* out, int cap) { return e ? e->engine.opTimes(out, cap) : 0; }
 float w2x_bench_resident(w2x_engine* e, int iters) { return e ? e->engine.benchResident(iters) : -1.f; }
 
 int w2x_calculate_tiles(int in_w, int in_h, int out_w, int out_h, int tile_in, int tile_out, int scaling,

@@ -142,11 +142,13 @@ struct Img2Img::Impl {
 
     // per-launch HIP-event profiling (profileFrame): events recorded on the compute stream around every launch
     bool profiling = false;
-    struct Stamp { int kind; hipEvent_t a, b; double flops; };
+    struct Stamp { int kind; hipEvent_t a, b; double flops; int op; };
+    std::vector<double> op_ms;   // per plan op, summed over the batches of the profiled frame
+    int cur_op = -1;
     std::vector<Stamp> stamps;
     void stamp_begin(int kind, double flops) {
         if (!profiling) return;
-        Stamp st{kind, nullptr, nullptr, flops};
+        Stamp st{kind, nullptr, nullptr, flops, cur_op};
         hipAssert(hipEventCreate(&st.a)); hipAssert(hipEventCreate(&st.b));
         hipAssert(hipEventRecord(st.a, stream));
         stamps.push_back(st);
@@ -230,9 +232,9 @@ struct Img2Img::Impl {
 
     // one pass of the network over the tiles currently in plan.in_tensor; the last op writes to `out_override`
     void run_network(void* out_override) {
-        for (int t : pool_tensors) hipAssert(hipMemsetAsync(tensors[t], 0, (size_t)plan.tensors[t].bytes(), stream));
         for (size_t i = 0; i < plan.ops.size(); ++i) {
             const Op& op = plan.ops[i];
+            cur_op = (int)i;
             switch (op.kind) {
                 case OP_GEMM: {
                     GemmParams p = gemm[i];
@@ -256,7 +258,7 @@ struct Img2Img::Impl {
                     const SeOp& s = op.se;
                     SeParams p;
                     p.pool = (const float*)tensors[s.pool]; p.scale = (float*)tensors[s.scale]; p.B = plan.B; p.C = s.C;
-                    p.Cs = plan.tensors[s.pool].C; p.Cmid = s.Cmid; p.inv_count = s.inv_count;
+                    p.Cs = plan.tensors[s.pool].C; p.Cmid = s.Cmid; p.inv_count = s.inv_count; p.nblocks = s.nblocks; p.Mrows = s.Mrows;
                     p.w1 = (const float*)blobs[s.w1]; p.b1 = (const float*)blobs[s.b1]; p.w2 = (const float*)blobs[s.w2]; p.b2 = (const float*)blobs[s.b2];
                     stamp_begin(2, 0);
                     hipAssert(launch_se(p, stream));
@@ -273,6 +275,7 @@ struct Img2Img::Impl {
                 default: throw std::runtime_error("plan: unknown op kind");
             }
         }
+        cur_op = -1;
     }
 
     template <class T> void ensure(T*& p, size_t& cap, size_t bytes) {
@@ -520,6 +523,7 @@ bool Img2Img::infer(const float* input, float* output) try {
 }
 
 int Img2Img::outputTileSize() const { return impl->loaded ? impl->plan.Tout : 0; }
+int Img2Img::opTimes(double* out, int cap) const { int n = (int)impl->op_ms.size(); for (int i = 0; i < n && i < cap; ++i) out[i] = impl->op_ms[i]; return n; }
 int Img2Img::scaling() const { return impl->loaded ? impl->cfg.scaling : 0; }
 double Img2Img::planFlops() const { return impl->loaded ? impl->plan.flops : 0.0; }
 float Img2Img::lastRenderMs() const { return impl->last_ms; }
@@ -549,9 +553,11 @@ bool Img2Img::profileFrame(double* out, int cap) try {
     impl->run_frame(impl->last_rows, impl->last_cols, impl->last_grid, false);
     impl->profiling = false;
     hipAssert(hipStreamSynchronize(impl->stream));
+    impl->op_ms.assign(impl->plan.ops.size(), 0.0);
     for (auto& st : impl->stamps) {
         float ms = 0.f;
         hipAssert(hipEventElapsedTime(&ms, st.a, st.b));
+        if (st.op >= 0) impl->op_ms[st.op] += ms;
         out[5 * st.kind] += ms; out[5 * st.kind + 1] += 1; out[5 * st.kind + 2] += st.flops;
     }
     if (!impl->stamps.empty()) { float ms = 0.f; hipAssert(hipEventElapsedTime(&ms, impl->stamps.front().a, impl->stamps.back().b)); out[25] = ms; }

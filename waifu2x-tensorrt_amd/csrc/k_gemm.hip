@@ -56,24 +56,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     int* s_ox = s_oy + BM;
     float* s_mean = (float*)(s_ox + BM);
     float* s_rstd = s_mean + BM;
-    float* s_pool = s_rstd + BM;  // [2][BN]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int wm = wv / WAVES_N, wn = wv % WAVES_N;
-    const int m0 = blockIdx.x * BM;
+    // row tiles never straddle batch items: blockIdx.x = b * tiles_per_image + tile (keeps every per-image reduction
+    // - squeeze-excite pooling - independent of the batch slot a tile sits in)
+    const int tpi = (p.Mrows + BM - 1) / BM;
+    const int tile_b = blockIdx.x / tpi;
+    const int ml0 = (blockIdx.x - tile_b * tpi) * BM;
     const int n0 = blockIdx.y * BN;
-    const int Mtotal = p.B * p.Mrows;
     const _Float16* __restrict__ Ag = (const _Float16*)p.a.p;
     const _Float16* __restrict__ Wg = (const _Float16*)p.wt;
 
     // ---- per-row bookkeeping
     for (int i = tid; i < BM; i += 256) {
-        int m = m0 + i;
+        int ml = ml0 + i;
         int aoff = -1, ob = 0, oy = 0, ox = 0;
         float mean = 0.f, rstd = 1.f;
-        if (m < Mtotal) {
-            int b = m / p.Mrows, ml = m - b * p.Mrows;
+        if (ml < p.Mrows) {
+            int b = tile_b;
             int y, x;
             if (p.amode == 1) { int pix = p.win_table[ml]; y = pix / p.aW; x = pix - y * p.aW; }
             else { y = ml / p.aW; x = ml - y * p.aW; }
@@ -86,7 +88,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         }
         s_aoff[i] = aoff; s_ob[i] = ob; s_oy[i] = oy; s_ox[i] = ox; s_mean[i] = mean; s_rstd[i] = rstd;
     }
-    if (p.pool_out) for (int i = tid; i < 2 * BN; i += 256) s_pool[i] = 0.f;
     __syncthreads();
 
     // ---- register staging of one sub-chunk
@@ -210,7 +211,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         const int groups = 256 / gs;
         const int items = BM * subs;
         const int jp = tid & (gs - 1);
-        const int b_first = s_ob[0];
         for (int q0 = 0; q0 < items; q0 += groups) {
             int q = q0 + tid / gs;
             if (q >= items) q = items - 1;   // clamp (duplicates are masked by `valid` below)
@@ -256,13 +256,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
                 for (int e = 0; e < OP; ++e) { h[e] = (_Float16)v[e]; v[e] = (float)h[e]; }
                 _Float16* op_ = Og + (size_t)((b * p.out.Hs + Y) * p.out.Ws + X) * Cso + ch;
                 if (OP == 8) *(uint4*)op_ = *(const uint4*)h; else *(uint2*)op_ = *(const uint2*)h;
-                if (p.pool_out) {
-                    int bs = b - b_first;
-#pragma unroll
-                    for (int e = 0; e < OP; ++e) {
-                        if (bs < 2) atomicAdd(&s_pool[bs * BN + ccol + e], v[e]);
-                        else atomicAdd(&p.pool_out[b * Cso + ch + e], v[e]);
-                    }
+                if (p.pool_out) {   // keep the final (fp16-rounded) values for the deterministic column sums below
+                    if (OP == 8) *(uint4*)(Cs + i * LDC + ccol) = *(const uint4*)h; else *(uint2*)(Cs + i * LDC + ccol) = *(const uint2*)h;
                 }
             }
             if (p.stats_out) {   // uniform branch; all lanes take part in the shuffles
@@ -285,11 +280,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
             }
         }
         if (p.pool_out) {
+            // squeeze-excite pooling without atomics: per-workgroup column sums in row order;
+            // se_kernel adds the partials of a batch item's workgroups in tile order.
             __syncthreads();
-            for (int t = tid; t < 2 * BN; t += 256) {
-                int bs = t / BN, c = t - bs * BN;
-                float v = s_pool[t];
-                if (v != 0.f && b_first + bs < p.B && n0 + c < p.N) atomicAdd(&p.pool_out[(b_first + bs) * Cso + n0 + c], v);
+            for (int c = tid; c < BN; c += 256) {
+                float sum = 0.f;
+                for (int i = 0; i < BM; ++i) if (s_aoff[i] >= 0) sum += (float)Cs[i * LDC + c];
+                if (n0 + c < p.N) p.pool_out[(size_t)blockIdx.x * Cso + n0 + c] = sum;
             }
         }
     }
@@ -300,7 +297,8 @@ hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
     constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16, LDA = KB + 8, LDC = BN + 8;
     constexpr int AB = (BM + BN) * LDA * 2, CB = BM * LDC * 2;
     constexpr int MAIN = AB > CB ? AB : CB;
-    constexpr int SMEM = MAIN + BM * 6 * 4 + 2 * BN * 4;
+    constexpr int SMEM = MAIN + BM * 6 * 4;
+    static_assert(BM == kGemmBM, "plan.h sizes the pooling partials for this tile height");
     auto kern = gemm_kernel<KB, WAVES_M, WAVES_N, WM, WN, AP, OP>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -308,8 +306,7 @@ hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    int Mtotal = p.B * p.Mrows;
-    dim3 grid((Mtotal + BM - 1) / BM, (p.N + BN - 1) / BN);
+    dim3 grid(p.B * ((p.Mrows + BM - 1) / BM), (p.N + BN - 1) / BN);
     hipLaunchKernelGGL(kern, grid, dim3(256), SMEM, s, p);
     return hipGetLastError();
 }

@@ -128,7 +128,12 @@ __global__ void se_kernel(const SeParams p) {
     float* mean = sm;            // [C]
     float* mid = sm + p.C;       // [Cmid]
     const int b = blockIdx.x;
-    for (int c = threadIdx.x; c < p.C; c += blockDim.x) mean[c] = p.pool[b * p.Cs + c] * p.inv_count;
+    for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+        // add the producing GEMM's per-workgroup partial sums in block order (deterministic)
+        float s = 0.f;
+        for (int t = 0; t < p.nblocks; ++t) s += p.pool[((size_t)b * p.nblocks + t) * p.Cs + c];
+        mean[c] = s * p.inv_count;
+    }
     __syncthreads();
     for (int m = threadIdx.x; m < p.Cmid; m += blockDim.x) {
         float a = p.b1[m];

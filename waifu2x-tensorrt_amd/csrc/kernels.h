@@ -5,6 +5,8 @@
 
 namespace w2x {
 
+constexpr int kGemmBM = 128;   // rows per GEMM workgroup tile (every instantiation)
+
 struct TView {           // device view of a channel-last tensor
     void* p = nullptr;
     int Hs = 0, Ws = 0, Cs = 0;  // stored dims
@@ -28,7 +30,7 @@ struct GemmParams {
     TView out;
     int omode = 0, r = 1, Cout = 0;
     float* stats_out = nullptr; float ln_eps = 1e-5f;
-    float* pool_out = nullptr;      // [B][out.Cs]
+    float* pool_out = nullptr;      // [B][ceil(Mrows/kGemmBM)][out.Cs] per-workgroup column sums (squeeze-excite)
 };
 
 struct AttnParams {
@@ -40,8 +42,9 @@ struct AttnParams {
 };
 
 struct SeParams {
-    const float* pool = nullptr; float* scale = nullptr;
+    const float* pool = nullptr; float* scale = nullptr;   // pool: [B][nblocks][Cs] partial sums from the producing GEMM (nblocks row tiles per batch item)
     int B = 0, C = 0, Cs = 0, Cmid = 0; float inv_count = 0.f;
+    int nblocks = 0, Mrows = 0;
     const float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
 };
 

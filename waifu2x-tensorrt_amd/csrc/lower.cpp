@@ -615,12 +615,14 @@ struct Lowerer {
         const TensorDesc& td = plan.tensors[x.v.t];
         if (x.v.y0 || x.v.x0 || x.v.H != td.H || x.v.W != td.W) fail(n, "squeeze-excite over a cropped view");
         Op& prod = plan.ops[it->second];
-        int pool = new_tensor(plan.B, 1, 1, td.C, 4);
+        int nblocks = (prod.g.Mrows + 127) / 128;   // kGemmBM rows per workgroup, tiles never straddle batch items
+        int pool = new_tensor(plan.B, 1, nblocks, td.C, 4);
         prod.g.pool_out = pool;
         Op op; op.kind = OP_SE; op.name = n->name.empty() ? "se" : n->name;
         SeOp& s = op.se;
         s.pool = pool; s.scale = new_tensor(plan.B, 1, 1, td.C, 4); s.C = C; s.Cmid = Cm;
         s.inv_count = 1.f / (float)(x.v.H * x.v.W);
+        s.nblocks = nblocks; s.Mrows = prod.g.Mrows;
         s.w1 = blob_f32(w1.f); s.w2 = blob_f32(w2.f);
         std::vector<float> b1(Cm, 0.f), b2(C, 0.f);
         if (c1->in.size() > 2 && !c1->in[2].empty()) b1 = g.cst(c1->in[2]).f;

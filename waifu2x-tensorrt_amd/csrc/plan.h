@@ -62,7 +62,7 @@ struct GemmOp {
     int Cout = 0;           // logical channels per output pixel (N for O_ROWS/O_WIN, N/(r*r) for O_PIXSHUF)
     int stats_out = -1;     // tensor fp32 [rows][2] to fill with LayerNorm statistics of the produced rows, or -1
     float ln_eps = 1e-5f;   // eps used for stats_out
-    int pool_out = -1;      // tensor fp32 [B][C]: per-(batch,channel) sum of the produced values (cunet SE squeeze)
+    int pool_out = -1;      // tensor fp32 [B][nblocks][C]: per-workgroup channel sums of the produced values (cunet SE squeeze)
 };
 
 struct AttnOp {
@@ -77,7 +77,8 @@ struct AttnOp {
 
 // cunet squeeze-excite gate: s = sigmoid(W2 relu(W1 mean + b1) + b2) on [B][C] vectors.
 struct SeOp {
-    int pool = -1;     // tensor fp32 [B][C] sums
+    int pool = -1;     // tensor fp32 [B][nblocks][C]: per-workgroup partial sums written by the producing GEMM
+    int nblocks = 0, Mrows = 0;
     int scale = -1;    // tensor fp32 [B][C] result
     int C = 0, Cmid = 0;
     float inv_count = 0.f;

@@ -18,6 +18,8 @@ TileGrid calculate_tiles(int inW, int inH, int outW, int outH, int tileInW, int 
     // :26-29
     g.outOvX = (int)std::lround(sOutW * overlapX);
     g.outOvY = (int)std::lround(sOutH * overlapY);
+    // degenerate geometry (overlap >= stride): the reference divides by zero here; report an empty grid instead
+    if (sInW - g.inOvX <= 0 || sInH - g.inOvY <= 0 || sOutW <= 0) return g;
     // :31-34
     g.nx = (int)std::lround(std::ceil((double)(inW - g.inOvX) / (sInW - g.inOvX)));
     g.ny = (int)std::lround(std::ceil((double)(inH - g.inOvY) / (sInH - g.inOvY)));

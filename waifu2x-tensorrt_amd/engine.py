@@ -109,6 +109,7 @@ def lib():
     L.w2x_last_render_ms.argtypes = [vp]; L.w2x_last_render_ms.restype = C.c_float
     L.w2x_bench_resident.argtypes = [vp, C.c_int]; L.w2x_bench_resident.restype = C.c_float
     L.w2x_profile_frame.argtypes = [vp, vp, C.c_int]; L.w2x_profile_frame.restype = C.c_int
+    L.w2x_op_times.argtypes = [vp, vp, C.c_int]; L.w2x_op_times.restype = C.c_int
     L.w2x_calculate_tiles.argtypes = [C.c_int] * 7 + [C.c_double, C.c_double, vp, vp, C.c_int]; L.w2x_calculate_tiles.restype = C.c_int
     L.w2x_tile_weights.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp]; L.w2x_tile_weights.restype = C.c_int
     L.w2x_describe_plan.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]; L.w2x_describe_plan.restype = C.c_int
@@ -120,7 +121,7 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "w2x_create", "w2x_destroy", "w2x_set_message_callback", "w2x_set_progress_callback", "w2x_build", "w2x_load",
-    "w2x_render", "w2x_infer", "w2x_output_tile_size", "w2x_plan_flops", "w2x_last_render_ms", "w2x_bench_resident", "w2x_profile_frame",
+    "w2x_render", "w2x_infer", "w2x_output_tile_size", "w2x_plan_flops", "w2x_last_render_ms", "w2x_bench_resident", "w2x_profile_frame", "w2x_op_times",
     "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_sha256_hex", "w2x_version"]
 
 
@@ -232,6 +233,11 @@ class Img2Img:
         d = {n: (float(out[5 * i]), int(out[5 * i + 1]), float(out[5 * i + 2])) for i, n in enumerate(names)}
         d["frame_ms"] = float(out[25])
         return d
+
+    def op_times(self) -> np.ndarray:
+        out = np.zeros(4096, np.float64)
+        n = self._L.w2x_op_times(self._h, out.ctypes.data, 4096)
+        return out[:n].copy()
 
 
 def calculate_tiles(in_w, in_h, out_w, out_h, tile_in, tile_out, scaling, overlap):
