@@ -51,7 +51,7 @@ def cpu_baseline(work: str, threads: int) -> dict:
     torch.set_num_threads(threads)
     path = sm.model_path(os.path.join(work, "cpu_b1"), MODEL, SCALE, NOISE)
     if not os.path.exists(path):
-        sm.export_onnx(sm.make_model(MODEL, SCALE, seed=1234 + NOISE), path, 1, TILE)
+        sm.export_onnx(sm.make_model(MODEL, SCALE, seed=1234 + NOISE), path, 1, TILE, dynamic=True)
     ex = onnx_exec.Executor(path)
     frame = synthetic_frame(0)
     n, ins, outs = pipeline.calculate_tiles(FRAME_W, FRAME_H, FRAME_W * SCALE, FRAME_H * SCALE, (TILE, TILE), (960, 960), SCALE, (BLEND, BLEND))
@@ -101,7 +101,7 @@ def main():
     work = os.path.join(a.work, f"rank{rank}")
     path = sm.model_path(work, MODEL, SCALE, NOISE)
     if not os.path.exists(path):
-        sm.export_onnx(sm.make_model(MODEL, SCALE, seed=1234 + NOISE), path, BATCH, TILE)
+        sm.export_onnx(sm.make_model(MODEL, SCALE, seed=1234 + NOISE), path, BATCH, TILE, dynamic=True)
     eng = pkg.Img2Img()
     bc = pkg.BuildConfig.fixed(BATCH, TILE, device=local_rank)
     if not eng.build(path, bc):
@@ -137,7 +137,7 @@ def main():
 
     prof = eng.profile_frame()
     if a.op_times and rank == 0:
-        desc = pkg.describe_plan(path, BATCH, TILE).splitlines()[2:]
+        desc = pkg.describe_plan(path, eng.pass_tiles, TILE).splitlines()[2:]
         for line, op_ms in zip(desc, eng.op_times()):
             print(f"{op_ms:8.3f} ms  {line[:150]}", file=sys.stderr)
     if rank == 0:
@@ -154,7 +154,8 @@ def main():
                        "frames_per_s": round(fps, 3), "device_ms_per_frame": round(ms, 3), "frames_per_rank": a.steps,
                        "parallelism": f"frame-sharded x{world}, no collectives",
                        "pcie_inclusive_ms_per_frame": round(pcie_ms_one, 2),
-                       "algorithmic_tflop_per_frame": round(eng.plan_flops * 12 / 1e12, 4)},
+                       "tiles_per_network_pass": eng.pass_tiles,
+                       "algorithmic_tflop_per_frame": round(eng.plan_flops / eng.pass_tiles * 48 / 1e12, 4)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 5), "traffic": None,
                          "kernel": "gemm_kernel (fused implicit-GEMM conv/linear)", "launches_per_frame": gemm_n,

@@ -55,7 +55,8 @@ int w2x_load(w2x_engine* e, const char* onnx_path, const w2x_render_config* cfg)
 int w2x_render(w2x_engine* e, const uint8_t* src, int rows, int cols, size_t src_step, uint8_t* dst, size_t dst_step);
 int w2x_infer(w2x_engine* e, const float* input_nchw, float* output_nchw);
 int w2x_output_tile_size(w2x_engine* e);
-double w2x_plan_flops(w2x_engine* e);
+double w2x_plan_flops(w2x_engine* e);   /* algorithmic FLOP of one network pass */
+int w2x_pass_tiles(w2x_engine* e);      /* tiles per network pass (batchSize x super-batch factor) */
 float w2x_last_render_ms(w2x_engine* e);
 float w2x_bench_resident(w2x_engine* e, int iters);
 /* out[5*k+{0,1,2}] = {ms, launches, algorithmic FLOP} for k = 0 gemm, 1 attention, 2 se/scale, 3 gather, 4 compose; out[25] = frame ms */

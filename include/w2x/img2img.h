@@ -44,6 +44,7 @@ public:
     int outputTileSize() const;
     int scaling() const;   // RenderConfig::scaling of the loaded configuration (0 before load)
     double planFlops() const;
+    int passTiles() const;   // tiles carried by one network pass (batchSize x super-batch factor)
     // Steady-state device timing of the last render() (ms), HIP events on the compute stream.
     float lastRenderMs() const;
     // Re-run the device part of the last render() (gather, network, compose; no H2D/D2H) `iters` times and return the

@@ -39,7 +39,7 @@ def onnx_model(model_dir):
         if key not in cache:
             root = os.path.join(model_dir, f"b{batch}_t{tile}_{'s' if small else 'f'}_o{opset}")
             path = sm.model_path(root, model, scale, noise)
-            sm.export_onnx(sm.make_model(model, scale, seed=1234 + noise, small=small), path, batch, tile, opset=opset)
+            sm.export_onnx(sm.make_model(model, scale, seed=1234 + noise, small=small), path, batch, tile, opset=opset, dynamic=True)
             cache[key] = path
         return cache[key]
 

@@ -155,3 +155,23 @@ def test_headline_config_properties(pkg, onnx_model):
     d = np.abs(o3.astype(int) - ref.astype(int))
     assert psnr(o3, ref) > 50.0 and d.max() <= 2, (psnr(o3, ref), d.max())
     eng.close()
+
+
+def test_super_batching_is_bit_identical(pkg, onnx_model, monkeypatch):
+    """One network pass may carry S reference batches (W2X_SUPERBATCH); frames, progress callbacks and infer() must not change."""
+    path = onnx_model("swin_unet/art", 4, 2, 64, small=True)
+    frame = smooth_frame(100, 140, 21)
+    res = []
+    for S in ("1", "3"):
+        monkeypatch.setenv("W2X_SUPERBATCH", S)
+        eng = make_engine(pkg, path, 2, 64, 4)
+        assert eng.pass_tiles == 2 * int(S)
+        prog = []
+        eng.setProgressCallback(lambda c, t, s: prog.append((c, t)))
+        out = eng.render(frame)
+        x = np.random.default_rng(3).random((2, 3, 64, 64), dtype=np.float32)
+        res.append((out, prog, eng.infer(x)))
+        eng.close()
+    assert np.array_equal(res[0][0], res[1][0])
+    assert res[0][1] == res[1][1]
+    assert np.array_equal(res[0][2], res[1][2])

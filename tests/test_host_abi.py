@@ -63,9 +63,11 @@ def test_lowering_covers_graph_and_counts_flops(pkg, onnx_model, model, scale, t
 
 
 def test_lowering_rejects_wrong_shape_and_garbage(pkg, onnx_model, tmp_path):
-    path = onnx_model("cunet/art", 2, 2, 64)
+    import synth_models as sm
+    path = sm.export_onnx(sm.make_model("cunet/art", 2), str(tmp_path / "static.onnx"), 2, 64, dynamic=False)
     with pytest.raises(pkg.W2xError):
         pkg.describe_plan(path, 3, 64)          # static batch 2 in the file
+    assert "in=[5,3,64,64]" in pkg.describe_plan(onnx_model("cunet/art", 2, 2, 64), 5, 64)   # dynamic batch axis: any batch
     bad = tmp_path / "bad.onnx"
     bad.write_bytes(b"\x00\x01garbage")
     with pytest.raises(pkg.W2xError):

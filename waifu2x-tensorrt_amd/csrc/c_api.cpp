@@ -65,6 +65,7 @@ int w2x_render(w2x_engine* e, const uint8_t* src, int rows, int cols, size_t src
 
 int w2x_infer(w2x_engine* e, const float* in, float* out) { return e && e->engine.infer(in, out) ? 1 : 0; }
 int w2x_output_tile_size(w2x_engine* e) { return e ? e->engine.outputTileSize() : 0; }
+int w2x_pass_tiles(w2x_engine* e) { return e ? e->engine.passTiles() : 0; }
 double w2x_plan_flops(w2x_engine* e) { return e ? e->engine.planFlops() : 0.0; }
 float w2x_last_render_ms(w2x_engine* e) { return e ? e->engine.lastRenderMs() : -1.f; }
 int w2x_profile_frame(w2x_engine* e, double* out, int cap) { return e && e->engine.profileFrame(out, cap) ? 1 : 0; }

@@ -254,6 +254,19 @@ struct Img2Img::Impl {
                     stamp_end();
                     break;
                 }
+                case OP_MLP: {
+                    const MlpOp& m = op.m;
+                    const TensorDesc& d = plan.tensors[m.x];
+                    MlpParams p;
+                    p.x = tensors[m.x]; p.y = tensors[m.y]; p.M = (long)d.B * d.H * d.W; p.C = m.C;
+                    p.w1 = blobs[m.w1]; p.b1 = (const float*)blobs[m.b1]; p.w2 = blobs[m.w2]; p.b2 = (const float*)blobs[m.b2];
+                    p.eps = m.eps; p.stats_out = m.stats_out >= 0 ? (float*)tensors[m.stats_out] : nullptr; p.eps_out = m.eps_out;
+                    if (d.C != m.C || plan.tensors[m.y].C != m.C) throw std::runtime_error("plan: MLP width mismatch");
+                    stamp_begin(0, op.flops);
+                    hipAssert(launch_mlp(p, stream));
+                    stamp_end();
+                    break;
+                }
                 case OP_SE: {
                     const SeOp& s = op.se;
                     SeParams p;
@@ -290,9 +303,11 @@ struct Img2Img::Impl {
     void run_frame(int rows, int cols, const TileGrid& grid, bool report) {
         const int B = plan.B, T = plan.T, To = plan.Tout;
         const int steps = cfg.tta ? 8 : 1;
-        const int batchCount = (int)std::lround(std::ceil((double)(grid.count * steps) / B));   // img2img_render.cpp:249
+        const int userB = plan.userB, S = B / userB;
+        const int batchCount = (int)std::lround(std::ceil((double)(grid.count * steps) / userB));   // img2img_render.cpp:249
+        const int passCount = (batchCount + S - 1) / S;
         const size_t slot_bytes = (size_t)To * To * 4 * sizeof(uint16_t);
-        for (int bi = 0; bi < batchCount; ++bi) {
+        for (int bi = 0; bi < passCount; ++bi) {
             const auto t0 = std::chrono::steady_clock::now();
             GatherParams gp;
             gp.frame = d_frame; gp.rows = rows; gp.cols = cols; gp.step = (size_t)cols * 3;
@@ -304,7 +319,8 @@ struct Img2Img::Impl {
             if (report) {
                 const auto t1 = std::chrono::steady_clock::now();
                 const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-                log(bi + 1, batchCount, 1000.0 / std::max(ms, 1e-6));                           // :336-338
+                for (int k = bi * S; k < std::min((bi + 1) * S, batchCount); ++k)
+                    log(k + 1, batchCount, 1000.0 * S / std::max(ms, 1e-6));                     // :336-338
             }
         }
         ComposeParams cp;
@@ -341,9 +357,26 @@ bool Img2Img::build(const std::string& onnxModelPath, const BuildConfig& config)
         return false;
     }
     // :81-88 parse ; :102-116 one profile - the plan is specialised for the opt shape, channels come from the model
+    // Super-batching: tiles are independent, so one network pass may carry several reference batches (S x batchSize
+    // tiles); results are bit-identical, launches per frame drop S-fold and the low-resolution stages fill all 256 CUs.
+    // W2X_SUPERBATCH overrides; default targets >= 12 tiles of 256x256 per pass, capped at 16 tiles.
+    int S = 1;
+    if (const char* env = getenv("W2X_SUPERBATCH")) S = std::max(1, atoi(env));
+    else if (config.optHeight >= 128) {
+        const double want = 12.0 * 256 * 256 / ((double)config.optBatchSize * config.optHeight * config.optWidth);
+        S = std::max(1, (int)std::lround(want));
+        while (S > 1 && S * config.optBatchSize > 16) --S;
+    }
     Plan plan;
     try {
-        plan = build_plan(onnxModelPath, config.optBatchSize, config.optChannels, config.optHeight, config.optWidth);
+        try {
+            plan = build_plan(onnxModelPath, config.optBatchSize * S, config.optChannels, config.optHeight, config.optWidth);
+        } catch (const std::exception&) {
+            if (S == 1) throw;
+            S = 1;   // e.g. a graph with a static batch dimension
+            plan = build_plan(onnxModelPath, config.optBatchSize, config.optChannels, config.optHeight, config.optWidth);
+        }
+        plan.userB = config.optBatchSize;
     } catch (const std::exception& e) {
         W2X_LOG(error, "Failed to parse ONNX model: " + std::string(e.what()) + ".");
         return false;
@@ -420,7 +453,7 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
     }
     const Plan& plan = impl->plan;
     // :197-203 - the input shape must be the one the plan was specialised for; T' is read from the plan
-    if (plan.B != config.batchSize || plan.Cin != config.channels || plan.T != config.height || plan.T != config.width) {
+    if (plan.userB != config.batchSize || plan.B % std::max(plan.userB, 1) || plan.Cin != config.channels || plan.T != config.height || plan.T != config.width) {
         W2X_LOG(error, "Failed to set input tensor shape.");
         return false;
     }
@@ -473,9 +506,9 @@ bool Img2Img::render(const Image& src, Image& dst) try {
     if (grid.count <= 0) { W2X_LOG(error, "Tile grid is empty."); return false; }
     for (const Rect& r : grid.out) if (r.w <= 0 || r.h <= 0) { W2X_LOG(error, "Tile grid does not fit the output (scaling does not match the model)."); return false; }
     // :246-267 step schedule: slot = step index, tile = step / stepsPerTile, aug = step % stepsPerTile, zero pad slots at the end
-    const int steps = cfg.tta ? 8 : 1, B = plan.B;
-    const int batchCount = (int)std::lround(std::ceil((double)(grid.count * steps) / B));
-    const int stepCount = batchCount * B;
+    const int steps = cfg.tta ? 8 : 1, B = plan.B, S = plan.B / plan.userB;
+    const int batchCount = (int)std::lround(std::ceil((double)(grid.count * steps) / plan.userB));
+    const int stepCount = ((batchCount + S - 1) / S) * B;   // reference batches rounded up to whole network passes
     impl->h_slots.resize(stepCount);
     for (int st = 0; st < stepCount; ++st) {
         int ti = st / steps, aug = st % steps;
@@ -505,16 +538,18 @@ bool Img2Img::infer(const float* input, float* output) try {
     if (!impl->loaded) { W2X_LOG(error, "Infer called before a successful load."); return false; }
     const Plan& plan = impl->plan;
     const size_t in_elems = (size_t)plan.B * 3 * plan.T * plan.T, out_elems = (size_t)plan.B * 3 * plan.Tout * plan.Tout;
+    const size_t user_in = (size_t)plan.userB * 3 * plan.T * plan.T, user_out = (size_t)plan.userB * 3 * plan.Tout * plan.Tout;
+    hipStream_t stream = impl->stream;
     if (!impl->d_blob_in) {
         hipAssert(hipMalloc((void**)&impl->d_blob_in, in_elems * sizeof(float)));      // img2img_load.cpp:228-232: f32 IO buffers
         hipAssert(hipMalloc((void**)&impl->d_blob_out, out_elems * sizeof(float)));
+        hipAssert(hipMemsetAsync(impl->d_blob_in, 0, in_elems * sizeof(float), stream));   // slots beyond the caller's batch stay zero
     }
-    hipStream_t stream = impl->stream;
-    hipAssert(hipMemcpyAsync(impl->d_blob_in, input, in_elems * sizeof(float), hipMemcpyHostToDevice, stream));
+    hipAssert(hipMemcpyAsync(impl->d_blob_in, input, user_in * sizeof(float), hipMemcpyHostToDevice, stream));
     hipAssert(launch_blob_to_nhwc(impl->d_blob_in, impl->tensors[plan.in_tensor], plan.B, plan.T, stream));
     impl->run_network(nullptr);                                                        // img2img_infer.cpp:80
     hipAssert(launch_nhwc_to_blob(impl->tensors[plan.out_tensor], impl->d_blob_out, plan.B, plan.Tout, stream));
-    hipAssert(hipMemcpyAsync(output, impl->d_blob_out, out_elems * sizeof(float), hipMemcpyDeviceToHost, stream));
+    hipAssert(hipMemcpyAsync(output, impl->d_blob_out, user_out * sizeof(float), hipMemcpyDeviceToHost, stream));
     hipAssert(hipStreamSynchronize(stream));
     return true;
 } catch (const std::exception& e) {
@@ -525,6 +560,7 @@ bool Img2Img::infer(const float* input, float* output) try {
 int Img2Img::outputTileSize() const { return impl->loaded ? impl->plan.Tout : 0; }
 int Img2Img::opTimes(double* out, int cap) const { int n = (int)impl->op_ms.size(); for (int i = 0; i < n && i < cap; ++i) out[i] = impl->op_ms[i]; return n; }
 int Img2Img::scaling() const { return impl->loaded ? impl->cfg.scaling : 0; }
+int Img2Img::passTiles() const { return impl->loaded ? impl->plan.B : 0; }
 double Img2Img::planFlops() const { return impl->loaded ? impl->plan.flops : 0.0; }
 float Img2Img::lastRenderMs() const { return impl->last_ms; }
 

@@ -1,0 +1,275 @@
+// Fused Swin MLP branch for gfx950:   y = x + W2 * GELU(W1 * LayerNorm(x) + b1) + b2      (C = 96 or 192, hidden 2C)
+// One launch replaces LayerNormalization + MatMul + Add + Div/Erf/Add/Mul/Mul + MatMul + Add + Add of the ONNX graph
+// (the layers TensorRT runs inside enqueueV3, /root/reference/src/tensorrt/img2img_infer.cpp:80).
+//
+// Per workgroup (256 threads = 4 waves): 128 token rows.  x is read once from HBM, normalised into LDS (fp16; gamma/beta
+// are folded into W1/b1), and the hidden activations never leave registers: GEMM1 is computed transposed
+// (H^T = W1 * Xn^T) so that its 16x16 accumulator tiles - GELU applied in place - are exactly the A fragments of
+// GEMM2 (k order permuted consistently on the W2 side: two 8-byte LDS reads per fragment).  W1/W2 stream through LDS in
+// chunks of 64 hidden units with register prefetch of the next chunk.  The output tile is staged through LDS so the
+// residual add and the HBM stores are 16-byte row pieces; LayerNorm statistics of the produced rows are emitted for
+// the next op when requested.
+#include "kernels.h"
+
+namespace w2x {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// erf via Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7) on the fast exp/rcp units; GELU(x) = 0.5 x (1 + erf(x/sqrt2))
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __expf(-z * z);
+    const float erf_abs = fmaf(-poly * t, e, 1.f);
+    const float erf_v = copysignf(erf_abs, x);
+    return 0.5f * x * (1.f + erf_v);
+}
+
+template <int C>
+__global__ __launch_bounds__(256, (C == 96 ? 2 : 1)) void mlp_kernel(const MlpParams p) {
+    constexpr int BM = 128, HC = 64;
+    constexpr int LDX = C + 8;            // Xs row stride (halves)
+    constexpr int LDW2 = HC + 8;          // W2s row stride
+    constexpr int NCH = 2 * C / HC;       // hidden chunks
+    constexpr int NT = C / 16;            // output n-tiles
+    constexpr int LPR = C == 96 ? 16 : 32;  // lanes per row in the row-piece phases
+    constexpr int PPR = C / 8;              // 16-byte pieces per row
+    constexpr int W1_PIECES = HC * C / 8, W2_PIECES = C * HC / 8;
+    constexpr int NW1 = W1_PIECES / 256, NW2 = W2_PIECES / 256;
+    static_assert(W1_PIECES % 256 == 0 && W2_PIECES % 256 == 0, "piece counts");
+    constexpr int LDC = C + 8;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    _Float16* Xs = (_Float16*)smem;                  // [BM][LDX]
+    _Float16* W1s = Xs + BM * LDX;                   // [HC][LDX]
+    _Float16* W2s = W1s + HC * LDX;                  // [C][LDW2]
+    _Float16* Cs = W1s;                              // epilogue tile [BM][LDC] aliases the weight buffers (+ part of nothing else)
+    static_assert((HC * LDX + C * LDW2) >= 0, "");
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long row0 = (long)blockIdx.x * BM;
+    const _Float16* __restrict__ X = (const _Float16*)p.x;
+    const _Float16* __restrict__ W1 = (const _Float16*)p.w1;   // [2C][C]
+    const _Float16* __restrict__ W2 = (const _Float16*)p.w2;   // [C][2C]
+
+    // ---- weight chunk prefetch (global -> registers) and staging (registers -> LDS)
+    u32x4 r1[NW1], r2[NW2];
+#define W2X_MLP_PREFETCH(CH)                                                                                         \
+    {                                                                                                                \
+        _Pragma("unroll") for (int t = 0; t < NW1; ++t) {                                                            \
+            const int idx = tid + t * 256, row = idx / PPR, kp = idx - row * PPR;                                    \
+            r1[t] = *(const u32x4*)(W1 + (size_t)((CH) * HC + row) * C + kp * 8);                                    \
+        }                                                                                                            \
+        _Pragma("unroll") for (int t = 0; t < NW2; ++t) {                                                            \
+            const int idx = tid + t * 256, row = idx / (HC / 8), kp = idx - row * (HC / 8);                          \
+            r2[t] = *(const u32x4*)(W2 + (size_t)row * (2 * C) + (CH) * HC + kp * 8);                                \
+        }                                                                                                            \
+    }
+#define W2X_MLP_STAGE()                                                                                              \
+    {                                                                                                                \
+        _Pragma("unroll") for (int t = 0; t < NW1; ++t) {                                                            \
+            const int idx = tid + t * 256, row = idx / PPR, kp = idx - row * PPR;                                    \
+            *(u32x4*)(W1s + row * LDX + kp * 8) = r1[t];                                                             \
+        }                                                                                                            \
+        _Pragma("unroll") for (int t = 0; t < NW2; ++t) {                                                            \
+            const int idx = tid + t * 256, row = idx / (HC / 8), kp = idx - row * (HC / 8);                          \
+            *(u32x4*)(W2s + row * LDW2 + kp * 8) = r2[t];                                                            \
+        }                                                                                                            \
+    }
+    W2X_MLP_PREFETCH(0);
+
+    // ---- LayerNorm of the 128 rows into Xs (LPR lanes per row, 8 channels per lane); all loads issued up front
+    {
+        const int li = tid & (LPR - 1);
+        constexpr int RPP = 256 / LPR, NPASS = BM / RPP;
+        half8 xr[NPASS];
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const long row = row0 + ps * RPP + tid / LPR;
+            half8 h = {};
+            if (row < p.M && li < PPR) h = *(const half8*)(X + row * C + li * 8);
+            xr[ps] = h;
+        }
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int r = ps * RPP + tid / LPR;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)xr[ps][e];
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[e];
+#pragma unroll
+            for (int m = LPR / 2; m > 0; m >>= 1) s += __shfl_xor(s, m);
+            const float mean = s * (1.f / C);
+            float q = 0.f;
+            if (li < PPR) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[e] -= mean; q += v[e] * v[e]; }
+            }
+#pragma unroll
+            for (int m = LPR / 2; m > 0; m >>= 1) q += __shfl_xor(q, m);
+            const float rstd = rsqrtf(q * (1.f / C) + p.eps);
+            if (li < PPR) {
+                half8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (_Float16)(v[e] * rstd);
+                *(half8*)(Xs + r * LDX + li * 8) = o;
+            }
+        }
+    }
+
+    float4v acc2[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc2[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, g = lane >> 4;
+    const int trow = wv * 32;   // this wave's 32 token rows
+
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+        __syncthreads();
+        W2X_MLP_STAGE();
+        __syncthreads();
+        if (ch + 1 < NCH) W2X_MLP_PREFETCH(ch + 1);
+        // GEMM1 (transposed): acc1[ht][tt] = W1s[16ht..][:] * Xs[trow+16tt..][:]^T   (rows = hidden, cols = tokens)
+        float4v acc1[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc1[i][0] = (float4v){0.f, 0.f, 0.f, 0.f}; acc1[i][1] = (float4v){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < C / 32; ++ks) {
+            half8 xb[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) xb[tt] = *(const half8*)(Xs + (trow + tt * 16 + fr) * LDX + ks * 32 + g * 8);
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+                half8 wa = *(const half8*)(W1s + (ht * 16 + fr) * LDX + ks * 32 + g * 8);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) acc1[ht][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb[tt], acc1[ht][tt], 0, 0, 0);
+            }
+        }
+        // bias + GELU in place; lane holds hidden rows 16ht + 4g + j of token column fr
+        half8 a2[2][2];   // [tt][k-step]: A fragments of GEMM2, k order = (ht even: j 0..3, ht odd: j 4..7)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float4v be = *(const float4v*)(p.b1 + ch * HC + (2 * ks) * 16 + g * 4);
+            const float4v bo = *(const float4v*)(p.b1 + ch * HC + (2 * ks + 1) * 16 + g * 4);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const float4v e = acc1[2 * ks][tt], o = acc1[2 * ks + 1][tt];
+                a2[tt][ks] = (half8){(_Float16)gelu_fast(e[0] + be[0]), (_Float16)gelu_fast(e[1] + be[1]), (_Float16)gelu_fast(e[2] + be[2]),
+                                     (_Float16)gelu_fast(e[3] + be[3]), (_Float16)gelu_fast(o[0] + bo[0]), (_Float16)gelu_fast(o[1] + bo[1]),
+                                     (_Float16)gelu_fast(o[2] + bo[2]), (_Float16)gelu_fast(o[3] + bo[3])};
+            }
+        }
+        // GEMM2: acc2[tt][nt] += H[tokens][hidden chunk] * W2s[16nt..][chunk]^T with the matching k permutation
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const _Float16* wp = W2s + (nt * 16 + fr) * LDW2 + ks * 32 + g * 4;
+                half4 lo = *(const half4*)wp, hi = *(const half4*)(wp + 16);
+                half8 wb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { wb[j] = lo[j]; wb[4 + j] = hi[j]; }
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) acc2[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[tt][ks], wb, acc2[tt][nt], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: residual pieces are fetched first (latency overlaps the tile write), accumulators + b2 -> fp16
+    //      tile in LDS, then row pieces: + residual x, store, statistics
+    const int li = tid & (LPR - 1);
+    constexpr int RPP = 256 / LPR, NPASS = BM / RPP;
+    half8 xres[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const long row = row0 + ps * RPP + tid / LPR;
+        half8 h = {};
+        if (row < p.M && li < PPR) h = *(const half8*)(X + row * C + li * 8);
+        xres[ps] = h;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float b2 = p.b2[nt * 16 + fr];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Cs[(trow + tt * 16 + g * 4 + j) * LDC + nt * 16 + fr] = (_Float16)(acc2[tt][nt][j] + b2);
+    }
+    __syncthreads();
+    {
+        _Float16* __restrict__ Y = (_Float16*)p.y;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int r = ps * RPP + tid / LPR;
+            const long row = row0 + r;
+            const bool ok = row < p.M && li < PPR;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            if (ok) {
+                half8 c = *(const half8*)(Cs + r * LDC + li * 8);
+                half8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { o[e] = (_Float16)((float)c[e] + (float)xres[ps][e]); v[e] = (float)o[e]; }
+                *(half8*)(Y + row * C + li * 8) = o;
+            }
+            if (p.stats_out) {
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += v[e];
+#pragma unroll
+                for (int m = LPR / 2; m > 0; m >>= 1) s += __shfl_xor(s, m);
+                const float mean = s * (1.f / C);
+                float q = 0.f;
+                if (ok) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { float d = v[e] - mean; q += d * d; }
+                }
+#pragma unroll
+                for (int m = LPR / 2; m > 0; m >>= 1) q += __shfl_xor(q, m);
+                if (ok && li == 0) { p.stats_out[2 * row] = mean; p.stats_out[2 * row + 1] = rsqrtf(q * (1.f / C) + p.eps_out); }
+            }
+        }
+    }
+}
+
+template <int C>
+hipError_t launch_mlp_c(const MlpParams& p, hipStream_t s) {
+    constexpr int BM = 128, HC = 64, LDX = C + 8, LDW2 = HC + 8, LDC = C + 8;
+    constexpr int W_BYTES = (HC * LDX + C * LDW2) * 2, C_BYTES = BM * LDC * 2;
+    constexpr int SMEM = BM * LDX * 2 + (W_BYTES > C_BYTES ? W_BYTES : C_BYTES);
+    auto kern = mlp_kernel<C>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid((unsigned)((p.M + BM - 1) / BM));
+    hipLaunchKernelGGL(kern, grid, dim3(256), SMEM, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_mlp(const MlpParams& p, hipStream_t s) {
+    if (p.C == 96) return launch_mlp_c<96>(p, s);
+    if (p.C == 192) return launch_mlp_c<192>(p, s);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace w2x

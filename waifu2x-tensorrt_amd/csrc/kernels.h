@@ -41,6 +41,17 @@ struct AttnParams {
     const int* maskid = nullptr;    // [nwin]
 };
 
+struct MlpParams {               // y = x + W2 gelu(W1 LN(x) + b1) + b2 on contiguous rows [M][C]
+    const void* x = nullptr; void* y = nullptr;
+    long M = 0; int C = 0;
+    const void* w1 = nullptr;      // fp16 [2C][C], LayerNorm gamma folded in
+    const float* b1 = nullptr;     // [2C], LayerNorm beta folded in
+    const void* w2 = nullptr;      // fp16 [C][2C]
+    const float* b2 = nullptr;     // [C]
+    float eps = 1e-5f;
+    float* stats_out = nullptr; float eps_out = 1e-5f;
+};
+
 struct SeParams {
     const float* pool = nullptr; float* scale = nullptr;   // pool: [B][nblocks][Cs] partial sums from the producing GEMM (nblocks row tiles per batch item)
     int B = 0, C = 0, Cs = 0, Cmid = 0; float inv_count = 0.f;
@@ -73,6 +84,7 @@ struct ComposeParams {
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 hipError_t launch_attn(const AttnParams& p, hipStream_t s);
+hipError_t launch_mlp(const MlpParams& p, hipStream_t s);
 hipError_t launch_se(const SeParams& p, hipStream_t s);
 hipError_t launch_scale(void* x, const float* scale, int B, int HW, int Cs, hipStream_t s);
 hipError_t launch_gather(const GatherParams& p, hipStream_t s);

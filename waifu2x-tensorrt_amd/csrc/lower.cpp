@@ -639,6 +639,43 @@ struct Lowerer {
         return true;
     }
 
+    // ---- post-pass: LN+fc1+GELU GEMM followed by fc2+residual GEMM  ->  one fused MLP op (k_mlp.hip)
+    void fuse_mlp() {
+        std::vector<Op> out;
+        for (size_t i = 0; i < plan.ops.size(); ++i) {
+            const Op& a = plan.ops[i];
+            bool fused = false;
+            if (i + 1 < plan.ops.size() && a.kind == OP_GEMM && plan.ops[i + 1].kind == OP_GEMM) {
+                const GemmOp& g1 = a.g; const GemmOp& g2 = plan.ops[i + 1].g;
+                const int C = g1.K;
+                auto plain = [&](const View& v) { const TensorDesc& t = plan.tensors[v.t]; return v.y0 == 0 && v.x0 == 0 && v.H == t.H && v.W == t.W; };
+                int hidden_users = 0;
+                for (auto& o : plan.ops) if (o.kind == OP_GEMM && (o.g.a.t == g1.out.t || o.g.res.t == g1.out.t || o.g.res2.t == g1.out.t)) ++hidden_users;
+                if ((C == 96 || C == 192) && g1.amode == A_ROWS && g1.ln && g1.act == ACT_GELU && g1.omode == O_ROWS && g1.res.t < 0 && !g1.has_clip &&
+                    g1.N == 2 * C && g1.stats_out < 0 && g1.pool_out < 0 && plain(g1.a) && plan.tensors[g1.a.t].C == C &&
+                    g2.amode == A_ROWS && !g2.ln && g2.act == ACT_NONE && g2.omode == O_ROWS && g2.a.t == g1.out.t && g2.K == 2 * C && g2.N == C &&
+                    g2.res.t == g1.a.t && g2.res2.t < 0 && !g2.has_clip && g2.pool_out < 0 && plain(g2.res) && hidden_users == 1 && g1.out.t != plan.out_tensor) {
+                    Op m; m.kind = OP_MLP; m.name = a.name + "+" + plan.ops[i + 1].name; m.flops = a.flops + plan.ops[i + 1].flops;
+                    m.m.x = g1.a.t; m.m.y = g2.out.t; m.m.C = C; m.m.w1 = g1.w; m.m.b1 = g1.bias; m.m.w2 = g2.w; m.m.b2 = g2.bias;
+                    m.m.eps = plan.ops[tensor_producer.at(g1.a.t)].g.ln_eps;
+                    m.m.stats_out = g2.stats_out; m.m.eps_out = g2.ln_eps;
+                    out.push_back(m);
+                    ++i; fused = true;
+                }
+            }
+            if (!fused) out.push_back(a);
+        }
+        plan.ops.swap(out);
+        // the row statistics of a tensor that only fused MLP ops normalise are no longer needed
+        for (auto& op : plan.ops) {
+            int* so = op.kind == OP_GEMM ? &op.g.stats_out : op.kind == OP_MLP ? &op.m.stats_out : nullptr;
+            if (!so || *so < 0) continue;
+            bool used = false;
+            for (auto& o : plan.ops) if (o.kind == OP_GEMM && o.g.stats_in == *so) used = true;
+            if (!used) *so = -1;
+        }
+    }
+
     // ---------------------------------------------------------------------------------------------------------
     Plan run() {
         const Shape& is = shp(g.input);
@@ -726,6 +763,7 @@ struct Lowerer {
         const TensorDesc& td = plan.tensors[y.v.t];
         if (y.v.y0 || y.v.x0 || y.v.H != td.H || y.v.W != td.W) throw std::runtime_error("graph output is a cropped view");
         plan.out_tensor = y.v.t; plan.Tout = (int)os[2]; plan.Cout = 3;
+        if (!getenv("W2X_NO_FUSE")) fuse_mlp();
         for (auto& op : plan.ops) plan.flops += op.flops;
         bool has_attn = false; for (auto& op : plan.ops) has_attn |= op.kind == OP_ATTN;
         plan.model_kind = has_attn ? "swin_unet" : "cunet";

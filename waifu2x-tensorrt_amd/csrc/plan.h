@@ -26,7 +26,7 @@ enum Act : int { ACT_NONE = 0, ACT_LEAKY = 1, ACT_GELU = 2, ACT_RELU = 3, ACT_SI
 enum AMode : int { A_ROWS = 0, A_WIN = 1, A_CONV = 2 };
 enum OMode : int { O_ROWS = 0, O_WIN = 1, O_PIXSHUF = 2 };
 
-enum OpKind : int { OP_GEMM = 0, OP_ATTN = 1, OP_SE = 2, OP_SCALE_ADD = 3 };
+enum OpKind : int { OP_GEMM = 0, OP_ATTN = 1, OP_SE = 2, OP_SCALE_ADD = 3, OP_MLP = 4 };
 
 // Constant data blob (weights, tables) referenced by ops; uploaded once at load().
 struct Blob {
@@ -85,17 +85,28 @@ struct SeOp {
     int w1 = -1, b1 = -1, w2 = -1, b2 = -1;  // blobs fp32
 };
 
+// fused Swin MLP branch (LayerNorm + fc1 + GELU + fc2 + residual) on contiguous token rows
+struct MlpOp {
+    int x = -1, y = -1;          // tensors [B][H][W][C]
+    int C = 0;
+    int w1 = -1, b1 = -1, w2 = -1, b2 = -1;   // blobs: fp16 [2C][C] (gamma folded), fp32 [2C] (beta folded), fp16 [C][2C], fp32 [C]
+    float eps = 1e-5f;
+    int stats_out = -1; float eps_out = 1e-5f;
+};
+
 struct Op {
     int kind = OP_GEMM;
     std::string name;
     GemmOp g;
     AttnOp at;
     SeOp se;
+    MlpOp m;
     double flops = 0;  // algorithmic 2*MACs of the ONNX nodes this op covers
 };
 
 struct Plan {
-    int B = 0, Cin = 3, T = 0;     // network input [B,3,T,T]
+    int B = 0, Cin = 3, T = 0;     // network input [B,3,T,T]; B = tiles per network pass (userB x super-batch factor)
+    int userB = 0;                 // RenderConfig::batchSize the plan was built for (B is a multiple of it)
     int Tout = 0, Cout = 3;        // network output [B,3,Tout,Tout]
     int in_tensor = -1, out_tensor = -1;
     std::vector<TensorDesc> tensors;

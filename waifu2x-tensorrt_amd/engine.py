@@ -105,6 +105,7 @@ def lib():
     L.w2x_render.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t]; L.w2x_render.restype = C.c_int
     L.w2x_infer.argtypes = [vp, vp, vp]; L.w2x_infer.restype = C.c_int
     L.w2x_output_tile_size.argtypes = [vp]; L.w2x_output_tile_size.restype = C.c_int
+    L.w2x_pass_tiles.argtypes = [vp]; L.w2x_pass_tiles.restype = C.c_int
     L.w2x_plan_flops.argtypes = [vp]; L.w2x_plan_flops.restype = C.c_double
     L.w2x_last_render_ms.argtypes = [vp]; L.w2x_last_render_ms.restype = C.c_float
     L.w2x_bench_resident.argtypes = [vp, C.c_int]; L.w2x_bench_resident.restype = C.c_float
@@ -121,7 +122,7 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "w2x_create", "w2x_destroy", "w2x_set_message_callback", "w2x_set_progress_callback", "w2x_build", "w2x_load",
-    "w2x_render", "w2x_infer", "w2x_output_tile_size", "w2x_plan_flops", "w2x_last_render_ms", "w2x_bench_resident", "w2x_profile_frame", "w2x_op_times",
+    "w2x_render", "w2x_infer", "w2x_output_tile_size", "w2x_plan_flops", "w2x_pass_tiles", "w2x_last_render_ms", "w2x_bench_resident", "w2x_profile_frame", "w2x_op_times",
     "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_sha256_hex", "w2x_version"]
 
 
@@ -192,6 +193,11 @@ class Img2Img:
         if dst is None:
             s = getattr(self, "_scaling", 0)
             dst = np.empty((src.shape[0] * s, src.shape[1] * s, 3), np.uint8)
+        s = getattr(self, "_scaling", 0)
+        if s and (dst.dtype != np.uint8 or dst.shape != (src.shape[0] * s, src.shape[1] * s, 3) or dst.strides[2] != 1 or dst.strides[1] != 3):
+            # the C ABI only sees pointers and steps, so the cv::Mat-style size check lives here
+            self._on_msg(int(Severity.error), f"[render@0] Output image has invalid size: expected {src.shape[1] * s}x{src.shape[0] * s}.".encode(), None)
+            return False
         ok = bool(self._L.w2x_render(self._h, src.ctypes.data, src.shape[0], src.shape[1], src.strides[0],
                                      dst.ctypes.data, dst.strides[0]))
         if ret_array:
@@ -212,6 +218,10 @@ class Img2Img:
     @property
     def output_tile_size(self) -> int:
         return self._L.w2x_output_tile_size(self._h)
+
+    @property
+    def pass_tiles(self) -> int:
+        return self._L.w2x_pass_tiles(self._h)
 
     @property
     def plan_flops(self) -> float:
