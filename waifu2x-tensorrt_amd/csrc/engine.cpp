@@ -194,7 +194,7 @@ struct Img2Img::Impl {
         blobs.assign(plan.blobs.size(), nullptr);
         for (size_t i = 0; i < plan.blobs.size(); ++i) {
             const auto& d = plan.blobs[i].data;
-            hipAssert(hipMalloc(&blobs[i], std::max<size_t>(d.size(), 16)));
+            hipAssert(hipMalloc(&blobs[i], d.size() + 256));   // slack: kernels may read a vector past a table's last row
             hipAssert(hipMemcpy(blobs[i], d.data(), d.size(), hipMemcpyHostToDevice));
         }
         gemm.assign(plan.ops.size(), GemmParams{});
@@ -251,6 +251,20 @@ struct Img2Img::Impl {
                     p.ntok = a.ws * a.ws; p.scale = a.scale; p.bias = blobs[a.bias]; p.maskid = (const int*)blobs[a.maskid];
                     stamp_begin(1, op.flops);
                     hipAssert(launch_attn(p, stream));
+                    stamp_end();
+                    break;
+                }
+                case OP_SWINATTN: {
+                    const SwinAttnOp& a = op.sa;
+                    const TensorDesc& d = plan.tensors[a.x];
+                    SwinAttnParams p;
+                    p.x = tensors[a.x]; p.y = tensors[a.y]; p.table = (const int*)blobs[a.table]; p.B = plan.B; p.nwin = a.nwin; p.C = a.C; p.hd = a.hd;
+                    p.wqkv = blobs[a.wqkv]; p.bqkv = (const float*)blobs[a.bqkv]; p.scale = a.scale; p.bias = blobs[a.bias]; p.maskid = (const int*)blobs[a.maskid];
+                    p.wproj = blobs[a.wproj]; p.bproj = (const float*)blobs[a.bproj]; p.eps = a.eps;
+                    p.stats_out = a.stats_out >= 0 ? (float*)tensors[a.stats_out] : nullptr; p.eps_out = a.eps_out;
+                    if (d.C != a.C || plan.tensors[a.y].C != a.C || d.H * d.W != a.nwin * a.ws * a.ws) throw std::runtime_error("plan: attention geometry mismatch");
+                    stamp_begin(1, op.flops);
+                    hipAssert(launch_swin_attn(p, stream));
                     stamp_end();
                     break;
                 }

@@ -22,7 +22,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // erf via Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7) on the fast exp/rcp units; GELU(x) = 0.5 x (1 + erf(x/sqrt2))
 __device__ __forceinline__ float gelu_fast(float x) {
     const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
     float poly = fmaf(1.061405429f, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);
     poly = fmaf(poly, t, -0.284496736f);
@@ -31,6 +31,17 @@ __device__ __forceinline__ float gelu_fast(float x) {
     const float erf_abs = fmaf(-poly * t, e, 1.f);
     const float erf_v = copysignf(erf_abs, x);
     return 0.5f * x * (1.f + erf_v);
+}
+
+// sum over aligned groups of LPR (16 or 32) lanes with DPP (no LDS crossbar): xor1, xor2, half-row mirror, row mirror
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    if (LPR == 32) v += __shfl_xor(v, 16);
+    return v;
 }
 
 template <int C>
@@ -107,16 +118,14 @@ __global__ __launch_bounds__(256, (C == 96 ? 2 : 1)) void mlp_kernel(const MlpPa
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) s += v[e];
-#pragma unroll
-            for (int m = LPR / 2; m > 0; m >>= 1) s += __shfl_xor(s, m);
+            s = group_sum<LPR>(s);
             const float mean = s * (1.f / C);
             float q = 0.f;
             if (li < PPR) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { v[e] -= mean; q += v[e] * v[e]; }
             }
-#pragma unroll
-            for (int m = LPR / 2; m > 0; m >>= 1) q += __shfl_xor(q, m);
+            q = group_sum<LPR>(q);
             const float rstd = rsqrtf(q * (1.f / C) + p.eps);
             if (li < PPR) {
                 half8 o;
@@ -231,16 +240,14 @@ __global__ __launch_bounds__(256, (C == 96 ? 2 : 1)) void mlp_kernel(const MlpPa
                 float s = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s += v[e];
-#pragma unroll
-                for (int m = LPR / 2; m > 0; m >>= 1) s += __shfl_xor(s, m);
+                s = group_sum<LPR>(s);
                 const float mean = s * (1.f / C);
                 float q = 0.f;
                 if (ok) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { float d = v[e] - mean; q += d * d; }
                 }
-#pragma unroll
-                for (int m = LPR / 2; m > 0; m >>= 1) q += __shfl_xor(q, m);
+                q = group_sum<LPR>(q);
                 if (ok && li == 0) { p.stats_out[2 * row] = mean; p.stats_out[2 * row + 1] = rsqrtf(q * (1.f / C) + p.eps_out); }
             }
         }

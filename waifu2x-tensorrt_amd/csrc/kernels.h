@@ -52,6 +52,21 @@ struct MlpParams {               // y = x + W2 gelu(W1 LN(x) + b1) + b2 on conti
     float* stats_out = nullptr; float eps_out = 1e-5f;
 };
 
+struct SwinAttnParams {          // y = x + proj(W-MSA(LN(x))) on token maps [B][H][W][C], window 6x6
+    const void* x = nullptr; void* y = nullptr;
+    const int* table = nullptr;    // int32[H*W]: window-order row -> pixel (shift + partition); also the scatter map
+    int B = 0, nwin = 0, C = 0, hd = 0;
+    const void* wqkv = nullptr;    // fp16 [3C][C], LayerNorm gamma folded in
+    const float* bqkv = nullptr;   // [3C], LayerNorm beta folded in
+    float scale = 1.f;
+    const void* bias = nullptr;    // fp16 [nmask][heads][36][36]
+    const int* maskid = nullptr;   // [nwin]
+    const void* wproj = nullptr;   // fp16 [C][C]
+    const float* bproj = nullptr;  // [C]
+    float eps = 1e-5f;
+    float* stats_out = nullptr; float eps_out = 1e-5f;
+};
+
 struct SeParams {
     const float* pool = nullptr; float* scale = nullptr;   // pool: [B][nblocks][Cs] partial sums from the producing GEMM (nblocks row tiles per batch item)
     int B = 0, C = 0, Cs = 0, Cmid = 0; float inv_count = 0.f;
@@ -85,6 +100,8 @@ struct ComposeParams {
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 hipError_t launch_attn(const AttnParams& p, hipStream_t s);
 hipError_t launch_mlp(const MlpParams& p, hipStream_t s);
+hipError_t launch_swin_attn(const SwinAttnParams& p, hipStream_t s);
+bool swin_attn_supported(int C, int heads, int hd, int ws);
 hipError_t launch_se(const SeParams& p, hipStream_t s);
 hipError_t launch_scale(void* x, const float* scale, int B, int HW, int Cs, hipStream_t s);
 hipError_t launch_gather(const GatherParams& p, hipStream_t s);

@@ -7,6 +7,7 @@
 #include <stdexcept>
 
 #include "common.h"
+#include "kernels.h"
 
 namespace w2x {
 namespace {
@@ -639,6 +640,51 @@ struct Lowerer {
         return true;
     }
 
+    // ---- post-pass: LN+qkv GEMM (window gather), attention core, proj GEMM (window scatter + residual) -> one op (k_swinattn.hip)
+    void fuse_attn() {
+        std::vector<Op> out;
+        for (size_t i = 0; i < plan.ops.size(); ++i) {
+            bool fused = false;
+            if (i + 2 < plan.ops.size() && plan.ops[i].kind == OP_GEMM && plan.ops[i + 1].kind == OP_ATTN && plan.ops[i + 2].kind == OP_GEMM) {
+                const GemmOp& q = plan.ops[i].g; const AttnOp& a = plan.ops[i + 1].at; const GemmOp& pr = plan.ops[i + 2].g;
+                const int C = q.K;
+                auto plain = [&](const View& v) { const TensorDesc& t = plan.tensors[v.t]; return v.y0 == 0 && v.x0 == 0 && v.H == t.H && v.W == t.W; };
+                if (swin_attn_supported(C, a.heads, a.hd, a.ws) && q.amode == A_WIN && q.ln && q.act == ACT_NONE && q.omode == O_ROWS && q.N == 3 * C &&
+                    q.res.t < 0 && !q.has_clip && q.stats_out < 0 && plain(q.a) && plan.tensors[q.a.t].C == C && a.qkv == q.out.t &&
+                    pr.amode == A_ROWS && pr.a.t == a.out && !pr.ln && pr.act == ACT_NONE && pr.omode == O_WIN && pr.win_table == q.win_table &&
+                    pr.K == C && pr.N == C && pr.res.t == q.a.t && pr.res2.t < 0 && !pr.has_clip && plain(pr.res) && pr.out.t != plan.out_tensor) {
+                    Op m; m.kind = OP_SWINATTN; m.name = plan.ops[i].name + "+attn+" + plan.ops[i + 2].name;
+                    m.flops = plan.ops[i].flops + plan.ops[i + 1].flops + plan.ops[i + 2].flops;
+                    SwinAttnOp& s = m.sa;
+                    s.x = q.a.t; s.y = pr.out.t; s.C = C; s.heads = a.heads; s.hd = a.hd; s.ws = a.ws; s.nwin = a.nwin; s.table = q.win_table;
+                    s.wqkv = q.w; s.bqkv = q.bias; s.wproj = pr.w; s.bproj = pr.bias; s.bias = a.bias; s.maskid = a.maskid; s.scale = a.scale;
+                    s.eps = plan.ops[tensor_producer.at(q.a.t)].kind == OP_GEMM ? plan.ops[tensor_producer.at(q.a.t)].g.ln_eps : 1e-5f;
+                    s.stats_out = pr.stats_out; s.eps_out = pr.ln_eps;
+                    out.push_back(m);
+                    i += 2; fused = true;
+                }
+            }
+            if (!fused) out.push_back(plan.ops[i]);
+        }
+        // tensor_producer indexes the old op list: rebuild it for the passes that follow
+        plan.ops.swap(out);
+        tensor_producer.clear();
+        for (size_t i = 0; i < plan.ops.size(); ++i) {
+            const Op& op = plan.ops[i];
+            if (op.kind == OP_GEMM) tensor_producer[op.g.out.t] = (int)i;
+            else if (op.kind == OP_ATTN) tensor_producer[op.at.out] = (int)i;
+            else if (op.kind == OP_SWINATTN) tensor_producer[op.sa.y] = (int)i;
+        }
+    }
+
+    // LayerNorm eps recorded by whichever op emits the statistics of tensor t
+    float eps_of(int t) {
+        auto it = tensor_producer.find(t);
+        if (it == tensor_producer.end()) return 1e-5f;
+        const Op& op = plan.ops[it->second];
+        return op.kind == OP_GEMM ? op.g.ln_eps : op.kind == OP_SWINATTN ? op.sa.eps_out : op.kind == OP_MLP ? op.m.eps_out : 1e-5f;
+    }
+
     // ---- post-pass: LN+fc1+GELU GEMM followed by fc2+residual GEMM  ->  one fused MLP op (k_mlp.hip)
     void fuse_mlp() {
         std::vector<Op> out;
@@ -657,7 +703,7 @@ struct Lowerer {
                     g2.res.t == g1.a.t && g2.res2.t < 0 && !g2.has_clip && g2.pool_out < 0 && plain(g2.res) && hidden_users == 1 && g1.out.t != plan.out_tensor) {
                     Op m; m.kind = OP_MLP; m.name = a.name + "+" + plan.ops[i + 1].name; m.flops = a.flops + plan.ops[i + 1].flops;
                     m.m.x = g1.a.t; m.m.y = g2.out.t; m.m.C = C; m.m.w1 = g1.w; m.m.b1 = g1.bias; m.m.w2 = g2.w; m.m.b2 = g2.bias;
-                    m.m.eps = plan.ops[tensor_producer.at(g1.a.t)].g.ln_eps;
+                    m.m.eps = eps_of(g1.a.t);
                     m.m.stats_out = g2.stats_out; m.m.eps_out = g2.ln_eps;
                     out.push_back(m);
                     ++i; fused = true;
@@ -668,7 +714,7 @@ struct Lowerer {
         plan.ops.swap(out);
         // the row statistics of a tensor that only fused MLP ops normalise are no longer needed
         for (auto& op : plan.ops) {
-            int* so = op.kind == OP_GEMM ? &op.g.stats_out : op.kind == OP_MLP ? &op.m.stats_out : nullptr;
+            int* so = op.kind == OP_GEMM ? &op.g.stats_out : op.kind == OP_MLP ? &op.m.stats_out : op.kind == OP_SWINATTN ? &op.sa.stats_out : nullptr;
             if (!so || *so < 0) continue;
             bool used = false;
             for (auto& o : plan.ops) if (o.kind == OP_GEMM && o.g.stats_in == *so) used = true;
@@ -763,7 +809,7 @@ struct Lowerer {
         const TensorDesc& td = plan.tensors[y.v.t];
         if (y.v.y0 || y.v.x0 || y.v.H != td.H || y.v.W != td.W) throw std::runtime_error("graph output is a cropped view");
         plan.out_tensor = y.v.t; plan.Tout = (int)os[2]; plan.Cout = 3;
-        if (!getenv("W2X_NO_FUSE")) fuse_mlp();
+        if (!getenv("W2X_NO_FUSE")) { if (!getenv("W2X_NO_FUSE_ATTN")) fuse_attn(); fuse_mlp(); }
         for (auto& op : plan.ops) plan.flops += op.flops;
         bool has_attn = false; for (auto& op : plan.ops) has_attn |= op.kind == OP_ATTN;
         plan.model_kind = has_attn ? "swin_unet" : "cunet";

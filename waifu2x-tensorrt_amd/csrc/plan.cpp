@@ -38,6 +38,8 @@ std::string Plan::describe() const {
             o << "se C=" << op.se.C << " Cmid=" << op.se.Cmid;
         } else if (op.kind == OP_SCALE_ADD) {
             o << "scale t" << op.se.pool;
+        } else if (op.kind == OP_SWINATTN) {
+            o << "swinattn C=" << op.sa.C << " heads=" << op.sa.heads << " hd=" << op.sa.hd << " nwin=" << op.sa.nwin << " stats=" << (op.sa.stats_out >= 0) << " t" << op.sa.x << "->t" << op.sa.y;
         } else if (op.kind == OP_MLP) {
             o << "mlp C=" << op.m.C << " M=" << (int64_t)tensors[op.m.x].B * tensors[op.m.x].H * tensors[op.m.x].W << " stats=" << (op.m.stats_out >= 0) << " t" << op.m.x << "->t" << op.m.y;
         }
@@ -60,19 +62,19 @@ struct Reader {
     std::vector<uint8_t> bytes() { uint64_t n = pod<uint64_t>(); if ((uint64_t)(e - p) < n) throw std::runtime_error("engine file truncated"); std::vector<uint8_t> v(p, p + n); p += n; return v; }
 };
 constexpr uint64_t kMagic = 0x3158325755464957ull;  // "WIFUW2X1"
-constexpr uint32_t kVersion = 6;
+constexpr uint32_t kVersion = 7;
 }  // namespace
 
 std::vector<uint8_t> Plan::serialize() const {
     Writer w;
     w.pod(kMagic); w.pod(kVersion);
-    w.pod<uint32_t>(sizeof(GemmOp)); w.pod<uint32_t>(sizeof(AttnOp)); w.pod<uint32_t>(sizeof(SeOp) + sizeof(MlpOp));
+    w.pod<uint32_t>(sizeof(GemmOp)); w.pod<uint32_t>(sizeof(AttnOp)); w.pod<uint32_t>(sizeof(SeOp) + sizeof(MlpOp) + sizeof(SwinAttnOp));
     w.pod(B); w.pod(userB); w.pod(Cin); w.pod(T); w.pod(Tout); w.pod(Cout); w.pod(in_tensor); w.pod(out_tensor); w.pod(flops);
     w.str(model_kind);
     w.pod<uint64_t>(tensors.size()); for (auto& t : tensors) w.pod(t);
     w.pod<uint64_t>(blobs.size()); for (auto& b : blobs) w.bytes(b.data);
     w.pod<uint64_t>(ops.size());
-    for (auto& op : ops) { w.pod(op.kind); w.str(op.name); w.pod(op.g); w.pod(op.at); w.pod(op.se); w.pod(op.m); w.pod(op.flops); }
+    for (auto& op : ops) { w.pod(op.kind); w.str(op.name); w.pod(op.g); w.pod(op.at); w.pod(op.se); w.pod(op.m); w.pod(op.sa); w.pod(op.flops); }
     return std::move(w.b);
 }
 
@@ -80,7 +82,7 @@ Plan Plan::deserialize(const uint8_t* p, size_t n) {
     Reader r{p, p + n};
     if (r.pod<uint64_t>() != kMagic) throw std::runtime_error("not a w2x engine file");
     if (r.pod<uint32_t>() != kVersion) throw std::runtime_error("engine file version mismatch");
-    if (r.pod<uint32_t>() != sizeof(GemmOp) || r.pod<uint32_t>() != sizeof(AttnOp) || r.pod<uint32_t>() != sizeof(SeOp) + sizeof(MlpOp)) throw std::runtime_error("engine file layout mismatch");
+    if (r.pod<uint32_t>() != sizeof(GemmOp) || r.pod<uint32_t>() != sizeof(AttnOp) || r.pod<uint32_t>() != sizeof(SeOp) + sizeof(MlpOp) + sizeof(SwinAttnOp)) throw std::runtime_error("engine file layout mismatch");
     Plan pl;
     pl.B = r.pod<int>(); pl.userB = r.pod<int>(); pl.Cin = r.pod<int>(); pl.T = r.pod<int>(); pl.Tout = r.pod<int>(); pl.Cout = r.pod<int>();
     pl.in_tensor = r.pod<int>(); pl.out_tensor = r.pod<int>(); pl.flops = r.pod<double>();
@@ -88,7 +90,7 @@ Plan Plan::deserialize(const uint8_t* p, size_t n) {
     uint64_t nt = r.pod<uint64_t>(); pl.tensors.resize(nt); for (auto& t : pl.tensors) t = r.pod<TensorDesc>();
     uint64_t nb = r.pod<uint64_t>(); pl.blobs.resize(nb); for (auto& b : pl.blobs) b.data = r.bytes();
     uint64_t no = r.pod<uint64_t>(); pl.ops.resize(no);
-    for (auto& op : pl.ops) { op.kind = r.pod<int>(); op.name = r.str(); op.g = r.pod<GemmOp>(); op.at = r.pod<AttnOp>(); op.se = r.pod<SeOp>(); op.m = r.pod<MlpOp>(); op.flops = r.pod<double>(); }
+    for (auto& op : pl.ops) { op.kind = r.pod<int>(); op.name = r.str(); op.g = r.pod<GemmOp>(); op.at = r.pod<AttnOp>(); op.se = r.pod<SeOp>(); op.m = r.pod<MlpOp>(); op.sa = r.pod<SwinAttnOp>(); op.flops = r.pod<double>(); }
     return pl;
 }
 

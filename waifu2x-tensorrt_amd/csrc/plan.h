@@ -26,7 +26,7 @@ enum Act : int { ACT_NONE = 0, ACT_LEAKY = 1, ACT_GELU = 2, ACT_RELU = 3, ACT_SI
 enum AMode : int { A_ROWS = 0, A_WIN = 1, A_CONV = 2 };
 enum OMode : int { O_ROWS = 0, O_WIN = 1, O_PIXSHUF = 2 };
 
-enum OpKind : int { OP_GEMM = 0, OP_ATTN = 1, OP_SE = 2, OP_SCALE_ADD = 3, OP_MLP = 4 };
+enum OpKind : int { OP_GEMM = 0, OP_ATTN = 1, OP_SE = 2, OP_SCALE_ADD = 3, OP_MLP = 4, OP_SWINATTN = 5 };
 
 // Constant data blob (weights, tables) referenced by ops; uploaded once at load().
 struct Blob {
@@ -94,6 +94,16 @@ struct MlpOp {
     int stats_out = -1; float eps_out = 1e-5f;
 };
 
+// fused Swin attention branch (LayerNorm + shift/partition + qkv + W-MSA + proj + reverse + residual)
+struct SwinAttnOp {
+    int x = -1, y = -1;
+    int C = 0, heads = 0, hd = 0, ws = 0, nwin = 0;
+    int table = -1;                 // blob int32[H*W]
+    int wqkv = -1, bqkv = -1, wproj = -1, bproj = -1, bias = -1, maskid = -1;
+    float scale = 1.f, eps = 1e-5f;
+    int stats_out = -1; float eps_out = 1e-5f;
+};
+
 struct Op {
     int kind = OP_GEMM;
     std::string name;
@@ -101,6 +111,7 @@ struct Op {
     AttnOp at;
     SeOp se;
     MlpOp m;
+    SwinAttnOp sa;
     double flops = 0;  // algorithmic 2*MACs of the ONNX nodes this op covers
 };
 
