@@ -24,7 +24,7 @@ def test_executor_matches_torch_module(onnx_model, model, scale, tile, small):
 
 def test_reader_sees_expected_structure(onnx_model):
     g = onnx_reader.load(onnx_model("swin_unet/art", 4, 1, 64, small=True))
-    assert g.opset == 17 and len(g.inputs) == 1 and g.inputs[0].shape == [1, 3, 64, 64]
+    assert g.opset == 17 and len(g.inputs) == 1 and g.inputs[0].shape == ["b", 3, 64, 64]
     ops = {n.op for n in g.nodes}
     assert {"Conv", "MatMul", "Softmax", "LayerNormalization", "Erf", "DepthToSpace", "Clip"} <= ops
     assert g.initializers["patch.0.weight"].shape == (24, 3, 3, 3)

@@ -259,7 +259,7 @@ struct Img2Img::Impl {
                     const TensorDesc& d = plan.tensors[a.x];
                     SwinAttnParams p;
                     p.x = tensors[a.x]; p.y = tensors[a.y]; p.table = (const int*)blobs[a.table]; p.B = plan.B; p.nwin = a.nwin; p.C = a.C; p.hd = a.hd;
-                    p.wqkv = blobs[a.wqkv]; p.bqkv = (const float*)blobs[a.bqkv]; p.scale = a.scale; p.bias = blobs[a.bias]; p.maskid = (const int*)blobs[a.maskid];
+                    p.wqkv = blobs[a.wqkv]; p.bqkv = (const float*)blobs[a.bqkv]; p.scale = a.scale; p.bias32 = (const float*)blobs[a.bias]; p.maskid = (const int*)blobs[a.maskid];
                     p.wproj = blobs[a.wproj]; p.bproj = (const float*)blobs[a.bproj]; p.eps = a.eps;
                     p.stats_out = a.stats_out >= 0 ? (float*)tensors[a.stats_out] : nullptr; p.eps_out = a.eps_out;
                     if (d.C != a.C || plan.tensors[a.y].C != a.C || d.H * d.W != a.nwin * a.ws * a.ws) throw std::runtime_error("plan: attention geometry mismatch");

@@ -30,29 +30,46 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// max / sum over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with v_permlane16/32_swap (no LDS traffic).
+// The swap exchanges rows/halves between TWO registers holding the same value; written as inline asm because the
+// __builtin_amdgcn_permlane*_swap pair-return folds both results onto one register when the inputs are equal
+// (checked on hardware).  "s_nop 1" = the two wait states a VALU write needs before a permlane reads it.
+__device__ __forceinline__ void swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float rows_max(float v) {
+    float a = v, b = v; swap16(a, b); v = fmaxf(a, b);
+    a = v; b = v; swap32(a, b); return fmaxf(a, b);
+}
+__device__ __forceinline__ float rows_sum(float v) {
+    float a = v, b = v; swap16(a, b); v = a + b;
+    a = v; b = v; swap32(a, b); return a + b;
+}
+
 template <int C, int HD>
 struct SwinCfg {
     static constexpr int NTOK = 36;
-    static constexpr int G = C == 96 ? 4 : 2;          // windows per workgroup
-    static constexpr int R = G * NTOK;                 // token rows
-    static constexpr int RT = (R + 15) / 16, RP = RT * 16;
-    static constexpr int RPQ = RP + 16;                // rows incl. the overrun of the last window's third 16-row tile
+    static constexpr int G = 2;                          // windows per workgroup
+    static constexpr int HPI = HD == 16 ? 2 : 1;         // heads per iteration: 3*HD*HPI = 96 weight rows per staged slice
+    static constexpr int R = G * NTOK;                   // token rows (72)
+    static constexpr int RT = (R + 15) / 16, RP = RT * 16;   // 5 tiles, 80 rows
+    static constexpr int RPQ = RP + 16;                  // rows incl. the overrun of the last window's third 16-row tile
     static constexpr int NH = C / HD;
-    static constexpr int LDX = C + 8, LDQ = HD + 8, LDV = RPQ + 8;
-    static constexpr int WROWS = (3 * HD > 96 ? 3 * HD : 96);   // weight buffer rows: a head's q,k,v rows or a 96-row proj chunk
-    static constexpr int XS = RP * LDX, OS = RP * LDX, QS = RPQ * LDQ, VS = HD * LDV, WS = WROWS * LDX;
-    static constexpr int SMEM = (XS + OS + 2 * QS + VS + WS) * 2;
+    static constexpr int LDX = C + 8, LDQ = HPI * HD + 8, LDV = RPQ + 8;
+    static constexpr int WROWS = 96;
+    static constexpr int XS = RP * LDX, OS = RP * LDX, QS = RPQ * LDQ, VS = HPI * HD * LDV, WS = WROWS * LDX;
+    static constexpr int SMEM = (XS + OS + 2 * QS + VS + WS) * 2 + 96 * 4;   // + the staged slice of the qkv bias
 };
 
 template <int C, int HD>
-__global__ __launch_bounds__(256, 1) void swin_attn_kernel(const SwinAttnParams p) {
+__global__ __launch_bounds__(256, (C == 96 ? 2 : 1)) void swin_attn_kernel(const SwinAttnParams p) {
     using K = SwinCfg<C, HD>;
-    constexpr int NTOK = K::NTOK, G = K::G, R = K::R, RT = K::RT, RP = K::RP, RPQ = K::RPQ, NH = K::NH;
+    constexpr int NTOK = K::NTOK, G = K::G, R = K::R, RT = K::RT, RP = K::RP, RPQ = K::RPQ, NH = K::NH, HPI = K::HPI;
+    static_assert(3 * HD * HPI == 96 && G == 2, "unit mapping below assumes 6 n-tiles per slice and 2 windows");
     constexpr int LDX = K::LDX, LDQ = K::LDQ, LDV = K::LDV;
     constexpr int LPR = C == 96 ? 16 : 32, PPR = C / 8, RPP = 256 / LPR;
     constexpr int NPASS = (RP + RPP - 1) / RPP;
-    constexpr int NTQ = 3 * HD / 16, NTH = HD / 16;     // n-tiles of a head's qkv slice / of one of q,k,v
-    constexpr int WQ_PIECES = 3 * HD * PPR, NWQ = (WQ_PIECES + 255) / 256;
+    constexpr int NTH = HD / 16;                         // 16-wide tiles per head of one of q,k,v
+    constexpr int WQ_PIECES = 96 * PPR, NWQ = (WQ_PIECES + 255) / 256;
     constexpr int WP_PIECES = 96 * PPR, NWP = (WP_PIECES + 255) / 256;
     constexpr int NPC = C / 96;                          // proj chunks of 96 output features
 
@@ -61,10 +78,12 @@ __global__ __launch_bounds__(256, 1) void swin_attn_kernel(const SwinAttnParams 
     _Float16* Os = Xs + K::XS;               // [RP][LDX]   attention output, all heads
     _Float16* Qs = Os + K::OS;               // [RPQ][LDQ]
     _Float16* Ks = Qs + K::QS;               // [RPQ][LDQ]
-    _Float16* VTs = Ks + K::QS;              // [HD][LDV]   v transposed: [feature][token]
+    _Float16* VTs = Ks + K::QS;              // [HPI*HD][LDV]   v transposed: [feature][token]
     _Float16* Ws = VTs + K::VS;              // [WROWS][LDX]
+    float* Bs = (float*)(Ws + K::WS);        // [96] qkv bias of the staged slice, same row order as Ws
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): unit loops branch on scalars
     const int fr = lane & 15, g = lane >> 4;
     const long win0 = (long)blockIdx.x * G;                 // first global window of this workgroup
     const long total_win = (long)p.B * p.nwin;
@@ -73,18 +92,23 @@ __global__ __launch_bounds__(256, 1) void swin_attn_kernel(const SwinAttnParams 
     const _Float16* __restrict__ Wqkv = (const _Float16*)p.wqkv;   // [3C][C]
     const _Float16* __restrict__ Wproj = (const _Float16*)p.wproj; // [C][C]
 
+    const float4v zero4 = {0.f, 0.f, 0.f, 0.f};
+    const half8 zero8 = {};
+
     // ---- weight prefetch helpers (global -> registers -> LDS)
     u32x4 rq[NWQ];
+    float rbias = 0.f;
 #define W2X_SA_PREFETCH_QKV(H)                                                                               \
     {                                                                                                        \
         _Pragma("unroll") for (int t = 0; t < NWQ; ++t) {                                                    \
             const int idx = tid + t * 256;                                                                   \
             if (WQ_PIECES % 256 == 0 || idx < WQ_PIECES) {                                                   \
                 const int rr = idx / PPR, kp = idx - rr * PPR;                                               \
-                const int grow = (rr / HD) * C + (H) * HD + (rr % HD);                                       \
+                const int grow = (rr / (HPI * HD)) * C + (H) * HD + (rr % (HPI * HD));                       \
                 rq[t] = *(const u32x4*)(Wqkv + (size_t)grow * C + kp * 8);                                   \
             }                                                                                                \
         }                                                                                                    \
+        if (tid < 96) rbias = p.bqkv[(tid / (HPI * HD)) * C + (H) * HD + (tid % (HPI * HD))];                \
     }
 #define W2X_SA_STAGE_QKV()                                                                                   \
     {                                                                                                        \
@@ -95,8 +119,16 @@ __global__ __launch_bounds__(256, 1) void swin_attn_kernel(const SwinAttnParams 
                 *(u32x4*)(Ws + rr * LDX + kp * 8) = rq[t];                                                   \
             }                                                                                                \
         }                                                                                                    \
+        if (tid < 96) Bs[tid] = rbias;                                                                       \
     }
     W2X_SA_PREFETCH_QKV(0);
+
+    // the two windows of this workgroup: batch item and table offset (wave-uniform 32-bit arithmetic)
+    const int iw0 = (int)win0, iw1 = iw0 + 1, itotal = (int)total_win;
+    const bool wok0 = iw0 < itotal, wok1 = iw1 < itotal;
+    const int wb0 = iw0 / p.nwin, wb1 = iw1 / p.nwin;
+    const int pixbase0 = wb0 * HW, pixbase1 = wb1 * HW;
+    const int tabbase0 = (iw0 - wb0 * p.nwin) * NTOK, tabbase1 = (iw1 - wb1 * p.nwin) * NTOK;
 
     // ---- gather + LayerNorm into Xs; zero what the MFMAs may touch beyond the written rows
     int my_pix[NPASS];   // source pixel row of this thread's row in each pass (-1: none)
@@ -108,8 +140,8 @@ __global__ __launch_bounds__(256, 1) void swin_attn_kernel(const SwinAttnParams 
             const int r = ps * RPP + tid / LPR;
             int pix = -1;
             if (r < R) {
-                const long wr = win0 * NTOK + r;             // global window-order row
-                if (wr < total_win * NTOK) { const long b = wr / HW; const int ml = (int)(wr - b * HW); pix = (int)(b * HW) + p.table[ml]; }
+                const int w = r >= NTOK ? 1 : 0;             // G == 2 windows per workgroup
+                if (w == 0 ? wok0 : wok1) pix = (w == 0 ? pixbase0 : pixbase1) + p.table[(w == 0 ? tabbase0 : tabbase1) + r - w * NTOK];
             }
             my_pix[ps] = pix;
             half8 h = {};
@@ -141,112 +173,137 @@ __global__ __launch_bounds__(256, 1) void swin_attn_kernel(const SwinAttnParams 
                 *(half8*)(Xs + r * LDX + li * 8) = o;
             }
         }
+        // rows [RP, RPQ) of q/k are only ever read as masked keys; they must be finite (bias = -inf is added to them)
+        for (int i = tid; i < (RPQ - RP) * LDQ; i += 256) { Qs[RP * LDQ + i] = (_Float16)0.f; Ks[RP * LDQ + i] = (_Float16)0.f; }
         // pad tokens of v^T must be finite (they are multiplied by P = 0): zero columns [RP, RPQ)
-        for (int i = tid; i < HD * (RPQ - RP); i += 256) { const int d = i / (RPQ - RP), c = i - d * (RPQ - RP); VTs[d * LDV + RP + c] = (_Float16)0.f; }
+        for (int i = tid; i < HPI * HD * (RPQ - RP); i += 256) { const int d = i / (RPQ - RP), c = i - d * (RPQ - RP); VTs[d * LDV + RP + c] = (_Float16)0.f; }
     }
 
-    const float4v zero4 = {0.f, 0.f, 0.f, 0.f};
-    const half8 zero8 = {};
+
+    // attention unit of this wave: window w (two waves per window); HPI == 2: one head of the pair each, all three query
+    // tiles; HPI == 1: query tiles {0,1} / {2}
+    const int aw = wv >> 1;
+    const int ahp = HPI == 2 ? (wv & 1) : 0;
+    const int qt0 = HPI == 2 ? 0 : ((wv & 1) ? 2 : 0);
+    const int qt1 = HPI == 2 ? 3 : ((wv & 1) ? 3 : 2);
+    const long agw = win0 + aw;
+    const bool aok = agw < total_win;
+    const int amask = aok ? p.maskid[(int)(agw % p.nwin)] : 0;
 
 #pragma unroll 1
-    for (int h = 0; h < NH; ++h) {
-        __syncthreads();                 // previous head's attention is done with Qs/Ks/VTs; Xs is complete
+    for (int h = 0; h < NH; h += HPI) {
+        // relative-position bias (+ shift mask) of this wave's unit: fp32, pre-multiplied by log2(e), keys 36..47 = -inf.
+        // Fetched now, used as the initial accumulator of the S^T products after the q,k,v phase.
+        float4v bv[3][3];
+        {
+            const float* bias = p.bias32 + ((size_t)amask * NH + h + ahp) * NTOK * 48;
+#pragma unroll
+            for (int qi = 0; qi < 3; ++qi)
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt) {
+                    const int qt = qt0 + qi, query = qt * 16 + fr, qrow = query < NTOK ? query : NTOK - 1;
+                    float4v t = zero4;
+                    if (qt < qt1) t = *(const float4v*)(bias + qrow * 48 + kt * 16 + g * 4);
+                    bv[qi][kt] = t;
+                }
+        }
+        __syncthreads();                 // previous iteration's attention is done with Qs/Ks/VTs; Xs is complete
         W2X_SA_STAGE_QKV();
         __syncthreads();
-        if (h + 1 < NH) W2X_SA_PREFETCH_QKV(h + 1);
-        // ---- q,k,v of this head for all rows: q,k transposed (rows = features), v normal (rows = tokens)
-        for (int mt = wv; mt < RT; mt += 4) {
-            float4v acc[NTQ];
-#pragma unroll
-            for (int nt = 0; nt < NTQ; ++nt) acc[nt] = zero4;
+        if (h + HPI < NH) W2X_SA_PREFETCH_QKV(h + HPI);
+        // ---- q,k,v of these heads for all rows.  15 units of (16-row tile, pair of 16-wide n-tiles): pair 0 = q, 1 = k
+        //      (computed transposed: rows = features), 2 = v (rows = tokens)
+        for (int u = wv; u < RT * 3; u += 4) {
+            const int mt = u / 3, np = u - mt * 3;
+            float4v acc[2] = {zero4, zero4};
 #pragma unroll
             for (int ks = 0; ks < C / 32; ++ks) {
                 const half8 xf = *(const half8*)(Xs + (mt * 16 + fr) * LDX + ks * 32 + g * 8);
 #pragma unroll
-                for (int nt = 0; nt < NTQ; ++nt) {
-                    const half8 wf = *(const half8*)(Ws + (nt * 16 + fr) * LDX + ks * 32 + g * 8);
-                    if (nt < 2 * NTH) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf, acc[nt], 0, 0, 0);
-                    else acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf, wf, acc[nt], 0, 0, 0);
+                for (int t = 0; t < 2; ++t) {
+                    const half8 wf = *(const half8*)(Ws + ((np * 2 + t) * 16 + fr) * LDX + ks * 32 + g * 8);
+                    if (np < 2) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf, acc[t], 0, 0, 0);
+                    else acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf, wf, acc[t], 0, 0, 0);
                 }
             }
 #pragma unroll
-            for (int nt = 0; nt < NTQ; ++nt) {
-                const int which = nt / NTH, ntl = nt - which * NTH;      // 0 q, 1 k, 2 v
-                if (which < 2) {
-                    const float4v b = *(const float4v*)(p.bqkv + which * C + h * HD + ntl * 16 + g * 4);
-                    const float sc = which == 0 ? p.scale : 1.f;
+            for (int t = 0; t < 2; ++t) {
+                const int f0 = t * 16;                               // feature offset inside the slice's q / k / v block (HPI*HD = 32 wide)
+                if (np < 2) {
+                    const float4v b = *(const float4v*)(Bs + np * (HPI * HD) + f0 + g * 4);
+                    const float sc = np == 0 ? p.scale * 1.44269504088896341f : 1.f;   // log2(e) folded into q: softmax uses exp2
                     half4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (_Float16)((acc[nt][j] + b[j]) * sc);
-                    *(half4*)((which == 0 ? Qs : Ks) + (mt * 16 + fr) * LDQ + ntl * 16 + g * 4) = o;
+                    for (int j = 0; j < 4; ++j) o[j] = (_Float16)((acc[t][j] + b[j]) * sc);
+                    *(half4*)((np == 0 ? Qs : Ks) + (mt * 16 + fr) * LDQ + f0 + g * 4) = o;
                 } else {
-                    const float b = p.bqkv[2 * C + h * HD + ntl * 16 + fr];
+                    const float b = Bs[2 * (HPI * HD) + f0 + fr];
                     half4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (_Float16)(acc[nt][j] + b);
-                    *(half4*)(VTs + (ntl * 16 + fr) * LDV + mt * 16 + g * 4) = o;
+                    for (int j = 0; j < 4; ++j) o[j] = (_Float16)(acc[t][j] + b);
+                    *(half4*)(VTs + (f0 + fr) * LDV + mt * 16 + g * 4) = o;
                 }
             }
         }
         __syncthreads();
-        // ---- attention of this head: C=96: wave = window, 3 query tiles; C=192: two waves per window (query tiles {0,1} / {2})
-        {
-            const int w = G == 4 ? wv : (wv >> 1);
-            const int qt0 = G == 4 ? 0 : ((wv & 1) ? 2 : 0);
-            const int qt1 = G == 4 ? 3 : ((wv & 1) ? 3 : 2);
-            const long gw = win0 + w;
-            if (gw < total_win) {
-                const int wl = (int)(gw % p.nwin);
-                const _Float16* bias = (const _Float16*)p.bias + ((size_t)p.maskid[wl] * NH + h) * NTOK * NTOK;
-                const int rbase = w * NTOK;
-                half8 kf[3];
+        // ---- attention of this wave's unit: the query tiles are processed in phases so their chains interleave
+        if (aok) {
+            const int rbase = aw * NTOK;
+            const int fo = ahp * HD;                                  // feature offset of this unit's head inside Qs/Ks/VTs
+            half8 kf[3];
 #pragma unroll
-                for (int kt = 0; kt < 3; ++kt) kf[kt] = (g * 8 < HD) ? *(const half8*)(Ks + (rbase + kt * 16 + fr) * LDQ + g * 8) : zero8;
-                for (int qt = qt0; qt < qt1; ++qt) {
-                    const half8 qf = (g * 8 < HD) ? *(const half8*)(Qs + (rbase + qt * 16 + fr) * LDQ + g * 8) : zero8;
-                    const int query = qt * 16 + fr;
-                    const int qrow = query < NTOK ? query : NTOK - 1;
-                    float s[3][4];
-                    float mx = -INFINITY;
+            for (int kt = 0; kt < 3; ++kt) kf[kt] = (g * 8 < HD) ? *(const half8*)(Ks + (rbase + kt * 16 + fr) * LDQ + fo + g * 8) : zero8;
+            float4v s[3][3];
 #pragma unroll
-                    for (int kt = 0; kt < 3; ++kt) {
-                        const float4v a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt], qf, zero4, 0, 0, 0);   // rows = keys, cols = queries
-                        const int k0 = kt * 16 + g * 4;
-                        half4 bv = {};
-                        if (k0 < NTOK) bv = *(const half4*)(bias + qrow * NTOK + k0);
+            for (int qi = 0; qi < 3; ++qi) {
+                if (qt0 + qi < qt1) {
+                    const half8 qf = (g * 8 < HD) ? *(const half8*)(Qs + (rbase + (qt0 + qi) * 16 + fr) * LDQ + fo + g * 8) : zero8;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float v = (k0 + j < NTOK) ? a[j] + (float)bv[j] : -INFINITY;
-                            s[kt][j] = v; mx = fmaxf(mx, v);
-                        }
-                    }
-                    mx = fmaxf(mx, __shfl_xor(mx, 16));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    for (int kt = 0; kt < 3; ++kt)   // rows = keys, cols = queries; accumulator starts at the bias: masked / pad keys = -inf
+                        s[qi][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt], qf, bv[qi][kt], 0, 0, 0);
+                }
+            }
+            float inv[3];
+            half8 pf0[3], pf1[3];
+#pragma unroll
+            for (int qi = 0; qi < 3; ++qi) {
+                if (qt0 + qi < qt1) {
+                    float mx = fmaxf(fmaxf(s[qi][0][0], s[qi][0][1]), fmaxf(s[qi][0][2], s[qi][0][3]));
+#pragma unroll
+                    for (int kt = 1; kt < 3; ++kt)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[qi][kt][j]);
+                    mx = rows_max(mx);
                     float l = 0.f;
 #pragma unroll
                     for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { const float e = __expf(s[kt][j] - mx); s[kt][j] = e; l += e; }
-                    l += __shfl_xor(l, 16);
-                    l += __shfl_xor(l, 32);
-                    const float inv = __builtin_amdgcn_rcpf(l);
-                    const half8 pf0 = {(_Float16)s[0][0], (_Float16)s[0][1], (_Float16)s[0][2], (_Float16)s[0][3],
-                                       (_Float16)s[1][0], (_Float16)s[1][1], (_Float16)s[1][2], (_Float16)s[1][3]};
-                    const half8 pf1 = {(_Float16)s[2][0], (_Float16)s[2][1], (_Float16)s[2][2], (_Float16)s[2][3],
-                                       (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                        for (int j = 0; j < 4; ++j) { const float e = __builtin_amdgcn_exp2f(s[qi][kt][j] - mx); s[qi][kt][j] = e; l += e; }
+                    l = rows_sum(l);
+                    inv[qi] = __builtin_amdgcn_rcpf(l);
+                    pf0[qi] = (half8){(_Float16)s[qi][0][0], (_Float16)s[qi][0][1], (_Float16)s[qi][0][2], (_Float16)s[qi][0][3],
+                                      (_Float16)s[qi][1][0], (_Float16)s[qi][1][1], (_Float16)s[qi][1][2], (_Float16)s[qi][1][3]};
+                    pf1[qi] = (half8){(_Float16)s[qi][2][0], (_Float16)s[qi][2][1], (_Float16)s[qi][2][2], (_Float16)s[qi][2][3],
+                                      (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                }
+            }
 #pragma unroll
-                    for (int dt = 0; dt < NTH; ++dt) {
-                        const _Float16* vp = VTs + (dt * 16 + fr) * LDV + rbase + g * 4;
-                        const half4 v0 = *(const half4*)vp, v1 = *(const half4*)(vp + 16), v2 = *(const half4*)(vp + 32);
-                        const half8 vf0 = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                        const half8 vf1 = {v2[0], v2[1], v2[2], v2[3], (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-                        float4v o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf0, pf0, zero4, 0, 0, 0);   // rows = features, cols = queries
-                        o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf1, pf1, o, 0, 0, 0);
+            for (int dt = 0; dt < NTH; ++dt) {
+                const _Float16* vp = VTs + (fo + dt * 16 + fr) * LDV + rbase + g * 4;
+                const half4 v0 = *(const half4*)vp, v1 = *(const half4*)(vp + 16), v2 = *(const half4*)(vp + 32);
+                const half8 vf0 = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                const half8 vf1 = {v2[0], v2[1], v2[2], v2[3], (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+                for (int qi = 0; qi < 3; ++qi) {
+                    if (qt0 + qi < qt1) {
+                        float4v o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf0, pf0[qi], zero4, 0, 0, 0);   // rows = features, cols = queries
+                        o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf1, pf1[qi], o, 0, 0, 0);
+                        const int query = (qt0 + qi) * 16 + fr;
                         if (query < NTOK) {
                             half4 oh;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) oh[j] = (_Float16)(o[j] * inv);
-                            *(half4*)(Os + (rbase + query) * LDX + h * HD + dt * 16 + g * 4) = oh;
+                            for (int j = 0; j < 4; ++j) oh[j] = (_Float16)(o[j] * inv[qi]);
+                            *(half4*)(Os + (rbase + query) * LDX + (h + ahp) * HD + dt * 16 + g * 4) = oh;
                         }
                     }
                 }
@@ -270,24 +327,23 @@ __global__ __launch_bounds__(256, 1) void swin_attn_kernel(const SwinAttnParams 
             if (WP_PIECES % 256 == 0 || idx < WP_PIECES) { const int rr = idx / PPR, kp = idx - rr * PPR; *(u32x4*)(Ws + rr * LDX + kp * 8) = rp[t]; }
         }
         __syncthreads();
-        for (int mt = wv; mt < RT; mt += 4) {
-            float4v acc[6];
-#pragma unroll
-            for (int nt = 0; nt < 6; ++nt) acc[nt] = zero4;
+        for (int u = wv; u < RT * 2; u += 4) {
+            const int mt = u >> 1, n3 = (u & 1) * 3;
+            float4v acc[3] = {zero4, zero4, zero4};
 #pragma unroll
             for (int ks = 0; ks < C / 32; ++ks) {
                 const half8 of = *(const half8*)(Os + (mt * 16 + fr) * LDX + ks * 32 + g * 8);
 #pragma unroll
-                for (int nt = 0; nt < 6; ++nt) {
-                    const half8 wf = *(const half8*)(Ws + (nt * 16 + fr) * LDX + ks * 32 + g * 8);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(of, wf, acc[nt], 0, 0, 0);
+                for (int t = 0; t < 3; ++t) {
+                    const half8 wf = *(const half8*)(Ws + ((n3 + t) * 16 + fr) * LDX + ks * 32 + g * 8);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(of, wf, acc[t], 0, 0, 0);
                 }
             }
 #pragma unroll
-            for (int nt = 0; nt < 6; ++nt) {
-                const float b = p.bproj[pc * 96 + nt * 16 + fr];
+            for (int t = 0; t < 3; ++t) {
+                const float b = p.bproj[pc * 96 + (n3 + t) * 16 + fr];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) Xs[(mt * 16 + g * 4 + j) * LDX + pc * 96 + nt * 16 + fr] = (_Float16)(acc[nt][j] + b);
+                for (int j = 0; j < 4; ++j) Xs[(mt * 16 + g * 4 + j) * LDX + pc * 96 + (n3 + t) * 16 + fr] = (_Float16)(acc[t][j] + b);
             }
         }
     }

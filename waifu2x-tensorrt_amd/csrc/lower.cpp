@@ -657,7 +657,17 @@ struct Lowerer {
                     m.flops = plan.ops[i].flops + plan.ops[i + 1].flops + plan.ops[i + 2].flops;
                     SwinAttnOp& s = m.sa;
                     s.x = q.a.t; s.y = pr.out.t; s.C = C; s.heads = a.heads; s.hd = a.hd; s.ws = a.ws; s.nwin = a.nwin; s.table = q.win_table;
-                    s.wqkv = q.w; s.bqkv = q.bias; s.wproj = pr.w; s.bproj = pr.bias; s.bias = a.bias; s.maskid = a.maskid; s.scale = a.scale;
+                    s.wqkv = q.w; s.bqkv = q.bias; s.wproj = pr.w; s.bproj = pr.bias; s.maskid = a.maskid; s.scale = a.scale;
+                    {   // fp32 bias table for the fused kernel: [nmask][heads][36][48], * log2(e), pad keys -inf
+                        const auto& src = plan.blobs[a.bias].data;
+                        const int ntok = a.ws * a.ws;
+                        std::vector<float> t((size_t)a.nmask * a.heads * ntok * 48, -INFINITY);
+                        for (int m2 = 0; m2 < a.nmask * a.heads; ++m2) for (int qq = 0; qq < ntok; ++qq) for (int kk = 0; kk < ntok; ++kk) {
+                            uint16_t hbits; memcpy(&hbits, &src[(((size_t)m2 * ntok + qq) * ntok + kk) * 2], 2);
+                            t[((size_t)m2 * ntok + qq) * 48 + kk] = f16_to_f32(hbits) * 1.44269504088896341f;
+                        }
+                        s.bias = blob_f32(t);
+                    }
                     s.eps = plan.ops[tensor_producer.at(q.a.t)].kind == OP_GEMM ? plan.ops[tensor_producer.at(q.a.t)].g.ln_eps : 1e-5f;
                     s.stats_out = pr.stats_out; s.eps_out = pr.ln_eps;
                     out.push_back(m);
