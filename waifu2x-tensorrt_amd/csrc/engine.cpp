@@ -125,7 +125,8 @@ struct Img2Img::Impl {
     RenderConfig cfg;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::vector<void*> tensors, blobs;
+    std::vector<void*> tensors, blobs;   // tensors point into one arena
+    void* arena_base = nullptr; size_t arena_bytes = 0;
     std::vector<GemmParams> gemm;      // per op (kind == OP_GEMM)
     std::vector<int> pool_tensors;
     int final_op = -1;
@@ -164,7 +165,7 @@ struct Img2Img::Impl {
 
     void release() {
         // img2img_base.cpp:6-10 frees the IO buffers; here everything the engine owns
-        for (void* p : tensors) if (p) hipFree(p);
+        if (arena_base) { hipFree(arena_base); arena_base = nullptr; }
         for (void* p : blobs) if (p) hipFree(p);
         tensors.clear(); blobs.clear(); gemm.clear(); pool_tensors.clear();
         for (void** p : {(void**)&d_frame, (void**)&d_out, &d_slab, (void**)&d_slots, (void**)&d_rampx, (void**)&d_rampy, (void**)&d_blob_in, (void**)&d_blob_out})
@@ -185,11 +186,59 @@ struct Img2Img::Impl {
     }
 
     void upload_plan() {
-        tensors.assign(plan.tensors.size(), nullptr);
-        for (size_t i = 0; i < plan.tensors.size(); ++i) {
-            size_t bytes = (size_t)plan.tensors[i].bytes();
-            hipAssert(hipMalloc(&tensors[i], bytes));
-            hipAssert(hipMemsetAsync(tensors[i], 0, bytes, stream));
+        // Activation arena: tensors whose lifetimes (first writer .. last reader, in op order) do not overlap share
+        // memory.  An op's outputs are placed before its inputs are released, so no op reads and writes one address.
+        {
+            const int nt = (int)plan.tensors.size(), nops = (int)plan.ops.size();
+            std::vector<int> first(nt, nops), last(nt, -1);
+            auto touch = [&](int t, int op) { if (t < 0) return; first[t] = std::min(first[t], op); last[t] = std::max(last[t], op); };
+            for (int i = 0; i < nops; ++i) {
+                const Op& op = plan.ops[i];
+                switch (op.kind) {
+                    case OP_GEMM: touch(op.g.a.t, i); touch(op.g.res.t, i); touch(op.g.res2.t, i); touch(op.g.stats_in, i);
+                                  touch(op.g.out.t, i); touch(op.g.stats_out, i); touch(op.g.pool_out, i); break;
+                    case OP_ATTN: touch(op.at.qkv, i); touch(op.at.out, i); break;
+                    case OP_SE: touch(op.se.pool, i); touch(op.se.scale, i); break;
+                    case OP_SCALE_ADD: touch(op.se.pool, i); touch(op.se.scale, i); break;
+                    case OP_MLP: touch(op.m.x, i); touch(op.m.y, i); touch(op.m.stats_out, i); break;
+                    case OP_SWINATTN: touch(op.sa.x, i); touch(op.sa.y, i); touch(op.sa.stats_out, i); break;
+                    default: break;
+                }
+            }
+            first[plan.in_tensor] = -1;                       // written by the gather kernel before op 0
+            last[plan.out_tensor] = nops;                     // read after the last op (infer) / replaced by the frame slab
+            struct Block { size_t off, size; };
+            std::vector<Block> free_list;
+            std::vector<size_t> off(nt, 0);
+            size_t arena = 0;
+            auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+            auto alloc = [&](size_t bytes) -> size_t {
+                bytes = align(bytes);
+                int best = -1;
+                for (int k = 0; k < (int)free_list.size(); ++k) if (free_list[k].size >= bytes && (best < 0 || free_list[k].size < free_list[best].size)) best = k;
+                if (best >= 0) { size_t o = free_list[best].off; free_list[best].off += bytes; free_list[best].size -= bytes; if (!free_list[best].size) free_list.erase(free_list.begin() + best); return o; }
+                if (!free_list.empty()) {   // grow the last free block if it touches the end of the arena
+                    for (int k = 0; k < (int)free_list.size(); ++k) if (free_list[k].off + free_list[k].size == arena) { size_t o = free_list[k].off; arena = o + bytes; free_list.erase(free_list.begin() + k); return o; }
+                }
+                size_t o = arena; arena += bytes; return o;
+            };
+            auto release = [&](size_t o, size_t bytes) {
+                bytes = align(bytes);
+                free_list.push_back({o, bytes});
+                std::sort(free_list.begin(), free_list.end(), [](const Block& a, const Block& b) { return a.off < b.off; });
+                for (size_t k = 0; k + 1 < free_list.size();) { if (free_list[k].off + free_list[k].size == free_list[k + 1].off) { free_list[k].size += free_list[k + 1].size; free_list.erase(free_list.begin() + k + 1); } else ++k; }
+            };
+            std::vector<char> placed(nt, 0);
+            for (int step = -1; step <= nops; ++step) {
+                for (int t = 0; t < nt; ++t) if (!placed[t] && first[t] == step && last[t] >= 0) { off[t] = alloc((size_t)plan.tensors[t].bytes()); placed[t] = 1; }
+                for (int t = 0; t < nt; ++t) if (placed[t] == 1 && last[t] == step) { release(off[t], (size_t)plan.tensors[t].bytes()); placed[t] = 2; }
+            }
+            for (int t = 0; t < nt; ++t) if (!placed[t]) { off[t] = alloc((size_t)plan.tensors[t].bytes()); placed[t] = 1; }   // unused tensors
+            hipAssert(hipMalloc(&arena_base, arena + 256));
+            hipAssert(hipMemsetAsync(arena_base, 0, arena + 256, stream));
+            arena_bytes = arena;
+            tensors.assign(nt, nullptr);
+            for (int t = 0; t < nt; ++t) tensors[t] = (uint8_t*)arena_base + off[t];
         }
         blobs.assign(plan.blobs.size(), nullptr);
         for (size_t i = 0; i < plan.blobs.size(); ++i) {
@@ -373,13 +422,14 @@ bool Img2Img::build(const std::string& onnxModelPath, const BuildConfig& config)
     // :81-88 parse ; :102-116 one profile - the plan is specialised for the opt shape, channels come from the model
     // Super-batching: tiles are independent, so one network pass may carry several reference batches (S x batchSize
     // tiles); results are bit-identical, launches per frame drop S-fold and the low-resolution stages fill all 256 CUs.
-    // W2X_SUPERBATCH overrides; default targets >= 12 tiles of 256x256 per pass, capped at 16 tiles.
+    // W2X_SUPERBATCH overrides; default targets the pixel count of 48 tiles of 256x256 per pass (one 1080p frame at
+    // config 3), capped at 64 tiles; small tiles (< 128) keep S = 1.
     int S = 1;
     if (const char* env = getenv("W2X_SUPERBATCH")) S = std::max(1, atoi(env));
     else if (config.optHeight >= 128) {
-        const double want = 12.0 * 256 * 256 / ((double)config.optBatchSize * config.optHeight * config.optWidth);
+        const double want = 48.0 * 256 * 256 / ((double)config.optBatchSize * config.optHeight * config.optWidth);
         S = std::max(1, (int)std::lround(want));
-        while (S > 1 && S * config.optBatchSize > 16) --S;
+        while (S > 1 && S * config.optBatchSize > 64) --S;
     }
     Plan plan;
     try {
@@ -482,6 +532,8 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
         return false;
     }
     impl->cfg = config;
+    W2X_LOG(info, "Loaded \"" + enginePath + "\": " + std::to_string(plan.ops.size()) + " ops, " + std::to_string(plan.B) + " tiles per pass, activation arena " +
+                      std::to_string(impl->arena_bytes >> 20) + " MiB.");
     // :262-269 blend ramps
     impl->ovx = (int)std::lround(plan.T * config.scaling * config.overlapX);
     impl->ovy = (int)std::lround(plan.T * config.scaling * config.overlapY);
