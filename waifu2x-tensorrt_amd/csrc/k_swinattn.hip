@@ -50,6 +50,8 @@ struct SwinCfg {
     static constexpr int NTOK = 36;
     static constexpr int G = 2;                          // windows per workgroup
     static constexpr int HPI = HD == 16 ? 2 : 1;         // heads per iteration: 3*HD*HPI = 96 weight rows per staged slice
+    static constexpr int NW = C == 96 ? 4 : 8;           // waves per workgroup: C=96 runs 2 workgroups per CU, C=192 (124 KB LDS) one
+    static constexpr int NT = NW * 64;
     static constexpr int R = G * NTOK;                   // token rows (72)
     static constexpr int RT = (R + 15) / 16, RP = RT * 16;   // 5 tiles, 80 rows
     static constexpr int RPQ = RP + 16;                  // rows incl. the overrun of the last window's third 16-row tile
@@ -61,16 +63,17 @@ struct SwinCfg {
 };
 
 template <int C, int HD>
-__global__ __launch_bounds__(256, (C == 96 ? 2 : 1)) void swin_attn_kernel(const SwinAttnParams p) {
+__global__ __launch_bounds__((C == 96 ? 256 : 512), 2) void swin_attn_kernel(const SwinAttnParams p) {
     using K = SwinCfg<C, HD>;
     constexpr int NTOK = K::NTOK, G = K::G, R = K::R, RT = K::RT, RP = K::RP, RPQ = K::RPQ, NH = K::NH, HPI = K::HPI;
     static_assert(3 * HD * HPI == 96 && G == 2, "unit mapping below assumes 6 n-tiles per slice and 2 windows");
     constexpr int LDX = K::LDX, LDQ = K::LDQ, LDV = K::LDV;
-    constexpr int LPR = C == 96 ? 16 : 32, PPR = C / 8, RPP = 256 / LPR;
+    constexpr int NW = K::NW, NT = K::NT;
+    constexpr int LPR = C == 96 ? 16 : 32, PPR = C / 8, RPP = NT / LPR;
     constexpr int NPASS = (RP + RPP - 1) / RPP;
     constexpr int NTH = HD / 16;                         // 16-wide tiles per head of one of q,k,v
-    constexpr int WQ_PIECES = 96 * PPR, NWQ = (WQ_PIECES + 255) / 256;
-    constexpr int WP_PIECES = 96 * PPR, NWP = (WP_PIECES + 255) / 256;
+    constexpr int WQ_PIECES = 96 * PPR, NWQ = (WQ_PIECES + NT - 1) / NT;
+    constexpr int WP_PIECES = 96 * PPR, NWP = (WP_PIECES + NT - 1) / NT;
     constexpr int NPC = C / 96;                          // proj chunks of 96 output features
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -101,8 +104,8 @@ __global__ __launch_bounds__(256, (C == 96 ? 2 : 1)) void swin_attn_kernel(const
 #define W2X_SA_PREFETCH_QKV(H)                                                                               \
     {                                                                                                        \
         _Pragma("unroll") for (int t = 0; t < NWQ; ++t) {                                                    \
-            const int idx = tid + t * 256;                                                                   \
-            if (WQ_PIECES % 256 == 0 || idx < WQ_PIECES) {                                                   \
+            const int idx = tid + t * NT;                                                                    \
+            if (WQ_PIECES % NT == 0 || idx < WQ_PIECES) {                                                    \
                 const int rr = idx / PPR, kp = idx - rr * PPR;                                               \
                 const int grow = (rr / (HPI * HD)) * C + (H) * HD + (rr % (HPI * HD));                       \
                 rq[t] = *(const u32x4*)(Wqkv + (size_t)grow * C + kp * 8);                                   \
@@ -113,8 +116,8 @@ __global__ __launch_bounds__(256, (C == 96 ? 2 : 1)) void swin_attn_kernel(const
 #define W2X_SA_STAGE_QKV()                                                                                   \
     {                                                                                                        \
         _Pragma("unroll") for (int t = 0; t < NWQ; ++t) {                                                    \
-            const int idx = tid + t * 256;                                                                   \
-            if (WQ_PIECES % 256 == 0 || idx < WQ_PIECES) {                                                   \
+            const int idx = tid + t * NT;                                                                    \
+            if (WQ_PIECES % NT == 0 || idx < WQ_PIECES) {                                                    \
                 const int rr = idx / PPR, kp = idx - rr * PPR;                                               \
                 *(u32x4*)(Ws + rr * LDX + kp * 8) = rq[t];                                                   \
             }                                                                                                \
@@ -174,31 +177,33 @@ __global__ __launch_bounds__(256, (C == 96 ? 2 : 1)) void swin_attn_kernel(const
             }
         }
         // rows [RP, RPQ) of q/k are only ever read as masked keys; they must be finite (bias = -inf is added to them)
-        for (int i = tid; i < (RPQ - RP) * LDQ; i += 256) { Qs[RP * LDQ + i] = (_Float16)0.f; Ks[RP * LDQ + i] = (_Float16)0.f; }
+        for (int i = tid; i < (RPQ - RP) * LDQ; i += NT) { Qs[RP * LDQ + i] = (_Float16)0.f; Ks[RP * LDQ + i] = (_Float16)0.f; }
         // pad tokens of v^T must be finite (they are multiplied by P = 0): zero columns [RP, RPQ)
-        for (int i = tid; i < HPI * HD * (RPQ - RP); i += 256) { const int d = i / (RPQ - RP), c = i - d * (RPQ - RP); VTs[d * LDV + RP + c] = (_Float16)0.f; }
+        for (int i = tid; i < HPI * HD * (RPQ - RP); i += NT) { const int d = i / (RPQ - RP), c = i - d * (RPQ - RP); VTs[d * LDV + RP + c] = (_Float16)0.f; }
     }
 
 
-    // attention unit of this wave: window w (two waves per window); HPI == 2: one head of the pair each, all three query
-    // tiles; HPI == 1: query tiles {0,1} / {2}
-    const int aw = wv >> 1;
-    const int ahp = HPI == 2 ? (wv & 1) : 0;
-    const int qt0 = HPI == 2 ? 0 : ((wv & 1) ? 2 : 0);
-    const int qt1 = HPI == 2 ? 3 : ((wv & 1) ? 3 : 2);
+    // attention unit of this wave
+    //   NW == 4 (HPI == 2): wave = (window, head of the pair), all three query tiles
+    //   NW == 8 (HPI == 1): waves 0..5 = (window, query tile), waves 6,7 idle in this phase
+    const int aw = NW == 4 ? (wv >> 1) : (wv < 6 ? wv / 3 : 0);
+    const int ahp = NW == 4 ? (wv & 1) : 0;
+    const int qt0 = NW == 4 ? 0 : wv % 3;
+    const int qt1 = NW == 4 ? 3 : qt0 + 1;
+    constexpr int NQI = NW == 4 ? 3 : 1;                  // query tiles per unit
     const long agw = win0 + aw;
-    const bool aok = agw < total_win;
+    const bool aok = agw < total_win && (NW == 4 || wv < 6);
     const int amask = aok ? p.maskid[(int)(agw % p.nwin)] : 0;
 
 #pragma unroll 1
     for (int h = 0; h < NH; h += HPI) {
         // relative-position bias (+ shift mask) of this wave's unit: fp32, pre-multiplied by log2(e), keys 36..47 = -inf.
         // Fetched now, used as the initial accumulator of the S^T products after the q,k,v phase.
-        float4v bv[3][3];
+        float4v bv[NQI][3];
         {
             const float* bias = p.bias32 + ((size_t)amask * NH + h + ahp) * NTOK * 48;
 #pragma unroll
-            for (int qi = 0; qi < 3; ++qi)
+            for (int qi = 0; qi < NQI; ++qi)
 #pragma unroll
                 for (int kt = 0; kt < 3; ++kt) {
                     const int qt = qt0 + qi, query = qt * 16 + fr, qrow = query < NTOK ? query : NTOK - 1;
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(256, (C == 96 ? 2 : 1)) void swin_attn_kernel(const
         if (h + HPI < NH) W2X_SA_PREFETCH_QKV(h + HPI);
         // ---- q,k,v of these heads for all rows.  15 units of (16-row tile, pair of 16-wide n-tiles): pair 0 = q, 1 = k
         //      (computed transposed: rows = features), 2 = v (rows = tokens)
-        for (int u = wv; u < RT * 3; u += 4) {
+        for (int u = wv; u < RT * 3; u += NW) {
             const int mt = u / 3, np = u - mt * 3;
             float4v acc[2] = {zero4, zero4};
 #pragma unroll
@@ -253,9 +258,9 @@ __global__ __launch_bounds__(256, (C == 96 ? 2 : 1)) void swin_attn_kernel(const
             half8 kf[3];
 #pragma unroll
             for (int kt = 0; kt < 3; ++kt) kf[kt] = (g * 8 < HD) ? *(const half8*)(Ks + (rbase + kt * 16 + fr) * LDQ + fo + g * 8) : zero8;
-            float4v s[3][3];
+            float4v s[NQI][3];
 #pragma unroll
-            for (int qi = 0; qi < 3; ++qi) {
+            for (int qi = 0; qi < NQI; ++qi) {
                 if (qt0 + qi < qt1) {
                     const half8 qf = (g * 8 < HD) ? *(const half8*)(Qs + (rbase + (qt0 + qi) * 16 + fr) * LDQ + fo + g * 8) : zero8;
 #pragma unroll
@@ -263,10 +268,10 @@ __global__ __launch_bounds__(256, (C == 96 ? 2 : 1)) void swin_attn_kernel(const
                         s[qi][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt], qf, bv[qi][kt], 0, 0, 0);
                 }
             }
-            float inv[3];
-            half8 pf0[3], pf1[3];
+            float inv[NQI];
+            half8 pf0[NQI], pf1[NQI];
 #pragma unroll
-            for (int qi = 0; qi < 3; ++qi) {
+            for (int qi = 0; qi < NQI; ++qi) {
                 if (qt0 + qi < qt1) {
                     float mx = fmaxf(fmaxf(s[qi][0][0], s[qi][0][1]), fmaxf(s[qi][0][2], s[qi][0][3]));
 #pragma unroll
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(256, (C == 96 ? 2 : 1)) void swin_attn_kernel(const
                 const half8 vf0 = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 const half8 vf1 = {v2[0], v2[1], v2[2], v2[3], (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
 #pragma unroll
-                for (int qi = 0; qi < 3; ++qi) {
+                for (int qi = 0; qi < NQI; ++qi) {
                     if (qt0 + qi < qt1) {
                         float4v o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf0, pf0[qi], zero4, 0, 0, 0);   // rows = features, cols = queries
                         o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf1, pf1[qi], o, 0, 0, 0);
@@ -317,17 +322,17 @@ __global__ __launch_bounds__(256, (C == 96 ? 2 : 1)) void swin_attn_kernel(const
     for (int pc = 0; pc < NPC; ++pc) {
 #pragma unroll
         for (int t = 0; t < NWP; ++t) {
-            const int idx = tid + t * 256;
-            if (WP_PIECES % 256 == 0 || idx < WP_PIECES) { const int rr = idx / PPR, kp = idx - rr * PPR; rp[t] = *(const u32x4*)(Wproj + (size_t)(pc * 96 + rr) * C + kp * 8); }
+            const int idx = tid + t * NT;
+            if (WP_PIECES % NT == 0 || idx < WP_PIECES) { const int rr = idx / PPR, kp = idx - rr * PPR; rp[t] = *(const u32x4*)(Wproj + (size_t)(pc * 96 + rr) * C + kp * 8); }
         }
         __syncthreads();     // all waves done with Ws (last head's qkv / previous chunk) and, for pc = 0, with Os writes
 #pragma unroll
         for (int t = 0; t < NWP; ++t) {
-            const int idx = tid + t * 256;
-            if (WP_PIECES % 256 == 0 || idx < WP_PIECES) { const int rr = idx / PPR, kp = idx - rr * PPR; *(u32x4*)(Ws + rr * LDX + kp * 8) = rp[t]; }
+            const int idx = tid + t * NT;
+            if (WP_PIECES % NT == 0 || idx < WP_PIECES) { const int rr = idx / PPR, kp = idx - rr * PPR; *(u32x4*)(Ws + rr * LDX + kp * 8) = rp[t]; }
         }
         __syncthreads();
-        for (int u = wv; u < RT * 2; u += 4) {
+        for (int u = wv; u < RT * 2; u += NW) {
             const int mt = u >> 1, n3 = (u & 1) * 3;
             float4v acc[3] = {zero4, zero4, zero4};
 #pragma unroll
@@ -407,7 +412,7 @@ hipError_t launch_sa(const SwinAttnParams& p, hipStream_t s) {
     }
     const long total_win = (long)p.B * p.nwin;
     dim3 grid((unsigned)((total_win + K::G - 1) / K::G));
-    hipLaunchKernelGGL(kern, grid, dim3(256), K::SMEM, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(K::NT), K::SMEM, s, p);
     return hipGetLastError();
 }
 
