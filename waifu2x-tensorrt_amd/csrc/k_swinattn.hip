@@ -20,6 +20,26 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// packed-fp16 row helpers: sum and sum of squares of 8 halves through v_dot2_f32_f16 (fp32 accumulation), and the
+// LayerNorm affine (x - mean) * rstd as one mixed-precision fma per element (fp16 in, fp32 scale/offset, one rounding)
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sum_sq8(const half8 v, float& s, float& q) {
+    const half2v one = {(_Float16)1.f, (_Float16)1.f};
+    s = 0.f; q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const half2v h = {v[2 * k], v[2 * k + 1]};
+        s = __builtin_amdgcn_fdot2(h, one, s, false);
+        q = __builtin_amdgcn_fdot2(h, h, q, false);
+    }
+}
+__device__ __forceinline__ half8 norm8(const half8 v, float rstd, float nm) {
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)fmaf((float)v[e], rstd, nm);
+    return o;
+}
+
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
@@ -154,27 +174,13 @@ __global__ __launch_bounds__((C == 96 ? 256 : 512), 2) void swin_attn_kernel(con
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int r = ps * RPP + tid / LPR;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (float)xr[ps][e];
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += v[e];
+            float s, q;
+            sum_sq8(xr[ps], s, q);                       // lanes beyond the row and rows without a source hold zeros
             s = group_sum<LPR>(s);
-            const float mean = s * (1.f / C);
-            float q = 0.f;
-            if (li < PPR) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { v[e] -= mean; q += v[e] * v[e]; }
-            }
             q = group_sum<LPR>(q);
-            const float rstd = rsqrtf(q * (1.f / C) + p.eps);
-            if (r < RP && li < PPR) {
-                half8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (_Float16)(v[e] * rstd);   // rows without a source are exact zeros
-                *(half8*)(Xs + r * LDX + li * 8) = o;
-            }
+            const float mean = s * (1.f / C);
+            const float rstd = rsqrtf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps);
+            if (r < RP && li < PPR) *(half8*)(Xs + r * LDX + li * 8) = norm8(xr[ps], rstd, -mean * rstd);   // source-less rows: 0*rstd - 0 = 0
         }
         // rows [RP, RPQ) of q/k are only ever read as masked keys; they must be finite (bias = -inf is added to them)
         for (int i = tid; i < (RPQ - RP) * LDQ; i += NT) { Qs[RP * LDQ + i] = (_Float16)0.f; Ks[RP * LDQ + i] = (_Float16)0.f; }
@@ -370,29 +376,18 @@ __global__ __launch_bounds__((C == 96 ? 256 : 512), 2) void swin_attn_kernel(con
             const int r = ps * RPP + tid / LPR;
             const int pix = my_pix[ps];
             const bool ok = pix >= 0 && li < PPR;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            half8 o = {};
             if (ok) {
-                const half8 c = *(const half8*)(Xs + r * LDX + li * 8);
-                half8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { o[e] = (_Float16)((float)c[e] + (float)xres[ps][e]); v[e] = (float)o[e]; }
+                o = *(const half8*)(Xs + r * LDX + li * 8) + xres[ps];     // fp16 + fp16 rounded once == fp32 add rounded to fp16
                 *(half8*)(Y + (size_t)pix * C + li * 8) = o;
             }
             if (p.stats_out) {
-                float s = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) s += v[e];
+                float s, q;
+                sum_sq8(o, s, q);
                 s = group_sum<LPR>(s);
-                const float mean = s * (1.f / C);
-                float q = 0.f;
-                if (ok) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; q += d * d; }
-                }
                 q = group_sum<LPR>(q);
-                if (ok && li == 0) { p.stats_out[2 * (size_t)pix] = mean; p.stats_out[2 * (size_t)pix + 1] = rsqrtf(q * (1.f / C) + p.eps_out); }
+                const float mean = s * (1.f / C);
+                if (ok && li == 0) { p.stats_out[2 * (size_t)pix] = mean; p.stats_out[2 * (size_t)pix + 1] = rsqrtf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps_out); }
             }
         }
     }
