@@ -203,18 +203,18 @@ __global__ __launch_bounds__((C == 96 ? 256 : 512), 2) void swin_attn_kernel(con
 
 #pragma unroll 1
     for (int h = 0; h < NH; h += HPI) {
-        // relative-position bias (+ shift mask) of this wave's unit: fp32, pre-multiplied by log2(e), keys 36..47 = -inf.
+        // relative-position bias (+ shift mask) of this wave's unit: fp32 [36][36], pre-multiplied by log2(e).
         // Fetched now, used as the initial accumulator of the S^T products after the q,k,v phase.
         float4v bv[NQI][3];
         {
-            const float* bias = p.bias32 + ((size_t)amask * NH + h + ahp) * NTOK * 48;
+            const float* bias = p.bias32 + ((size_t)amask * NH + h + ahp) * NTOK * NTOK;
 #pragma unroll
             for (int qi = 0; qi < NQI; ++qi)
 #pragma unroll
                 for (int kt = 0; kt < 3; ++kt) {
                     const int qt = qt0 + qi, query = qt * 16 + fr, qrow = query < NTOK ? query : NTOK - 1;
                     float4v t = zero4;
-                    if (qt < qt1) t = *(const float4v*)(bias + qrow * 48 + kt * 16 + g * 4);
+                    if (qt < qt1) { if (kt < 2) t = *(const float4v*)(bias + qrow * NTOK + kt * 16 + g * 4); else t[0] = bias[qrow * NTOK + 32 + g]; }
                     bv[qi][kt] = t;
                 }
         }
@@ -263,14 +263,17 @@ __global__ __launch_bounds__((C == 96 ? 256 : 512), 2) void swin_attn_kernel(con
             const int fo = ahp * HD;                                  // feature offset of this unit's head inside Qs/Ks/VTs
             half8 kf[3];
 #pragma unroll
-            for (int kt = 0; kt < 3; ++kt) kf[kt] = (g * 8 < HD) ? *(const half8*)(Ks + (rbase + kt * 16 + fr) * LDQ + fo + g * 8) : zero8;
+            for (int kt = 0; kt < 2; ++kt) kf[kt] = (g * 8 < HD) ? *(const half8*)(Ks + (rbase + kt * 16 + fr) * LDQ + fo + g * 8) : zero8;
+            // third key tile: only keys 32..35 exist.  They are placed on tile rows 0,4,8,12 (one per lane group g, register
+            // j = 0), so the softmax below touches 9 instead of 12 values per lane; rows 4g+1..3 repeat key 32+g and are ignored.
+            kf[2] = (g * 8 < HD) ? *(const half8*)(Ks + (rbase + 32 + (fr >> 2)) * LDQ + fo + g * 8) : zero8;
             float4v s[NQI][3];
 #pragma unroll
             for (int qi = 0; qi < NQI; ++qi) {
                 if (qt0 + qi < qt1) {
                     const half8 qf = (g * 8 < HD) ? *(const half8*)(Qs + (rbase + (qt0 + qi) * 16 + fr) * LDQ + fo + g * 8) : zero8;
 #pragma unroll
-                    for (int kt = 0; kt < 3; ++kt)   // rows = keys, cols = queries; accumulator starts at the bias: masked / pad keys = -inf
+                    for (int kt = 0; kt < 3; ++kt)   // rows = keys, cols = queries; accumulator starts at the bias (shift mask included)
                         s[qi][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt], qf, bv[qi][kt], 0, 0, 0);
                 }
             }
@@ -281,29 +284,29 @@ __global__ __launch_bounds__((C == 96 ? 256 : 512), 2) void swin_attn_kernel(con
                 if (qt0 + qi < qt1) {
                     float mx = fmaxf(fmaxf(s[qi][0][0], s[qi][0][1]), fmaxf(s[qi][0][2], s[qi][0][3]));
 #pragma unroll
-                    for (int kt = 1; kt < 3; ++kt)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[qi][kt][j]);
-                    mx = rows_max(mx);
+                    for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[qi][1][j]);
+                    mx = rows_max(fmaxf(mx, s[qi][2][0]));
                     float l = 0.f;
 #pragma unroll
-                    for (int kt = 0; kt < 3; ++kt)
+                    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { const float e = __builtin_amdgcn_exp2f(s[qi][kt][j] - mx); s[qi][kt][j] = e; l += e; }
+                    { const float e = __builtin_amdgcn_exp2f(s[qi][2][0] - mx); s[qi][2][0] = e; l += e; }
                     l = rows_sum(l);
                     inv[qi] = __builtin_amdgcn_rcpf(l);
                     pf0[qi] = (half8){(_Float16)s[qi][0][0], (_Float16)s[qi][0][1], (_Float16)s[qi][0][2], (_Float16)s[qi][0][3],
                                       (_Float16)s[qi][1][0], (_Float16)s[qi][1][1], (_Float16)s[qi][1][2], (_Float16)s[qi][1][3]};
-                    pf1[qi] = (half8){(_Float16)s[qi][2][0], (_Float16)s[qi][2][1], (_Float16)s[qi][2][2], (_Float16)s[qi][2][3],
+                    pf1[qi] = (half8){(_Float16)s[qi][2][0], (_Float16)0.f, (_Float16)0.f, (_Float16)0.f,
                                       (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
                 }
             }
 #pragma unroll
             for (int dt = 0; dt < NTH; ++dt) {
                 const _Float16* vp = VTs + (fo + dt * 16 + fr) * LDV + rbase + g * 4;
-                const half4 v0 = *(const half4*)vp, v1 = *(const half4*)(vp + 16), v2 = *(const half4*)(vp + 32);
+                const half4 v0 = *(const half4*)vp, v1 = *(const half4*)(vp + 16);
+                const _Float16 v2 = VTs[(fo + dt * 16 + fr) * LDV + rbase + 32 + g];      // key 32+g: k slot 8g of the second product
                 const half8 vf0 = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                const half8 vf1 = {v2[0], v2[1], v2[2], v2[3], (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                const half8 vf1 = {v2, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
 #pragma unroll
                 for (int qi = 0; qi < NQI; ++qi) {
                     if (qt0 + qi < qt1) {

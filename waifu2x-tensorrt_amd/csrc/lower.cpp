@@ -658,13 +658,13 @@ struct Lowerer {
                     SwinAttnOp& s = m.sa;
                     s.x = q.a.t; s.y = pr.out.t; s.C = C; s.heads = a.heads; s.hd = a.hd; s.ws = a.ws; s.nwin = a.nwin; s.table = q.win_table;
                     s.wqkv = q.w; s.bqkv = q.bias; s.wproj = pr.w; s.bproj = pr.bias; s.maskid = a.maskid; s.scale = a.scale;
-                    {   // fp32 bias table for the fused kernel: [nmask][heads][36][48], * log2(e), pad keys -inf
+                    {   // fp32 bias table for the fused kernel: [nmask][heads][36][36], * log2(e)
                         const auto& src = plan.blobs[a.bias].data;
                         const int ntok = a.ws * a.ws;
-                        std::vector<float> t((size_t)a.nmask * a.heads * ntok * 48, -INFINITY);
+                        std::vector<float> t((size_t)a.nmask * a.heads * ntok * ntok, 0.f);
                         for (int m2 = 0; m2 < a.nmask * a.heads; ++m2) for (int qq = 0; qq < ntok; ++qq) for (int kk = 0; kk < ntok; ++kk) {
                             uint16_t hbits; memcpy(&hbits, &src[(((size_t)m2 * ntok + qq) * ntok + kk) * 2], 2);
-                            t[((size_t)m2 * ntok + qq) * 48 + kk] = f16_to_f32(hbits) * 1.44269504088896341f;
+                            t[((size_t)m2 * ntok + qq) * ntok + kk] = f16_to_f32(hbits) * 1.44269504088896341f;
                         }
                         s.bias = blob_f32(t);
                     }
