@@ -8,6 +8,7 @@
 #include "lower.h"
 #include "sha256.h"
 #include "tiles.h"
+#include "kernels.h"
 
 struct w2x_engine {
     w2x::Img2Img engine;
@@ -102,6 +103,8 @@ void w2x_sha256_hex(const void* data, size_t len, char* out) {
     std::string h = w2x::sha256_hex(data, len);
     memcpy(out, h.c_str(), 65);
 }
+
+int w2x_debug_attn_stamps(unsigned long long* out) { return w2x::read_swin_attn_stamps(out) == hipSuccess ? 1 : 0; }
 
 const char* w2x_version(void) { return "w2x-hip 0.1 (gfx950)"; }
 

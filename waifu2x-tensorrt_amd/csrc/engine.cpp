@@ -307,7 +307,7 @@ struct Img2Img::Impl {
                     const SwinAttnOp& a = op.sa;
                     const TensorDesc& d = plan.tensors[a.x];
                     SwinAttnParams p;
-                    p.x = tensors[a.x]; p.y = tensors[a.y]; p.table = (const int*)blobs[a.table]; p.B = plan.B; p.nwin = a.nwin; p.C = a.C; p.hd = a.hd;
+                    p.x = tensors[a.x]; p.y = tensors[a.y]; p.table = (const int*)blobs[a.table]; p.H = a.H; p.W = a.W; p.ry = a.ry; p.rx = a.rx; p.B = plan.B; p.nwin = a.nwin; p.C = a.C; p.hd = a.hd;
                     p.wqkv = blobs[a.wqkv]; p.bqkv = (const float*)blobs[a.bqkv]; p.scale = a.scale; p.bias32 = (const float*)blobs[a.bias]; p.maskid = (const int*)blobs[a.maskid];
                     p.wproj = blobs[a.wproj]; p.bproj = (const float*)blobs[a.bproj]; p.eps = a.eps;
                     p.stats_out = a.stats_out >= 0 ? (float*)tensors[a.stats_out] : nullptr; p.eps_out = a.eps_out;

@@ -11,6 +11,7 @@
 // (k order permuted consistently on the V^T side).  The head outputs are collected in LDS, multiplied by Wproj, and
 // the result tile goes through LDS so the residual add and the scattered HBM stores are 16-byte row pieces.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace w2x {
 namespace {
@@ -65,6 +66,20 @@ __device__ __forceinline__ float rows_sum(float v) {
     a = v; b = v; swap32(a, b); return a + b;
 }
 
+// Diagnostic build only (W2X_STAMPS=1 at run time selects it): per-phase s_memtime deltas summed over all waves.
+// g_sa_stamps[k]: 0 gather+LN, 1 barrier A + stage + barrier B, 2 q/k/v products, 3 barrier C, 4 attention, 5 proj (incl. barriers),
+// 6 final row pass, 7 waves counted.
+__device__ unsigned long long g_sa_stamps[8];
+#define W2X_STAMP(K)                                                                                        \
+    if (STAMPS) {                                                                                           \
+        unsigned long long t_;                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        if (lane == 0) atomicAdd(&g_sa_stamps[K], t_ - tprev);                                              \
+        tprev = t_;                                                                                         \
+    }
+
 template <int C, int HD>
 struct SwinCfg {
     static constexpr int NTOK = 36;
@@ -82,7 +97,7 @@ struct SwinCfg {
     static constexpr int SMEM = (XS + OS + 2 * QS + VS + WS) * 2 + 96 * 4;   // + the staged slice of the qkv bias
 };
 
-template <int C, int HD>
+template <int C, int HD, bool STAMPS>
 __global__ __launch_bounds__((C == 96 ? 256 : 512), 2) void swin_attn_kernel(const SwinAttnParams p) {
     using K = SwinCfg<C, HD>;
     constexpr int NTOK = K::NTOK, G = K::G, R = K::R, RT = K::RT, RP = K::RP, RPQ = K::RPQ, NH = K::NH, HPI = K::HPI;
@@ -117,9 +132,12 @@ __global__ __launch_bounds__((C == 96 ? 256 : 512), 2) void swin_attn_kernel(con
 
     const float4v zero4 = {0.f, 0.f, 0.f, 0.f};
     const half8 zero8 = {};
+    unsigned long long tprev = 0;
+    if (STAMPS) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); if (lane == 0) atomicAdd(&g_sa_stamps[7], 1ull); }
 
     // ---- weight prefetch helpers (global -> registers -> LDS)
     u32x4 rq[NWQ];
+    u32x4 rp[NWP];
     float rbias = 0.f;
 #define W2X_SA_PREFETCH_QKV(H)                                                                               \
     {                                                                                                        \
@@ -151,7 +169,10 @@ __global__ __launch_bounds__((C == 96 ? 256 : 512), 2) void swin_attn_kernel(con
     const bool wok0 = iw0 < itotal, wok1 = iw1 < itotal;
     const int wb0 = iw0 / p.nwin, wb1 = iw1 / p.nwin;
     const int pixbase0 = wb0 * HW, pixbase1 = wb1 * HW;
-    const int tabbase0 = (iw0 - wb0 * p.nwin) * NTOK, tabbase1 = (iw1 - wb1 * p.nwin) * NTOK;
+    const int wl0 = iw0 - wb0 * p.nwin, wl1 = iw1 - wb1 * p.nwin;      // window index inside its batch item
+    const int tabbase0 = wl0 * NTOK, tabbase1 = wl1 * NTOK;
+    const int nwx = p.W / 6;
+    const int wy0 = wl0 / nwx, wx0 = wl0 - wy0 * nwx, wy1 = wl1 / nwx, wx1 = wl1 - wy1 * nwx;
 
     // ---- gather + LayerNorm into Xs; zero what the MFMAs may touch beyond the written rows
     int my_pix[NPASS];   // source pixel row of this thread's row in each pass (-1: none)
@@ -164,7 +185,15 @@ __global__ __launch_bounds__((C == 96 ? 256 : 512), 2) void swin_attn_kernel(con
             int pix = -1;
             if (r < R) {
                 const int w = r >= NTOK ? 1 : 0;             // G == 2 windows per workgroup
-                if (w == 0 ? wok0 : wok1) pix = (w == 0 ? pixbase0 : pixbase1) + p.table[(w == 0 ? tabbase0 : tabbase1) + r - w * NTOK];
+                if (w == 0 ? wok0 : wok1) {
+                    const int t = r - w * NTOK;
+                    if (p.ry >= 0) {   // closed form of the window table: no dependent lookup in front of the x loads
+                        const int ty = t / 6, tx = t - ty * 6;
+                        int y = (w == 0 ? wy0 : wy1) * 6 + ty + p.ry, x = (w == 0 ? wx0 : wx1) * 6 + tx + p.rx;
+                        y -= y >= p.H ? p.H : 0; x -= x >= p.W ? p.W : 0;
+                        pix = (w == 0 ? pixbase0 : pixbase1) + y * p.W + x;
+                    } else pix = (w == 0 ? pixbase0 : pixbase1) + p.table[(w == 0 ? tabbase0 : tabbase1) + t];
+                }
             }
             my_pix[ps] = pix;
             half8 h = {};
@@ -218,10 +247,19 @@ __global__ __launch_bounds__((C == 96 ? 256 : 512), 2) void swin_attn_kernel(con
                     bv[qi][kt] = t;
                 }
         }
+        W2X_STAMP(h == 0 ? 0 : 4)
         __syncthreads();                 // previous iteration's attention is done with Qs/Ks/VTs; Xs is complete
         W2X_SA_STAGE_QKV();
         __syncthreads();
-        if (h + HPI < NH) W2X_SA_PREFETCH_QKV(h + HPI);
+        W2X_STAMP(1)
+        if (h + HPI < NH) W2X_SA_PREFETCH_QKV(h + HPI)
+        else {   // last iteration: fetch the first proj weight chunk now, it is staged after the attention phase
+#pragma unroll
+            for (int t = 0; t < NWP; ++t) {
+                const int idx = tid + t * NT;
+                if (WP_PIECES % NT == 0 || idx < WP_PIECES) { const int rr = idx / PPR, kp = idx - rr * PPR; rp[t] = *(const u32x4*)(Wproj + (size_t)rr * C + kp * 8); }
+            }
+        }
         // ---- q,k,v of these heads for all rows.  15 units of (16-row tile, pair of 16-wide n-tiles): pair 0 = q, 1 = k
         //      (computed transposed: rows = features), 2 = v (rows = tokens)
         for (int u = wv; u < RT * 3; u += NW) {
@@ -256,7 +294,9 @@ __global__ __launch_bounds__((C == 96 ? 256 : 512), 2) void swin_attn_kernel(con
                 }
             }
         }
+        W2X_STAMP(2)
         __syncthreads();
+        W2X_STAMP(3)
         // ---- attention of this wave's unit: the query tiles are processed in phases so their chains interleave
         if (aok) {
             const int rbase = aw * NTOK;
@@ -325,14 +365,16 @@ __global__ __launch_bounds__((C == 96 ? 256 : 512), 2) void swin_attn_kernel(con
         }
     }
 
+    W2X_STAMP(4)
     // ---- proj: out = Os * Wproj^T + b, 96 output features per staged chunk; the tile is written over Xs
-    u32x4 rp[NWP];
 #pragma unroll 1
     for (int pc = 0; pc < NPC; ++pc) {
+        if (pc > 0) {
 #pragma unroll
-        for (int t = 0; t < NWP; ++t) {
-            const int idx = tid + t * NT;
-            if (WP_PIECES % NT == 0 || idx < WP_PIECES) { const int rr = idx / PPR, kp = idx - rr * PPR; rp[t] = *(const u32x4*)(Wproj + (size_t)(pc * 96 + rr) * C + kp * 8); }
+            for (int t = 0; t < NWP; ++t) {
+                const int idx = tid + t * NT;
+                if (WP_PIECES % NT == 0 || idx < WP_PIECES) { const int rr = idx / PPR, kp = idx - rr * PPR; rp[t] = *(const u32x4*)(Wproj + (size_t)(pc * 96 + rr) * C + kp * 8); }
+            }
         }
         __syncthreads();     // all waves done with Ws (last head's qkv / previous chunk) and, for pc = 0, with Os writes
 #pragma unroll
@@ -362,6 +404,7 @@ __global__ __launch_bounds__((C == 96 ? 256 : 512), 2) void swin_attn_kernel(con
         }
     }
     __syncthreads();
+    W2X_STAMP(5)
 
     // ---- row pieces: + residual x (same gather table), scatter store, LayerNorm statistics for the next op
     {
@@ -394,6 +437,7 @@ __global__ __launch_bounds__((C == 96 ? 256 : 512), 2) void swin_attn_kernel(con
             }
         }
     }
+    W2X_STAMP(6)
 #undef W2X_SA_PREFETCH_QKV
 #undef W2X_SA_STAGE_QKV
 }
@@ -401,10 +445,12 @@ __global__ __launch_bounds__((C == 96 ? 256 : 512), 2) void swin_attn_kernel(con
 template <int C, int HD>
 hipError_t launch_sa(const SwinAttnParams& p, hipStream_t s) {
     using K = SwinCfg<C, HD>;
-    auto kern = swin_attn_kernel<C, HD>;
+    static const bool stamps = getenv("W2X_STAMPS") != nullptr;
+    auto kern = stamps ? swin_attn_kernel<C, HD, true> : swin_attn_kernel<C, HD, false>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
+        hipError_t e = hipFuncSetAttribute((const void*)swin_attn_kernel<C, HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)swin_attn_kernel<C, HD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -415,6 +461,14 @@ hipError_t launch_sa(const SwinAttnParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+// copies and clears the diagnostic stamp counters (8 values)
+hipError_t read_swin_attn_stamps(unsigned long long* out) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sa_stamps), sizeof(unsigned long long) * 8);
+    if (e != hipSuccess) return e;
+    unsigned long long z[8] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_sa_stamps), z, sizeof(z));
+}
 
 bool swin_attn_supported(int C, int heads, int hd, int ws) {
     return ws == 6 && heads * hd == C && ((C == 96 && hd == 16) || (C == 192 && hd == 32));

@@ -55,6 +55,7 @@ struct MlpParams {               // y = x + W2 gelu(W1 LN(x) + b1) + b2 on conti
 struct SwinAttnParams {          // y = x + proj(W-MSA(LN(x))) on token maps [B][H][W][C], window 6x6
     const void* x = nullptr; void* y = nullptr;
     const int* table = nullptr;    // int32[H*W]: window-order row -> pixel (shift + partition); also the scatter map
+    int H = 0, W = 0, ry = -1, rx = -1;   // ry >= 0: closed form of the table, pixel = ((y+ry)%H)*W + (x+rx)%W (no lookup)
     int B = 0, nwin = 0, C = 0, hd = 0;
     const void* wqkv = nullptr;    // fp16 [3C][C], LayerNorm gamma folded in
     const float* bqkv = nullptr;   // [3C], LayerNorm beta folded in
@@ -102,6 +103,7 @@ hipError_t launch_attn(const AttnParams& p, hipStream_t s);
 hipError_t launch_mlp(const MlpParams& p, hipStream_t s);
 hipError_t launch_swin_attn(const SwinAttnParams& p, hipStream_t s);
 bool swin_attn_supported(int C, int heads, int hd, int ws);
+hipError_t read_swin_attn_stamps(unsigned long long* out);   // diagnostic (W2X_STAMPS=1): per-phase cycle sums, see k_swinattn.hip
 hipError_t launch_se(const SeParams& p, hipStream_t s);
 hipError_t launch_scale(void* x, const float* scale, int B, int HW, int Cs, hipStream_t s);
 hipError_t launch_gather(const GatherParams& p, hipStream_t s);

@@ -670,6 +670,16 @@ struct Lowerer {
                     }
                     s.eps = plan.ops[tensor_producer.at(q.a.t)].kind == OP_GEMM ? plan.ops[tensor_producer.at(q.a.t)].g.ln_eps : 1e-5f;
                     s.stats_out = pr.stats_out; s.eps_out = pr.ln_eps;
+                    {   // closed form of the window table (shift + partition), verified entry by entry
+                        const TensorDesc& xd = plan.tensors[q.a.t];
+                        const int32_t* tb = (const int32_t*)plan.blobs[q.win_table].data.data();
+                        s.H = xd.H; s.W = xd.W; s.ry = tb[0] / xd.W; s.rx = tb[0] % xd.W;
+                        const int nwx = xd.W / a.ws;
+                        for (int y = 0; y < xd.H && s.ry >= 0; ++y) for (int x = 0; x < xd.W; ++x) {
+                            const int row = (((y / a.ws) * nwx + x / a.ws) * a.ws + y % a.ws) * a.ws + x % a.ws;
+                            if (tb[row] != ((y + s.ry) % xd.H) * xd.W + (x + s.rx) % xd.W) { s.ry = s.rx = -1; break; }
+                        }
+                    }
                     out.push_back(m);
                     i += 2; fused = true;
                 }

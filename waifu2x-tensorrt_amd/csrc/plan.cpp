@@ -62,7 +62,7 @@ struct Reader {
     std::vector<uint8_t> bytes() { uint64_t n = pod<uint64_t>(); if ((uint64_t)(e - p) < n) throw std::runtime_error("engine file truncated"); std::vector<uint8_t> v(p, p + n); p += n; return v; }
 };
 constexpr uint64_t kMagic = 0x3158325755464957ull;  // "WIFUW2X1"
-constexpr uint32_t kVersion = 7;
+constexpr uint32_t kVersion = 8;
 }  // namespace
 
 std::vector<uint8_t> Plan::serialize() const {

@@ -99,6 +99,7 @@ struct SwinAttnOp {
     int x = -1, y = -1;
     int C = 0, heads = 0, hd = 0, ws = 0, nwin = 0;
     int table = -1;                 // blob int32[H*W]
+    int H = 0, W = 0, ry = -1, rx = -1;   // if ry >= 0 the table equals pixel = ((y+ry)%H)*W + (x+rx)%W of the window-order (y,x): computed in-kernel
     int wqkv = -1, bqkv = -1, wproj = -1, bproj = -1, bias = -1, maskid = -1;
     float scale = 1.f, eps = 1e-5f;
     int stats_out = -1; float eps_out = 1e-5f;
