@@ -230,20 +230,21 @@ __global__ __launch_bounds__((C == 96 ? 256 : 512), 2) void swin_attn_kernel(con
     const bool aok = agw < total_win && (NW == 4 || wv < 6);
     const int amask = aok ? p.maskid[(int)(agw % p.nwin)] : 0;
 
-#pragma unroll 1
-    for (int h = 0; h < NH; h += HPI) {
-        // relative-position bias (+ shift mask) of this wave's unit: fp32 [36][36], pre-multiplied by log2(e).
+#pragma unroll
+    for (int h = 0; h < NH; h += HPI) {   // fully unrolled: the weight prefetch registers are renamed statically, so the loads issued
+                                          // for iteration h+1 are only waited for when that iteration stages them
+        // relative-position bias (+ shift mask) of this wave's unit: fp32, pre-multiplied by log2(e), stored in load order.
         // Fetched now, used as the initial accumulator of the S^T products after the q,k,v phase.
         float4v bv[NQI][3];
         {
-            const float* bias = p.bias32 + ((size_t)amask * NH + h + ahp) * NTOK * NTOK;
+            const float* bias = p.bias32 + ((size_t)amask * NH + h + ahp) * (3 * 576) + lane * 4;   // load-order layout, see lower.cpp
 #pragma unroll
             for (int qi = 0; qi < NQI; ++qi)
 #pragma unroll
                 for (int kt = 0; kt < 3; ++kt) {
-                    const int qt = qt0 + qi, query = qt * 16 + fr, qrow = query < NTOK ? query : NTOK - 1;
+                    const int qt = qt0 + qi;
                     float4v t = zero4;
-                    if (qt < qt1) { if (kt < 2) t = *(const float4v*)(bias + qrow * NTOK + kt * 16 + g * 4); else t[0] = bias[qrow * NTOK + 32 + g]; }
+                    if (qt < qt1) { if (kt < 2) t = *(const float4v*)(bias + qt * 576 + kt * 256); else t[0] = bias[qt * 576 + 512 - lane * 3]; }
                     bv[qi][kt] = t;
                 }
         }

@@ -60,7 +60,7 @@ struct SwinAttnParams {          // y = x + proj(W-MSA(LN(x))) on token maps [B]
     const void* wqkv = nullptr;    // fp16 [3C][C], LayerNorm gamma folded in
     const float* bqkv = nullptr;   // [3C], LayerNorm beta folded in
     float scale = 1.f;
-    const float* bias32 = nullptr; // fp32 [nmask][heads][36][36]: (rel-pos bias + shift mask) * log2(e)
+    const float* bias32 = nullptr; // fp32 [nmask][heads][3][576]: (rel-pos bias + shift mask) * log2(e) in the kernel's lane order (lower.cpp)
     const int* maskid = nullptr;   // [nwin]
     const void* wproj = nullptr;   // fp16 [C][C]
     const float* bproj = nullptr;  // [C]

@@ -658,13 +658,23 @@ struct Lowerer {
                     SwinAttnOp& s = m.sa;
                     s.x = q.a.t; s.y = pr.out.t; s.C = C; s.heads = a.heads; s.hd = a.hd; s.ws = a.ws; s.nwin = a.nwin; s.table = q.win_table;
                     s.wqkv = q.w; s.bqkv = q.bias; s.wproj = pr.w; s.bproj = pr.bias; s.maskid = a.maskid; s.scale = a.scale;
-                    {   // fp32 bias table for the fused kernel: [nmask][heads][36][36], * log2(e)
+                    {   // fp32 bias table for the fused kernel, * log2(e), stored in the kernel's load order so every wave load is one
+                        // contiguous 1 KB (or 256 B) block: [nmask][heads][query tile 3][ A: key tile 0 [64 lanes][4] | B: key tile 1
+                        // [64 lanes][4] | C: keys 32..35 [64 lanes][1] ],  lane = 16*g + fr <-> query 16*qt + fr, keys 16*kt + 4*g + j.
                         const auto& src = plan.blobs[a.bias].data;
                         const int ntok = a.ws * a.ws;
-                        std::vector<float> t((size_t)a.nmask * a.heads * ntok * ntok, 0.f);
-                        for (int m2 = 0; m2 < a.nmask * a.heads; ++m2) for (int qq = 0; qq < ntok; ++qq) for (int kk = 0; kk < ntok; ++kk) {
+                        const int per_qt = 64 * 4 * 2 + 64, per_unit = 3 * per_qt;
+                        std::vector<float> t((size_t)a.nmask * a.heads * per_unit, 0.f);
+                        auto at = [&](int m2, int qq, int kk) -> float {
+                            if (qq >= ntok) qq = ntok - 1;
                             uint16_t hbits; memcpy(&hbits, &src[(((size_t)m2 * ntok + qq) * ntok + kk) * 2], 2);
-                            t[((size_t)m2 * ntok + qq) * ntok + kk] = f16_to_f32(hbits) * 1.44269504088896341f;
+                            return f16_to_f32(hbits) * 1.44269504088896341f;
+                        };
+                        for (int m2 = 0; m2 < a.nmask * a.heads; ++m2) for (int qt = 0; qt < 3; ++qt) for (int lane = 0; lane < 64; ++lane) {
+                            const int fr = lane & 15, gg = lane >> 4, qq = qt * 16 + fr;
+                            float* base = &t[(size_t)m2 * per_unit + (size_t)qt * per_qt];
+                            for (int kt = 0; kt < 2; ++kt) for (int j = 0; j < 4; ++j) base[kt * 256 + lane * 4 + j] = at(m2, qq, kt * 16 + gg * 4 + j);
+                            base[512 + lane] = at(m2, qq, 32 + gg);
                         }
                         s.bias = blob_f32(t);
                     }
