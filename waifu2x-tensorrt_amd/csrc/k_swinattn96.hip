@@ -1,0 +1,315 @@
+// Fused Swin attention branch, C = 96 / 6 heads of 16 / window 6x6, "wave-private heads" variant for gfx950.
+//     y = x + proj( W-MSA( LayerNorm(x) ) )
+// Same math and data layout as k_swinattn.hip (which keeps serving C = 192); the difference is the schedule:
+// a workgroup = 4 waves = 2 windows; wave (w, hp) owns window w and the heads 2*it + hp (it = 0..2).  For its
+// (window, head) the wave computes q, k, v^T itself (48 padded rows x 16 features each, weights read straight from
+// L2 as MFMA fragments, prefetched one head ahead) into a wave-private LDS slab, runs S^T = K Q^T -> softmax -> O^T = V^T P^T,
+// and writes its 16 output features to the shared O tile.  No workgroup barrier inside the head loop - only three in the
+// whole kernel (after LayerNorm, before proj, before the final row pass) - so the two workgroups sharing a CU never stall
+// on each other's skew.  Costs: the 12 pad rows of every 48-row slab are computed for nothing (MFMA time is not the limiter).
+#include "kernels.h"
+
+namespace w2x {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void sum_sq8(const half8 v, float& s, float& q) {
+    const half2v one = {(_Float16)1.f, (_Float16)1.f};
+    s = 0.f; q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const half2v h = {v[2 * k], v[2 * k + 1]};
+        s = __builtin_amdgcn_fdot2(h, one, s, false);
+        q = __builtin_amdgcn_fdot2(h, h, q, false);
+    }
+}
+__device__ __forceinline__ half8 norm8(const half8 v, float rstd, float nm) {
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)fmaf((float)v[e], rstd, nm);
+    return o;
+}
+// sum over aligned groups of 16 lanes with DPP
+__device__ __forceinline__ float group_sum16(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+// max / sum over the four 16-lane rows of a wave (see k_swinattn.hip for why this is inline asm on two registers)
+__device__ __forceinline__ void swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float rows_max(float v) { float a = v, b = v; swap16(a, b); v = fmaxf(a, b); a = v; b = v; swap32(a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float rows_sum(float v) { float a = v, b = v; swap16(a, b); v = a + b; a = v; b = v; swap32(a, b); return a + b; }
+
+constexpr int C = 96, HD = 16, NH = 6, NTOK = 36, G = 2, R = G * NTOK, RT = 5, RP = RT * 16;
+constexpr int RPX = 96;                    // rows of the normalised-x tile: a 48-row slab of window 1 reaches row 83
+constexpr int LDX = C + 8;                 // 104 halves
+constexpr int LDQ = HD + 8, LDV = 48 + 8;  // private q / k rows, v^T rows
+constexpr int XS = RPX * LDX, OS = RP * LDX;
+constexpr int PRIV = 2 * 48 * LDQ + HD * LDV;      // halves per wave: q, k, v^T
+constexpr int SMEM96 = (XS + OS + 4 * PRIV) * 2;
+constexpr int LPR = 16, PPR = C / 8, RPP = 256 / LPR, NPASS = RP / RPP;   // row-piece phases: 16 lanes per row, 5 passes
+
+__global__ __launch_bounds__(256, 2) void swin_attn96_kernel(const SwinAttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    _Float16* Xs = (_Float16*)smem;              // [RPX][LDX] normalised x; rows >= R are zero; later the output tile
+    _Float16* Os = Xs + XS;                      // [RP][LDX]  attention output, all heads
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    _Float16* Qp = Os + OS + wv * PRIV;          // [48][LDQ]
+    _Float16* Kp = Qp + 48 * LDQ;                // [48][LDQ]
+    _Float16* VTp = Kp + 48 * LDQ;               // [HD][LDV]
+
+    const int iw0 = blockIdx.x * G, iw1 = iw0 + 1, itotal = p.B * p.nwin;
+    const bool wok0 = iw0 < itotal, wok1 = iw1 < itotal;
+    const int HW = p.nwin * NTOK;
+    const int wb0 = iw0 / p.nwin, wb1 = iw1 / p.nwin;
+    const int pixbase0 = wb0 * HW, pixbase1 = wb1 * HW;
+    const int wl0 = iw0 - wb0 * p.nwin, wl1 = iw1 - wb1 * p.nwin;
+    const int nwx = p.W / 6;
+    const int wy0 = wl0 / nwx, wx0 = wl0 - wy0 * nwx, wy1 = wl1 / nwx, wx1 = wl1 - wy1 * nwx;
+    const _Float16* __restrict__ X = (const _Float16*)p.x;
+    const _Float16* __restrict__ Wqkv = (const _Float16*)p.wqkv;   // [3C][C]
+    const _Float16* __restrict__ Wproj = (const _Float16*)p.wproj; // [C][C]
+    const float4v zero4 = {0.f, 0.f, 0.f, 0.f};
+    const half8 zero8 = {};
+
+    // this wave's attention unit
+    const int aw = wv >> 1, ahp = wv & 1;
+    const bool aok = aw == 0 ? wok0 : wok1;
+    const int amask = aok ? p.maskid[aw == 0 ? wl0 : wl1] : 0;
+    const int rbase = aw * NTOK;
+
+    // weight fragments of head h (q, k, v rows h*16 + fr; 3 k-steps): lane reads 16 bytes at [row][ks*32 + 8g]
+    half8 wcur[9], wnext[9];
+    const _Float16* wlane = Wqkv + (size_t)fr * C + g * 8;
+#define W2X_LOAD_W(DST, H)                                                                                   \
+    {                                                                                                        \
+        _Pragma("unroll") for (int m = 0; m < 3; ++m)                                                        \
+            _Pragma("unroll") for (int ks = 0; ks < 3; ++ks)                                                 \
+                DST[m * 3 + ks] = *(const half8*)(wlane + (size_t)(m * C + (H) * HD) * C + ks * 32);         \
+    }
+    W2X_LOAD_W(wcur, ahp);
+
+    // ---- gather + LayerNorm into Xs
+    int my_pix[NPASS];
+    {
+        const int li = tid & (LPR - 1);
+        half8 xr[NPASS];
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int r = ps * RPP + tid / LPR;
+            int pix = -1;
+            if (r < R) {
+                const int w = r >= NTOK ? 1 : 0;
+                if (w == 0 ? wok0 : wok1) {
+                    const int t = r - w * NTOK;
+                    if (p.ry >= 0) {
+                        const int ty = t / 6, tx = t - ty * 6;
+                        int y = (w == 0 ? wy0 : wy1) * 6 + ty + p.ry, x = (w == 0 ? wx0 : wx1) * 6 + tx + p.rx;
+                        y -= y >= p.H ? p.H : 0; x -= x >= p.W ? p.W : 0;
+                        pix = (w == 0 ? pixbase0 : pixbase1) + y * p.W + x;
+                    } else pix = (w == 0 ? pixbase0 : pixbase1) + p.table[(w == 0 ? wl0 : wl1) * NTOK + t];
+                }
+            }
+            my_pix[ps] = pix;
+            half8 h = {};
+            if (pix >= 0 && li < PPR) h = *(const half8*)(X + (size_t)pix * C + li * 8);
+            xr[ps] = h;
+        }
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int r = ps * RPP + tid / LPR;
+            float s, q;
+            sum_sq8(xr[ps], s, q);
+            s = group_sum16(s);
+            q = group_sum16(q);
+            const float mean = s * (1.f / C);
+            const float rstd = rsqrtf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps);
+            if (li < PPR) *(half8*)(Xs + r * LDX + li * 8) = norm8(xr[ps], rstd, -mean * rstd);
+        }
+        // rows [RP, RPX) are only read as pad rows of window 1's slab: zero them
+        for (int i = tid; i < (RPX - RP) * PPR; i += 256) { const int r = RP + i / PPR, c = i % PPR; *(half8*)(Xs + r * LDX + c * 8) = zero8; }
+    }
+    __syncthreads();
+
+    const float qscale = p.scale * 1.44269504088896341f;   // log2(e) folded into q: softmax uses exp2
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int h = 2 * it + ahp;
+        // bias (+ shift mask) of this unit in load order (lower.cpp): 3 query tiles x (2 x float4 + 1 float) per lane
+        float4v bv[3][3];
+        {
+            const float* bias = p.bias32 + ((size_t)amask * NH + h) * (3 * 576) + lane * 4;
+#pragma unroll
+            for (int qi = 0; qi < 3; ++qi) {
+                bv[qi][0] = *(const float4v*)(bias + qi * 576);
+                bv[qi][1] = *(const float4v*)(bias + qi * 576 + 256);
+                float4v t = zero4; t[0] = bias[qi * 576 + 512 - lane * 3];
+                bv[qi][2] = t;
+            }
+        }
+        const float4v bq = *(const float4v*)(p.bqkv + h * HD + g * 4);
+        const float4v bk = *(const float4v*)(p.bqkv + C + h * HD + g * 4);
+        const float bvv = p.bqkv[2 * C + h * HD + fr];
+        if (it < 2) W2X_LOAD_W(wnext, h + 2);
+
+        // ---- q, k (transposed: rows = features) and v (rows = tokens) of the 48-row slab of this window
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) {
+            float4v aq = zero4, ak = zero4, av = zero4;
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                const half8 xf = *(const half8*)(Xs + (rbase + mt * 16 + fr) * LDX + ks * 32 + g * 8);
+                aq = __builtin_amdgcn_mfma_f32_16x16x32_f16(wcur[ks], xf, aq, 0, 0, 0);
+                ak = __builtin_amdgcn_mfma_f32_16x16x32_f16(wcur[3 + ks], xf, ak, 0, 0, 0);
+                av = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf, wcur[6 + ks], av, 0, 0, 0);
+            }
+            half4 oq, ok, ov;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { oq[j] = (_Float16)((aq[j] + bq[j]) * qscale); ok[j] = (_Float16)(ak[j] + bk[j]); ov[j] = (_Float16)(av[j] + bvv); }
+            *(half4*)(Qp + (mt * 16 + fr) * LDQ + g * 4) = oq;
+            *(half4*)(Kp + (mt * 16 + fr) * LDQ + g * 4) = ok;
+            *(half4*)(VTp + fr * LDV + mt * 16 + g * 4) = ov;
+        }
+        // ---- attention on the private slab (key tile 2 holds keys 32..35 on tile rows 0,4,8,12)
+        {
+            half8 kf[3];
+            kf[0] = g < 2 ? *(const half8*)(Kp + fr * LDQ + g * 8) : zero8;
+            kf[1] = g < 2 ? *(const half8*)(Kp + (16 + fr) * LDQ + g * 8) : zero8;
+            kf[2] = g < 2 ? *(const half8*)(Kp + (32 + (fr >> 2)) * LDQ + g * 8) : zero8;
+            float4v s[3][3];
+#pragma unroll
+            for (int qi = 0; qi < 3; ++qi) {
+                const half8 qf = g < 2 ? *(const half8*)(Qp + (qi * 16 + fr) * LDQ + g * 8) : zero8;
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt) s[qi][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt], qf, bv[qi][kt], 0, 0, 0);
+            }
+            float inv[3];
+            half8 pf0[3], pf1[3];
+#pragma unroll
+            for (int qi = 0; qi < 3; ++qi) {
+                float mx = fmaxf(fmaxf(s[qi][0][0], s[qi][0][1]), fmaxf(s[qi][0][2], s[qi][0][3]));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[qi][1][j]);
+                mx = rows_max(fmaxf(mx, s[qi][2][0]));
+                float l = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const float e = __builtin_amdgcn_exp2f(s[qi][kt][j] - mx); s[qi][kt][j] = e; l += e; }
+                { const float e = __builtin_amdgcn_exp2f(s[qi][2][0] - mx); s[qi][2][0] = e; l += e; }
+                l = rows_sum(l);
+                inv[qi] = __builtin_amdgcn_rcpf(l);
+                pf0[qi] = (half8){(_Float16)s[qi][0][0], (_Float16)s[qi][0][1], (_Float16)s[qi][0][2], (_Float16)s[qi][0][3],
+                                  (_Float16)s[qi][1][0], (_Float16)s[qi][1][1], (_Float16)s[qi][1][2], (_Float16)s[qi][1][3]};
+                pf1[qi] = (half8){(_Float16)s[qi][2][0], (_Float16)0.f, (_Float16)0.f, (_Float16)0.f,
+                                  (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            }
+            const _Float16* vp = VTp + fr * LDV + g * 4;
+            const half4 v0 = *(const half4*)vp, v1 = *(const half4*)(vp + 16);
+            const _Float16 v2 = VTp[fr * LDV + 32 + g];
+            const half8 vf0 = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            const half8 vf1 = {v2, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+            for (int qi = 0; qi < 3; ++qi) {
+                float4v o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf0, pf0[qi], zero4, 0, 0, 0);   // rows = features, cols = queries
+                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf1, pf1[qi], o, 0, 0, 0);
+                const int query = qi * 16 + fr;
+                if (aok && query < NTOK) {
+                    half4 oh;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) oh[j] = (_Float16)(o[j] * inv[qi]);
+                    *(half4*)(Os + (rbase + query) * LDX + h * HD + g * 4) = oh;
+                }
+            }
+        }
+        if (it < 2) {
+#pragma unroll
+            for (int m = 0; m < 9; ++m) wcur[m] = wnext[m];
+        }
+    }
+#undef W2X_LOAD_W
+    __syncthreads();      // every wave's head outputs are in Os; nobody reads Xs any more
+
+    // ---- proj: out = Os * Wproj^T + b -> tile over Xs.  10 units of (16-row tile, 3 n-tiles), weights as fragments from L2
+    for (int u = wv; u < RT * 2; u += 4) {
+        const int mt = u >> 1, n3 = (u & 1) * 3;
+        half8 wf[3][3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) wf[t][ks] = *(const half8*)(Wproj + (size_t)((n3 + t) * 16 + fr) * C + ks * 32 + g * 8);
+        float4v acc[3] = {zero4, zero4, zero4};
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const half8 of = *(const half8*)(Os + (mt * 16 + fr) * LDX + ks * 32 + g * 8);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(of, wf[t][ks], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const float b = p.bproj[(n3 + t) * 16 + fr];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Xs[(mt * 16 + g * 4 + j) * LDX + (n3 + t) * 16 + fr] = (_Float16)(acc[t][j] + b);
+        }
+    }
+    __syncthreads();
+
+    // ---- row pieces: + residual x, scatter store, LayerNorm statistics for the next op
+    {
+        _Float16* __restrict__ Y = (_Float16*)p.y;
+        const int li = tid & (LPR - 1);
+        half8 xres[NPASS];
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            half8 h = {};
+            if (my_pix[ps] >= 0 && li < PPR) h = *(const half8*)(X + (size_t)my_pix[ps] * C + li * 8);
+            xres[ps] = h;
+        }
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int r = ps * RPP + tid / LPR;
+            const int pix = my_pix[ps];
+            const bool ok = pix >= 0 && li < PPR;
+            half8 o = {};
+            if (ok) {
+                o = *(const half8*)(Xs + r * LDX + li * 8) + xres[ps];
+                *(half8*)(Y + (size_t)pix * C + li * 8) = o;
+            }
+            if (p.stats_out) {
+                float s, q;
+                sum_sq8(o, s, q);
+                s = group_sum16(s);
+                q = group_sum16(q);
+                const float mean = s * (1.f / C);
+                if (ok && li == 0) { p.stats_out[2 * (size_t)pix] = mean; p.stats_out[2 * (size_t)pix + 1] = rsqrtf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps_out); }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_swin_attn96(const SwinAttnParams& p, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)swin_attn96_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM96);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const long total_win = (long)p.B * p.nwin;
+    dim3 grid((unsigned)((total_win + G - 1) / G));
+    hipLaunchKernelGGL(swin_attn96_kernel, grid, dim3(256), SMEM96, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace w2x
