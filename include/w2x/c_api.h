@@ -59,7 +59,8 @@ double w2x_plan_flops(w2x_engine* e);   /* algorithmic FLOP of one network pass 
 int w2x_pass_tiles(w2x_engine* e);      /* tiles per network pass (batchSize x super-batch factor) */
 float w2x_last_render_ms(w2x_engine* e);
 float w2x_bench_resident(w2x_engine* e, int iters);
-/* out[5*k+{0,1,2}] = {ms, launches, algorithmic FLOP} for k = 0 gemm, 1 attention, 2 se/scale, 3 gather, 4 compose; out[25] = frame ms */
+/* out[5*k+{0,1,2}] = {ms, launches, algorithmic FLOP} for k = 0 gemm, 1 attention, 2 se/scale, 3 gather, 4 compose, 5 fused mlp;
+   out[30] = frame ms; cap >= 31 */
 int w2x_profile_frame(w2x_engine* e, double* out, int cap);
 /* ms per plan op (same order as w2x_describe_plan) of the last w2x_profile_frame; returns the op count */
 int w2x_op_times(w2x_engine* e, double* out, int cap);

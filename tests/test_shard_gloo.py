@@ -1,0 +1,50 @@
+"""N > 1 path on CPU: two gloo ranks shard frames the way bench.py does (frame f -> rank f mod N), with the same
+barrier + max-over-ranks timing reduction; no data-path collective is involved."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import shard
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard.frames_for_rank(total, rank, world)
+    shard.barrier(dist)
+    wall = 1.0 + rank * 0.5 + len(mine) * 0.01          # stand-in for the timed region of this rank
+    mx = shard.max_over_ranks(wall, dist)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    q.put((rank, mine, mx, gathered))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_partition_frames_and_reduce_max():
+    world, total = 2, 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs: p.join(60); assert p.exitcode == 0
+    frames = sorted(f for _, mine, _, _ in res for f in mine)
+    assert frames == list(range(total))                               # every frame rendered exactly once
+    assert res[0][1] == [0, 2, 4, 6] and res[1][1] == [1, 3, 5]
+    expect = max(1.0 + r * 0.5 + len(shard.frames_for_rank(total, r, world)) * 0.01 for r in range(world))
+    assert all(abs(mx - expect) < 1e-12 for _, _, mx, _ in res)       # both ranks agree on the max
+    assert all(g == [res[0][1], res[1][1]] for _, _, _, g in res)
+
+
+def test_single_process_helpers_without_dist():
+    assert shard.frames_for_rank(5, 0, 1) == [0, 1, 2, 3, 4]
+    assert shard.max_over_ranks(3.5) == 3.5
+    shard.barrier(None)

@@ -325,7 +325,7 @@ struct Img2Img::Impl {
                     p.w1 = blobs[m.w1]; p.b1 = (const float*)blobs[m.b1]; p.w2 = blobs[m.w2]; p.b2 = (const float*)blobs[m.b2];
                     p.eps = m.eps; p.stats_out = m.stats_out >= 0 ? (float*)tensors[m.stats_out] : nullptr; p.eps_out = m.eps_out;
                     if (d.C != m.C || plan.tensors[m.y].C != m.C) throw std::runtime_error("plan: MLP width mismatch");
-                    stamp_begin(0, op.flops);
+                    stamp_begin(5, op.flops);
                     hipAssert(launch_mlp(p, stream));
                     stamp_end();
                     break;
@@ -647,10 +647,10 @@ float Img2Img::benchResident(int iters) try {
 
 // Per-kernel-family device time of one resident frame, measured with HIP events on the compute stream.
 // out[5*k + {0,1,2}] = {milliseconds, launches, algorithmic FLOP} for k = 0 gemm, 1 attention, 2 se/scale, 3 gather,
-// 4 compose; out[25] = wall ms of the whole frame (first launch start to last launch end).
+// 4 compose, 5 fused mlp; out[30] = wall ms of the whole frame (first launch start to last launch end).
 bool Img2Img::profileFrame(double* out, int cap) try {
-    if (!impl->loaded || impl->last_rows == 0 || cap < 26) return false;
-    for (int i = 0; i < 26; ++i) out[i] = 0;
+    if (!impl->loaded || impl->last_rows == 0 || cap < 31) return false;
+    for (int i = 0; i < 31; ++i) out[i] = 0;
     impl->profiling = true; impl->stamps.clear();
     impl->run_frame(impl->last_rows, impl->last_cols, impl->last_grid, false);
     impl->profiling = false;
@@ -662,7 +662,7 @@ bool Img2Img::profileFrame(double* out, int cap) try {
         if (st.op >= 0) impl->op_ms[st.op] += ms;
         out[5 * st.kind] += ms; out[5 * st.kind + 1] += 1; out[5 * st.kind + 2] += st.flops;
     }
-    if (!impl->stamps.empty()) { float ms = 0.f; hipAssert(hipEventElapsedTime(&ms, impl->stamps.front().a, impl->stamps.back().b)); out[25] = ms; }
+    if (!impl->stamps.empty()) { float ms = 0.f; hipAssert(hipEventElapsedTime(&ms, impl->stamps.front().a, impl->stamps.back().b)); out[30] = ms; }
     for (auto& st : impl->stamps) { hipEventDestroy(st.a); hipEventDestroy(st.b); }
     impl->stamps.clear();
     return true;

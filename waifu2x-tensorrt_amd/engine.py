@@ -236,12 +236,12 @@ class Img2Img:
 
     def profile_frame(self) -> dict:
         """HIP-event time per kernel family for one resident frame: {family: (ms, launches, flop)}, plus 'frame_ms'."""
-        out = np.zeros(26, np.float64)
-        if not self._L.w2x_profile_frame(self._h, out.ctypes.data, 26):
+        out = np.zeros(31, np.float64)
+        if not self._L.w2x_profile_frame(self._h, out.ctypes.data, 31):
             raise W2xError(self.last_error() or "profile failed")
-        names = ["gemm", "attention", "se_scale", "gather", "compose"]
+        names = ["gemm", "attention", "se_scale", "gather", "compose", "mlp"]
         d = {n: (float(out[5 * i]), int(out[5 * i + 1]), float(out[5 * i + 2])) for i, n in enumerate(names)}
-        d["frame_ms"] = float(out[25])
+        d["frame_ms"] = float(out[30])
         return d
 
     def op_times(self) -> np.ndarray:
