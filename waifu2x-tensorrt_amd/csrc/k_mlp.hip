@@ -151,8 +151,9 @@ __global__ __launch_bounds__(256, (C == 96 ? 2 : 1)) void mlp_kernel(const MlpPa
     const int fr = lane & 15, g = lane >> 4;
     const int trow = wv * 32;   // this wave's 32 token rows
 
-#pragma unroll 1
-    for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {   // fully unrolled: prefetch registers are renamed statically, so the loads for chunk ch+1
+                                         // are only waited for when that chunk is staged (a rolled loop makes hipcc wait right away)
         __syncthreads();
         W2X_MLP_STAGE();
         __syncthreads();
