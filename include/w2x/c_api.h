@@ -77,6 +77,7 @@ int w2x_describe_plan(const char* onnx_path, int batch, int tile, char* buf, siz
 void w2x_sha256_hex(const void* data, size_t len, char* out);
 /* diagnostic: per-phase cycle sums of the fused attention kernel when W2X_STAMPS=1 (8 values, cleared on read) */
 int w2x_debug_attn_stamps(unsigned long long* out);
+int w2x_debug_mlp_stamps(unsigned long long* out);   /* 16 values: [C==192][phase] */
 const char* w2x_version(void);
 
 #ifdef __cplusplus

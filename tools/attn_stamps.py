@@ -22,3 +22,14 @@ v = list(buf); names = ["gather+LN", "barrierA+stage+barrierB", "qkv products", 
 tot = sum(v[:7])
 for n, x in zip(names, v):
     print(f"{n:26s} {x:16d}  {100.0 * x / tot if n != 'waves' else 0:5.1f}%  per-wave {x / max(v[7], 1):9.0f} cyc")
+
+mb = (ctypes.c_ulonglong * 16)()
+L.w2x_debug_mlp_stamps(mb)
+eng.bench_resident(2)
+L.w2x_debug_mlp_stamps(mb)
+mn = ["load+LN", "barriers+stage", "GEMM1", "GELU", "GEMM2", "epilogue", "-", "waves"]
+for ci, cname in enumerate(("mlp C=96", "mlp C=192")):
+    v = list(mb)[8 * ci:8 * ci + 8]; tot = sum(v[:6])
+    print(cname)
+    for n, x in zip(mn, v):
+        if n != "-": print(f"    {n:18s} {100.0 * x / max(tot, 1) if n != 'waves' else 0:5.1f}%  per-wave {x / max(v[7], 1):9.0f}")

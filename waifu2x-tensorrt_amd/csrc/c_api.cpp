@@ -104,6 +104,7 @@ void w2x_sha256_hex(const void* data, size_t len, char* out) {
     memcpy(out, h.c_str(), 65);
 }
 
+int w2x_debug_mlp_stamps(unsigned long long* out) { return w2x::read_mlp_stamps(out) == hipSuccess ? 1 : 0; }
 int w2x_debug_attn_stamps(unsigned long long* out) { return w2x::read_swin_attn_stamps(out) == hipSuccess ? 1 : 0; }
 
 const char* w2x_version(void) { return "w2x-hip 0.1 (gfx950)"; }

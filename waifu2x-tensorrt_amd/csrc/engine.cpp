@@ -280,13 +280,17 @@ struct Img2Img::Impl {
     }
 
     // one pass of the network over the tiles currently in plan.in_tensor; the last op writes to `out_override`
-    void run_network(void* out_override) {
+    // `live` = tiles of this pass that carry image data; the zero-pad slots the reference appends to fill its last batch
+    // (img2img_render.cpp:281) are never read back (:298-299), so they are not computed at all.
+    void run_network(void* out_override, int live = -1) {
+        if (live < 0 || live > plan.B) live = plan.B;
         for (size_t i = 0; i < plan.ops.size(); ++i) {
             const Op& op = plan.ops[i];
             cur_op = (int)i;
             switch (op.kind) {
                 case OP_GEMM: {
                     GemmParams p = gemm[i];
+                    p.B = live;
                     if ((int)i == final_op && out_override) p.out.p = out_override;
                     stamp_begin(0, op.flops);
                     hipAssert(launch_gemm(p, stream));
@@ -296,7 +300,7 @@ struct Img2Img::Impl {
                 case OP_ATTN: {
                     const AttnOp& a = op.at;
                     AttnParams p;
-                    p.qkv = tensors[a.qkv]; p.out = tensors[a.out]; p.B = plan.B; p.nwin = a.nwin; p.heads = a.heads; p.hd = a.hd;
+                    p.qkv = tensors[a.qkv]; p.out = tensors[a.out]; p.B = live; p.nwin = a.nwin; p.heads = a.heads; p.hd = a.hd;
                     p.ntok = a.ws * a.ws; p.scale = a.scale; p.bias = blobs[a.bias]; p.maskid = (const int*)blobs[a.maskid];
                     stamp_begin(1, op.flops);
                     hipAssert(launch_attn(p, stream));
@@ -307,7 +311,7 @@ struct Img2Img::Impl {
                     const SwinAttnOp& a = op.sa;
                     const TensorDesc& d = plan.tensors[a.x];
                     SwinAttnParams p;
-                    p.x = tensors[a.x]; p.y = tensors[a.y]; p.table = (const int*)blobs[a.table]; p.H = a.H; p.W = a.W; p.ry = a.ry; p.rx = a.rx; p.B = plan.B; p.nwin = a.nwin; p.C = a.C; p.hd = a.hd;
+                    p.x = tensors[a.x]; p.y = tensors[a.y]; p.table = (const int*)blobs[a.table]; p.H = a.H; p.W = a.W; p.ry = a.ry; p.rx = a.rx; p.B = live; p.nwin = a.nwin; p.C = a.C; p.hd = a.hd;
                     p.wqkv = blobs[a.wqkv]; p.bqkv = (const float*)blobs[a.bqkv]; p.scale = a.scale; p.bias32 = (const float*)blobs[a.bias]; p.maskid = (const int*)blobs[a.maskid];
                     p.wproj = blobs[a.wproj]; p.bproj = (const float*)blobs[a.bproj]; p.eps = a.eps;
                     p.stats_out = a.stats_out >= 0 ? (float*)tensors[a.stats_out] : nullptr; p.eps_out = a.eps_out;
@@ -321,7 +325,7 @@ struct Img2Img::Impl {
                     const MlpOp& m = op.m;
                     const TensorDesc& d = plan.tensors[m.x];
                     MlpParams p;
-                    p.x = tensors[m.x]; p.y = tensors[m.y]; p.M = (long)d.B * d.H * d.W; p.C = m.C;
+                    p.x = tensors[m.x]; p.y = tensors[m.y]; p.M = (long)live * d.H * d.W; p.C = m.C;
                     p.w1 = blobs[m.w1]; p.b1 = (const float*)blobs[m.b1]; p.w2 = blobs[m.w2]; p.b2 = (const float*)blobs[m.b2];
                     p.eps = m.eps; p.stats_out = m.stats_out >= 0 ? (float*)tensors[m.stats_out] : nullptr; p.eps_out = m.eps_out;
                     if (d.C != m.C || plan.tensors[m.y].C != m.C) throw std::runtime_error("plan: MLP width mismatch");
@@ -333,7 +337,7 @@ struct Img2Img::Impl {
                 case OP_SE: {
                     const SeOp& s = op.se;
                     SeParams p;
-                    p.pool = (const float*)tensors[s.pool]; p.scale = (float*)tensors[s.scale]; p.B = plan.B; p.C = s.C;
+                    p.pool = (const float*)tensors[s.pool]; p.scale = (float*)tensors[s.scale]; p.B = live; p.C = s.C;
                     p.Cs = plan.tensors[s.pool].C; p.Cmid = s.Cmid; p.inv_count = s.inv_count; p.nblocks = s.nblocks; p.Mrows = s.Mrows;
                     p.w1 = (const float*)blobs[s.w1]; p.b1 = (const float*)blobs[s.b1]; p.w2 = (const float*)blobs[s.w2]; p.b2 = (const float*)blobs[s.b2];
                     stamp_begin(2, 0);
@@ -344,7 +348,7 @@ struct Img2Img::Impl {
                 case OP_SCALE_ADD: {
                     const TensorDesc& d = plan.tensors[op.se.pool];
                     stamp_begin(2, 0);
-                    hipAssert(launch_scale(tensors[op.se.pool], (const float*)tensors[op.se.scale], d.B, d.H * d.W, d.C, stream));
+                    hipAssert(launch_scale(tensors[op.se.pool], (const float*)tensors[op.se.scale], live, d.H * d.W, d.C, stream));
                     stamp_end();
                     break;
                 }
@@ -370,6 +374,11 @@ struct Img2Img::Impl {
         const int batchCount = (int)std::lround(std::ceil((double)(grid.count * steps) / userB));   // img2img_render.cpp:249
         const int passCount = (batchCount + S - 1) / S;
         const size_t slot_bytes = (size_t)To * To * 4 * sizeof(uint16_t);
+        const bool poison = getenv("W2X_POISON") != nullptr;   // test hook: stale activations become fp16 NaNs
+        if (poison) {
+            hipAssert(hipMemsetAsync(arena_base, 0x7E, arena_bytes, stream));
+            hipAssert(hipMemsetAsync(d_slab, 0x7E, slab_cap, stream));
+        }
         for (int bi = 0; bi < passCount; ++bi) {
             const auto t0 = std::chrono::steady_clock::now();
             GatherParams gp;
@@ -378,7 +387,8 @@ struct Img2Img::Impl {
             stamp_begin(3, 0);
             hipAssert(launch_gather(gp, stream));
             stamp_end();
-            run_network((uint8_t*)d_slab + (size_t)bi * B * slot_bytes);
+            const int live = std::max(0, std::min(B, grid.count * steps - bi * B));
+            run_network((uint8_t*)d_slab + (size_t)bi * B * slot_bytes, live);
             if (report) {
                 const auto t1 = std::chrono::steady_clock::now();
                 const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();

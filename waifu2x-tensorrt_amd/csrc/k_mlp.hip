@@ -10,6 +10,7 @@
 // residual add and the HBM stores are 16-byte row pieces; LayerNorm statistics of the produced rows are emitted for
 // the next op when requested.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace w2x {
 namespace {
@@ -64,7 +65,20 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
-template <int C>
+// Diagnostic build only (W2X_STAMPS=1): per-phase s_memtime deltas summed over all waves.
+// g_mlp_stamps[C==192][k]: 0 load+LN, 1 barriers+stage, 2 GEMM1, 3 GELU, 4 GEMM2, 5 epilogue, 7 waves
+__device__ unsigned long long g_mlp_stamps[2][8];
+#define W2X_MSTAMP(K)                                                                                       \
+    if (STAMPS) {                                                                                           \
+        unsigned long long t_;                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        if (lane == 0) atomicAdd(&g_mlp_stamps[C == 192][K], t_ - tprev);                                   \
+        tprev = t_;                                                                                         \
+    }
+
+template <int C, bool STAMPS>
 __global__ __launch_bounds__(256, (C == 96 ? 2 : 1)) void mlp_kernel(const MlpParams p) {
     constexpr int BM = 128, HC = 64;
     constexpr int LDX = C + 8;            // Xs row stride (halves)
@@ -86,6 +100,8 @@ __global__ __launch_bounds__(256, (C == 96 ? 2 : 1)) void mlp_kernel(const MlpPa
     static_assert((HC * LDX + C * LDW2) >= 0, "");
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned long long tprev = 0;
+    if (STAMPS) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); if (lane == 0) atomicAdd(&g_mlp_stamps[C == 192][7], 1ull); }
     const long row0 = (long)blockIdx.x * BM;
     const _Float16* __restrict__ X = (const _Float16*)p.x;
     const _Float16* __restrict__ W1 = (const _Float16*)p.w1;   // [2C][C]
@@ -154,9 +170,11 @@ __global__ __launch_bounds__(256, (C == 96 ? 2 : 1)) void mlp_kernel(const MlpPa
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {   // fully unrolled: prefetch registers are renamed statically, so the loads for chunk ch+1
                                          // are only waited for when that chunk is staged (a rolled loop makes hipcc wait right away)
+        W2X_MSTAMP(ch == 0 ? 0 : 4)
         __syncthreads();
         W2X_MLP_STAGE();
         __syncthreads();
+        W2X_MSTAMP(1)
         if (ch + 1 < NCH) W2X_MLP_PREFETCH(ch + 1);
         // GEMM1 (transposed): acc1[ht][tt] = W1s[16ht..][:] * Xs[trow+16tt..][:]^T   (rows = hidden, cols = tokens)
         float4v acc1[4][2];
@@ -174,6 +192,7 @@ __global__ __launch_bounds__(256, (C == 96 ? 2 : 1)) void mlp_kernel(const MlpPa
                 for (int tt = 0; tt < 2; ++tt) acc1[ht][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb[tt], acc1[ht][tt], 0, 0, 0);
             }
         }
+        W2X_MSTAMP(2)
         // bias + GELU in place; lane holds hidden rows 16ht + 4g + j of token column fr
         half8 a2[2][2];   // [tt][k-step]: A fragments of GEMM2, k order = (ht even: j 0..3, ht odd: j 4..7)
 #pragma unroll
@@ -188,6 +207,7 @@ __global__ __launch_bounds__(256, (C == 96 ? 2 : 1)) void mlp_kernel(const MlpPa
                                      (_Float16)gelu_fast(o[2] + bo[2]), (_Float16)gelu_fast(o[3] + bo[3])};
             }
         }
+        W2X_MSTAMP(3)
         // GEMM2: acc2[tt][nt] += H[tokens][hidden chunk] * W2s[16nt..][chunk]^T with the matching k permutation
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -203,6 +223,7 @@ __global__ __launch_bounds__(256, (C == 96 ? 2 : 1)) void mlp_kernel(const MlpPa
             }
         }
     }
+    W2X_MSTAMP(4)
     __syncthreads();
 
     // ---- epilogue: residual pieces are fetched first (latency overlaps the tile write), accumulators + b2 -> fp16
@@ -248,6 +269,7 @@ __global__ __launch_bounds__(256, (C == 96 ? 2 : 1)) void mlp_kernel(const MlpPa
             }
         }
     }
+    W2X_MSTAMP(5)
 }
 
 template <int C>
@@ -255,10 +277,12 @@ hipError_t launch_mlp_c(const MlpParams& p, hipStream_t s) {
     constexpr int BM = 128, HC = 64, LDX = C + 8, LDW2 = HC + 8, LDC = C + 8;
     constexpr int W_BYTES = (HC * LDX + C * LDW2) * 2, C_BYTES = BM * LDC * 2;
     constexpr int SMEM = BM * LDX * 2 + (W_BYTES > C_BYTES ? W_BYTES : C_BYTES);
-    auto kern = mlp_kernel<C>;
+    static const bool stamps = getenv("W2X_STAMPS") != nullptr;
+    auto kern = stamps ? mlp_kernel<C, true> : mlp_kernel<C, false>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        hipError_t e = hipFuncSetAttribute((const void*)mlp_kernel<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mlp_kernel<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -268,6 +292,13 @@ hipError_t launch_mlp_c(const MlpParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+hipError_t read_mlp_stamps(unsigned long long* out) {   // diagnostic: 16 values, cleared on read
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_stamps), sizeof(unsigned long long) * 16);
+    if (e != hipSuccess) return e;
+    unsigned long long z[16] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_stamps), z, sizeof(z));
+}
 
 hipError_t launch_mlp(const MlpParams& p, hipStream_t s) {
     if (p.C == 96) return launch_mlp_c<96>(p, s);

@@ -103,6 +103,7 @@ hipError_t launch_attn(const AttnParams& p, hipStream_t s);
 hipError_t launch_mlp(const MlpParams& p, hipStream_t s);
 hipError_t launch_swin_attn(const SwinAttnParams& p, hipStream_t s);
 bool swin_attn_supported(int C, int heads, int hd, int ws);
+hipError_t read_mlp_stamps(unsigned long long* out);         // diagnostic (W2X_STAMPS=1): 2 x 8 per-phase cycle sums, see k_mlp.hip
 hipError_t read_swin_attn_stamps(unsigned long long* out);   // diagnostic (W2X_STAMPS=1): per-phase cycle sums, see k_swinattn.hip
 hipError_t launch_se(const SeParams& p, hipStream_t s);
 hipError_t launch_scale(void* x, const float* scale, int B, int HW, int Cs, hipStream_t s);

@@ -123,7 +123,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "w2x_create", "w2x_destroy", "w2x_set_message_callback", "w2x_set_progress_callback", "w2x_build", "w2x_load",
     "w2x_render", "w2x_infer", "w2x_output_tile_size", "w2x_plan_flops", "w2x_pass_tiles", "w2x_last_render_ms", "w2x_bench_resident", "w2x_profile_frame", "w2x_op_times",
-    "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_sha256_hex", "w2x_debug_attn_stamps", "w2x_version"]
+    "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_sha256_hex", "w2x_debug_attn_stamps", "w2x_debug_mlp_stamps", "w2x_version"]
 
 
 class Img2Img:
