@@ -475,12 +475,13 @@ bool swin_attn_supported(int C, int heads, int hd, int ws) {
     return ws == 6 && heads * hd == C && ((C == 96 && hd == 16) || (C == 192 && hd == 32));
 }
 
-hipError_t launch_swin_attn96(const SwinAttnParams& p, hipStream_t s);   // k_swinattn96.hip
+hipError_t launch_swin_attn96(const SwinAttnParams& p, hipStream_t s);    // k_swinattn96.hip
+hipError_t launch_swin_attn192(const SwinAttnParams& p, hipStream_t s);   // k_swinattn192.hip
 
 hipError_t launch_swin_attn(const SwinAttnParams& p, hipStream_t s) {
-    static const bool v1 = getenv("W2X_SA_V1") != nullptr;   // A/B switch: barrier-staged variant for C = 96
+    static const bool v1 = getenv("W2X_SA_V1") != nullptr;   // A/B switch: the barrier-staged kernel of this file
     if (p.C == 96 && p.hd == 16) return v1 ? launch_sa<96, 16>(p, s) : launch_swin_attn96(p, s);
-    if (p.C == 192 && p.hd == 32) return launch_sa<192, 32>(p, s);
+    if (p.C == 192 && p.hd == 32) return v1 ? launch_sa<192, 32>(p, s) : launch_swin_attn192(p, s);
     return hipErrorInvalidValue;
 }
 

@@ -1,0 +1,349 @@
+// Fused Swin attention branch, C = 192 / 6 heads of 32 / window 6x6, register-resident variant for gfx950.
+//     y = x + proj( W-MSA( LayerNorm(x) ) )
+// Same math, parameters and bias-table layout as k_swinattn.hip; the schedule follows k_swinattn96.hip (a workgroup =
+// 4 waves = 2 windows, wave (w, hp) owns window w and the heads 2*it + hp) and goes one step further: with a head
+// dimension of 32 the accumulator layout of v_mfma_f32_16x16x32_f16 (lane (col, g) holds rows 4g..4g+3) IS an operand
+// layout (lane (row|col, g) holds 8 k-values) once two 16-feature tiles are paired, with the k order permuted the same
+// way on both sides.  So
+//     q^T, k^T (rows = features) -> B / A operands of S^T = K Q^T      straight from the accumulators,
+//     v (rows = tokens)          -> A operand of O^T = V^T P^T         straight from the accumulators,
+//     S^T after the softmax      -> B operand of O^T                   (as in the other variants),
+// and q, k, v, S, P never touch LDS.  LDS only holds the normalised x slab (MFMA operand of the q/k/v products, read by
+// both waves of a window) and the head outputs (operand of proj).  Weights come from L2 as fragments, one 32x192 matrix
+// (12 fragments) ahead of its use.  Three workgroup barriers in the whole kernel.
+//
+// Window slab: 48 rows; tokens 0..31 on rows 0..31, tokens 32..35 on rows 32, 36, 40, 44, zero rows between.  That puts
+// key 32+g on row 4g of the third key tile (one per lane group, register j = 0: the softmax touches 9 instead of 12
+// values per lane, the layout the bias table is stored for) and - because q, k and v are all computed from the same slab -
+// needs no data movement for it: the third tiles of K, V and Q come out of the MFMAs already arranged that way.
+#include "kernels.h"
+
+namespace w2x {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void sum_sq8(const half8 v, float& s, float& q) {
+    const half2v one = {(_Float16)1.f, (_Float16)1.f};
+    s = 0.f; q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const half2v h = {v[2 * k], v[2 * k + 1]};
+        s = __builtin_amdgcn_fdot2(h, one, s, false);
+        q = __builtin_amdgcn_fdot2(h, h, q, false);
+    }
+}
+__device__ __forceinline__ half8 norm8(const half8 v, float rstd, float nm) {
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)fmaf((float)v[e], rstd, nm);
+    return o;
+}
+// see k_swinattn.hip for why the swaps are inline asm on two registers
+__device__ __forceinline__ void swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float rows_max(float v) { float a = v, b = v; swap16(a, b); v = fmaxf(a, b); a = v; b = v; swap32(a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float rows_sum(float v) { float a = v, b = v; swap16(a, b); v = a + b; a = v; b = v; swap32(a, b); return a + b; }
+// sum over aligned groups of 32 lanes: DPP inside the 16-lane rows, one row swap across
+__device__ __forceinline__ float group_sum32(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    float a = v, b = v; swap16(a, b);
+    return a + b;
+}
+
+constexpr int C = 192, HD = 32, NH = 6, NTOK = 36, G = 2, R = G * NTOK, RT = 5, RP = RT * 16;
+constexpr int SLAB = 48, RPX = G * SLAB;       // slab rows per window / in the tile
+constexpr int LDX = C + 8;                     // 200 halves: 400-byte rows, 16-byte pieces rotate over the banks
+constexpr int XS = RPX * LDX, OS = RP * LDX;
+constexpr int SMEM192 = (XS + OS) * 2;
+constexpr int LPR = 32, PPR = C / 8, RPP = 256 / LPR, NPASS = R / RPP;   // row passes: 32 lanes per row, 8 rows per pass, 9 passes
+static_assert(R % RPP == 0, "row passes");
+
+__device__ __forceinline__ int slab_row(int t) { return t < 32 ? t : 32 + 4 * (t - 32); }
+
+__global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    _Float16* Xs = (_Float16*)smem;              // [RPX][LDX] normalised x slabs; later the output tile [RP][LDX]
+    _Float16* Os = Xs + XS;                      // [RP][LDX]  attention output, all heads, token order
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+
+    const int iw0 = blockIdx.x * G, iw1 = iw0 + 1, itotal = p.B * p.nwin;
+    const bool wok0 = iw0 < itotal, wok1 = iw1 < itotal;
+    const int HW = p.nwin * NTOK;
+    const int wb0 = iw0 / p.nwin, wb1 = iw1 / p.nwin;
+    const int pixbase0 = wb0 * HW, pixbase1 = wb1 * HW;
+    const int wl0 = iw0 - wb0 * p.nwin, wl1 = iw1 - wb1 * p.nwin;
+    const int nwx = p.W / 6;
+    const int wy0 = wl0 / nwx, wx0 = wl0 - wy0 * nwx, wy1 = wl1 / nwx, wx1 = wl1 - wy1 * nwx;
+    const _Float16* __restrict__ X = (const _Float16*)p.x;
+    const _Float16* __restrict__ Wqkv = (const _Float16*)p.wqkv;   // [3C][C]
+    const _Float16* __restrict__ Wproj = (const _Float16*)p.wproj; // [C][C]
+    const float4v zero4 = {0.f, 0.f, 0.f, 0.f};
+    const half8 zero8 = {};
+
+    // this wave's attention unit
+    const int aw = wv >> 1, ahp = wv & 1;
+    const bool aok = aw == 0 ? wok0 : wok1;
+    const int amask = aok ? p.maskid[aw == 0 ? wl0 : wl1] : 0;
+    const int sbase = aw * SLAB, tbase = aw * NTOK;
+
+    // weight fragments of one 32 x 192 matrix (M = 0 q, 1 k, 2 v) of head H: fragment [ft*6 + ks] = rows ft*16 + fr,
+    // columns ks*32 + 8g .. +7.  Two register sets alternate (the unrolled matrix sequence indexes them statically).
+    half8 wr[2][12];
+    const _Float16* wlane = Wqkv + (size_t)fr * C + g * 8;
+#define W2X_LOAD_W(SET, M, H)                                                                                \
+    {                                                                                                        \
+        _Pragma("unroll") for (int ft = 0; ft < 2; ++ft)                                                     \
+            _Pragma("unroll") for (int ks = 0; ks < 6; ++ks)                                                 \
+                wr[SET][ft * 6 + ks] = *(const half8*)(wlane + (size_t)((M) * C + (H) * HD + ft * 16) * C + ks * 32); \
+    }
+    W2X_LOAD_W(0, 0, ahp);
+
+    // ---- gather + LayerNorm into the slabs
+    int my_pix[NPASS];
+    {
+        const int li = tid & (LPR - 1);
+        half8 xr[NPASS];
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int r = ps * RPP + tid / LPR;          // token row 0..71
+            const int w = r >= NTOK ? 1 : 0;
+            int pix = -1;
+            if (w == 0 ? wok0 : wok1) {
+                const int t = r - w * NTOK;
+                if (p.ry >= 0) {
+                    const int ty = t / 6, tx = t - ty * 6;
+                    int y = (w == 0 ? wy0 : wy1) * 6 + ty + p.ry, x = (w == 0 ? wx0 : wx1) * 6 + tx + p.rx;
+                    y -= y >= p.H ? p.H : 0; x -= x >= p.W ? p.W : 0;
+                    pix = (w == 0 ? pixbase0 : pixbase1) + y * p.W + x;
+                } else pix = (w == 0 ? pixbase0 : pixbase1) + p.table[(w == 0 ? wl0 : wl1) * NTOK + t];
+            }
+            my_pix[ps] = pix;
+            half8 h = {};
+            if (pix >= 0 && li < PPR) h = *(const half8*)(X + (size_t)pix * C + li * 8);
+            xr[ps] = h;
+        }
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int r = ps * RPP + tid / LPR;
+            const int w = r >= NTOK ? 1 : 0;
+            float s, q;
+            sum_sq8(xr[ps], s, q);
+            s = group_sum32(s);
+            q = group_sum32(q);
+            const float mean = s * (1.f / C);
+            const float rstd = rsqrtf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps);
+            if (li < PPR) *(half8*)(Xs + (w * SLAB + slab_row(r - w * NTOK)) * LDX + li * 8) = norm8(xr[ps], rstd, -mean * rstd);
+        }
+        // the 12 rows between tokens 32..35 of each slab are multiplied like the rest (results ignored): keep them finite
+        for (int i = tid; i < G * 12 * PPR; i += 256) {
+            const int rr = i / PPR, c = i - rr * PPR, w = rr / 12, k = rr - w * 12;
+            *(half8*)(Xs + (w * SLAB + 33 + (k / 3) * 4 + (k % 3)) * LDX + c * 8) = zero8;
+        }
+    }
+    __syncthreads();
+
+    const float qscale = p.scale * 1.44269504088896341f;   // log2(e) folded into q: softmax uses exp2
+    const int lane2 = g * 16 + (fr >> 2);                  // bias-table lane of the query this lane holds in query tile 2
+    half8 wp[3][6];                                        // proj fragments of this wave's three n-tiles, fetched at the end of the last head
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int h = 2 * it + ahp;
+        half8 qf[3], kf[3], vf0[2], vf1[2];
+        // ---- q^T and k^T: rows = features (A = weights), columns = slab rows (B = x)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int cur = (it * 3 + m) & 1;
+            W2X_LOAD_W(cur ^ 1, m + 1, h);                                     // next matrix of this head (k, then v)
+            float4v a[2][3] = {{zero4, zero4, zero4}, {zero4, zero4, zero4}};
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                half8 xf[3];
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt) xf[tt] = *(const half8*)(Xs + (sbase + tt * 16 + fr) * LDX + ks * 32 + g * 8);
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                    for (int tt = 0; tt < 3; ++tt) a[ft][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[cur][ft * 6 + ks], xf[tt], a[ft][tt], 0, 0, 0);
+            }
+            const float4v b0 = *(const float4v*)(p.bqkv + m * C + h * HD + g * 4);
+            const float4v b1 = *(const float4v*)(p.bqkv + m * C + h * HD + 16 + g * 4);
+            const float sc = m == 0 ? qscale : 1.f;
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt) {
+                half8 f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { f[j] = (_Float16)((a[0][tt][j] + b0[j]) * sc); f[4 + j] = (_Float16)((a[1][tt][j] + b1[j]) * sc); }
+                if (m == 0) qf[tt] = f; else kf[tt] = f;
+            }
+        }
+        // bias (+ shift mask) of this unit in load order (lower.cpp): per query tile 2 x float4 + 1 float per lane;
+        // fetched under the v products, it is the initial accumulator of S^T
+        float4v s[3][3];
+        {
+            const float* bias = p.bias32 + ((size_t)amask * NH + h) * (3 * 576);
+#pragma unroll
+            for (int qi = 0; qi < 3; ++qi) {
+                const int bl = qi < 2 ? lane : lane2;
+                s[qi][0] = *(const float4v*)(bias + qi * 576 + bl * 4);
+                s[qi][1] = *(const float4v*)(bias + qi * 576 + 256 + bl * 4);
+                float4v t = zero4; t[0] = bias[qi * 576 + 512 + bl];
+                s[qi][2] = t;
+            }
+        }
+        // ---- v: rows = slab rows (A = x), columns = features (B = weights)
+        {
+            const int cur = (it * 3 + 2) & 1;
+            if (it < 2) W2X_LOAD_W(cur ^ 1, 0, h + 2)                          // q of the next head
+            float4v a[3][2] = {{zero4, zero4}, {zero4, zero4}, {zero4, zero4}};
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                half8 xf[3];
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt) xf[tt] = *(const half8*)(Xs + (sbase + tt * 16 + fr) * LDX + ks * 32 + g * 8);
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                    for (int tt = 0; tt < 3; ++tt) a[tt][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[tt], wr[cur][ft * 6 + ks], a[tt][ft], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) {
+                const float bvv = p.bqkv[2 * C + h * HD + ft * 16 + fr];
+                half8 f0, f1 = zero8;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { f0[j] = (_Float16)(a[0][ft][j] + bvv); f0[4 + j] = (_Float16)(a[1][ft][j] + bvv); }
+                f1[0] = (_Float16)(a[2][ft][0] + bvv);                          // slab row 32 + 4g = token 32 + g
+                vf0[ft] = f0; vf1[ft] = f1;
+            }
+        }
+        // ---- S^T = K Q^T on top of the bias, softmax over the keys (lane-local + two row swaps)
+#pragma unroll
+        for (int qi = 0; qi < 3; ++qi)
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) s[qi][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt], qf[qi], s[qi][kt], 0, 0, 0);
+        float inv[3];
+        half8 pf0[3], pf1[3];
+#pragma unroll
+        for (int qi = 0; qi < 3; ++qi) {
+            float mx = fmaxf(fmaxf(s[qi][0][0], s[qi][0][1]), fmaxf(s[qi][0][2], s[qi][0][3]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[qi][1][j]);
+            mx = rows_max(fmaxf(mx, s[qi][2][0]));
+            float l = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float e = __builtin_amdgcn_exp2f(s[qi][kt][j] - mx); s[qi][kt][j] = e; l += e; }
+            { const float e = __builtin_amdgcn_exp2f(s[qi][2][0] - mx); s[qi][2][0] = e; l += e; }
+            l = rows_sum(l);
+            inv[qi] = __builtin_amdgcn_rcpf(l);
+            pf0[qi] = (half8){(_Float16)s[qi][0][0], (_Float16)s[qi][0][1], (_Float16)s[qi][0][2], (_Float16)s[qi][0][3],
+                              (_Float16)s[qi][1][0], (_Float16)s[qi][1][1], (_Float16)s[qi][1][2], (_Float16)s[qi][1][3]};
+            half8 t = zero8; t[0] = (_Float16)s[qi][2][0];
+            pf1[qi] = t;
+        }
+        if (it == 2) {   // the weight registers are free now: fetch this wave's proj fragments under the last products
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) wp[t][ks] = *(const half8*)(Wproj + (size_t)((wv * 3 + t) * 16 + fr) * C + ks * 32 + g * 8);
+        }
+        // ---- O^T = V^T P^T: rows = features, columns = queries; scaled by 1/l and parked in Os (token order)
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int qi = 0; qi < 3; ++qi) {
+                float4v o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf0[ft], pf0[qi], zero4, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf1[ft], pf1[qi], o, 0, 0, 0);
+                const int query = qi < 2 ? qi * 16 + fr : 32 + (fr >> 2);
+                if (aok && (qi < 2 || (fr & 3) == 0)) {
+                    half4 oh;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) oh[j] = (_Float16)(o[j] * inv[qi]);
+                    *(half4*)(Os + (tbase + query) * LDX + h * HD + ft * 16 + g * 4) = oh;
+                }
+            }
+    }
+#undef W2X_LOAD_W
+    __syncthreads();      // every wave's head outputs are in Os; nobody reads the slabs any more
+
+    // ---- proj: out = Os * Wproj^T + b -> tile over Xs.  Wave w owns output columns 48w .. 48w+47 for all five row tiles.
+    {
+        float bp[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) bp[t] = p.bproj[(wv * 3 + t) * 16 + fr];
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt) {
+            float4v acc[3] = {zero4, zero4, zero4};
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                const half8 of = *(const half8*)(Os + (mt * 16 + fr) * LDX + ks * 32 + g * 8);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(of, wp[t][ks], acc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Xs[(mt * 16 + g * 4 + j) * LDX + (wv * 3 + t) * 16 + fr] = (_Float16)(acc[t][j] + bp[t]);
+        }
+    }
+    __syncthreads();
+
+    // ---- row pieces: + residual x, scatter store, LayerNorm statistics for the next op
+    {
+        _Float16* __restrict__ Y = (_Float16*)p.y;
+        const int li = tid & (LPR - 1);
+        half8 xres[NPASS];
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            half8 h = {};
+            if (my_pix[ps] >= 0 && li < PPR) h = *(const half8*)(X + (size_t)my_pix[ps] * C + li * 8);
+            xres[ps] = h;
+        }
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int r = ps * RPP + tid / LPR;
+            const int pix = my_pix[ps];
+            const bool ok = pix >= 0 && li < PPR;
+            half8 o = {};
+            if (ok) {
+                o = *(const half8*)(Xs + r * LDX + li * 8) + xres[ps];
+                *(half8*)(Y + (size_t)pix * C + li * 8) = o;
+            }
+            if (p.stats_out) {
+                float s, q;
+                sum_sq8(o, s, q);
+                s = group_sum32(s);
+                q = group_sum32(q);
+                const float mean = s * (1.f / C);
+                if (ok && li == 0) { p.stats_out[2 * (size_t)pix] = mean; p.stats_out[2 * (size_t)pix + 1] = rsqrtf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps_out); }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_swin_attn192(const SwinAttnParams& p, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)swin_attn192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM192);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const long total_win = (long)p.B * p.nwin;
+    dim3 grid((unsigned)((total_win + G - 1) / G));
+    hipLaunchKernelGGL(swin_attn192_kernel, grid, dim3(256), SMEM192, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace w2x
