@@ -75,7 +75,7 @@ int w2x_tile_weights(int which, int overlap_x, int overlap_y, int size, float* o
 int w2x_describe_plan(const char* onnx_path, int batch, int tile, char* buf, size_t cap);
 /* sha256 hex digest (names engine files; utilities/sha256.h:39-94). out: 65 bytes. */
 void w2x_sha256_hex(const void* data, size_t len, char* out);
-/* diagnostic: per-phase cycle sums of the fused attention kernel when W2X_STAMPS=1 (8 values, cleared on read) */
+/* diagnostic: per-phase cycle sums of the fused attention kernels when W2X_STAMPS=1 (2 x 8 values, cleared on read) */
 int w2x_debug_attn_stamps(unsigned long long* out);
 int w2x_debug_mlp_stamps(unsigned long long* out);   /* 16 values: [C==192][phase] */
 const char* w2x_version(void);

@@ -14,14 +14,17 @@ assert eng.build(path, pkg.BuildConfig.fixed(4, 256)) and eng.load(path, pkg.Ren
 frame = np.random.default_rng(0).integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
 eng.render(frame)
 L = pkg.lib()
-buf = (ctypes.c_ulonglong * 8)()
+buf = (ctypes.c_ulonglong * 16)()
 L.w2x_debug_attn_stamps(buf)
 eng.bench_resident(2)
 L.w2x_debug_attn_stamps(buf)
-v = list(buf); names = ["gather+LN", "barrierA+stage+barrierB", "qkv products", "barrier C", "attention", "proj", "final rows", "waves"]
-tot = sum(v[:7])
-for n, x in zip(names, v):
-    print(f"{n:26s} {x:16d}  {100.0 * x / tot if n != 'waves' else 0:5.1f}%  per-wave {x / max(v[7], 1):9.0f} cyc")
+for title, v, names in (("barrier-staged kernel (k_swinattn.hip)", list(buf)[:8], ["gather+LN", "barrierA+stage+barrierB", "qkv products", "barrier C", "attention", "proj", "final rows", "waves"]),
+                        ("C=192 register-resident kernel", list(buf)[8:], ["gather+LN+barrier", "q,k products", "v products", "S+softmax", "O+store", "barrier+proj", "barrier+final rows", "waves"])):
+    tot = sum(v[:7])
+    if not tot: continue
+    print(title)
+    for n, x in zip(names, v):
+        print(f"    {n:26s} {x:16d}  {100.0 * x / tot if n != 'waves' else 0:5.1f}%  per-wave {x / max(v[7], 1):9.0f} cyc")
 
 mb = (ctypes.c_ulonglong * 16)()
 L.w2x_debug_mlp_stamps(mb)

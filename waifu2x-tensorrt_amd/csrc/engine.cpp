@@ -126,6 +126,7 @@ struct Img2Img::Impl {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<void*> tensors, blobs;   // tensors point into one arena
+    std::vector<void*> frag_blobs;       // per blob id: fragment-major copy of a weight matrix (or null)
     void* arena_base = nullptr; size_t arena_bytes = 0;
     std::vector<GemmParams> gemm;      // per op (kind == OP_GEMM)
     std::vector<int> pool_tensors;
@@ -167,6 +168,8 @@ struct Img2Img::Impl {
         // img2img_base.cpp:6-10 frees the IO buffers; here everything the engine owns
         if (arena_base) { hipFree(arena_base); arena_base = nullptr; }
         for (void* p : blobs) if (p) hipFree(p);
+        for (void* p : frag_blobs) if (p) hipFree(p);
+        frag_blobs.clear();
         tensors.clear(); blobs.clear(); gemm.clear(); pool_tensors.clear();
         for (void** p : {(void**)&d_frame, (void**)&d_out, &d_slab, (void**)&d_slots, (void**)&d_rampx, (void**)&d_rampy, (void**)&d_blob_in, (void**)&d_blob_out})
             if (*p) { hipFree(*p); *p = nullptr; }
@@ -246,6 +249,26 @@ struct Img2Img::Impl {
             hipAssert(hipMalloc(&blobs[i], d.size() + 256));   // slack: kernels may read a vector past a table's last row
             hipAssert(hipMemcpy(blobs[i], d.data(), d.size(), hipMemcpyHostToDevice));
         }
+        // fragment-major copies of the attention weights for the register-resident C = 192 kernel: tile (16 rows) x
+        // k-step (32 columns) blocks of 64 lanes x 8 halves, lane = (row & 15) + 16 * (column / 8 & 3)
+        frag_blobs.assign(plan.blobs.size(), nullptr);
+        auto frag_major = [&](int blob, int N, int K) {
+            if (frag_blobs[blob]) return;
+            const auto& d = plan.blobs[blob].data;
+            if (d.size() != (size_t)N * K * 2 || N % 16 || K % 32) throw std::runtime_error("plan: attention weight shape");
+            const uint16_t* w = (const uint16_t*)d.data();
+            std::vector<uint16_t> f((size_t)N * K);
+            const int KS = K / 32;
+            for (int nt = 0; nt < N / 16; ++nt)
+                for (int ks = 0; ks < KS; ++ks)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e)
+                            f[(((size_t)nt * KS + ks) * 64 + lane) * 8 + e] = w[(size_t)(nt * 16 + (lane & 15)) * K + ks * 32 + (lane >> 4) * 8 + e];
+            hipAssert(hipMalloc(&frag_blobs[blob], f.size() * 2 + 256));
+            hipAssert(hipMemcpy(frag_blobs[blob], f.data(), f.size() * 2, hipMemcpyHostToDevice));
+        };
+        for (const Op& op : plan.ops)
+            if (op.kind == OP_SWINATTN && op.sa.C == 192) { frag_major(op.sa.wqkv, 3 * op.sa.C, op.sa.C); frag_major(op.sa.wproj, op.sa.C, op.sa.C); }
         gemm.assign(plan.ops.size(), GemmParams{});
         for (size_t i = 0; i < plan.ops.size(); ++i) {
             const Op& op = plan.ops[i];
@@ -314,6 +337,7 @@ struct Img2Img::Impl {
                     p.x = tensors[a.x]; p.y = tensors[a.y]; p.table = (const int*)blobs[a.table]; p.H = a.H; p.W = a.W; p.ry = a.ry; p.rx = a.rx; p.B = live; p.nwin = a.nwin; p.C = a.C; p.hd = a.hd;
                     p.wqkv = blobs[a.wqkv]; p.bqkv = (const float*)blobs[a.bqkv]; p.scale = a.scale; p.bias32 = (const float*)blobs[a.bias]; p.maskid = (const int*)blobs[a.maskid];
                     p.wproj = blobs[a.wproj]; p.bproj = (const float*)blobs[a.bproj]; p.eps = a.eps;
+                    p.wqkv_frag = frag_blobs[a.wqkv]; p.wproj_frag = frag_blobs[a.wproj];
                     p.stats_out = a.stats_out >= 0 ? (float*)tensors[a.stats_out] : nullptr; p.eps_out = a.eps_out;
                     if (d.C != a.C || plan.tensors[a.y].C != a.C || d.H * d.W != a.nwin * a.ws * a.ws) throw std::runtime_error("plan: attention geometry mismatch");
                     stamp_begin(1, op.flops);

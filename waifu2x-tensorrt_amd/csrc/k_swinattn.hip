@@ -463,12 +463,16 @@ hipError_t launch_sa(const SwinAttnParams& p, hipStream_t s) {
 
 }  // namespace
 
-// copies and clears the diagnostic stamp counters (8 values)
+hipError_t read_swin_attn192_stamps(unsigned long long* out);   // k_swinattn192.hip
+
+// copies and clears the diagnostic stamp counters: out[0..7] this file's kernel, out[8..15] the C = 192 register-resident one
 hipError_t read_swin_attn_stamps(unsigned long long* out) {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sa_stamps), sizeof(unsigned long long) * 8);
     if (e != hipSuccess) return e;
     unsigned long long z[8] = {};
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_sa_stamps), z, sizeof(z));
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_sa_stamps), z, sizeof(z));
+    if (e != hipSuccess) return e;
+    return read_swin_attn192_stamps(out + 8);
 }
 
 bool swin_attn_supported(int C, int heads, int hd, int ws) {
@@ -481,7 +485,7 @@ hipError_t launch_swin_attn192(const SwinAttnParams& p, hipStream_t s);   // k_s
 hipError_t launch_swin_attn(const SwinAttnParams& p, hipStream_t s) {
     static const bool v1 = getenv("W2X_SA_V1") != nullptr;   // A/B switch: the barrier-staged kernel of this file
     if (p.C == 96 && p.hd == 16) return v1 ? launch_sa<96, 16>(p, s) : launch_swin_attn96(p, s);
-    if (p.C == 192 && p.hd == 32) return v1 ? launch_sa<192, 32>(p, s) : launch_swin_attn192(p, s);
+    if (p.C == 192 && p.hd == 32) return (v1 || !p.wqkv_frag || !p.wproj_frag) ? launch_sa<192, 32>(p, s) : launch_swin_attn192(p, s);
     return hipErrorInvalidValue;
 }
 

@@ -17,6 +17,7 @@
 // values per lane, the layout the bias table is stored for) and - because q, k and v are all computed from the same slab -
 // needs no data movement for it: the third tiles of K, V and Q come out of the MFMAs already arranged that way.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace w2x {
 namespace {
@@ -67,6 +68,21 @@ static_assert(R % RPP == 0, "row passes");
 
 __device__ __forceinline__ int slab_row(int t) { return t < 32 ? t : 32 + 4 * (t - 32); }
 
+// Diagnostic build only (W2X_STAMPS=1 at run time selects it): per-phase s_memtime deltas summed over all waves.
+// g_sa192_stamps[k]: 0 gather+LN+barrier, 1 q and k products, 2 v products, 3 S + softmax, 4 O + store, 5 barrier + proj,
+// 6 barrier + final rows, 7 waves counted.
+__device__ unsigned long long g_sa192_stamps[8];
+#define W2X_STAMP(K)                                                                                        \
+    if (STAMPS) {                                                                                           \
+        unsigned long long t_;                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        if (lane == 0) atomicAdd(&g_sa192_stamps[K], t_ - tprev);                                           \
+        tprev = t_;                                                                                         \
+    }
+
+template <bool STAMPS>
 __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* Xs = (_Float16*)smem;              // [RPX][LDX] normalised x slabs; later the output tile [RP][LDX]
@@ -85,10 +101,12 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
     const int nwx = p.W / 6;
     const int wy0 = wl0 / nwx, wx0 = wl0 - wy0 * nwx, wy1 = wl1 / nwx, wx1 = wl1 - wy1 * nwx;
     const _Float16* __restrict__ X = (const _Float16*)p.x;
-    const _Float16* __restrict__ Wqkv = (const _Float16*)p.wqkv;   // [3C][C]
-    const _Float16* __restrict__ Wproj = (const _Float16*)p.wproj; // [C][C]
+    const _Float16* __restrict__ Wqkv = (const _Float16*)p.wqkv_frag;    // [36 row tiles][6 k-steps][64 lanes][8]
+    const _Float16* __restrict__ Wproj = (const _Float16*)p.wproj_frag;  // [12 row tiles][6 k-steps][64 lanes][8]
     const float4v zero4 = {0.f, 0.f, 0.f, 0.f};
     const half8 zero8 = {};
+    unsigned long long tprev = 0;
+    if (STAMPS) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); if (lane == 0) atomicAdd(&g_sa192_stamps[7], 1ull); }
 
     // this wave's attention unit
     const int aw = wv >> 1, ahp = wv & 1;
@@ -97,14 +115,14 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
     const int sbase = aw * SLAB, tbase = aw * NTOK;
 
     // weight fragments of one 32 x 192 matrix (M = 0 q, 1 k, 2 v) of head H: fragment [ft*6 + ks] = rows ft*16 + fr,
-    // columns ks*32 + 8g .. +7.  Two register sets alternate (the unrolled matrix sequence indexes them statically).
+    // columns ks*32 + 8g .. +7; stored fragment-major, so the twelve loads are twelve consecutive KiB.
+    // Two register sets alternate (the unrolled matrix sequence indexes them statically).
     half8 wr[2][12];
-    const _Float16* wlane = Wqkv + (size_t)fr * C + g * 8;
+    const _Float16* wlane = Wqkv + lane * 8;
 #define W2X_LOAD_W(SET, M, H)                                                                                \
     {                                                                                                        \
-        _Pragma("unroll") for (int ft = 0; ft < 2; ++ft)                                                     \
-            _Pragma("unroll") for (int ks = 0; ks < 6; ++ks)                                                 \
-                wr[SET][ft * 6 + ks] = *(const half8*)(wlane + (size_t)((M) * C + (H) * HD + ft * 16) * C + ks * 32); \
+        _Pragma("unroll") for (int f = 0; f < 12; ++f)                                                       \
+            wr[SET][f] = *(const half8*)(wlane + (size_t)(((M) * NH + (H)) * 12 + f) * 512);                 \
     }
     W2X_LOAD_W(0, 0, ahp);
 
@@ -151,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
         }
     }
     __syncthreads();
+    W2X_STAMP(0)
 
     const float qscale = p.scale * 1.44269504088896341f;   // log2(e) folded into q: softmax uses exp2
     const int lane2 = g * 16 + (fr >> 2);                  // bias-table lane of the query this lane holds in query tile 2
@@ -186,6 +205,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
                 if (m == 0) qf[tt] = f; else kf[tt] = f;
             }
         }
+        W2X_STAMP(1)
         // bias (+ shift mask) of this unit in load order (lower.cpp): per query tile 2 x float4 + 1 float per lane;
         // fetched under the v products, it is the initial accumulator of S^T
         float4v s[3][3];
@@ -225,6 +245,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
                 vf0[ft] = f0; vf1[ft] = f1;
             }
         }
+        W2X_STAMP(2)
         // ---- S^T = K Q^T on top of the bias, softmax over the keys (lane-local + two row swaps)
 #pragma unroll
         for (int qi = 0; qi < 3; ++qi)
@@ -251,11 +272,12 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
             half8 t = zero8; t[0] = (_Float16)s[qi][2][0];
             pf1[qi] = t;
         }
+        W2X_STAMP(3)
         if (it == 2) {   // the weight registers are free now: fetch this wave's proj fragments under the last products
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
-                for (int ks = 0; ks < 6; ++ks) wp[t][ks] = *(const half8*)(Wproj + (size_t)((wv * 3 + t) * 16 + fr) * C + ks * 32 + g * 8);
+                for (int ks = 0; ks < 6; ++ks) wp[t][ks] = *(const half8*)(Wproj + (size_t)(((wv * 3 + t) * 6 + ks) * 64 + lane) * 8);
         }
         // ---- O^T = V^T P^T: rows = features, columns = queries; scaled by 1/l and parked in Os (token order)
 #pragma unroll
@@ -272,6 +294,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
                     *(half4*)(Os + (tbase + query) * LDX + h * HD + ft * 16 + g * 4) = oh;
                 }
             }
+        W2X_STAMP(4)
     }
 #undef W2X_LOAD_W
     __syncthreads();      // every wave's head outputs are in Os; nobody reads the slabs any more
@@ -297,6 +320,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
         }
     }
     __syncthreads();
+    W2X_STAMP(5)
 
     // ---- row pieces: + residual x, scatter store, LayerNorm statistics for the next op
     {
@@ -329,20 +353,32 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
             }
         }
     }
+    W2X_STAMP(6)
 }
 
 }  // namespace
 
+// copies and clears the diagnostic stamp counters (8 values)
+hipError_t read_swin_attn192_stamps(unsigned long long* out) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sa192_stamps), sizeof(unsigned long long) * 8);
+    if (e != hipSuccess) return e;
+    unsigned long long z[8] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_sa192_stamps), z, sizeof(z));
+}
+
 hipError_t launch_swin_attn192(const SwinAttnParams& p, hipStream_t s) {
+    static const bool stamps = getenv("W2X_STAMPS") != nullptr;
+    auto kern = stamps ? swin_attn192_kernel<true> : swin_attn192_kernel<false>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)swin_attn192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM192);
+        hipError_t e = hipFuncSetAttribute((const void*)swin_attn192_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM192);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)swin_attn192_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM192);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const long total_win = (long)p.B * p.nwin;
     dim3 grid((unsigned)((total_win + G - 1) / G));
-    hipLaunchKernelGGL(swin_attn192_kernel, grid, dim3(256), SMEM192, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(256), SMEM192, s, p);
     return hipGetLastError();
 }
 
