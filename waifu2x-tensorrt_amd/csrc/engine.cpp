@@ -249,7 +249,7 @@ struct Img2Img::Impl {
             hipAssert(hipMalloc(&blobs[i], d.size() + 256));   // slack: kernels may read a vector past a table's last row
             hipAssert(hipMemcpy(blobs[i], d.data(), d.size(), hipMemcpyHostToDevice));
         }
-        // fragment-major copies of the attention weights for the register-resident C = 192 kernel: tile (16 rows) x
+        // fragment-major copies of the attention weights for the kernels that read them straight from L2: tile (16 rows) x
         // k-step (32 columns) blocks of 64 lanes x 8 halves, lane = (row & 15) + 16 * (column / 8 & 3)
         frag_blobs.assign(plan.blobs.size(), nullptr);
         auto frag_major = [&](int blob, int N, int K) {
@@ -268,7 +268,7 @@ struct Img2Img::Impl {
             hipAssert(hipMemcpy(frag_blobs[blob], f.data(), f.size() * 2, hipMemcpyHostToDevice));
         };
         for (const Op& op : plan.ops)
-            if (op.kind == OP_SWINATTN && op.sa.C == 192) { frag_major(op.sa.wqkv, 3 * op.sa.C, op.sa.C); frag_major(op.sa.wproj, op.sa.C, op.sa.C); }
+            if (op.kind == OP_SWINATTN) { frag_major(op.sa.wqkv, 3 * op.sa.C, op.sa.C); frag_major(op.sa.wproj, op.sa.C, op.sa.C); }
         gemm.assign(plan.ops.size(), GemmParams{});
         for (size_t i = 0; i < plan.ops.size(); ++i) {
             const Op& op = plan.ops[i];

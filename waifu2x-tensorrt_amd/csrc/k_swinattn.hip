@@ -484,8 +484,9 @@ hipError_t launch_swin_attn192(const SwinAttnParams& p, hipStream_t s);   // k_s
 
 hipError_t launch_swin_attn(const SwinAttnParams& p, hipStream_t s) {
     static const bool v1 = getenv("W2X_SA_V1") != nullptr;   // A/B switch: the barrier-staged kernel of this file
-    if (p.C == 96 && p.hd == 16) return v1 ? launch_sa<96, 16>(p, s) : launch_swin_attn96(p, s);
-    if (p.C == 192 && p.hd == 32) return (v1 || !p.wqkv_frag || !p.wproj_frag) ? launch_sa<192, 32>(p, s) : launch_swin_attn192(p, s);
+    const bool staged = v1 || !p.wqkv_frag || !p.wproj_frag;
+    if (p.C == 96 && p.hd == 16) return staged ? launch_sa<96, 16>(p, s) : launch_swin_attn96(p, s);
+    if (p.C == 192 && p.hd == 32) return staged ? launch_sa<192, 32>(p, s) : launch_swin_attn192(p, s);
     return hipErrorInvalidValue;
 }
 

@@ -77,8 +77,8 @@ __global__ __launch_bounds__(256, 2) void swin_attn96_kernel(const SwinAttnParam
     const int nwx = p.W / 6;
     const int wy0 = wl0 / nwx, wx0 = wl0 - wy0 * nwx, wy1 = wl1 / nwx, wx1 = wl1 - wy1 * nwx;
     const _Float16* __restrict__ X = (const _Float16*)p.x;
-    const _Float16* __restrict__ Wqkv = (const _Float16*)p.wqkv;   // [3C][C]
-    const _Float16* __restrict__ Wproj = (const _Float16*)p.wproj; // [C][C]
+    const _Float16* __restrict__ Wqkv = (const _Float16*)p.wqkv_frag;    // [18 row tiles][3 k-steps][64 lanes][8] (engine.cpp frag_major)
+    const _Float16* __restrict__ Wproj = (const _Float16*)p.wproj_frag;  // [6 row tiles][3 k-steps][64 lanes][8]
     const float4v zero4 = {0.f, 0.f, 0.f, 0.f};
     const half8 zero8 = {};
 
@@ -88,14 +88,15 @@ __global__ __launch_bounds__(256, 2) void swin_attn96_kernel(const SwinAttnParam
     const int amask = aok ? p.maskid[aw == 0 ? wl0 : wl1] : 0;
     const int rbase = aw * NTOK;
 
-    // weight fragments of head h (q, k, v rows h*16 + fr; 3 k-steps): lane reads 16 bytes at [row][ks*32 + 8g]
+    // weight fragments of head h (q, k, v rows h*16 + fr; 3 k-steps): lane holds [row][ks*32 + 8g .. +7]; stored
+    // fragment-major, so each load is one contiguous KiB (row-major fragments touch 16 half cache lines each)
     half8 wcur[9], wnext[9];
-    const _Float16* wlane = Wqkv + (size_t)fr * C + g * 8;
+    const _Float16* wlane = Wqkv + lane * 8;
 #define W2X_LOAD_W(DST, H)                                                                                   \
     {                                                                                                        \
         _Pragma("unroll") for (int m = 0; m < 3; ++m)                                                        \
             _Pragma("unroll") for (int ks = 0; ks < 3; ++ks)                                                 \
-                DST[m * 3 + ks] = *(const half8*)(wlane + (size_t)(m * C + (H) * HD) * C + ks * 32);         \
+                DST[m * 3 + ks] = *(const half8*)(wlane + (size_t)((m * NH + (H)) * 3 + ks) * 512);          \
     }
     W2X_LOAD_W(wcur, ahp);
 
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn96_kernel(const SwinAttnParam
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) wf[t][ks] = *(const half8*)(Wproj + (size_t)((n3 + t) * 16 + fr) * C + ks * 32 + g * 8);
+            for (int ks = 0; ks < 3; ++ks) wf[t][ks] = *(const half8*)(Wproj + (size_t)(((n3 + t) * 3 + ks) * 64 + lane) * 8);
         float4v acc[3] = {zero4, zero4, zero4};
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {

@@ -67,7 +67,7 @@ struct SwinAttnParams {          // y = x + proj(W-MSA(LN(x))) on token maps [B]
     float eps = 1e-5f;
     float* stats_out = nullptr; float eps_out = 1e-5f;
     // the same two matrices in MFMA-fragment order (engine.cpp frag_major): [16-row tile][32-column k-step][lane][8], so a
-    // wave's fragment load is one contiguous KiB.  Required by the C = 192 register-resident kernel.
+    // wave's fragment load is one contiguous KiB.  Required by k_swinattn96.hip / k_swinattn192.hip.
     const void* wqkv_frag = nullptr; const void* wproj_frag = nullptr;
 };
 
