@@ -1,12 +1,17 @@
-// Fused Swin attention branch, C = 96 / 6 heads of 16 / window 6x6, "wave-private heads" variant for gfx950.
+// Fused Swin attention branch, C = 96 / 6 heads of 16 / window 6x6, register-resident variant for gfx950.
 //     y = x + proj( W-MSA( LayerNorm(x) ) )
-// Same math and data layout as k_swinattn.hip (which keeps serving C = 192); the difference is the schedule:
-// a workgroup = 4 waves = 2 windows; wave (w, hp) owns window w and the heads 2*it + hp (it = 0..2).  For its
-// (window, head) the wave computes q, k, v^T itself (48 padded rows x 16 features each, weights read straight from
-// L2 as MFMA fragments, prefetched one head ahead) into a wave-private LDS slab, runs S^T = K Q^T -> softmax -> O^T = V^T P^T,
-// and writes its 16 output features to the shared O tile.  No workgroup barrier inside the head loop - only three in the
-// whole kernel (after LayerNorm, before proj, before the final row pass) - so the two workgroups sharing a CU never stall
-// on each other's skew.  Costs: the 12 pad rows of every 48-row slab are computed for nothing (MFMA time is not the limiter).
+// Same math, parameters and bias-table layout as k_swinattn.hip; the schedule is the one of k_swinattn192.hip:
+// a workgroup = 4 waves = 2 windows; wave (w, hp) owns window w and the heads 2*it + hp (it = 0..2), reads its weights
+// straight from L2 as MFMA fragments (fragment-major copy, one head ahead) and keeps q, k, v, S and P in registers.
+// With a head dimension of 16 the accumulator layout (lane (col, g) holds rows 4g..4g+3) is exactly the operand layout
+// of v_mfma_f32_16x16x16_f16 (lane (row|col, g) holds k = 4g..4g+3), so
+//     q^T, k^T (rows = features)  -> B / A operands of S^T = K Q^T,
+//     v (rows = tokens)           -> A operand of O^T = V^T P^T,
+//     S^T after the softmax       -> B operand of O^T
+// need no LDS round trip and no permutation.  The q/k/v products use v_mfma_f32_16x16x32_f16 over the 96 channels.
+// LDS holds the normalised x slabs (48 rows per window: tokens 0..31, then tokens 32..35 on rows 32, 36, 40, 44 so that
+// key 32+g sits on row 4g of the third key tile - see k_swinattn192.hip) and the head outputs for proj.
+// Three workgroup barriers in the whole kernel.
 #include "kernels.h"
 
 namespace w2x {
@@ -48,25 +53,22 @@ __device__ __forceinline__ float rows_max(float v) { float a = v, b = v; swap16(
 __device__ __forceinline__ float rows_sum(float v) { float a = v, b = v; swap16(a, b); v = a + b; a = v; b = v; swap32(a, b); return a + b; }
 
 constexpr int C = 96, HD = 16, NH = 6, NTOK = 36, G = 2, R = G * NTOK, RT = 5, RP = RT * 16;
-constexpr int RPX = 96;                    // rows of the normalised-x tile: a 48-row slab of window 1 reaches row 83
+constexpr int SLAB = 48, RPX = G * SLAB;   // slab rows per window / in the tile
 constexpr int LDX = C + 8;                 // 104 halves
-constexpr int LDQ = HD + 8, LDV = 48 + 8;  // private q / k rows, v^T rows
 constexpr int XS = RPX * LDX, OS = RP * LDX;
-constexpr int PRIV = 2 * 48 * LDQ + HD * LDV;      // halves per wave: q, k, v^T
-constexpr int SMEM96 = (XS + OS + 4 * PRIV) * 2;
-constexpr int LPR = 16, PPR = C / 8, RPP = 256 / LPR, NPASS = RP / RPP;   // row-piece phases: 16 lanes per row, 5 passes
+constexpr int SMEM96 = (XS + OS) * 2;
+constexpr int LPR = 16, PPR = C / 8, RPP = 256 / LPR, NPASS = (R + RPP - 1) / RPP;   // row passes: 16 lanes per row, 16 rows per pass, 5 passes
 
-__global__ __launch_bounds__(256, 2) void swin_attn96_kernel(const SwinAttnParams p) {
+__device__ __forceinline__ int slab_row(int t) { return t < 32 ? t : 32 + 4 * (t - 32); }
+
+__global__ __launch_bounds__(256, 3) void swin_attn96_kernel(const SwinAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    _Float16* Xs = (_Float16*)smem;              // [RPX][LDX] normalised x; rows >= R are zero; later the output tile
-    _Float16* Os = Xs + XS;                      // [RP][LDX]  attention output, all heads
+    _Float16* Xs = (_Float16*)smem;              // [RPX][LDX] normalised x slabs; later the output tile [RP][LDX]
+    _Float16* Os = Xs + XS;                      // [RP][LDX]  attention output, all heads, token order
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, g = lane >> 4;
-    _Float16* Qp = Os + OS + wv * PRIV;          // [48][LDQ]
-    _Float16* Kp = Qp + 48 * LDQ;                // [48][LDQ]
-    _Float16* VTp = Kp + 48 * LDQ;               // [HD][LDV]
 
     const int iw0 = blockIdx.x * G, iw1 = iw0 + 1, itotal = p.B * p.nwin;
     const bool wok0 = iw0 < itotal, wok1 = iw1 < itotal;
@@ -86,28 +88,28 @@ __global__ __launch_bounds__(256, 2) void swin_attn96_kernel(const SwinAttnParam
     const int aw = wv >> 1, ahp = wv & 1;
     const bool aok = aw == 0 ? wok0 : wok1;
     const int amask = aok ? p.maskid[aw == 0 ? wl0 : wl1] : 0;
-    const int rbase = aw * NTOK;
+    const int sbase = aw * SLAB, tbase = aw * NTOK;
 
     // weight fragments of head h (q, k, v rows h*16 + fr; 3 k-steps): lane holds [row][ks*32 + 8g .. +7]; stored
     // fragment-major, so each load is one contiguous KiB (row-major fragments touch 16 half cache lines each)
-    half8 wcur[9], wnext[9];
+    half8 wr[2][9];
     const _Float16* wlane = Wqkv + lane * 8;
-#define W2X_LOAD_W(DST, H)                                                                                   \
+#define W2X_LOAD_W(SET, H)                                                                                   \
     {                                                                                                        \
         _Pragma("unroll") for (int m = 0; m < 3; ++m)                                                        \
             _Pragma("unroll") for (int ks = 0; ks < 3; ++ks)                                                 \
-                DST[m * 3 + ks] = *(const half8*)(wlane + (size_t)((m * NH + (H)) * 3 + ks) * 512);          \
+                wr[SET][m * 3 + ks] = *(const half8*)(wlane + (size_t)((m * NH + (H)) * 3 + ks) * 512);      \
     }
-    W2X_LOAD_W(wcur, ahp);
+    W2X_LOAD_W(0, ahp);
 
-    // ---- gather + LayerNorm into Xs
+    // ---- gather + LayerNorm into the slabs
     int my_pix[NPASS];
     {
         const int li = tid & (LPR - 1);
         half8 xr[NPASS];
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
-            const int r = ps * RPP + tid / LPR;
+            const int r = ps * RPP + tid / LPR;          // token row 0..71 (the last pass is half empty)
             int pix = -1;
             if (r < R) {
                 const int w = r >= NTOK ? 1 : 0;
@@ -129,117 +131,106 @@ __global__ __launch_bounds__(256, 2) void swin_attn96_kernel(const SwinAttnParam
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int r = ps * RPP + tid / LPR;
+            const int w = r >= NTOK ? 1 : 0;
             float s, q;
             sum_sq8(xr[ps], s, q);
             s = group_sum16(s);
             q = group_sum16(q);
             const float mean = s * (1.f / C);
             const float rstd = rsqrtf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps);
-            if (li < PPR) *(half8*)(Xs + r * LDX + li * 8) = norm8(xr[ps], rstd, -mean * rstd);
+            if (r < R && li < PPR) *(half8*)(Xs + (w * SLAB + slab_row(r - w * NTOK)) * LDX + li * 8) = norm8(xr[ps], rstd, -mean * rstd);
         }
-        // rows [RP, RPX) are only read as pad rows of window 1's slab: zero them
-        for (int i = tid; i < (RPX - RP) * PPR; i += 256) { const int r = RP + i / PPR, c = i % PPR; *(half8*)(Xs + r * LDX + c * 8) = zero8; }
+        // the 12 rows between tokens 32..35 of each slab are multiplied like the rest (results ignored): keep them finite
+        for (int i = tid; i < G * 12 * PPR; i += 256) {
+            const int rr = i / PPR, c = i - rr * PPR, w = rr / 12, k = rr - w * 12;
+            *(half8*)(Xs + (w * SLAB + 33 + (k / 3) * 4 + (k % 3)) * LDX + c * 8) = zero8;
+        }
     }
     __syncthreads();
 
     const float qscale = p.scale * 1.44269504088896341f;   // log2(e) folded into q: softmax uses exp2
+    const int lane2 = g * 16 + (fr >> 2);                  // bias-table lane of the query this lane holds in query tile 2
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
         const int h = 2 * it + ahp;
-        // bias (+ shift mask) of this unit in load order (lower.cpp): 3 query tiles x (2 x float4 + 1 float) per lane
-        float4v bv[3][3];
+        const int cur = it & 1;
+        if (it < 2) W2X_LOAD_W(cur ^ 1, h + 2);
+        // bias (+ shift mask) of this unit in load order (lower.cpp): per query tile 2 x float4 + 1 float per lane;
+        // it is the initial accumulator of S^T
+        float4v s[3][3];
         {
-            const float* bias = p.bias32 + ((size_t)amask * NH + h) * (3 * 576) + lane * 4;
+            const float* bias = p.bias32 + ((size_t)amask * NH + h) * (3 * 576);
 #pragma unroll
             for (int qi = 0; qi < 3; ++qi) {
-                bv[qi][0] = *(const float4v*)(bias + qi * 576);
-                bv[qi][1] = *(const float4v*)(bias + qi * 576 + 256);
-                float4v t = zero4; t[0] = bias[qi * 576 + 512 - lane * 3];
-                bv[qi][2] = t;
+                const int bl = qi < 2 ? lane : lane2;
+                s[qi][0] = *(const float4v*)(bias + qi * 576 + bl * 4);
+                s[qi][1] = *(const float4v*)(bias + qi * 576 + 256 + bl * 4);
+                float4v t = zero4; t[0] = bias[qi * 576 + 512 + bl];
+                s[qi][2] = t;
+            }
+        }
+        // ---- q^T, k^T (rows = features: A = weights, B = x) and v (rows = slab rows: A = x, B = weights)
+        float4v aq[3] = {zero4, zero4, zero4}, ak[3] = {zero4, zero4, zero4}, av[3] = {zero4, zero4, zero4};
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt) {
+                const half8 xf = *(const half8*)(Xs + (sbase + tt * 16 + fr) * LDX + ks * 32 + g * 8);
+                aq[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[cur][ks], xf, aq[tt], 0, 0, 0);
+                ak[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[cur][3 + ks], xf, ak[tt], 0, 0, 0);
+                av[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf, wr[cur][6 + ks], av[tt], 0, 0, 0);
             }
         }
         const float4v bq = *(const float4v*)(p.bqkv + h * HD + g * 4);
         const float4v bk = *(const float4v*)(p.bqkv + C + h * HD + g * 4);
         const float bvv = p.bqkv[2 * C + h * HD + fr];
-        if (it < 2) W2X_LOAD_W(wnext, h + 2);
-
-        // ---- q, k (transposed: rows = features) and v (rows = tokens) of the 48-row slab of this window
+        half4 qf[3], kf[3], vf[3];
 #pragma unroll
-        for (int mt = 0; mt < 3; ++mt) {
-            float4v aq = zero4, ak = zero4, av = zero4;
+        for (int tt = 0; tt < 3; ++tt)
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) {
-                const half8 xf = *(const half8*)(Xs + (rbase + mt * 16 + fr) * LDX + ks * 32 + g * 8);
-                aq = __builtin_amdgcn_mfma_f32_16x16x32_f16(wcur[ks], xf, aq, 0, 0, 0);
-                ak = __builtin_amdgcn_mfma_f32_16x16x32_f16(wcur[3 + ks], xf, ak, 0, 0, 0);
-                av = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf, wcur[6 + ks], av, 0, 0, 0);
-            }
-            half4 oq, ok, ov;
+            for (int j = 0; j < 4; ++j) { qf[tt][j] = (_Float16)((aq[tt][j] + bq[j]) * qscale); kf[tt][j] = (_Float16)(ak[tt][j] + bk[j]); vf[tt][j] = (_Float16)(av[tt][j] + bvv); }
+        // ---- S^T = K Q^T on top of the bias (k = the 16 features), softmax over the keys
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { oq[j] = (_Float16)((aq[j] + bq[j]) * qscale); ok[j] = (_Float16)(ak[j] + bk[j]); ov[j] = (_Float16)(av[j] + bvv); }
-            *(half4*)(Qp + (mt * 16 + fr) * LDQ + g * 4) = oq;
-            *(half4*)(Kp + (mt * 16 + fr) * LDQ + g * 4) = ok;
-            *(half4*)(VTp + fr * LDV + mt * 16 + g * 4) = ov;
+        for (int qi = 0; qi < 3; ++qi)
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) s[qi][kt] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf[kt], qf[qi], s[qi][kt], 0, 0, 0);
+        float inv[3];
+        half4 pf[3][3];
+#pragma unroll
+        for (int qi = 0; qi < 3; ++qi) {
+            float mx = fmaxf(fmaxf(s[qi][0][0], s[qi][0][1]), fmaxf(s[qi][0][2], s[qi][0][3]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[qi][1][j]);
+            mx = rows_max(fmaxf(mx, s[qi][2][0]));
+            float l = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float e = __builtin_amdgcn_exp2f(s[qi][kt][j] - mx); s[qi][kt][j] = e; l += e; }
+            { const float e = __builtin_amdgcn_exp2f(s[qi][2][0] - mx); s[qi][2][0] = e; l += e; }
+            l = rows_sum(l);
+            inv[qi] = __builtin_amdgcn_rcpf(l);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) pf[qi][kt] = (half4){(_Float16)s[qi][kt][0], (_Float16)s[qi][kt][1], (_Float16)s[qi][kt][2], (_Float16)s[qi][kt][3]};
+            pf[qi][2] = (half4){(_Float16)s[qi][2][0], (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};   // slab row 32 + 4g = token 32 + g
         }
-        // ---- attention on the private slab (key tile 2 holds keys 32..35 on tile rows 0,4,8,12)
-        {
-            half8 kf[3];
-            kf[0] = g < 2 ? *(const half8*)(Kp + fr * LDQ + g * 8) : zero8;
-            kf[1] = g < 2 ? *(const half8*)(Kp + (16 + fr) * LDQ + g * 8) : zero8;
-            kf[2] = g < 2 ? *(const half8*)(Kp + (32 + (fr >> 2)) * LDQ + g * 8) : zero8;
-            float4v s[3][3];
+        // ---- O^T = V^T P^T: rows = features, columns = queries (k = 16 keys per product); parked in Os (token order)
 #pragma unroll
-            for (int qi = 0; qi < 3; ++qi) {
-                const half8 qf = g < 2 ? *(const half8*)(Qp + (qi * 16 + fr) * LDQ + g * 8) : zero8;
+        for (int qi = 0; qi < 3; ++qi) {
+            float4v o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf[0], pf[qi][0], zero4, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf[1], pf[qi][1], o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf[2], pf[qi][2], o, 0, 0, 0);
+            const int query = qi < 2 ? qi * 16 + fr : 32 + (fr >> 2);
+            if (aok && (qi < 2 || (fr & 3) == 0)) {
+                half4 oh;
 #pragma unroll
-                for (int kt = 0; kt < 3; ++kt) s[qi][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt], qf, bv[qi][kt], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) oh[j] = (_Float16)(o[j] * inv[qi]);
+                *(half4*)(Os + (tbase + query) * LDX + h * HD + g * 4) = oh;
             }
-            float inv[3];
-            half8 pf0[3], pf1[3];
-#pragma unroll
-            for (int qi = 0; qi < 3; ++qi) {
-                float mx = fmaxf(fmaxf(s[qi][0][0], s[qi][0][1]), fmaxf(s[qi][0][2], s[qi][0][3]));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[qi][1][j]);
-                mx = rows_max(fmaxf(mx, s[qi][2][0]));
-                float l = 0.f;
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { const float e = __builtin_amdgcn_exp2f(s[qi][kt][j] - mx); s[qi][kt][j] = e; l += e; }
-                { const float e = __builtin_amdgcn_exp2f(s[qi][2][0] - mx); s[qi][2][0] = e; l += e; }
-                l = rows_sum(l);
-                inv[qi] = __builtin_amdgcn_rcpf(l);
-                pf0[qi] = (half8){(_Float16)s[qi][0][0], (_Float16)s[qi][0][1], (_Float16)s[qi][0][2], (_Float16)s[qi][0][3],
-                                  (_Float16)s[qi][1][0], (_Float16)s[qi][1][1], (_Float16)s[qi][1][2], (_Float16)s[qi][1][3]};
-                pf1[qi] = (half8){(_Float16)s[qi][2][0], (_Float16)0.f, (_Float16)0.f, (_Float16)0.f,
-                                  (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-            }
-            const _Float16* vp = VTp + fr * LDV + g * 4;
-            const half4 v0 = *(const half4*)vp, v1 = *(const half4*)(vp + 16);
-            const _Float16 v2 = VTp[fr * LDV + 32 + g];
-            const half8 vf0 = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            const half8 vf1 = {v2, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-#pragma unroll
-            for (int qi = 0; qi < 3; ++qi) {
-                float4v o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf0, pf0[qi], zero4, 0, 0, 0);   // rows = features, cols = queries
-                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf1, pf1[qi], o, 0, 0, 0);
-                const int query = qi * 16 + fr;
-                if (aok && query < NTOK) {
-                    half4 oh;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) oh[j] = (_Float16)(o[j] * inv[qi]);
-                    *(half4*)(Os + (rbase + query) * LDX + h * HD + g * 4) = oh;
-                }
-            }
-        }
-        if (it < 2) {
-#pragma unroll
-            for (int m = 0; m < 9; ++m) wcur[m] = wnext[m];
         }
     }
 #undef W2X_LOAD_W
-    __syncthreads();      // every wave's head outputs are in Os; nobody reads Xs any more
+    __syncthreads();      // every wave's head outputs are in Os; nobody reads the slabs any more
 
     // ---- proj: out = Os * Wproj^T + b -> tile over Xs.  10 units of (16-row tile, 3 n-tiles), weights as fragments from L2
     for (int u = wv; u < RT * 2; u += 4) {
