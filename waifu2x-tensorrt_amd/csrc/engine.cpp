@@ -12,6 +12,7 @@
 
 #include "../../include/w2x/img2img.h"
 #include "common.h"
+#include "fragorder.h"
 #include "kernels.h"
 #include "lower.h"
 #include "plan.h"
@@ -249,26 +250,28 @@ struct Img2Img::Impl {
             hipAssert(hipMalloc(&blobs[i], d.size() + 256));   // slack: kernels may read a vector past a table's last row
             hipAssert(hipMemcpy(blobs[i], d.data(), d.size(), hipMemcpyHostToDevice));
         }
-        // fragment-major copies of the attention weights for the kernels that read them straight from L2: tile (16 rows) x
-        // k-step (32 columns) blocks of 64 lanes x 8 halves, lane = (row & 15) + 16 * (column / 8 & 3)
+        // fragment-major copies (fragorder.h) of the weights that kernels read straight from L2
         frag_blobs.assign(plan.blobs.size(), nullptr);
-        auto frag_major = [&](int blob, int N, int K) {
-            if (frag_blobs[blob]) return;
-            const auto& d = plan.blobs[blob].data;
-            if (d.size() != (size_t)N * K * 2 || N % 16 || K % 32) throw std::runtime_error("plan: attention weight shape");
-            const uint16_t* w = (const uint16_t*)d.data();
-            std::vector<uint16_t> f((size_t)N * K);
-            const int KS = K / 32;
-            for (int nt = 0; nt < N / 16; ++nt)
-                for (int ks = 0; ks < KS; ++ks)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int e = 0; e < 8; ++e)
-                            f[(((size_t)nt * KS + ks) * 64 + lane) * 8 + e] = w[(size_t)(nt * 16 + (lane & 15)) * K + ks * 32 + (lane >> 4) * 8 + e];
+        auto upload_frag = [&](int blob, const std::vector<uint16_t>& f) {
             hipAssert(hipMalloc(&frag_blobs[blob], f.size() * 2 + 256));
             hipAssert(hipMemcpy(frag_blobs[blob], f.data(), f.size() * 2, hipMemcpyHostToDevice));
         };
+        auto frag_major_blob = [&](int blob, int N, int K) {
+            if (frag_blobs[blob]) return;
+            const auto& d = plan.blobs[blob].data;
+            if (d.size() != (size_t)N * K * 2) throw std::runtime_error("plan: weight shape");
+            upload_frag(blob, frag_major((const uint16_t*)d.data(), N, K));
+        };
+        auto frag_w2_blob = [&](int blob, int Cc) {
+            if (frag_blobs[blob]) return;
+            const auto& d = plan.blobs[blob].data;
+            if (d.size() != (size_t)Cc * Cc * 4) throw std::runtime_error("plan: mlp weight shape");
+            upload_frag(blob, frag_w2((const uint16_t*)d.data(), Cc));
+        };
         for (const Op& op : plan.ops)
-            if (op.kind == OP_SWINATTN) { frag_major(op.sa.wqkv, 3 * op.sa.C, op.sa.C); frag_major(op.sa.wproj, op.sa.C, op.sa.C); }
+            if (op.kind == OP_MLP && (op.m.C == 96 || op.m.C == 192)) { frag_major_blob(op.m.w1, 2 * op.m.C, op.m.C); frag_w2_blob(op.m.w2, op.m.C); }
+        for (const Op& op : plan.ops)
+            if (op.kind == OP_SWINATTN) { frag_major_blob(op.sa.wqkv, 3 * op.sa.C, op.sa.C); frag_major_blob(op.sa.wproj, op.sa.C, op.sa.C); }
         gemm.assign(plan.ops.size(), GemmParams{});
         for (size_t i = 0; i < plan.ops.size(); ++i) {
             const Op& op = plan.ops[i];
@@ -351,6 +354,7 @@ struct Img2Img::Impl {
                     MlpParams p;
                     p.x = tensors[m.x]; p.y = tensors[m.y]; p.M = (long)live * d.H * d.W; p.C = m.C;
                     p.w1 = blobs[m.w1]; p.b1 = (const float*)blobs[m.b1]; p.w2 = blobs[m.w2]; p.b2 = (const float*)blobs[m.b2];
+                    p.w1_frag = frag_blobs[m.w1]; p.w2_frag = frag_blobs[m.w2];
                     p.eps = m.eps; p.stats_out = m.stats_out >= 0 ? (float*)tensors[m.stats_out] : nullptr; p.eps_out = m.eps_out;
                     if (d.C != m.C || plan.tensors[m.y].C != m.C) throw std::runtime_error("plan: MLP width mismatch");
                     stamp_begin(5, op.flops);

@@ -1,0 +1,41 @@
+// Host-side re-ordering of fp16 weight matrices into MFMA-fragment order for the kernels that read weights straight
+// from L2 (k_swinattn96.hip, k_swinattn192.hip, k_mlp2.hip): a wave's fragment load becomes one contiguous KiB instead
+// of 16 half cache lines.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <vector>
+
+namespace w2x {
+
+// W [N][K] row-major -> [N/16 row tiles][K/32 k-steps][64 lanes][8]: lane = (row & 15) + 16 * g holds columns ks*32 + 8g .. +7
+inline std::vector<uint16_t> frag_major(const uint16_t* w, int N, int K) {
+    if (N % 16 || K % 32) throw std::runtime_error("frag_major: shape");
+    std::vector<uint16_t> f((size_t)N * K);
+    const int KS = K / 32;
+    for (int nt = 0; nt < N / 16; ++nt)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e)
+                    f[(((size_t)nt * KS + ks) * 64 + lane) * 8 + e] = w[(size_t)(nt * 16 + (lane & 15)) * K + ks * 32 + (lane >> 4) * 8 + e];
+    return f;
+}
+
+// Second MLP matrix W2 [C][2C] -> [2C/32 chunks][C/16 n-tiles][64 lanes][8]: lane (n & 15, g) holds the hidden units of the
+// chunk in the order the GELU'd accumulators of the transposed first product present them (slots 0..3: 4g+j, 4..7: 16+4g+j)
+inline std::vector<uint16_t> frag_w2(const uint16_t* w, int C) {
+    if (C % 16) throw std::runtime_error("frag_w2: shape");
+    const int H2 = 2 * C, NT = C / 16, NCH = H2 / 32;
+    std::vector<uint16_t> f((size_t)C * H2);
+    for (int ch = 0; ch < NCH; ++ch)
+        for (int nt = 0; nt < NT; ++nt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int g = lane >> 4, hid = ch * 32 + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4));
+                    f[(((size_t)ch * NT + nt) * 64 + lane) * 8 + e] = w[(size_t)(nt * 16 + (lane & 15)) * H2 + hid];
+                }
+    return f;
+}
+
+}  // namespace w2x

@@ -301,7 +301,11 @@ hipError_t read_mlp_stamps(unsigned long long* out) {   // diagnostic: 16 values
     return hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_stamps), z, sizeof(z));
 }
 
+hipError_t launch_mlp2(const MlpParams& p, hipStream_t s);   // k_mlp2.hip
+
 hipError_t launch_mlp(const MlpParams& p, hipStream_t s) {
+    static const bool v1 = getenv("W2X_MLP_V1") != nullptr;   // A/B switch: the LDS-staged kernel of this file
+    if (!v1 && p.w1_frag && p.w2_frag && (p.C == 96 || p.C == 192)) return launch_mlp2(p, s);
     if (p.C == 96) return launch_mlp_c<96>(p, s);
     if (p.C == 192) return launch_mlp_c<192>(p, s);
     return hipErrorInvalidValue;

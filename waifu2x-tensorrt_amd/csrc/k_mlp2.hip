@@ -1,0 +1,251 @@
+// Fused transformer MLP branch for gfx950, wave-private variant:   y = x + W2 * gelu(W1 * LayerNorm(x) + b1) + b2
+// Same math and parameters as k_mlp.hip (which stages weight chunks through LDS behind workgroup barriers); here
+// every wave owns 16*TT token rows from the first load to the last store and there is no workgroup barrier at all:
+//   * x rows arrive as one flat, fully coalesced stream into the wave's LDS slab; each lane then reads the 16-byte pieces
+//     it will later use as MFMA fragments, LayerNorm statistics are the lane's own sums plus two row swaps, and the
+//     normalised pieces go back in place (piece (row, 8 channels) is touched by exactly one lane; LDS program order is
+//     the only ordering needed, see W2X_PHASE_FENCE);
+//   * weights are read straight from L2 as MFMA fragments in fragment-major order (engine.cpp: one contiguous KiB per
+//     wave load).  The fragment registers form a ring: right after the last MFMA that uses a fragment of hidden chunk c,
+//     the same registers are refilled with that fragment of chunk c+1, i.e. a prefetch distance of one whole chunk
+//     (2*KS + NT fragments) without a second register set;
+//   * GEMM1 is computed transposed (rows = 32 hidden units of the chunk, columns = tokens) so that the GELU'd
+//     accumulators are, as they stand, the A fragments of GEMM2 with a permuted k order (W2 is stored with the same
+//     permutation) - no LDS round trip between the two products;
+//   * the result tile goes through the slab once so that residual add and stores are flat 16-byte pieces again.
+// TT = 4 (64 rows per wave) for C = 96 and TT = 2 for C = 192: a weight fragment feeds TT MFMAs, and the 64 B/clk
+// L1 -> register path sustains 4 SIMDs of MFMAs only from about 4 uses per fragment on.
+#include "kernels.h"
+#include <cstdlib>
+
+namespace w2x {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+// GELU(x) = max(x,0) - 0.5 u 2^-q(u), u = min(|x|, 6.5): see k_mlp.hip / tools/fit_gelu.py (|err| < 3.2e-7)
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float u = fminf(fabsf(x), 6.5f);
+    float q = fmaf(-2.992485764e-05f, u, 7.398797018e-04f);
+    q = fmaf(q, u, -7.977479093e-03f);
+    q = fmaf(q, u, 5.323820859e-02f);
+    q = fmaf(q, u, 4.589156733e-01f);
+    q = fmaf(q, u, 1.151147085e+00f);
+    const float e = __builtin_amdgcn_exp2f(-(q * u));
+    return fmaf(-0.5f * u, e, fmaxf(x, 0.f));
+}
+__device__ __forceinline__ void sum_sq8(const half8 v, float& s, float& q) {
+    const half2v one = {(_Float16)1.f, (_Float16)1.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const half2v h = {v[2 * k], v[2 * k + 1]};
+        s = __builtin_amdgcn_fdot2(h, one, s, false);
+        q = __builtin_amdgcn_fdot2(h, h, q, false);
+    }
+}
+// sum over the four 16-lane rows of a wave (see k_swinattn.hip for why the swaps are inline asm on two registers)
+__device__ __forceinline__ void swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float rows_sum(float v) { float a = v, b = v; swap16(a, b); v = a + b; a = v; b = v; swap32(a, b); return a + b; }
+__device__ __forceinline__ half8 norm8(const half8 v, float rstd, float nm) {
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)fmaf((float)v[e], rstd, nm);
+    return o;
+}
+
+// The phases below hand data from lane to lane through the wave's own LDS slab.  The hardware executes a wave's LDS
+// instructions in order, so no s_barrier / s_waitcnt is needed - but the compiler must neither forward a lane's own store
+// to its later load nor move slab accesses across a phase boundary (without this, hipcc 7.2 kept the normalised rows of
+// the last token tile in registers, sank their stores below the main loop and produced wrong rows for that tile;
+// tools/mlp_ab.hip is the regression check).  A compiler-level fence emits no instruction.
+#define W2X_PHASE_FENCE() asm volatile("" ::: "memory")
+
+template <int C, int TT>
+struct Mlp2Cfg {
+    static constexpr int RW = 16 * TT;           // rows per wave
+    static constexpr int NWV = 4;                // independent waves per workgroup
+    static constexpr int BM = NWV * RW;          // rows per workgroup
+    static constexpr int LDX = C + 8;            // slab row stride in halves: 16-byte pieces rotate over the banks
+    static constexpr int PPR = C / 8;            // 16-byte pieces per row
+    static constexpr int KS = C / 32;            // k-steps of GEMM1
+    static constexpr int NT = C / 16;            // output n-tiles of GEMM2
+    static constexpr int NCH = 2 * C / 32;       // hidden chunks of 32
+    static constexpr int NP = RW * PPR / 64;     // flat 16-byte pieces per lane
+    static constexpr int SLAB = RW * LDX * 2;    // bytes per wave
+    static constexpr int SMEM = NWV * SLAB;
+    static_assert(RW * PPR % 64 == 0, "flat piece count");
+};
+
+template <int C, int TT>
+__global__ __launch_bounds__(256, 2) void mlp2_kernel(const MlpParams p) {
+    using K = Mlp2Cfg<C, TT>;
+    constexpr int RW = K::RW, LDX = K::LDX, PPR = K::PPR, KS = K::KS, NT = K::NT, NCH = K::NCH, NP = K::NP;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    _Float16* Xw = (_Float16*)(smem + wv * K::SLAB);          // [RW][LDX]
+
+    const long row0 = ((long)blockIdx.x * K::NWV + wv) * RW;       // first row of this wave
+    const long nrows = p.M - row0 < RW ? p.M - row0 : RW;     // may be <= 0: the wave then only runs dead arithmetic
+    const int npieces = nrows > 0 ? (int)nrows * PPR : 0;
+    const _Float16* __restrict__ X = (const _Float16*)p.x + row0 * C;
+    const _Float16* __restrict__ W1 = (const _Float16*)p.w1_frag + lane * 8;   // [NCH*2 row tiles][KS][64][8]
+    const _Float16* __restrict__ W2 = (const _Float16*)p.w2_frag + lane * 8;   // [NCH][NT][64][8], k order of the GELU'd accumulators
+
+    // ---- weight ring: chunk 0
+    half8 w1r[2 * KS], w2r[NT];
+#pragma unroll
+    for (int f = 0; f < 2 * KS; ++f) w1r[f] = *(const half8*)(W1 + (size_t)f * 512);
+#pragma unroll
+    for (int f = 0; f < NT; ++f) w2r[f] = *(const half8*)(W2 + (size_t)f * 512);
+
+    // ---- x rows: flat coalesced load -> slab
+    {
+        half8 xr[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int idx = k * 64 + lane;
+            half8 h = {};
+            if (idx < npieces) h = *(const half8*)(X + (size_t)idx * 8);
+            xr[k] = h;
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int idx = k * 64 + lane, r = idx / PPR, c = idx - r * PPR;
+            *(half8*)(Xw + r * LDX + c * 8) = xr[k];
+        }
+    }
+    W2X_PHASE_FENCE();
+    // ---- LayerNorm in fragment layout: lane (fr, g) holds channels ks*32 + 8g .. +7 of row 16tt + fr, so the row sums are the
+    //      lane's own KS pieces plus the three other lane groups (two row swaps); normalised pieces go back in place
+    //      (rows without data hold zeros: 0 * rstd - 0)
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+        half8 raw[KS];
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { raw[ks] = *(const half8*)(Xw + (tt * 16 + fr) * LDX + ks * 32 + g * 8); sum_sq8(raw[ks], s, q); }
+        s = rows_sum(s);
+        q = rows_sum(q);
+        const float mean = s * (1.f / C);
+        const float rstd = rsqrtf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps);
+        const float nm = -mean * rstd;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) *(half8*)(Xw + (tt * 16 + fr) * LDX + ks * 32 + g * 8) = norm8(raw[ks], rstd, nm);
+    }
+    W2X_PHASE_FENCE();
+    float4v acc2[TT][NT];
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc2[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {   // fully unrolled: the ring registers are renamed statically
+        // GEMM1 (transposed): acc1[ht][tt] = W1[32ch + 16ht ..][:] * Xn[16tt ..][:]^T   (rows = hidden, columns = tokens)
+        float4v acc1[2][TT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) acc1[i][tt] = (float4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            half8 xb[TT];
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) xb[tt] = *(const half8*)(Xw + (tt * 16 + fr) * LDX + ks * 32 + g * 8);
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht) {
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) acc1[ht][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1r[ht * KS + ks], xb[tt], acc1[ht][tt], 0, 0, 0);
+                if (ch + 1 < NCH) w1r[ht * KS + ks] = *(const half8*)(W1 + (size_t)(((ch + 1) * 2 + ht) * KS + ks) * 512);
+            }
+        }
+        // bias + GELU in place; lane holds hidden rows 16ht + 4g + j of token column fr -> A fragment of GEMM2 for the
+        // k order (ht 0: slots 0..3, ht 1: slots 4..7)
+        half8 a2[TT];
+        {
+            const float4v be = *(const float4v*)(p.b1 + ch * 32 + g * 4);
+            const float4v bo = *(const float4v*)(p.b1 + ch * 32 + 16 + g * 4);
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+                const float4v e = acc1[0][tt], o = acc1[1][tt];
+                a2[tt] = (half8){(_Float16)gelu_fast(e[0] + be[0]), (_Float16)gelu_fast(e[1] + be[1]), (_Float16)gelu_fast(e[2] + be[2]),
+                                 (_Float16)gelu_fast(e[3] + be[3]), (_Float16)gelu_fast(o[0] + bo[0]), (_Float16)gelu_fast(o[1] + bo[1]),
+                                 (_Float16)gelu_fast(o[2] + bo[2]), (_Float16)gelu_fast(o[3] + bo[3])};
+            }
+        }
+        // GEMM2: acc2[tt][nt] += H[tokens][chunk] * W2[16nt ..][chunk]^T
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) acc2[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[tt], w2r[nt], acc2[tt][nt], 0, 0, 0);
+            if (ch + 1 < NCH) w2r[nt] = *(const half8*)(W2 + (size_t)((ch + 1) * NT + nt) * 512);
+        }
+    }
+
+    W2X_PHASE_FENCE();
+    // ---- epilogue: residual pieces are requested first, accumulators + b2 -> fp16 tile in the slab, then flat pieces
+    half8 xres[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int idx = k * 64 + lane;
+        half8 h = {};
+        if (idx < npieces) h = *(const half8*)(X + (size_t)idx * 8);
+        xres[k] = h;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float b2 = p.b2[nt * 16 + fr];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Xw[(tt * 16 + g * 4 + j) * LDX + nt * 16 + fr] = (_Float16)(acc2[tt][nt][j] + b2);
+    }
+    W2X_PHASE_FENCE();
+    _Float16* __restrict__ Y = (_Float16*)p.y + row0 * C;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int idx = k * 64 + lane, r = idx / PPR, c = idx - r * PPR;
+        const half8 o = *(const half8*)(Xw + r * LDX + c * 8) + xres[k];     // fp16 + fp16 rounded once == fp32 add rounded to fp16
+        if (idx < npieces) *(half8*)(Y + (size_t)idx * 8) = o;
+        if (p.stats_out) *(half8*)(Xw + r * LDX + c * 8) = o;
+    }
+    W2X_PHASE_FENCE();
+    if (p.stats_out && lane < nrows) {   // LayerNorm statistics of the produced rows for an un-fused consumer
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int c = 0; c < PPR; ++c) sum_sq8(*(const half8*)(Xw + lane * LDX + c * 8), s, q);
+        const float mean = s * (1.f / C);
+        p.stats_out[2 * (row0 + lane)] = mean;
+        p.stats_out[2 * (row0 + lane) + 1] = rsqrtf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps_out);
+    }
+}
+
+template <int C, int TT>
+hipError_t launch_mlp2_c(const MlpParams& p, hipStream_t s) {
+    using K = Mlp2Cfg<C, TT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)mlp2_kernel<C, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid((unsigned)((p.M + K::BM - 1) / K::BM));
+    hipLaunchKernelGGL((mlp2_kernel<C, TT>), grid, dim3(K::NWV * 64), K::SMEM, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_mlp2(const MlpParams& p, hipStream_t s) {
+    if (p.C == 96) return launch_mlp2_c<96, 4>(p, s);
+    if (p.C == 192) return launch_mlp2_c<192, 2>(p, s);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace w2x

@@ -50,6 +50,9 @@ struct MlpParams {               // y = x + W2 gelu(W1 LN(x) + b1) + b2 on conti
     const float* b2 = nullptr;     // [C]
     float eps = 1e-5f;
     float* stats_out = nullptr; float eps_out = 1e-5f;
+    // fragment-major copies for k_mlp2.hip (engine.cpp): w1 as [hidden tile][k-step][lane][8]; w2 as
+    // [chunk of 32 hidden][n-tile][lane][8] with the k order of the GELU'd accumulators (slots 0..3: hidden 4g+j, 4..7: 16+4g+j)
+    const void* w1_frag = nullptr; const void* w2_frag = nullptr;
 };
 
 struct SwinAttnParams {          // y = x + proj(W-MSA(LN(x))) on token maps [B][H][W][C], window 6x6
