@@ -57,10 +57,12 @@ __device__ __forceinline__ half8 norm8(const half8 v, float rstd, float nm) {
 }
 
 // The phases below hand data from lane to lane through the wave's own LDS slab.  The hardware executes a wave's LDS
-// instructions in order, so no s_barrier / s_waitcnt is needed - but the compiler must neither forward a lane's own store
-// to its later load nor move slab accesses across a phase boundary (without this, hipcc 7.2 kept the normalised rows of
-// the last token tile in registers, sank their stores below the main loop and produced wrong rows for that tile;
-// tools/mlp_ab.hip is the regression check).  A compiler-level fence emits no instruction.
+// instructions in order, so no s_barrier / s_waitcnt is needed; the compiler-level fence (no instruction emitted) keeps
+// hipcc from forwarding a lane's own store to its later load or moving slab accesses across a phase boundary.
+// History: a first version exchanged per-row LayerNorm statistics through a small float table in the slab
+// (ds_write_b64 by lane = row, ds_read_b64 by the fragment lanes a few instructions later).  That exchange returned stale
+// values on the second wave of a SIMD at full problem size (tools/mlp_ab.hip reproduces it: first workgroup per CU always
+// right, co-resident ones wrong, not cured by s_waitcnt / s_barrier) and was replaced by register swaps.
 #define W2X_PHASE_FENCE() asm volatile("" ::: "memory")
 
 template <int C, int TT>
