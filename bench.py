@@ -26,6 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 MODEL, SCALE, NOISE, BATCH, TILE, BLEND = "swin_unet/art", 4, 3, 4, 256, 0.0625
 FRAME_W, FRAME_H = 1920, 1080
 MFMA_F16_PEAK_TFLOPS = 2500.0        # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0                # spec; ~6300 achievable (same guide)
 OUT_MPIX = FRAME_W * SCALE * FRAME_H * SCALE / 1e6
 
 
@@ -135,36 +136,71 @@ def main():
     wall_max = shard.max_over_ranks(wall, dist, device=torch.device("cuda", local_rank) if dist is not None else None)
 
     prof = eng.profile_frame()
+    desc = pkg.describe_plan(path, eng.pass_tiles, TILE).splitlines()[2:]
+    op_ms = eng.op_times()
     if a.op_times and rank == 0:
-        desc = pkg.describe_plan(path, eng.pass_tiles, TILE).splitlines()[2:]
-        for line, op_ms in zip(desc, eng.op_times()):
-            print(f"{op_ms:8.3f} ms  {line[:150]}", file=sys.stderr)
+        for line, t in zip(desc, op_ms):
+            print(f"{t:8.3f} ms  {line[:150]}", file=sys.stderr)
     if rank == 0:
+        import re
         fps = a.steps * world / wall_max
-        # dominant kernel family of the frame (by summed HIP-event time on the compute stream)
-        kernel_names = {"attention": "swin_attn96_kernel / swin_attn_kernel<192,32> (fused LN + window MSA + proj + residual)",
-                        "mlp": "mlp_kernel (fused LN + fc1 + GELU + fc2 + residual)", "gemm": "gemm_kernel (fused implicit-GEMM conv/linear)"}
-        dom = max(kernel_names, key=lambda k: prof[k][0])
-        dom_ms, dom_n, dom_flop = prof[dom]
-        achieved = dom_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        n_tiles = pkg.calculate_tiles(FRAME_W, FRAME_H, FRAME_W * SCALE, FRAME_H * SCALE, TILE, eng.output_tile_size, SCALE, (BLEND, BLEND))[0]
+        live = n_tiles / eng.pass_tiles          # the zero-pad slots of the last batch are not computed (plan FLOPs are per pass of pass_tiles)
+        # dominant kernel of the frame: plan ops grouped by the kernel that serves them, by summed HIP-event time
+        # (measured on the compute stream by w2x_profile_frame / w2x_op_times)
+        symbols = {("swinattn", 96): "swin_attn96_kernel", ("swinattn", 192): "swin_attn192_kernel",
+                   ("mlp", 96): "mlp2_kernel<96,4>", ("mlp", 192): "mlp2_kernel<192,2>"}
+        groups = {}
+        for line, t in zip(desc, op_ms):
+            m = re.match(r"\s*\d+ (\w+) (.*?)flops=(\d+)", line)
+            if not m: continue
+            kind, rest, flops = m.group(1), m.group(2), int(m.group(3)) * live
+            cm = re.search(r"\bC=(\d+)", rest)
+            key = (kind, int(cm.group(1))) if kind in ("swinattn", "mlp") and cm else (kind, 0)
+            nbytes = 0.0
+            if key[0] == "swinattn":    # read x + write y: tiles * windows * 36 tokens * C * 2 B, each way
+                nbytes = 2.0 * n_tiles * int(re.search(r"nwin=(\d+)", rest).group(1)) * 36 * key[1] * 2
+            elif key[0] == "mlp":
+                nbytes = 2.0 * int(re.search(r"M=(\d+)", rest).group(1)) * live * key[1] * 2
+            g = groups.setdefault(key, [0.0, 0, 0.0, 0.0]); g[0] += t; g[1] += 1; g[2] += flops; g[3] += nbytes
+        dom = max(groups, key=lambda k: groups[k][0])
+        dom_ms, dom_n, dom_flop, dom_bytes = groups[dom]
+        tflops = dom_flop / (dom_ms * 1e-3) / 1e12
+        gbs = dom_bytes / (dom_ms * 1e-3) / 1e9
+        t_mfma, t_hbm = dom_flop / (MFMA_F16_PEAK_TFLOPS * 1e12), dom_bytes / (HBM_PEAK_GBS * 1e9)
+        hbm_bound = t_hbm > t_mfma               # the roofline that binds this kernel = the larger of the two floor times
+        roof = {"bound": "hbm" if hbm_bound else "mfma",
+                "achieved": round(gbs if hbm_bound else tflops, 2), "peak": HBM_PEAK_GBS if hbm_bound else MFMA_F16_PEAK_TFLOPS,
+                "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tflops / MFMA_F16_PEAK_TFLOPS), 5), "traffic": None,
+                "kernel": symbols.get(dom, "gemm_kernel<...>" if dom[0] == "gemm" else dom[0]),
+                "launches_per_frame": dom_n, "avg_launch_us": round(dom_ms * 1e3 / dom_n, 2),
+                "algorithmic_gflop_per_launch": round(dom_flop / dom_n / 1e9, 3),
+                "algorithmic_mbyte_per_launch": round(dom_bytes / dom_n / 1e6, 3),
+                "other_roof": {"unit": "TFLOP/s" if hbm_bound else "GB/s", "achieved": round(tflops if hbm_bound else gbs, 2),
+                               "frac": round((tflops / MFMA_F16_PEAK_TFLOPS) if hbm_bound else (gbs / HBM_PEAK_GBS), 5)},
+                "kernels_ms_per_frame": {symbols.get(k, k[0]): round(v[0], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])}}
+        tr = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/profile_round.sh)
+        if os.path.exists(tr):
+            try:
+                t = json.load(open(tr)).get(roof["kernel"])
+                if t: roof["traffic"] = t["bytes_per_launch"]; roof["traffic_source"] = t["source"]
+            except Exception:
+                pass
         line = {
             "metric": "upscaled MPix/s, 1080p->4K swin_unet/art fp16",
             "value": round(fps * OUT_MPIX, 2), "unit": "MPix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(wall_max * 1e3 / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": "configs[2]: swin_unet/art scale4 noise3 batch4 tile256 fp16, 1920x1080 frame, blend=0.0625 "
-                                   "(45 tiles, 12 batches); synthetic-weight graph of that architecture, frame resident in HBM",
+                                   f"({n_tiles} tiles, 12 batches); synthetic-weight graph of that architecture, frame resident in HBM",
                        "frames_per_s": round(fps, 3), "device_ms_per_frame": round(ms, 3), "frames_per_rank": a.steps,
                        "parallelism": f"frame-sharded x{world}, no collectives",
                        "pcie_inclusive_ms_per_frame": round(pcie_ms_one, 2),
                        "tiles_per_network_pass": eng.pass_tiles,
-                       "algorithmic_tflop_per_frame": round(eng.plan_flops / eng.pass_tiles * 48 / 1e12, 4)},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 5), "traffic": None,
-                         "kernel": kernel_names[dom], "launches_per_frame": dom_n,
-                         "avg_launch_us": round(dom_ms * 1e3 / max(dom_n, 1), 2),
-                         "algorithmic_gflop_per_launch": round(dom_flop / max(dom_n, 1) / 1e9, 3),
-                         "families_ms_per_frame": {k: round(v[0], 3) for k, v in prof.items() if k != "frame_ms"}},
+                       "algorithmic_tflop_per_frame": round(eng.plan_flops * live / 1e12, 4),
+                       "families_ms_per_frame": {k: round(v[0], 3) for k, v in prof.items() if k != "frame_ms"}},
+            "roofline": roof,
         }
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(a.work, threads=min(os.cpu_count() or 1, 32))
