@@ -110,6 +110,9 @@ def main():
     rc = pkg.RenderConfig(deviceId=local_rank, batchSize=BATCH, height=TILE, width=TILE, scaling=SCALE, overlap=(BLEND, BLEND))
     if not eng.load(path, rc):
         raise SystemExit("load failed: " + eng.last_error())
+    if rank == 0:
+        for _, m in eng.messages[-2:]:
+            print("[w2x] " + m, file=sys.stderr)
 
     import shard
     my_frames = shard.frames_for_rank(a.steps * world, rank, world)       # frame f -> rank f mod N; each rank renders K frames
