@@ -53,6 +53,12 @@ int w2x_build(w2x_engine* e, const char* onnx_path, const w2x_build_config* cfg)
 int w2x_load(w2x_engine* e, const char* onnx_path, const w2x_render_config* cfg);
 /* src/dst: interleaved 8-bit BGR, `step` bytes per row; dst must be rows*scaling x cols*scaling. */
 int w2x_render(w2x_engine* e, const uint8_t* src, int rows, int cols, size_t src_step, uint8_t* dst, size_t dst_step);
+/* Multi-GPU split of ONE frame (no reference counterpart: main.cpp:70-74 is single-device): strip `part` of
+ * `parts` = a contiguous range of the reference's column-major tile order (img2img_render.cpp:43-44) plus the output columns
+ * it alone composes.  w2x_strip_plan is pure host logic: out[0..3] = first_tile, tile_count, x0, x1 (x in output pixels). */
+int w2x_render_strip(w2x_engine* e, const uint8_t* src, int rows, int cols, size_t src_step, uint8_t* dst, size_t dst_step, int part, int parts);
+int w2x_strip_plan(int in_w, int in_h, int out_w, int out_h, int tile_in, int tile_out, int scaling, double overlap_x, double overlap_y,
+                   int part, int parts, int* out4);
 int w2x_infer(w2x_engine* e, const float* input_nchw, float* output_nchw);
 int w2x_output_tile_size(w2x_engine* e);
 double w2x_plan_flops(w2x_engine* e);   /* algorithmic FLOP of one network pass */

@@ -35,6 +35,9 @@ public:
     bool load(const std::string& path, const RenderConfig& config);
     // img2img.h:20 - dst must be rows*scaling x cols*scaling (caller pre-sizes it, main.cpp:234-235)
     bool render(const Image& src, Image& dst);
+    // One device's share of a single frame spread over `parts` devices (tile-column strips): composes and writes only
+    // the output columns of strip `part` (w2x_strip_plan); identical bytes to render() there.  render() == renderStrip(.., 0, 1).
+    bool renderStrip(const Image& src, Image& dst, int part, int parts);
     void setMessageCallback(MessageCallback callback);   // img2img.h:21
     void setProgressCallback(ProgressCallback callback); // img2img.h:22
 
@@ -56,6 +59,7 @@ public:
 
     struct Impl;
 private:
+    bool renderPart(const Image& src, Image& dst, int part, int parts, const char* who);
     std::unique_ptr<Impl> impl;
 };
 

@@ -180,6 +180,27 @@ def test_pad_slots_are_skipped_and_stale_memory_is_never_read(pkg, onnx_model, m
     eng.close()
 
 
+@pytest.mark.parametrize("model,scale,tile,tta,shape", [("swin_unet/art", 4, 64, False, (150, 330)), ("cunet/art", 2, 64, True, (100, 260))])
+def test_strips_reassemble_the_frame_bit_exactly(pkg, onnx_model, model, scale, tile, tta, shape):
+    """one frame split over N devices by tile-column strips.  Rendering the strips one after another on this
+    GPU into one buffer must give exactly the bytes of the whole-frame render (same contributions, same order)."""
+    path = onnx_model(model, scale, 2, tile, small=model.startswith("swin"))
+    eng = make_engine(pkg, path, 2, tile, scale, tta=tta)
+    frame = smooth_frame(*shape, 31)
+    whole = eng.render(frame)
+    for parts in (2, 3, 5):
+        out = np.full_like(whole, 77)
+        for part in range(parts):
+            assert eng.render_strip(frame, out, part, parts), eng.last_error()
+        assert np.array_equal(out, whole), parts
+    # a strip writes nothing outside its own columns
+    out = np.full_like(whole, 77)
+    assert eng.render_strip(frame, out, 1, 2)
+    _, cnt, x0, x1 = pkg.strip_plan(shape[1], shape[0], shape[1] * scale, shape[0] * scale, tile, eng.output_tile_size, scale, (0.0625, 0.0625), 1, 2)
+    assert cnt > 0 and (out[:, :x0] == 77).all() and np.array_equal(out[:, x0:x1], whole[:, x0:x1])
+    eng.close()
+
+
 def test_super_batching_is_bit_identical(pkg, onnx_model, monkeypatch):
     """One network pass may carry S reference batches (W2X_SUPERBATCH); frames, progress callbacks and infer() must not change."""
     path = onnx_model("swin_unet/art", 4, 2, 64, small=True)

@@ -89,3 +89,29 @@ def test_error_convention_without_gpu_or_engine(pkg, onnx_model, tmp_path):
     assert eng.load(str(tmp_path / "nope.onnx"), cfg) is False
     assert re.match(r"\[load@\d+\] ", seen[-1][1])
     eng.close()
+
+
+@pytest.mark.parametrize("W,H,T,s,Tout,ov", [(1920, 1080, 256, 4, 960, 0.0625), (1920, 1080, 256, 2, 440, 0.0625), (3840, 2160, 640, 4, 2496, 0.0625),
+                                             (1920, 1080, 256, 4, 960, 0.0), (300, 200, 64, 2, 56, 0.125), (1920, 1080, 400, 4, 1536, 0.03125)])
+@pytest.mark.parametrize("parts", [1, 2, 3, 8, 16])
+def test_strip_plan_partitions_a_frame(pkg, W, H, T, s, Tout, ov, parts):
+    """Multi-GPU split of one frame: the strips' output column ranges tile [0, W*s) without gaps or overlap, each
+    strip's tiles are a contiguous range of the reference's tile order, and every tile that covers one of its pixels
+    (per the oracle's rects) is inside that range - so composing a strip never needs another device's tiles."""
+    n, _, outs = P.calculate_tiles(W, H, W * s, H * s, (T, T), (Tout, Tout), s, (ov, ov))
+    xs = []
+    for part in range(parts):
+        first, cnt, x0, x1 = pkg.strip_plan(W, H, W * s, H * s, T, Tout, s, (ov, ov), part, parts)
+        if cnt == 0:
+            assert x0 == x1 == 0
+            continue
+        assert 0 <= first and first + cnt <= n and x0 < x1
+        xs.append((x0, x1))
+        for t, r in enumerate(outs):
+            covers = r.x < x1 and r.x + r.w > x0
+            assert (not covers) or first <= t < first + cnt, (part, t, r.astuple())
+    xs.sort()
+    assert xs[0][0] == 0 and xs[-1][1] == W * s
+    assert all(a[1] == b[0] for a, b in zip(xs, xs[1:]))
+    if parts == 1:
+        assert pkg.strip_plan(W, H, W * s, H * s, T, Tout, s, (ov, ov), 0, 1) == (0, n, 0, W * s)

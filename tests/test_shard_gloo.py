@@ -48,3 +48,40 @@ def test_single_process_helpers_without_dist():
     assert shard.frames_for_rank(5, 0, 1) == [0, 1, 2, 3, 4]
     assert shard.max_over_ranks(3.5) == 3.5
     shard.barrier(None)
+
+
+def _strip_worker(rank, world, port, q):
+    """Single-frame mode: each rank asks the library (host logic only, no GPU) for its tile-column strip, fills its columns of a
+    stand-in output with its rank id, and rank 0 gathers the column ranges - the writer-side reassembly of SURVEY 8e."""
+    import importlib
+    import numpy as np
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("waifu2x-tensorrt_amd")
+    first, cnt, x0, x1 = pkg.strip_plan(1920, 1080, 7680, 4320, 256, 960, 4, (0.0625, 0.0625), rank, world)
+    cols = torch.zeros(7680, dtype=torch.int32)
+    cols[x0:x1] = rank + 1
+    dist.all_reduce(cols)                      # test-only check that the ranges are disjoint and complete (not a data-path collective)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (first, cnt, x0, x1))
+    q.put((rank, gathered, bool(((cols >= 1) & (cols <= world)).all()), int((cols == rank + 1).sum())))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_split_one_frame_into_tile_column_strips():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path: sys.path.insert(0, root)
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_strip_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs: p.join(60); assert p.exitcode == 0
+    plans = res[0][1]
+    assert all(r[1] == plans for r in res) and all(r[2] for r in res)
+    # config 3: 9x5 tiles; rank 0 owns tile columns 0..3, rank 1 columns 4..8 plus column 3 again for the blend band
+    assert plans[0] == (0, 20, 0, 4 * 896) and plans[1] == (15, 30, 4 * 896, 7680)
+    assert res[0][3] == 4 * 896 and res[1][3] == 7680 - 4 * 896

@@ -64,6 +64,24 @@ int w2x_render(w2x_engine* e, const uint8_t* src, int rows, int cols, size_t src
     return e->engine.render(s, d) ? 1 : 0;
 }
 
+int w2x_render_strip(w2x_engine* e, const uint8_t* src, int rows, int cols, size_t src_step, uint8_t* dst, size_t dst_step, int part, int parts) {
+    if (!e) return 0;
+    w2x::Image s; s.data = const_cast<uint8_t*>(src); s.rows = rows; s.cols = cols; s.step = src_step;
+    w2x::Image d; d.data = dst; d.step = dst_step;
+    const int sc = e->engine.scaling();
+    d.rows = rows * sc; d.cols = cols * sc;
+    return e->engine.renderStrip(s, d, part, parts) ? 1 : 0;
+}
+
+int w2x_strip_plan(int in_w, int in_h, int out_w, int out_h, int tile_in, int tile_out, int scaling, double overlap_x, double overlap_y,
+                   int part, int parts, int* out4) {
+    if (!out4) return 0;
+    w2x::TileGrid g = w2x::calculate_tiles(in_w, in_h, out_w, out_h, tile_in, tile_in, tile_out, tile_out, scaling, overlap_x, overlap_y);
+    w2x::StripPlan sp = w2x::strip_plan(g, out_w, tile_out, part, parts);
+    out4[0] = sp.first_tile; out4[1] = sp.tile_count; out4[2] = sp.x0; out4[3] = sp.x1;
+    return 1;
+}
+
 int w2x_infer(w2x_engine* e, const float* in, float* out) { return e && e->engine.infer(in, out) ? 1 : 0; }
 int w2x_output_tile_size(w2x_engine* e) { return e ? e->engine.outputTileSize() : 0; }
 int w2x_pass_tiles(w2x_engine* e) { return e ? e->engine.passTiles() : 0; }

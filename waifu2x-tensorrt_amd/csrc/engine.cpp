@@ -20,6 +20,7 @@
 #include "tiles.h"
 
 #define W2X_LOG(sev, message) impl->log(sev, message, __FUNCTION__, __LINE__)
+#define W2X_LOG_AS(who, sev, message) impl->log(sev, message, who, __LINE__)
 
 namespace w2x {
 
@@ -161,6 +162,7 @@ struct Img2Img::Impl {
     // last frame (for benchResident)
     int last_rows = 0, last_cols = 0, last_batches = 0;
     TileGrid last_grid;
+    StripPlan last_strip;
     float last_ms = 0.f;
 
     ~Impl() { release(); }
@@ -395,11 +397,11 @@ struct Img2Img::Impl {
     }
 
     // device part of one frame: gather -> network per batch -> compose.  Frame must already be in d_frame.
-    void run_frame(int rows, int cols, const TileGrid& grid, bool report) {
+    void run_frame(int rows, int cols, const TileGrid& grid, bool report, const StripPlan& sp) {
         const int B = plan.B, T = plan.T, To = plan.Tout;
         const int steps = cfg.tta ? 8 : 1;
         const int userB = plan.userB, S = B / userB;
-        const int batchCount = (int)std::lround(std::ceil((double)(grid.count * steps) / userB));   // img2img_render.cpp:249
+        const int batchCount = (int)std::lround(std::ceil((double)(sp.tile_count * steps) / userB));   // img2img_render.cpp:249
         const int passCount = (batchCount + S - 1) / S;
         const size_t slot_bytes = (size_t)To * To * 4 * sizeof(uint16_t);
         const bool poison = getenv("W2X_POISON") != nullptr;   // test hook: stale activations become fp16 NaNs
@@ -415,7 +417,7 @@ struct Img2Img::Impl {
             stamp_begin(3, 0);
             hipAssert(launch_gather(gp, stream));
             stamp_end();
-            const int live = std::max(0, std::min(B, grid.count * steps - bi * B));
+            const int live = std::max(0, std::min(B, sp.tile_count * steps - bi * B));
             run_network((uint8_t*)d_slab + (size_t)bi * B * slot_bytes, live);
             if (report) {
                 const auto t1 = std::chrono::steady_clock::now();
@@ -431,6 +433,7 @@ struct Img2Img::Impl {
         const bool overlapping = cfg.overlapX != 0 || cfg.overlapY != 0;                      // :244
         cp.ovx = overlapping ? ovx : 0; cp.ovy = overlapping ? ovy : 0;
         cp.ramp_x = d_rampx; cp.ramp_y = d_rampy; cp.tta = cfg.tta ? 1 : 0; cp.tta_bug_compat = cfg.ttaBugCompat ? 1 : 0;
+        cp.x0 = sp.x0; cp.x1 = sp.x1; cp.first_tile = sp.first_tile;
         stamp_begin(4, 0);
         hipAssert(launch_compose(cp, stream));
         stamp_end();
@@ -590,14 +593,21 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
     return false;
 }
 
-bool Img2Img::render(const Image& src, Image& dst) try {
-    if (!impl->loaded) { W2X_LOG(error, "Render called before a successful load."); return false; }
+bool Img2Img::render(const Image& src, Image& dst) { return renderPart(src, dst, 0, 1, "render"); }
+
+// One GPU's share of a frame when a single image is spread over several devices: renders and writes only the
+// output columns strip_plan() assigns to `part`; the other columns of dst are left untouched.  part 0 of 1 = render().
+bool Img2Img::renderStrip(const Image& src, Image& dst, int part, int parts) { return renderPart(src, dst, part, parts, "renderStrip"); }
+
+bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, const char* who) try {
+    if (!impl->loaded) { W2X_LOG_AS(who, error, "Render called before a successful load."); return false; }
+    if (parts <= 0 || part < 0 || part >= parts) { W2X_LOG_AS(who, error, "Invalid strip index."); return false; }
     const RenderConfig& cfg = impl->cfg;
     const Plan& plan = impl->plan;
     const int rows = src.rows, cols = src.cols, s = cfg.scaling;
-    if (!src.data || rows <= 0 || cols <= 0 || src.step < (size_t)cols * 3) { W2X_LOG(error, "Input image is empty or has an invalid step."); return false; }
+    if (!src.data || rows <= 0 || cols <= 0 || src.step < (size_t)cols * 3) { W2X_LOG_AS(who, error, "Input image is empty or has an invalid step."); return false; }
     if (!dst.data || dst.rows != rows * s || dst.cols != cols * s || dst.step < (size_t)dst.cols * 3) {
-        W2X_LOG(error, "Output image has invalid size: expected " + std::to_string(cols * s) + "x" + std::to_string(rows * s) + ".");
+        W2X_LOG_AS(who, error, "Output image has invalid size: expected " + std::to_string(cols * s) + "x" + std::to_string(rows * s) + ".");
         return false;
     }
     hipStream_t stream = impl->stream;
@@ -607,17 +617,19 @@ bool Img2Img::render(const Image& src, Image& dst) try {
     hipAssert(hipMemcpy2DAsync(impl->d_frame, (size_t)cols * 3, src.data, src.step, (size_t)cols * 3, rows, hipMemcpyHostToDevice, stream));
     // :232-240
     TileGrid grid = calculate_tiles(cols, rows, cols * s, rows * s, plan.T, plan.T, plan.Tout, plan.Tout, s, cfg.overlapX, cfg.overlapY);
-    if (grid.count <= 0) { W2X_LOG(error, "Tile grid is empty."); return false; }
-    for (const Rect& r : grid.out) if (r.w <= 0 || r.h <= 0) { W2X_LOG(error, "Tile grid does not fit the output (scaling does not match the model)."); return false; }
+    if (grid.count <= 0) { W2X_LOG_AS(who, error, "Tile grid is empty."); return false; }
+    for (const Rect& r : grid.out) if (r.w <= 0 || r.h <= 0) { W2X_LOG_AS(who, error, "Tile grid does not fit the output (scaling does not match the model)."); return false; }
+    const StripPlan sp = strip_plan(grid, cols * s, plan.Tout, part, parts);
+    if (sp.tile_count == 0) return true;                       // more devices than tile columns: this one has no share
     // :246-267 step schedule: slot = step index, tile = step / stepsPerTile, aug = step % stepsPerTile, zero pad slots at the end
     const int steps = cfg.tta ? 8 : 1, B = plan.B, S = plan.B / plan.userB;
-    const int batchCount = (int)std::lround(std::ceil((double)(grid.count * steps) / plan.userB));
+    const int batchCount = (int)std::lround(std::ceil((double)(sp.tile_count * steps) / plan.userB));
     const int stepCount = ((batchCount + S - 1) / S) * B;   // reference batches rounded up to whole network passes
     impl->h_slots.resize(stepCount);
     for (int st = 0; st < stepCount; ++st) {
         int ti = st / steps, aug = st % steps;
         TileSlot sl{0, 0, aug, 0};
-        if (ti < grid.count) { sl.x = grid.in[ti].x; sl.y = grid.in[ti].y; sl.valid = 1; }
+        if (ti < sp.tile_count) { sl.x = grid.in[sp.first_tile + ti].x; sl.y = grid.in[sp.first_tile + ti].y; sl.valid = 1; }
         impl->h_slots[st] = sl;
     }
     impl->ensure(impl->d_slots, impl->slots_cap, (size_t)stepCount * sizeof(TileSlot));
@@ -625,16 +637,16 @@ bool Img2Img::render(const Image& src, Image& dst) try {
     impl->ensure(impl->d_slab, impl->slab_cap, (size_t)stepCount * plan.Tout * plan.Tout * 4 * sizeof(uint16_t));
 
     hipAssert(hipEventRecord(impl->ev0, stream));
-    impl->run_frame(rows, cols, grid, true);
+    impl->run_frame(rows, cols, grid, true, sp);
     hipAssert(hipEventRecord(impl->ev1, stream));
     // :344 download ; the reference leaves the sync commented out (:345, quirk Q10) - we wait before handing dst back
-    hipAssert(hipMemcpy2DAsync(dst.data, dst.step, impl->d_out, (size_t)dst.cols * 3, (size_t)dst.cols * 3, dst.rows, hipMemcpyDeviceToHost, stream));
+    hipAssert(hipMemcpy2DAsync(dst.data + (size_t)sp.x0 * 3, dst.step, impl->d_out + (size_t)sp.x0 * 3, (size_t)dst.cols * 3, (size_t)(sp.x1 - sp.x0) * 3, dst.rows, hipMemcpyDeviceToHost, stream));
     hipAssert(hipStreamSynchronize(stream));
     hipAssert(hipEventElapsedTime(&impl->last_ms, impl->ev0, impl->ev1));
-    impl->last_rows = rows; impl->last_cols = cols; impl->last_grid = grid;
+    impl->last_rows = rows; impl->last_cols = cols; impl->last_grid = grid; impl->last_strip = sp;
     return true;
 } catch (const std::exception& e) {
-    W2X_LOG(error, "Render failed unexpectedly: " + std::string(e.what()) + ".");
+    W2X_LOG_AS(who, error, "Render failed unexpectedly: " + std::string(e.what()) + ".");
     return false;
 }
 
@@ -672,7 +684,7 @@ float Img2Img::benchResident(int iters) try {
     if (!impl->loaded || impl->last_rows == 0 || iters <= 0) return -1.f;
     hipStream_t stream = impl->stream;
     hipAssert(hipEventRecord(impl->ev0, stream));
-    for (int i = 0; i < iters; ++i) impl->run_frame(impl->last_rows, impl->last_cols, impl->last_grid, false);
+    for (int i = 0; i < iters; ++i) impl->run_frame(impl->last_rows, impl->last_cols, impl->last_grid, false, impl->last_strip);
     hipAssert(hipEventRecord(impl->ev1, stream));
     hipAssert(hipStreamSynchronize(stream));
     float ms = 0.f;
@@ -690,7 +702,7 @@ bool Img2Img::profileFrame(double* out, int cap) try {
     if (!impl->loaded || impl->last_rows == 0 || cap < 31) return false;
     for (int i = 0; i < 31; ++i) out[i] = 0;
     impl->profiling = true; impl->stamps.clear();
-    impl->run_frame(impl->last_rows, impl->last_cols, impl->last_grid, false);
+    impl->run_frame(impl->last_rows, impl->last_cols, impl->last_grid, false, impl->last_strip);
     impl->profiling = false;
     hipAssert(hipStreamSynchronize(impl->stream));
     impl->op_ms.assign(impl->plan.ops.size(), 0.0);

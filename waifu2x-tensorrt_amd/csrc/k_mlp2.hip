@@ -65,10 +65,10 @@ __device__ __forceinline__ half8 norm8(const half8 v, float rstd, float nm) {
 // right, co-resident ones wrong, not cured by s_waitcnt / s_barrier) and was replaced by register swaps.
 #define W2X_PHASE_FENCE() asm volatile("" ::: "memory")
 
-template <int C, int TT>
+template <int C, int TT, int NW>
 struct Mlp2Cfg {
     static constexpr int RW = 16 * TT;           // rows per wave
-    static constexpr int NWV = 4;                // independent waves per workgroup
+    static constexpr int NWV = NW;               // independent waves per workgroup
     static constexpr int BM = NWV * RW;          // rows per workgroup
     static constexpr int LDX = C + 8;            // slab row stride in halves: 16-byte pieces rotate over the banks
     static constexpr int PPR = C / 8;            // 16-byte pieces per row
@@ -81,9 +81,9 @@ struct Mlp2Cfg {
     static_assert(RW * PPR % 64 == 0, "flat piece count");
 };
 
-template <int C, int TT>
-__global__ __launch_bounds__(256, 2) void mlp2_kernel(const MlpParams p) {
-    using K = Mlp2Cfg<C, TT>;
+template <int C, int TT, int NW>
+__global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 8 / NW)) void mlp2_kernel(const MlpParams p) {
+    using K = Mlp2Cfg<C, TT, NW>;
     constexpr int RW = K::RW, LDX = K::LDX, PPR = K::PPR, KS = K::KS, NT = K::NT, NCH = K::NCH, NP = K::NP;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -228,25 +228,26 @@ __global__ __launch_bounds__(256, 2) void mlp2_kernel(const MlpParams p) {
     }
 }
 
-template <int C, int TT>
+template <int C, int TT, int NW>
 hipError_t launch_mlp2_c(const MlpParams& p, hipStream_t s) {
-    using K = Mlp2Cfg<C, TT>;
+    using K = Mlp2Cfg<C, TT, NW>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)mlp2_kernel<C, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
+        hipError_t e = hipFuncSetAttribute((const void*)mlp2_kernel<C, TT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid((unsigned)((p.M + K::BM - 1) / K::BM));
-    hipLaunchKernelGGL((mlp2_kernel<C, TT>), grid, dim3(K::NWV * 64), K::SMEM, s, p);
+    hipLaunchKernelGGL((mlp2_kernel<C, TT, NW>), grid, dim3(K::NWV * 64), K::SMEM, s, p);
     return hipGetLastError();
 }
 
 }  // namespace
 
 hipError_t launch_mlp2(const MlpParams& p, hipStream_t s) {
-    if (p.C == 96) return launch_mlp2_c<96, 4>(p, s);
-    if (p.C == 192) return launch_mlp2_c<192, 2>(p, s);
+    static const int nw = getenv("W2X_MLP2_NW") ? atoi(getenv("W2X_MLP2_NW")) : 4;   // waves per workgroup (tuning switch)
+    if (p.C == 96) return nw == 8 ? launch_mlp2_c<96, 4, 8>(p, s) : launch_mlp2_c<96, 4, 4>(p, s);
+    if (p.C == 192) return nw == 8 ? launch_mlp2_c<192, 2, 8>(p, s) : launch_mlp2_c<192, 2, 4>(p, s);
     return hipErrorInvalidValue;
 }
 

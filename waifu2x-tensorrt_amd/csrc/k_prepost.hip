@@ -69,12 +69,13 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherParams p) {
 }
 
 __global__ __launch_bounds__(256) void compose_kernel(const ComposeParams p) {
-    const long total = (long)p.outW * p.outH;
+    const int x1 = p.x1 > 0 ? p.x1 : p.outW, sw = x1 - p.x0;
+    const long total = (long)sw * p.outH;
     const int To = p.To, n = To - 1;
     const int steps = p.tta ? 8 : 1;
     const half4* tiles = (const half4*)p.tiles;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int Y = (int)(i / p.outW), X = (int)(i - (long)Y * p.outW);
+        int Y = (int)(i / sw), X = p.x0 + (int)(i - (long)Y * sw);
         // candidate tile columns/rows: origin = idx*stride, extent To (clipped to the canvas)
         int i0 = X - To + 1; i0 = i0 <= 0 ? 0 : (i0 + p.stride_x - 1) / p.stride_x;
         int i1 = min(p.nx - 1, X / p.stride_x);
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void compose_kernel(const ComposeParams p) {
             for (int tj = j0; tj <= j1; ++tj) {
                 const int oy = tj * p.stride_y, ly = Y - oy;
                 const int rh = oy + To > p.outH ? p.outH - oy : To;
-                const long tile = (long)ti * p.ny + tj;
+                const long tile = (long)ti * p.ny + tj - p.first_tile;
                 const half4* tp = tiles + tile * steps * (long)To * To;
                 float v0, v1, v2;
                 if (!p.tta) {
@@ -199,7 +200,7 @@ hipError_t launch_gather(const GatherParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_compose(const ComposeParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(compose_kernel, dim3(grid_for((long)p.outW * p.outH)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(compose_kernel, dim3(grid_for((long)((p.x1 > 0 ? p.x1 : p.outW) - p.x0) * p.outH)), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 hipError_t launch_se(const SeParams& p, hipStream_t s) {

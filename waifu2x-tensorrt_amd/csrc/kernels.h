@@ -102,6 +102,9 @@ struct ComposeParams {
     const float* ramp_y = nullptr;
     int tta = 0;
     int tta_bug_compat = 0;
+    // strip rendering (one GPU of several composes only its columns): output columns [x0, x1) and the global index of
+    // the tile held by slot 0 (x1 = 0: the whole canvas)
+    int x0 = 0, x1 = 0; long first_tile = 0;
 };
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);

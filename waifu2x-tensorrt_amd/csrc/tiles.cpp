@@ -65,4 +65,19 @@ std::vector<float> tile_weight_mask(int which, int ovx, int ovy, int size) {
     return m;
 }
 
+StripPlan strip_plan(const TileGrid& g, int outW, int tileOutW, int part, int parts) {
+    StripPlan sp;
+    if (parts <= 0 || part < 0 || part >= parts || g.nx <= 0) return sp;
+    const int c0 = (int)((long)part * g.nx / parts), c1 = (int)((long)(part + 1) * g.nx / parts);
+    if (c0 >= c1) return sp;                                  // more parts than tile columns: nothing to do
+    const int stride = tileOutW - g.outOvX;                   // output origin of tile column i = i * stride (img2img_render.cpp:54-55)
+    sp.x0 = c0 * stride;
+    sp.x1 = c1 < g.nx ? c1 * stride : outW;
+    int cc0 = c0;                                             // first tile column whose extent reaches x0
+    while (cc0 > 0 && (cc0 - 1) * stride + tileOutW > sp.x0) --cc0;
+    sp.first_tile = cc0 * g.ny;
+    sp.tile_count = (c1 - cc0) * g.ny;
+    return sp;
+}
+
 }  // namespace w2x

@@ -103,6 +103,8 @@ def lib():
     L.w2x_build.argtypes = [vp, C.c_char_p, C.POINTER(_BuildConfig)]; L.w2x_build.restype = C.c_int
     L.w2x_load.argtypes = [vp, C.c_char_p, C.POINTER(_RenderConfig)]; L.w2x_load.restype = C.c_int
     L.w2x_render.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t]; L.w2x_render.restype = C.c_int
+    L.w2x_render_strip.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_int]; L.w2x_render_strip.restype = C.c_int
+    L.w2x_strip_plan.argtypes = [C.c_int] * 7 + [C.c_double, C.c_double, C.c_int, C.c_int, vp]; L.w2x_strip_plan.restype = C.c_int
     L.w2x_infer.argtypes = [vp, vp, vp]; L.w2x_infer.restype = C.c_int
     L.w2x_output_tile_size.argtypes = [vp]; L.w2x_output_tile_size.restype = C.c_int
     L.w2x_pass_tiles.argtypes = [vp]; L.w2x_pass_tiles.restype = C.c_int
@@ -123,7 +125,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "w2x_create", "w2x_destroy", "w2x_set_message_callback", "w2x_set_progress_callback", "w2x_build", "w2x_load",
     "w2x_render", "w2x_infer", "w2x_output_tile_size", "w2x_plan_flops", "w2x_pass_tiles", "w2x_last_render_ms", "w2x_bench_resident", "w2x_profile_frame", "w2x_op_times",
-    "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_sha256_hex", "w2x_debug_attn_stamps", "w2x_debug_mlp_stamps", "w2x_version"]
+    "w2x_render_strip", "w2x_strip_plan", "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_sha256_hex", "w2x_debug_attn_stamps", "w2x_debug_mlp_stamps", "w2x_version"]
 
 
 class Img2Img:
@@ -206,6 +208,16 @@ class Img2Img:
             return dst
         return ok
 
+    def render_strip(self, src: np.ndarray, dst: np.ndarray, part: int, parts: int) -> bool:
+        """One device's share of a frame split into tile-column strips (w2x_render_strip): writes only its columns of dst."""
+        s = getattr(self, "_scaling", 0)
+        if src.dtype != np.uint8 or src.ndim != 3 or src.shape[2] != 3 or src.strides[2] != 1 or src.strides[1] != 3:
+            raise ValueError("src must be a uint8 [rows, cols, 3] BGR array with packed pixels")
+        if dst.dtype != np.uint8 or dst.shape != (src.shape[0] * s, src.shape[1] * s, 3) or dst.strides[2] != 1 or dst.strides[1] != 3:
+            raise ValueError("dst must be a packed uint8 array of the scaled size")
+        return bool(self._L.w2x_render_strip(self._h, src.ctypes.data, src.shape[0], src.shape[1], src.strides[0],
+                                             dst.ctypes.data, dst.strides[0], int(part), int(parts)))
+
     def infer(self, x: np.ndarray) -> np.ndarray:
         """Private trt::Img2Img::infer (img2img_infer.cpp:41-93) as a test hook: [B,3,T,T] f32 -> [B,3,T',T'] f32."""
         x = np.ascontiguousarray(x, np.float32)
@@ -248,6 +260,13 @@ class Img2Img:
         out = np.zeros(4096, np.float64)
         n = self._L.w2x_op_times(self._h, out.ctypes.data, 4096)
         return out[:n].copy()
+
+
+def strip_plan(in_w, in_h, out_w, out_h, tile_in, tile_out, scaling, overlap, part, parts):
+    """Host logic of the multi-GPU single-frame split -> (first_tile, tile_count, x0, x1)."""
+    out = np.zeros(4, np.int32)
+    lib().w2x_strip_plan(in_w, in_h, out_w, out_h, tile_in, tile_out, scaling, float(overlap[0]), float(overlap[1]), int(part), int(parts), out.ctypes.data)
+    return tuple(int(v) for v in out)
 
 
 def calculate_tiles(in_w, in_h, out_w, out_h, tile_in, tile_out, scaling, overlap):
