@@ -360,8 +360,13 @@ def export_onnx(net: nn.Module, path: str, batch: int, tile: int, opset: int = 1
     kw = {}
     if dynamic:
         kw["dynamic_axes"] = {"x": {0: "b"}, "y": {0: "b"}}
+    # tracing must not record an autograd graph: with trainable parameters every intermediate of the example run stays
+    # alive until the end, which at batch 16 / tile 640 is hundreds of GB of host memory
+    net.eval()
+    for prm in net.parameters():
+        prm.requires_grad_(False)
     import warnings
-    with warnings.catch_warnings():
+    with warnings.catch_warnings(), torch.no_grad():
         warnings.simplefilter("ignore")
         torch.onnx.export(net, (x,), path, dynamo=False, opset_version=opset,
                           input_names=["x"], output_names=["y"], do_constant_folding=True, **kw)
