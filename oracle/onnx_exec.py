@@ -49,13 +49,23 @@ class Executor:
             torch.set_num_threads(self.threads)
         env = dict(self.consts)
         env[self.input_name] = _t(np.asarray(x, np.float32))
+        # values are dropped after their last reader: a swin_unet graph has ~700 runtime nodes and keeping every
+        # intermediate alive costs tens to hundreds of GB at tile 256..640
+        last = {}
+        for k, n in enumerate(self.g.nodes):
+            for i in n.inputs:
+                if i: last[i] = k
+        pinned = set(self.consts) | {o.name for o in self.g.outputs} | set(keep)
         with torch.no_grad():
-            for n in self.g.nodes:
+            for k, n in enumerate(self.g.nodes):
                 outs = self._node(n, [env[i] if i else None for i in n.inputs])
                 if not isinstance(outs, (tuple, list)):
                     outs = (outs,)
                 for name, v in zip(n.outputs, outs):
                     env[name] = v
+                for i in n.inputs:
+                    if i and last.get(i) == k and i not in pinned:
+                        env.pop(i, None)
         y = env[self.g.outputs[0].name].numpy()
         if keep:
             return {k: env[k].numpy() for k in keep} | {"y": y}
