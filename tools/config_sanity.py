@@ -48,7 +48,7 @@ def run(tag, model, scale, noise, batch, tile, hw, tta=False, oracle_hw=None):
     if oracle_hw:
         fs = frame(oracle_hw[0], oracle_hw[1], 5)
         o = eng.render(fs)
-        ref = pipeline.render(fs, onnx_exec.Executor(path).run, batch=batch, tile=tile, scaling=scale, overlap=(0.0625, 0.0625), tta=tta, net_dtype=np.float16)
+        ref = pipeline.render(fs, onnx_exec.Executor(path).run, batch=1, tile=tile, scaling=scale, overlap=(0.0625, 0.0625), tta=tta, net_dtype=np.float16)
         d = np.abs(o.astype(int) - ref.astype(int))
         mse = float(np.mean(d.astype(np.float64) ** 2)); psnr = 99.0 if mse == 0 else 10 * np.log10(255 ** 2 / mse)
         msg += f"; oracle {oracle_hw[1]}x{oracle_hw[0]}: max LSB diff {d.max()}, PSNR {psnr:.1f} dB"
