@@ -1,0 +1,116 @@
+"""The reference's command line (src/main.cpp:18-153, 197-209, 240-257) rebuilt as waifu2x-tensorrt_amd/w2x: option set,
+validation, model path / suffix / output naming, and the built-in still-image codecs.  No GPU needed: --print-config stops
+after parsing, `convert` only touches the codecs."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W2X = os.path.join(ROOT, "waifu2x-tensorrt_amd", "w2x")
+BASE = ["--model", "swin_unet/art", "--scale", "4", "--noise", "3", "--batchSize", "4", "--tileSize", "256"]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built(pkg):          # pkg builds the library (and the CLI with it)
+    assert os.path.exists(W2X), "w2x was not built"
+
+
+def run(*args):
+    return subprocess.run([W2X, *args], capture_output=True, text=True, timeout=120)
+
+
+def test_render_options_and_derived_names(tmp_path):
+    img = tmp_path / "picture.one.png"
+    img.write_bytes(b"x")
+    out = tmp_path / "o"; out.mkdir()
+    r = run(*BASE, "render", "-i", str(img), "-o", str(out), "--tta", "--blend", "1/32", "--crf", "30", "--print-config")
+    assert r.returncode == 0, r.stderr
+    c = json.loads(r.stdout)
+    assert c["command"] == "render" and c["tta"] and c["blend"] == 1 / 32 and c["crf"] == 30 and c["codec"] == "libx264" and c["pix_fmt"] == "yuv420p"
+    assert c["model_path"] == "models/swin_unet/art/noise3_scale4x.onnx"                                  # main.cpp:201-204
+    assert c["suffix"] == "(swin_unet_art)(noise3)(scale4)(tta)"                                          # main.cpp:205-209
+    assert c["outputs"] == [str(out / "picture.one(swin_unet_art)(noise3)(scale4)(tta).png")]             # main.cpp:240-250
+    # options may follow the subcommand (fallthrough), --nosuffix keeps the stem, defaults as in the reference
+    r = run("render", "-i", str(img), "--nosuffix", "--model", "cunet/art", "--scale", "1", "--noise", "0", "--batchSize", "1", "--tileSize", "64", "--print-config")
+    c = json.loads(r.stdout)
+    assert c["model_path"] == "models/cunet/art/noise0_.onnx" and c["suffix"] == "(cunet_art)(noise0)" and c["blend"] == 1 / 16 and c["device"] == 0
+    assert c["outputs"] == [str(tmp_path / "picture.one.png")]
+    r = run("--model", "swin_unet/photo", "--scale", "2", "--noise", "-1", "--batchSize", "2", "--tileSize", "400", "build", "--print-config")
+    assert json.loads(r.stdout)["model_path"] == "models/swin_unet/photo/scale2x.onnx"
+
+
+@pytest.mark.parametrize("args,msg", [
+    (["--model", "cunet/art", "--scale", "4", "--noise", "0", "--batchSize", "1", "--tileSize", "64", "build"], "cunet/art does not support scale factor 4."),
+    (["--model", "cunet/art", "--scale", "1", "--noise", "-1", "--batchSize", "1", "--tileSize", "64", "build"], "Noise level -1 does not support scale factor 1."),
+    (["--model", "esrgan", "--scale", "2", "--noise", "0", "--batchSize", "1", "--tileSize", "64", "build"], "--model"),
+    (["--model", "cunet/art", "--scale", "3", "--noise", "0", "--batchSize", "1", "--tileSize", "64", "build"], "--scale"),
+    (["--model", "cunet/art", "--scale", "2", "--noise", "0", "--batchSize", "0", "--tileSize", "64", "build"], "--batchSize"),
+    (["--model", "cunet/art", "--scale", "2", "--noise", "0", "--batchSize", "1", "--tileSize", "100", "build"], "--tileSize"),
+    (["--model", "cunet/art", "--scale", "2", "--noise", "0", "--batchSize", "1", "--tileSize", "64"], "subcommand"),
+    (["--model", "cunet/art", "--scale", "2", "--noise", "0", "--batchSize", "1", "--tileSize", "64", "build", "render"], "subcommand"),
+    (["--scale", "2", "--noise", "0", "--batchSize", "1", "--tileSize", "64", "build"], "--model is required"),
+    (BASE + ["render"], "--input is required"),
+    (BASE + ["render", "-i", "/nonexistent/file.png"], "does not exist"),
+    (BASE + ["render", "-i", ".", "--blend", "0.3"], "--blend"),
+    (BASE + ["render", "-i", ".", "--crf", "52"], "--crf"),
+    (BASE + ["--precision", "int8", "build"], "--precision"),
+    (BASE + ["build", "--bogus"], "not expected"),
+])
+def test_invalid_command_lines_are_rejected(args, msg):
+    r = run(*args, "--print-config")
+    assert r.returncode != 0 and msg in r.stderr, (r.returncode, r.stderr)
+
+
+def test_help_lists_the_reference_flags():
+    r = run("--help")
+    assert r.returncode == 0
+    for flag in ("--model", "--scale", "--noise", "--batchSize", "--tileSize", "--device", "--precision", "render", "build",
+                 "--input", "--recursive", "--output", "--nosuffix", "--blend", "--tta", "--codec", "--pix_fmt", "--crf"):
+        assert flag in r.stdout
+
+
+def test_builtin_png_and_ppm_codecs_round_trip(tmp_path):
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    Image.fromarray(a).save(tmp_path / "rgb.png")
+    assert run("convert", "-i", str(tmp_path / "rgb.png"), "-o", str(tmp_path / "a.ppm")).returncode == 0
+    assert run("convert", "-i", str(tmp_path / "a.ppm"), "-o", str(tmp_path / "b.png")).returncode == 0
+    assert np.array_equal(np.array(Image.open(tmp_path / "b.png")), a)
+    variants = {"gray": Image.fromarray(a[..., 0]), "rgba": Image.fromarray(np.dstack([a, a[..., :1]])),
+                "pal16": Image.fromarray(a).quantize(16), "pal256": Image.fromarray(a).quantize(256), "bilevel": Image.fromarray(a[..., 0] > 127)}
+    for name, im in variants.items():       # gray, alpha (dropped like the reference), 4/8-bit palette, 1-bit
+        im.save(tmp_path / f"{name}.png")
+        assert run("convert", "-i", str(tmp_path / f"{name}.png"), "-o", str(tmp_path / f"{name}_o.png")).returncode == 0, name
+        assert np.array_equal(np.array(Image.open(tmp_path / f"{name}_o.png")), np.array(Image.open(tmp_path / f"{name}.png").convert("RGB"))), name
+    r = run("convert", "-i", str(tmp_path / "missing.png"), "-o", str(tmp_path / "x.png"))
+    assert r.returncode != 0 and "cannot open" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_build_and_render_match_the_library(pkg, tmp_path):
+    """End to end on the GPU box: `w2x build` then `w2x render` on a PNG give the bytes Img2Img.render gives."""
+    Image = pytest.importorskip("PIL.Image")
+    import synth_models as sm
+    models = tmp_path / "models"
+    path = sm.model_path(str(tmp_path), "swin_unet/art", 4, 3)          # <tmp>/models/swin_unet/art/noise3_scale4x.onnx
+    sm.export_onnx(sm.make_model("swin_unet/art", 4, seed=5, small=True), path, 2, 64, dynamic=True)
+    rng = np.random.default_rng(1)
+    rgb = rng.integers(0, 256, (90, 130, 3), dtype=np.uint8)
+    Image.fromarray(rgb).save(tmp_path / "in.png")
+    out = tmp_path / "out"; out.mkdir()
+    common = ["--models", str(models), "--model", "swin_unet/art", "--scale", "4", "--noise", "3", "--batchSize", "2", "--tileSize", "64"]
+    r = run(*common, "build")
+    assert r.returncode == 0, r.stderr
+    r = run(*common, "render", "-i", str(tmp_path / "in.png"), "-o", str(out))
+    assert r.returncode == 0, r.stderr
+    assert "batch" in r.stderr                                          # progress line, main.cpp:190-193
+    got = np.array(Image.open(out / "in(swin_unet_art)(noise3)(scale4).png"))
+    eng = pkg.Img2Img()
+    assert eng.load(path, pkg.RenderConfig(batchSize=2, height=64, width=64, scaling=4)), eng.last_error()
+    ref = eng.render(np.ascontiguousarray(rgb[..., ::-1]))              # the library works on BGR
+    eng.close()
+    assert np.array_equal(got, ref[..., ::-1])
