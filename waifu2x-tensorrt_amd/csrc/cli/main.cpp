@@ -82,6 +82,7 @@ int main(int argc, char** argv) {
             BuildConfig c;
             c.deviceId = o.device; c.precision = prec;
             c.minBatchSize = c.optBatchSize = c.maxBatchSize = o.batchSize;
+            c.minChannels = c.optChannels = c.maxChannels = 3;                       // main.cpp:280-282
             c.minWidth = c.optWidth = c.maxWidth = c.minHeight = c.optHeight = c.maxHeight = o.tileSize;
             return engine.build(modelPath, c) ? 0 : -1;
         }
@@ -93,7 +94,7 @@ int main(int argc, char** argv) {
             engines.back()->setMessageCallback(on_message);
             if (d == 0) engines.back()->setProgressCallback(on_progress);
             RenderConfig c;
-            c.deviceId = o.device + d; c.precision = prec; c.batchSize = o.batchSize; c.height = c.width = o.tileSize; c.scaling = o.scale;
+            c.deviceId = o.device + d; c.precision = prec; c.batchSize = o.batchSize; c.channels = 3; c.height = c.width = o.tileSize; c.scaling = o.scale;
             c.overlapX = c.overlapY = o.blend; c.tta = o.tta;
             if (!engines.back()->load(modelPath, c)) return -1;
         }

@@ -35,7 +35,10 @@ inline void hipAssert(hipError_t e) {
 std::string hipGetDeviceName(int deviceId) {
     hipDeviceProp_t prop{};
     hipAssert(hipGetDeviceProperties(&prop, deviceId));
-    return prop.name;
+    // The marketing name depends on which libdrm data file the process finds (empty or generic on some boxes, and different
+    // between the ROCm runtime and the copy bundled with PyTorch); a plan is tied to the ISA and the CU count, so that is the key.
+    std::string arch = prop.gcnArchName;
+    return arch + " x" + std::to_string(prop.multiProcessorCount);
 }
 
 std::string precision_name(Precision p) { return p == Precision::FP16 ? "FP16" : "TF32"; }
