@@ -161,6 +161,19 @@ def test_headline_config_properties(pkg, onnx_model):
     eng.close()
 
 
+def test_large_tile_graph_matches_oracle(pkg, onnx_model):
+    """BASELINE config 4's tile size (400: 64x64 windows per tile, odd tile counts per pass) on a one-tile frame with TTA off;
+    tools/config_sanity.py runs configs 2, 4 and 5 at full size."""
+    path = onnx_model("swin_unet/photo", 4, 1, 400)
+    eng = make_engine(pkg, path, 2, 400, 4)
+    frame = smooth_frame(100, 380, 17)
+    out = eng.render(frame)
+    ref = pipeline.render(frame, onnx_exec.Executor(path).run, batch=1, tile=400, scaling=4, overlap=(0.0625, 0.0625), net_dtype=np.float16)
+    d = np.abs(out.astype(int) - ref.astype(int))
+    assert psnr(out, ref) > 50.0 and d.max() <= 2, (psnr(out, ref), d.max())
+    eng.close()
+
+
 def test_pad_slots_are_skipped_and_stale_memory_is_never_read(pkg, onnx_model, monkeypatch):
     """The zero-pad slots of the last batch (img2img_render.cpp:281) are not computed; W2X_POISON turns every stale
     activation into an fp16 NaN before each frame, so any read of a skipped slot would show up in the picture."""
