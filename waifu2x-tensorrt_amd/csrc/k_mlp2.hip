@@ -65,7 +65,7 @@ __device__ __forceinline__ half8 norm8(const half8 v, float rstd, float nm) {
 // right, co-resident ones wrong, not cured by s_waitcnt / s_barrier) and was replaced by register swaps.
 #define W2X_PHASE_FENCE() asm volatile("" ::: "memory")
 
-template <int C, int TT, int NW>
+template <int C, int TT, int NW, bool SHARE>
 struct Mlp2Cfg {
     static constexpr int RW = 16 * TT;           // rows per wave
     static constexpr int NWV = NW;               // independent waves per workgroup
@@ -77,13 +77,16 @@ struct Mlp2Cfg {
     static constexpr int NCH = 2 * C / 32;       // hidden chunks of 32
     static constexpr int NP = RW * PPR / 64;     // flat 16-byte pieces per lane
     static constexpr int SLAB = RW * LDX * 2;    // bytes per wave
-    static constexpr int SMEM = NWV * SLAB;
+    static constexpr int NF = 2 * KS + NT;       // weight fragments (KiB) per hidden chunk
+    static constexpr int WBUF = NF * 1024;       // SHARE: one staged chunk; two of them alias the slabs (x lives in registers by then)
+    static constexpr int SMEM = SHARE ? (NWV * SLAB > 2 * WBUF ? NWV * SLAB : 2 * WBUF) : NWV * SLAB;
+    static_assert(!SHARE || NF % NWV == 0, "fragments per wave");
     static_assert(RW * PPR % 64 == 0, "flat piece count");
 };
 
-template <int C, int TT, int NW>
+template <int C, int TT, int NW, bool SHARE>
 __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 8 / NW)) void mlp2_kernel(const MlpParams p) {
-    using K = Mlp2Cfg<C, TT, NW>;
+    using K = Mlp2Cfg<C, TT, NW, SHARE>;
     constexpr int RW = K::RW, LDX = K::LDX, PPR = K::PPR, KS = K::KS, NT = K::NT, NCH = K::NCH, NP = K::NP;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -99,12 +102,22 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 8 / NW)) void mlp2_kernel(c
     const _Float16* __restrict__ W1 = (const _Float16*)p.w1_frag + lane * 8;   // [NCH*2 row tiles][KS][64][8]
     const _Float16* __restrict__ W2 = (const _Float16*)p.w2_frag + lane * 8;   // [NCH][NT][64][8], k order of the GELU'd accumulators
 
-    // ---- weight ring: chunk 0
+    // ---- weights.  !SHARE: per-wave register ring, chunk 0 now.  SHARE: the four waves stage each chunk once into LDS
+    //      (two buffers over the slab area; wave w brings fragments w*NFW .. of the next chunk while the current one is consumed)
+    constexpr int NF = K::NF, NFW = NF / K::NWV;
     half8 w1r[2 * KS], w2r[NT];
+    half8 stg[NFW];
+    _Float16* WB = (_Float16*)smem;
+    auto frag_src = [&](int ch, int f) { return f < 2 * KS ? W1 + (size_t)(ch * 2 * KS + f) * 512 : W2 + (size_t)(ch * NT + (f - 2 * KS)) * 512; };
+    if (SHARE) {
 #pragma unroll
-    for (int f = 0; f < 2 * KS; ++f) w1r[f] = *(const half8*)(W1 + (size_t)f * 512);
+        for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)frag_src(0, wv * NFW + i);
+    } else {
 #pragma unroll
-    for (int f = 0; f < NT; ++f) w2r[f] = *(const half8*)(W2 + (size_t)f * 512);
+        for (int f = 0; f < 2 * KS; ++f) w1r[f] = *(const half8*)(W1 + (size_t)f * 512);
+#pragma unroll
+        for (int f = 0; f < NT; ++f) w2r[f] = *(const half8*)(W2 + (size_t)f * 512);
+    }
 
     // ---- x rows: flat coalesced load -> slab
     {
@@ -141,6 +154,17 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 8 / NW)) void mlp2_kernel(c
         for (int ks = 0; ks < KS; ++ks) *(half8*)(Xw + (tt * 16 + fr) * LDX + ks * 32 + g * 8) = norm8(raw[ks], rstd, nm);
     }
     W2X_PHASE_FENCE();
+    half8 xreg[TT][KS];
+    if (SHARE) {
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) xreg[tt][ks] = *(const half8*)(Xw + (tt * 16 + fr) * LDX + ks * 32 + g * 8);
+        __syncthreads();                       // every wave holds its rows in registers: the slab area becomes weight buffers
+#pragma unroll
+        for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[i];
+        __syncthreads();
+    }
     float4v acc2[TT][NT];
 #pragma unroll
     for (int i = 0; i < TT; ++i)
@@ -150,6 +174,11 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 8 / NW)) void mlp2_kernel(c
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {   // fully unrolled: the ring registers are renamed statically
         // GEMM1 (transposed): acc1[ht][tt] = W1[32ch + 16ht ..][:] * Xn[16tt ..][:]^T   (rows = hidden, columns = tokens)
+        const _Float16* wcur = WB + (size_t)(ch & 1) * (K::WBUF / 2) + lane * 8;      // SHARE: this chunk's fragments in LDS
+        if (SHARE && ch + 1 < NCH) {
+#pragma unroll
+            for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)frag_src(ch + 1, wv * NFW + i);
+        }
         float4v acc1[2][TT];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -159,12 +188,13 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 8 / NW)) void mlp2_kernel(c
         for (int ks = 0; ks < KS; ++ks) {
             half8 xb[TT];
 #pragma unroll
-            for (int tt = 0; tt < TT; ++tt) xb[tt] = *(const half8*)(Xw + (tt * 16 + fr) * LDX + ks * 32 + g * 8);
+            for (int tt = 0; tt < TT; ++tt) xb[tt] = SHARE ? xreg[tt][ks] : *(const half8*)(Xw + (tt * 16 + fr) * LDX + ks * 32 + g * 8);
 #pragma unroll
             for (int ht = 0; ht < 2; ++ht) {
+                const half8 wa = SHARE ? *(const half8*)(wcur + (size_t)(ht * KS + ks) * 512) : w1r[ht * KS + ks];
 #pragma unroll
-                for (int tt = 0; tt < TT; ++tt) acc1[ht][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1r[ht * KS + ks], xb[tt], acc1[ht][tt], 0, 0, 0);
-                if (ch + 1 < NCH) w1r[ht * KS + ks] = *(const half8*)(W1 + (size_t)(((ch + 1) * 2 + ht) * KS + ks) * 512);
+                for (int tt = 0; tt < TT; ++tt) acc1[ht][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb[tt], acc1[ht][tt], 0, 0, 0);
+                if (!SHARE && ch + 1 < NCH) w1r[ht * KS + ks] = *(const half8*)(W1 + (size_t)(((ch + 1) * 2 + ht) * KS + ks) * 512);
             }
         }
         // bias + GELU in place; lane holds hidden rows 16ht + 4g + j of token column fr -> A fragment of GEMM2 for the
@@ -184,9 +214,17 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 8 / NW)) void mlp2_kernel(c
         // GEMM2: acc2[tt][nt] += H[tokens][chunk] * W2[16nt ..][chunk]^T
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
+            const half8 wb = SHARE ? *(const half8*)(wcur + (size_t)(2 * KS + nt) * 512) : w2r[nt];
 #pragma unroll
-            for (int tt = 0; tt < TT; ++tt) acc2[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[tt], w2r[nt], acc2[tt][nt], 0, 0, 0);
-            if (ch + 1 < NCH) w2r[nt] = *(const half8*)(W2 + (size_t)((ch + 1) * NT + nt) * 512);
+            for (int tt = 0; tt < TT; ++tt) acc2[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[tt], wb, acc2[tt][nt], 0, 0, 0);
+            if (!SHARE && ch + 1 < NCH) w2r[nt] = *(const half8*)(W2 + (size_t)((ch + 1) * NT + nt) * 512);
+        }
+        if (SHARE) {   // hand the next chunk over: the other buffer was last read one iteration ago, before the previous barrier
+            if (ch + 1 < NCH) {
+#pragma unroll
+                for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)((ch + 1) & 1) * (K::WBUF / 2) + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[i];
+            }
+            __syncthreads();
         }
     }
 
@@ -228,17 +266,17 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 8 / NW)) void mlp2_kernel(c
     }
 }
 
-template <int C, int TT, int NW>
+template <int C, int TT, int NW, bool SHARE>
 hipError_t launch_mlp2_c(const MlpParams& p, hipStream_t s) {
-    using K = Mlp2Cfg<C, TT, NW>;
+    using K = Mlp2Cfg<C, TT, NW, SHARE>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)mlp2_kernel<C, TT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
+        hipError_t e = hipFuncSetAttribute((const void*)mlp2_kernel<C, TT, NW, SHARE>, hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid((unsigned)((p.M + K::BM - 1) / K::BM));
-    hipLaunchKernelGGL((mlp2_kernel<C, TT, NW>), grid, dim3(K::NWV * 64), K::SMEM, s, p);
+    hipLaunchKernelGGL((mlp2_kernel<C, TT, NW, SHARE>), grid, dim3(K::NWV * 64), K::SMEM, s, p);
     return hipGetLastError();
 }
 
@@ -246,8 +284,9 @@ hipError_t launch_mlp2_c(const MlpParams& p, hipStream_t s) {
 
 hipError_t launch_mlp2(const MlpParams& p, hipStream_t s) {
     static const int nw = getenv("W2X_MLP2_NW") ? atoi(getenv("W2X_MLP2_NW")) : 4;   // waves per workgroup (tuning switch)
-    if (p.C == 96) return nw == 8 ? launch_mlp2_c<96, 4, 8>(p, s) : launch_mlp2_c<96, 4, 4>(p, s);
-    if (p.C == 192) return nw == 8 ? launch_mlp2_c<192, 2, 8>(p, s) : launch_mlp2_c<192, 2, 4>(p, s);
+    static const bool ring = getenv("W2X_MLP2_RING") != nullptr;   // A/B switch: per-wave register ring instead of LDS-shared chunks
+    if (p.C == 96) return ring ? (nw == 8 ? launch_mlp2_c<96, 4, 8, false>(p, s) : launch_mlp2_c<96, 4, 4, false>(p, s)) : launch_mlp2_c<96, 4, 4, true>(p, s);
+    if (p.C == 192) return ring ? (nw == 8 ? launch_mlp2_c<192, 2, 8, false>(p, s) : launch_mlp2_c<192, 2, 4, false>(p, s)) : launch_mlp2_c<192, 2, 4, true>(p, s);
     return hipErrorInvalidValue;
 }
 
