@@ -286,7 +286,7 @@ hipError_t launch_mlp2(const MlpParams& p, hipStream_t s) {
     static const int nw = getenv("W2X_MLP2_NW") ? atoi(getenv("W2X_MLP2_NW")) : 4;   // waves per workgroup (tuning switch)
     static const bool ring = getenv("W2X_MLP2_RING") != nullptr;   // A/B switch: per-wave register ring instead of LDS-shared chunks
     if (p.C == 96) return ring ? (nw == 8 ? launch_mlp2_c<96, 4, 8, false>(p, s) : launch_mlp2_c<96, 4, 4, false>(p, s)) : launch_mlp2_c<96, 4, 4, true>(p, s);
-    if (p.C == 192) return ring ? (nw == 8 ? launch_mlp2_c<192, 2, 8, false>(p, s) : launch_mlp2_c<192, 2, 4, false>(p, s)) : launch_mlp2_c<192, 2, 4, true>(p, s);
+    if (p.C == 192) return ring ? (nw == 8 ? launch_mlp2_c<192, 2, 8, false>(p, s) : launch_mlp2_c<192, 2, 4, false>(p, s)) : (nw == 8 ? launch_mlp2_c<192, 2, 8, true>(p, s) : launch_mlp2_c<192, 2, 4, true>(p, s));
     return hipErrorInvalidValue;
 }
 
