@@ -273,6 +273,9 @@ struct Img2Img::Impl {
             if (d.size() != (size_t)Cc * Cc * 4) throw std::runtime_error("plan: mlp weight shape");
             upload_frag(blob, frag_w2((const uint16_t*)d.data(), Cc));
         };
+        for (const Op& op : plan.ops)   // pixel-shuffle projections served by k_pixgemm.hip
+            if (op.kind == OP_GEMM && op.g.omode == 2 && op.g.amode == 0 && op.g.K % 32 == 0 && op.g.N % 16 == 0 &&
+                plan.blobs[op.g.w].data.size() == (size_t)op.g.N * op.g.K * 2) frag_major_blob(op.g.w, op.g.N, op.g.K);
         for (const Op& op : plan.ops)
             if (op.kind == OP_MLP && (op.m.C == 96 || op.m.C == 192)) { frag_major_blob(op.m.w1, 2 * op.m.C, op.m.C); frag_w2_blob(op.m.w2, op.m.C); }
         for (const Op& op : plan.ops)
@@ -287,7 +290,7 @@ struct Img2Img::Impl {
             p.B = plan.B; p.Mrows = g.Mrows; p.aW = g.aW;
             p.win_table = g.win_table >= 0 ? (const int*)blobs[g.win_table] : nullptr;
             p.K = g.K; p.N = g.N; p.Kw = round_up(g.K, 8);
-            p.wt = blobs[g.w]; p.bias = (const float*)blobs[g.bias];
+            p.wt = blobs[g.w]; p.wt_frag = frag_blobs[g.w]; p.bias = (const float*)blobs[g.bias];
             p.ln = g.ln; p.csum = g.csum >= 0 ? (const float*)blobs[g.csum] : nullptr;
             p.stats_in = g.stats_in >= 0 ? (const float*)tensors[g.stats_in] : nullptr;
             p.act = g.act; p.alpha = g.alpha; p.has_clip = g.has_clip; p.clip_lo = g.clip_lo; p.clip_hi = g.clip_hi;
@@ -324,7 +327,7 @@ struct Img2Img::Impl {
                     p.B = live;
                     if ((int)i == final_op && out_override) p.out.p = out_override;
                     stamp_begin(0, op.flops);
-                    hipAssert(launch_gemm(p, stream));
+                    hipAssert(pixgemm_supported(p) ? launch_pixgemm(p, stream) : launch_gemm(p, stream));
                     stamp_end();
                     break;
                 }

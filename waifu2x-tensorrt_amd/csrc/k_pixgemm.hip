@@ -1,0 +1,185 @@
+// Pixel-shuffle projection for gfx950:   out[b][y*r+dy][x*r+dx][:] = x[b][y][x][:] * W[(dy*r+dx)*Cso .. +Cso][:]^T + bias (+ residual)
+// i.e. the Swin "patch expand" (Linear C -> r*r*Cso, DepthToSpace, skip add).  Same result as gemm_kernel with omode 2
+// (k_gemm.hip), which serves every other shape; this variant exists because these launches are memory-bound (1.25 GB
+// moved for 0.1 TFLOP on config 3's last up-projection) and the general kernel's load -> compute -> store phases per
+// workgroup keep too few bytes in flight (1.8 TB/s).  Schedule, as in k_mlp2.hip:
+//   * a wave owns 32 token rows from load to store; rows arrive as a flat coalesced stream, pass through LDS once and stay
+//     in registers as MFMA A fragments for the whole kernel;
+//   * the weight matrix streams through LDS in stages of G n-tiles (fragment-major copy, fragorder.h), staged once per
+//     workgroup by its four waves, double-buffered, one barrier per stage;
+//   * when the Cso columns of one sub-pixel are complete the wave turns them around through its own LDS tile and issues
+//     the residual loads and the 16-byte stores for that sub-pixel while the next one is being computed.
+#include "kernels.h"
+#include <cstdlib>
+
+namespace w2x {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+#define W2X_PHASE_FENCE() asm volatile("" ::: "memory")
+
+template <int K, int CSO, int G>
+struct PixCfg {
+    static constexpr int TT = 2, RW = 16 * TT, BM = 4 * RW;   // rows per wave / workgroup
+    static constexpr int KS = K / 32, NTS = CSO / 16;          // k-steps, n-tiles per sub-pixel
+    static constexpr int LDO = CSO + 8, LDXI = K + 8;          // LDS row strides (halves): output tile, input staging
+    static constexpr int PPI = K / 8, PPO = CSO / 8;           // 16-byte pieces per input row / output pixel
+    static constexpr int NPI = RW * PPI / 64, NPO = RW * PPO / 64;
+    static constexpr int NF = G * KS, NFW = NF / 4;            // fragments per stage / per wave
+    static constexpr int WBUF = NF * 1024;
+    static constexpr int OTILE = RW * LDO * 2 + RW * 8;        // per wave: output tile + (out, res) base offsets per row
+    static constexpr int IN_BYTES = 4 * RW * LDXI * 2;         // input staging aliases everything (dead before the first stage)
+    static constexpr int MAIN = 2 * WBUF + 4 * OTILE;
+    static constexpr int SMEM = MAIN > IN_BYTES ? MAIN : IN_BYTES;
+    static_assert(NTS % G == 0 && NF % 4 == 0 && RW * PPI % 64 == 0 && RW * PPO % 64 == 0, "tiling");
+};
+
+template <int K, int CSO, int G>
+__global__ __launch_bounds__(256, 2) void pixgemm_kernel(const GemmParams p) {
+    using C = PixCfg<K, CSO, G>;
+    constexpr int TT = C::TT, RW = C::RW, KS = C::KS, NTS = C::NTS, LDO = C::LDO, LDXI = C::LDXI, NFW = C::NFW;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    _Float16* WB = (_Float16*)smem;                                          // [2][NF][64][8]
+    _Float16* Ot = (_Float16*)(smem + 2 * C::WBUF + wv * C::OTILE);           // [RW][LDO]
+    int* Rb = (int*)(smem + 2 * C::WBUF + wv * C::OTILE + RW * LDO * 2);      // [RW][2] element offsets of sub-pixel (0,0): out, res
+    _Float16* Xin = (_Float16*)(smem + wv * RW * LDXI * 2);                   // input staging (aliases the above)
+
+    const long M = (long)p.B * p.Mrows;
+    const long row0 = ((long)blockIdx.x * 4 + wv) * RW;
+    const long nrows = M - row0 < RW ? M - row0 : RW;
+    const int npieces = nrows > 0 ? (int)nrows * C::PPI : 0;
+    const _Float16* __restrict__ X = (const _Float16*)p.a.p + row0 * K;
+    const _Float16* __restrict__ Wf = (const _Float16*)p.wt_frag + lane * 8;  // [N/16][KS][64][8]
+    const int r = p.r, nsub = r * r, nstage = nsub * NTS / G;
+
+    // ---- stage 0 of the weights is requested first, then the rows
+    half8 stg[NFW];
+#pragma unroll
+    for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)(Wf + (size_t)(wv * NFW + i) * 512);
+    {
+        half8 xr[C::NPI];
+#pragma unroll
+        for (int k = 0; k < C::NPI; ++k) {
+            const int idx = k * 64 + lane;
+            half8 h = {};
+            if (idx < npieces) h = *(const half8*)(X + (size_t)idx * 8);
+            xr[k] = h;
+        }
+#pragma unroll
+        for (int k = 0; k < C::NPI; ++k) {
+            const int idx = k * 64 + lane, rr = idx / C::PPI, c = idx - rr * C::PPI;
+            *(half8*)(Xin + rr * LDXI + c * 8) = xr[k];
+        }
+    }
+    W2X_PHASE_FENCE();
+    half8 xa[TT][KS];                              // A fragments: lane (row fr of tile tt, g) holds channels ks*32 + 8g .. +7
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xa[tt][ks] = *(const half8*)(Xin + (tt * 16 + fr) * LDXI + ks * 32 + g * 8);
+    // per-row output / residual offsets of sub-pixel (0,0), computed once
+    int my_ob = 0, my_rb = 0;
+    if (lane < RW) {
+        const long gr = row0 + lane;
+        if (gr < M) {
+            const int b = (int)(gr / p.Mrows), ml = (int)(gr - (long)b * p.Mrows);
+            const int oy = ml / p.aW, ox = ml - oy * p.aW;
+            my_ob = ((b * p.out.Hs + oy * r) * p.out.Ws + ox * r) * CSO;
+            my_rb = p.res.p ? ((b * p.res.Hs + oy * r + p.res.y0) * p.res.Ws + ox * r + p.res.x0) * p.res.Cs : 0;
+        }
+    }
+    __syncthreads();                               // all rows are in registers: the staging area becomes weight buffers + tiles
+    if (lane < RW) { Rb[2 * lane] = my_ob; Rb[2 * lane + 1] = my_rb; }
+#pragma unroll
+    for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[i];
+    __syncthreads();
+
+    _Float16* __restrict__ Og = (_Float16*)p.out.p;
+    const _Float16* __restrict__ Rg = (const _Float16*)p.res.p;
+    for (int st = 0; st < nstage; ++st) {
+        const _Float16* wcur = WB + (size_t)(st & 1) * (C::WBUF / 2) + lane * 8;
+        if (st + 1 < nstage) {
+#pragma unroll
+            for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)(Wf + (size_t)((st + 1) * C::NF + wv * NFW + i) * 512);
+        }
+        const int sg = st * G / NTS, nt0 = st * G - sg * NTS;     // sub-pixel and first n-tile inside it
+#pragma unroll
+        for (int t = 0; t < G; ++t) {
+            float4v acc[TT];
+            const float b = p.bias[(sg * NTS + nt0 + t) * 16 + fr];
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) acc[tt] = (float4v){b, b, b, b};         // bias = initial accumulator
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const half8 wb = *(const half8*)(wcur + (size_t)(t * KS + ks) * 512);
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[tt][ks], wb, acc[tt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Ot[(tt * 16 + g * 4 + j) * LDO + (nt0 + t) * 16 + fr] = (_Float16)acc[tt][j];
+        }
+        if (nt0 + G == NTS) {                      // sub-pixel sg complete: residual add and store as 16-byte pieces
+            W2X_PHASE_FENCE();
+            const int dy = sg / r, dx = sg - dy * r;
+            const int oshift = (dy * p.out.Ws + dx) * CSO, rshift = (dy * p.res.Ws + dx) * p.res.Cs;
+#pragma unroll
+            for (int k = 0; k < C::NPO; ++k) {
+                const int idx = k * 64 + lane, rr = idx / C::PPO, c = idx - rr * C::PPO;
+                if (rr < nrows) {
+                    half8 o = *(const half8*)(Ot + rr * LDO + c * 8);
+                    if (Rg) o += *(const half8*)(Rg + (size_t)Rb[2 * rr + 1] + rshift + c * 8);   // fp16 + fp16 rounded once == fp32 add rounded to fp16
+                    *(half8*)(Og + (size_t)Rb[2 * rr] + oshift + c * 8) = o;
+                }
+            }
+            W2X_PHASE_FENCE();
+        }
+        if (st + 1 < nstage) {
+#pragma unroll
+            for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)((st + 1) & 1) * (C::WBUF / 2) + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[i];
+        }
+        __syncthreads();
+    }
+}
+
+template <int K, int CSO, int G>
+hipError_t launch_pix(const GemmParams& p, hipStream_t s) {
+    using C = PixCfg<K, CSO, G>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)pixgemm_kernel<K, CSO, G>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const long M = (long)p.B * p.Mrows;
+    dim3 grid((unsigned)((M + C::BM - 1) / C::BM));
+    hipLaunchKernelGGL((pixgemm_kernel<K, CSO, G>), grid, dim3(256), C::SMEM, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// true if this launch can take the streaming kernel (everything else stays on gemm_kernel)
+bool pixgemm_supported(const GemmParams& p) {
+    static const bool off = getenv("W2X_NO_PIXGEMM") != nullptr;   // A/B switch
+    if (off || !p.wt_frag || p.omode != 2 || p.amode != 0 || p.ln || p.act != 0 || p.has_clip || p.stats_out || p.pool_out || p.res2.p) return false;
+    if (p.stride != 1 || p.a.y0 || p.a.x0 || p.a.Ws != p.aW || (long)p.a.Hs * p.a.Ws != p.Mrows || p.a.Cs != p.K || p.Kw != p.K) return false;
+    if (p.N != p.r * p.r * p.out.Cs || p.Cout != p.out.Cs) return false;
+    if (p.res.p && (p.res.Cs != p.out.Cs)) return false;
+    return (p.K == 192 && (p.out.Cs == 96 || p.out.Cs == 192));
+}
+
+hipError_t launch_pixgemm(const GemmParams& p, hipStream_t s) {
+    if (p.K == 192 && p.out.Cs == 96) return launch_pix<192, 96, 2>(p, s);
+    if (p.K == 192 && p.out.Cs == 192) return launch_pix<192, 192, 2>(p, s);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace w2x

@@ -20,6 +20,7 @@ struct GemmParams {
     const int* win_table = nullptr;
     int K = 0, N = 0, Kw = 0;       // Kw: row stride of wt (K rounded up to 8, zero padded)
     const void* wt = nullptr;       // fp16 [N][Kw]
+    const void* wt_frag = nullptr;  // fragment-major copy (fragorder.h) for k_pixgemm.hip, or null
     const float* bias = nullptr;    // [N]
     const float* csum = nullptr;    // [N] (ln)
     const float* stats_in = nullptr;  // [pixels of a][2]
@@ -108,6 +109,8 @@ struct ComposeParams {
 };
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
+bool pixgemm_supported(const GemmParams& p);                    // k_pixgemm.hip: streaming kernel for pixel-shuffle projections
+hipError_t launch_pixgemm(const GemmParams& p, hipStream_t s);
 hipError_t launch_attn(const AttnParams& p, hipStream_t s);
 hipError_t launch_mlp(const MlpParams& p, hipStream_t s);
 hipError_t launch_swin_attn(const SwinAttnParams& p, hipStream_t s);
