@@ -164,19 +164,106 @@ hipError_t launch_pix(const GemmParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Image head: Linear 96 -> 64 = 4x4 sub-pixels x 4 stored channels, DepthToSpace(4), Clip.  The whole weight matrix is 12
+// fragments, so every wave keeps it in registers (no LDS staging, no barrier) and owns 64 rows; an n-tile holds the four
+// horizontally adjacent output pixels of one output row, so a 16-byte piece of the tile is two finished pixels.
+__global__ __launch_bounds__(256, 2) void toimage_kernel(const GemmParams p) {
+    constexpr int K = 96, KS = 3, TT = 4, RW = 64, N = 64, NT = 4, LDXI = K + 8, LDO = N + 8, PPI = K / 8, NPI = RW * PPI / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    _Float16* Xin = (_Float16*)(smem + wv * RW * LDXI * 2);   // [RW][LDXI] rows; later the output tile [RW][LDO]
+    const long M = (long)p.B * p.Mrows;
+    const long row0 = ((long)blockIdx.x * 4 + wv) * RW;
+    const long nrows = M - row0 < RW ? M - row0 : RW;
+    const int npieces = nrows > 0 ? (int)nrows * PPI : 0;
+    const _Float16* __restrict__ X = (const _Float16*)p.a.p + row0 * K;
+    const _Float16* __restrict__ Wf = (const _Float16*)p.wt_frag + lane * 8;
+    half8 wf[NT][KS];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wf[t][ks] = *(const half8*)(Wf + (size_t)(t * KS + ks) * 512);
+    {
+        half8 xr[NPI];
+#pragma unroll
+        for (int k = 0; k < NPI; ++k) {
+            const int idx = k * 64 + lane;
+            half8 h = {};
+            if (idx < npieces) h = *(const half8*)(X + (size_t)idx * 8);
+            xr[k] = h;
+        }
+#pragma unroll
+        for (int k = 0; k < NPI; ++k) {
+            const int idx = k * 64 + lane, rr = idx / PPI, c = idx - rr * PPI;
+            *(half8*)(Xin + rr * LDXI + c * 8) = xr[k];
+        }
+    }
+    W2X_PHASE_FENCE();
+    float4v acc[TT][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float b = p.bias[t * 16 + fr];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) acc[tt][t] = (float4v){b, b, b, b};
+    }
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const half8 xa = *(const half8*)(Xin + (tt * 16 + fr) * LDXI + ks * 32 + g * 8);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[tt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa, wf[t][ks], acc[tt][t], 0, 0, 0);
+        }
+    W2X_PHASE_FENCE();
+    _Float16* Ot = Xin;
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = acc[tt][t][j];
+                if (p.has_clip) v = fminf(fmaxf((float)(_Float16)v, p.clip_lo), p.clip_hi);
+                Ot[(tt * 16 + g * 4 + j) * LDO + t * 16 + fr] = (_Float16)v;
+            }
+    W2X_PHASE_FENCE();
+    _Float16* __restrict__ Og = (_Float16*)p.out.p;
+    // 8 pieces per row: piece c = output row dy = c / 2, pixels dx = 2 * (c & 1), +1
+#pragma unroll
+    for (int k = 0; k < RW * 8 / 64; ++k) {
+        const int idx = k * 64 + lane, rr = idx >> 3, c = idx & 7;
+        const long gr = row0 + rr;
+        if (gr < M) {
+            const int b = (int)(gr / p.Mrows), ml = (int)(gr - (long)b * p.Mrows);
+            const int oy = ml / p.aW, ox = ml - oy * p.aW;
+            const size_t off = ((size_t)(b * p.out.Hs + oy * 4 + (c >> 1)) * p.out.Ws + ox * 4 + (c & 1) * 2) * 4;
+            *(half8*)(Og + off) = *(const half8*)(Ot + rr * LDO + c * 8);
+        }
+    }
+}
+
 }  // namespace
 
 // true if this launch can take the streaming kernel (everything else stays on gemm_kernel)
 bool pixgemm_supported(const GemmParams& p) {
     static const bool off = getenv("W2X_NO_PIXGEMM") != nullptr;   // A/B switch
-    if (off || !p.wt_frag || p.omode != 2 || p.amode != 0 || p.ln || p.act != 0 || p.has_clip || p.stats_out || p.pool_out || p.res2.p) return false;
+    if (off || !p.wt_frag || p.omode != 2 || p.amode != 0 || p.ln || p.act != 0 || p.stats_out || p.pool_out || p.res2.p) return false;
     if (p.stride != 1 || p.a.y0 || p.a.x0 || p.a.Ws != p.aW || (long)p.a.Hs * p.a.Ws != p.Mrows || p.a.Cs != p.K || p.Kw != p.K) return false;
-    if (p.N != p.r * p.r * p.out.Cs || p.Cout != p.out.Cs) return false;
-    if (p.res.p && (p.res.Cs != p.out.Cs)) return false;
+    if (p.N != p.r * p.r * p.out.Cs) return false;
+    if (p.K == 96 && p.out.Cs == 4 && p.r == 4 && p.N == 64 && !p.res.p) return true;                 // image head
+    if (p.has_clip || p.Cout != p.out.Cs || (p.res.p && p.res.Cs != p.out.Cs)) return false;
     return (p.K == 192 && (p.out.Cs == 96 || p.out.Cs == 192));
 }
 
 hipError_t launch_pixgemm(const GemmParams& p, hipStream_t s) {
+    if (p.out.Cs == 4) {
+        constexpr int SM = 4 * 64 * 104 * 2;
+        const long M = (long)p.B * p.Mrows;
+        hipLaunchKernelGGL(toimage_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), SM, s, p);
+        return hipGetLastError();
+    }
     if (p.K == 192 && p.out.Cs == 96) return launch_pix<192, 96, 2>(p, s);
     if (p.K == 192 && p.out.Cs == 192) return launch_pix<192, 192, 2>(p, s);
     return hipErrorInvalidValue;
