@@ -13,8 +13,10 @@
 //     accumulators are, as they stand, the A fragments of GEMM2 with a permuted k order (W2 is stored with the same
 //     permutation) - no LDS round trip between the two products;
 //   * the result tile goes through the slab once so that residual add and stores are flat 16-byte pieces again.
-// TT = 4 (64 rows per wave) for C = 96 and TT = 2 for C = 192: a weight fragment feeds TT MFMAs, and the 64 B/clk
-// L1 -> register path sustains 4 SIMDs of MFMAs only from about 4 uses per fragment on.
+// Register-ring mode (W2X_MLP2_RING=1): TT = 4 (64 rows per wave) for C = 96 and TT = 2 for C = 192 - a weight fragment feeds
+// TT MFMAs, and the 64 B/clk L1 -> register path sustains 4 SIMDs of MFMAs only from about 4 uses per fragment on.
+// Default (SHARE): the four waves of a workgroup stage each chunk once into LDS instead (the weight stream from L2 was 56 % of
+// the C = 192 kernel's time); TT = 2 for both widths, which leaves C = 96 at 140 VGPRs = 3 waves per SIMD.
 #include "kernels.h"
 #include <cstdlib>
 
@@ -85,7 +87,7 @@ struct Mlp2Cfg {
 };
 
 template <int C, int TT, int NW, bool SHARE>
-__global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 8 / NW)) void mlp2_kernel(const MlpParams p) {
+__global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (SHARE && TT <= 2 && C == 96 ? 3 : 8 / NW))) void mlp2_kernel(const MlpParams p) {
     using K = Mlp2Cfg<C, TT, NW, SHARE>;
     constexpr int RW = K::RW, LDX = K::LDX, PPR = K::PPR, KS = K::KS, NT = K::NT, NCH = K::NCH, NP = K::NP;
 
@@ -285,7 +287,7 @@ hipError_t launch_mlp2_c(const MlpParams& p, hipStream_t s) {
 hipError_t launch_mlp2(const MlpParams& p, hipStream_t s) {
     static const int nw = getenv("W2X_MLP2_NW") ? atoi(getenv("W2X_MLP2_NW")) : 4;   // waves per workgroup (tuning switch)
     static const bool ring = getenv("W2X_MLP2_RING") != nullptr;   // A/B switch: per-wave register ring instead of LDS-shared chunks
-    if (p.C == 96) return ring ? (nw == 8 ? launch_mlp2_c<96, 4, 8, false>(p, s) : launch_mlp2_c<96, 4, 4, false>(p, s)) : launch_mlp2_c<96, 4, 4, true>(p, s);
+    if (p.C == 96) return ring ? (nw == 8 ? launch_mlp2_c<96, 4, 8, false>(p, s) : launch_mlp2_c<96, 4, 4, false>(p, s)) : (getenv("W2X_MLP2_TT4") ? launch_mlp2_c<96, 4, 4, true>(p, s) : launch_mlp2_c<96, 2, 4, true>(p, s));   // shared weights: 32 rows per wave, 3 waves per SIMD
     if (p.C == 192) return ring ? (nw == 8 ? launch_mlp2_c<192, 2, 8, false>(p, s) : launch_mlp2_c<192, 2, 4, false>(p, s)) : (nw == 8 ? launch_mlp2_c<192, 2, 8, true>(p, s) : launch_mlp2_c<192, 2, 4, true>(p, s));
     return hipErrorInvalidValue;
 }
