@@ -274,7 +274,7 @@ struct Img2Img::Impl {
             upload_frag(blob, frag_w2((const uint16_t*)d.data(), Cc));
         };
         for (const Op& op : plan.ops)   // pixel-shuffle projections served by k_pixgemm.hip
-            if (op.kind == OP_GEMM && op.g.omode == 2 && op.g.amode == 0 && op.g.K % 32 == 0 && op.g.N % 16 == 0 &&
+            if (op.kind == OP_GEMM && ((op.g.omode == 2 && op.g.amode == 0) || (op.g.amode == 2 && op.g.kh == 2 && op.g.kw == 2 && op.g.stride == 2)) && op.g.K % 32 == 0 && op.g.N % 16 == 0 &&
                 plan.blobs[op.g.w].data.size() == (size_t)op.g.N * op.g.K * 2) frag_major_blob(op.g.w, op.g.N, op.g.K);
         for (const Op& op : plan.ops)
             if (op.kind == OP_MLP && (op.m.C == 96 || op.m.C == 192)) { frag_major_blob(op.m.w1, 2 * op.m.C, op.m.C); frag_w2_blob(op.m.w2, op.m.C); }

@@ -1,3 +1,6 @@
+// Streaming GEMM kernels for the memory-bound projections of the Swin U-Net (pixel-shuffle up-projection, image head, patch
+// merge); gemm_kernel (k_gemm.hip) serves every other shape and remains the reference for these.
+//
 // Pixel-shuffle projection for gfx950:   out[b][y*r+dy][x*r+dx][:] = x[b][y][x][:] * W[(dy*r+dx)*Cso .. +Cso][:]^T + bias (+ residual)
 // i.e. the Swin "patch expand" (Linear C -> r*r*Cso, DepthToSpace, skip add).  Same result as gemm_kernel with omode 2
 // (k_gemm.hip), which serves every other shape; this variant exists because these launches are memory-bound (1.25 GB
@@ -244,11 +247,146 @@ __global__ __launch_bounds__(256, 2) void toimage_kernel(const GemmParams p) {
     }
 }
 
+// Patch merge: Conv 2x2 stride 2 (Cin -> 192).  Output pixel (y, x) reads the input pixels (2y+ky, 2x+kx): for each ky one
+// contiguous run of 2*Cin halves, so K = 4*Cin is walked in sub-chunks of 192 contiguous channels.  A wave owns 32 output
+// pixels and all 192 output columns (accumulators stay in registers over the whole K), rows of a sub-chunk pass through the
+// wave's LDS slab into A fragments, weights stream through LDS in stages of two n-tiles shared by the four waves.
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void merge_kernel(const GemmParams p) {
+    constexpr int K = 4 * CIN, N = 192, NT = N / 16, KST = K / 32, NQ = K / 192, QPK = 2 * CIN / 192;   // sub-chunks total / per ky
+    constexpr int TT = 2, RW = 32, G = 2, NF = G * 6, NFW = NF / 4, LDS_ROW = 200, PPC = 24, NPI = RW * PPC / 64;
+    constexpr int WBUF = NF * 1024, SLAB = RW * LDS_ROW * 2 + RW * 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    _Float16* WB = (_Float16*)smem;
+    _Float16* Sl = (_Float16*)(smem + 2 * WBUF + wv * SLAB);              // [RW][200]: input sub-chunk, later the output tile
+    int* Tb = (int*)(smem + 2 * WBUF + wv * SLAB + RW * LDS_ROW * 2);      // [RW] element offset of input pixel (2y, 2x), -1: no row
+    const long M = (long)p.B * p.Mrows;
+    const long row0 = ((long)blockIdx.x * 4 + wv) * RW;
+    const long nrows = M - row0 < RW ? M - row0 : RW;
+    const _Float16* __restrict__ Xg = (const _Float16*)p.a.p;
+    const _Float16* __restrict__ Wf = (const _Float16*)p.wt_frag + lane * 8;   // [NT][KST][64][8]
+    auto frag_src = [&](int stage, int f) {   // stage = q * (NT / G) + s; fragment f = t * 6 + ks  ->  n-tile s*G + t, k-step q*6 + ks
+        const int q = stage / (NT / G), s2 = stage - q * (NT / G), t = f / 6, ks = f - t * 6;
+        return Wf + (size_t)((s2 * G + t) * KST + q * 6 + ks) * 512;
+    };
+    half8 stg[NFW];
+#pragma unroll
+    for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)frag_src(0, wv * NFW + i);
+    if (lane < RW) {
+        const long gr = row0 + lane;
+        int off = -1;
+        if (gr < M) {
+            const int b = (int)(gr / p.Mrows), ml = (int)(gr - (long)b * p.Mrows);
+            const int oy = ml / p.aW, ox = ml - oy * p.aW;
+            off = ((b * p.a.Hs + oy * 2 + p.a.y0) * p.a.Ws + ox * 2 + p.a.x0) * CIN;
+        }
+        Tb[lane] = off;
+    }
+#pragma unroll
+    for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[i];
+    __syncthreads();
+
+    float4v acc[TT][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float b = p.bias[t * 16 + fr];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) acc[tt][t] = (float4v){b, b, b, b};
+    }
+    constexpr int NSTAGE = NQ * (NT / G);
+    int stage = 0;
+#pragma unroll 1
+    for (int q = 0; q < NQ; ++q) {
+        // rows of this sub-chunk: 192 contiguous halves per output pixel
+        const int ky = q / QPK, inner = (q - ky * QPK) * 192;
+        const int shift = ky * p.a.Ws * CIN + inner;
+        {
+            half8 xr[NPI];
+#pragma unroll
+            for (int k = 0; k < NPI; ++k) {
+                const int idx = k * 64 + lane, rr = idx / PPC, c = idx - rr * PPC;
+                const int off = Tb[rr];
+                half8 h = {};
+                if (off >= 0) h = *(const half8*)(Xg + (size_t)off + shift + c * 8);
+                xr[k] = h;
+            }
+#pragma unroll
+            for (int k = 0; k < NPI; ++k) {
+                const int idx = k * 64 + lane, rr = idx / PPC, c = idx - rr * PPC;
+                *(half8*)(Sl + rr * LDS_ROW + c * 8) = xr[k];
+            }
+        }
+        W2X_PHASE_FENCE();
+        half8 xa[TT][6];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) xa[tt][ks] = *(const half8*)(Sl + (tt * 16 + fr) * LDS_ROW + ks * 32 + g * 8);
+        W2X_PHASE_FENCE();
+#pragma unroll
+        for (int s2 = 0; s2 < NT / G; ++s2, ++stage) {
+            const _Float16* wcur = WB + (size_t)(stage & 1) * (WBUF / 2) + lane * 8;
+            if (stage + 1 < NSTAGE) {
+#pragma unroll
+                for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)frag_src(stage + 1, wv * NFW + i);
+            }
+#pragma unroll
+            for (int t = 0; t < G; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) {
+                    const half8 wb = *(const half8*)(wcur + (size_t)(t * 6 + ks) * 512);
+#pragma unroll
+                    for (int tt = 0; tt < TT; ++tt) acc[tt][s2 * G + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[tt][ks], wb, acc[tt][s2 * G + t], 0, 0, 0);
+                }
+            if (stage + 1 < NSTAGE) {
+#pragma unroll
+                for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)((stage + 1) & 1) * (WBUF / 2) + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[i];
+            }
+            __syncthreads();
+        }
+    }
+    // ---- output tile through the slab, flat 16-byte stores (rows of the output are contiguous)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Sl[(tt * 16 + g * 4 + j) * LDS_ROW + t * 16 + fr] = (_Float16)acc[tt][t][j];
+    W2X_PHASE_FENCE();
+    _Float16* __restrict__ Og = (_Float16*)p.out.p + row0 * N;
+    const int npieces = nrows > 0 ? (int)nrows * PPC : 0;
+#pragma unroll
+    for (int k = 0; k < NPI; ++k) {
+        const int idx = k * 64 + lane, rr = idx / PPC, c = idx - rr * PPC;
+        if (idx < npieces) *(half8*)(Og + (size_t)idx * 8) = *(const half8*)(Sl + rr * LDS_ROW + c * 8);
+    }
+}
+
+template <int CIN>
+hipError_t launch_merge(const GemmParams& p, hipStream_t s) {
+    constexpr int SM = 2 * 12 * 1024 + 4 * (32 * 200 * 2 + 32 * 4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)merge_kernel<CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, SM);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const long M = (long)p.B * p.Mrows;
+    hipLaunchKernelGGL(merge_kernel<CIN>, dim3((unsigned)((M + 127) / 128)), dim3(256), SM, s, p);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 // true if this launch can take the streaming kernel (everything else stays on gemm_kernel)
 bool pixgemm_supported(const GemmParams& p) {
     static const bool off = getenv("W2X_NO_PIXGEMM") != nullptr;   // A/B switch
+    if (!off && p.wt_frag && p.amode == 2 && p.kh == 2 && p.kw == 2 && p.stride == 2 && p.omode == 0 && !p.ln && p.act == 0 && !p.has_clip &&
+        !p.stats_out && !p.pool_out && !p.res.p && !p.res2.p && p.N == 192 && p.out.Cs == 192 && p.Kw == p.K &&
+        (p.a.Cs == 96 || p.a.Cs == 192) && p.K == 4 * p.a.Cs && (long)p.out.Hs * p.out.Ws == p.Mrows && p.out.Ws == p.aW) return true;   // patch merge
     if (off || !p.wt_frag || p.omode != 2 || p.amode != 0 || p.ln || p.act != 0 || p.stats_out || p.pool_out || p.res2.p) return false;
     if (p.stride != 1 || p.a.y0 || p.a.x0 || p.a.Ws != p.aW || (long)p.a.Hs * p.a.Ws != p.Mrows || p.a.Cs != p.K || p.Kw != p.K) return false;
     if (p.N != p.r * p.r * p.out.Cs) return false;
@@ -258,6 +396,7 @@ bool pixgemm_supported(const GemmParams& p) {
 }
 
 hipError_t launch_pixgemm(const GemmParams& p, hipStream_t s) {
+    if (p.amode == 2) return p.a.Cs == 96 ? launch_merge<96>(p, s) : launch_merge<192>(p, s);
     if (p.out.Cs == 4) {
         constexpr int SM = 4 * 64 * 104 * 2;
         const long M = (long)p.B * p.Mrows;
