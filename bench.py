@@ -152,7 +152,7 @@ def main():
         # dominant kernel of the frame: plan ops grouped by the kernel that serves them, by summed HIP-event time
         # (measured on the compute stream by w2x_profile_frame / w2x_op_times)
         symbols = {("swinattn", 96): "swin_attn96_kernel", ("swinattn", 192): "swin_attn192_kernel",
-                   ("mlp", 96): "mlp2_kernel<96,4>", ("mlp", 192): "mlp2_kernel<192,2>"}
+                   ("mlp", 96): "mlp2_kernel<96,2>", ("mlp", 192): "mlp2_kernel<192,2>"}
         groups = {}
         for line, t in zip(desc, op_ms):
             m = re.match(r"\s*\d+ (\w+) (.*?)flops=(\d+)", line)
@@ -176,7 +176,7 @@ def main():
                 "achieved": round(gbs if hbm_bound else tflops, 2), "peak": HBM_PEAK_GBS if hbm_bound else MFMA_F16_PEAK_TFLOPS,
                 "unit": "GB/s" if hbm_bound else "TFLOP/s",
                 "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tflops / MFMA_F16_PEAK_TFLOPS), 5), "traffic": None,
-                "kernel": symbols.get(dom, "gemm_kernel<...>" if dom[0] == "gemm" else dom[0]),
+                "kernel": symbols.get(dom, "gemm_kernel / pixgemm kernels" if dom[0] == "gemm" else dom[0]),
                 "launches_per_frame": dom_n, "avg_launch_us": round(dom_ms * 1e3 / dom_n, 2),
                 "algorithmic_gflop_per_launch": round(dom_flop / dom_n / 1e9, 3),
                 "algorithmic_mbyte_per_launch": round(dom_bytes / dom_n / 1e6, 3),

@@ -13,11 +13,11 @@ def per_kernel(d, counter):
     return acc
 
 def symbol(name):
-    m = re.search(r"(swin_attn96_kernel|swin_attn192_kernel|compose_kernel|gather_kernel)", name)
+    m = re.search(r"(swin_attn96_kernel|swin_attn192_kernel|compose_kernel|gather_kernel|toimage_kernel)", name)
     if m: return m.group(1)
-    m = re.search(r"mlp2_kernel<(\d+), (\d+)(?:, \d+)?>", name)
+    m = re.search(r"mlp2_kernel<(\d+), (\d+)[^>]*>", name)
     if m: return f"mlp2_kernel<{m.group(1)},{m.group(2)}>"
-    m = re.search(r"(gemm_kernel<[^>]*>|mlp_kernel<[^>]*>|swin_attn_kernel<[^>]*>)", name)
+    m = re.search(r"(pixgemm_kernel<[^>]*>|merge_kernel<[^>]*>|gemm_kernel<[^>]*>|mlp_kernel<[^>]*>|swin_attn_kernel<[^>]*>)", name)
     return m.group(1) if m else None
 
 root, out, tag = sys.argv[1], sys.argv[2], sys.argv[3]
