@@ -329,6 +329,25 @@ struct Img2Img::Impl {
                     stamp_begin(0, op.flops);
                     hipAssert(pixgemm_supported(p) ? launch_pixgemm(p, stream) : launch_gemm(p, stream));
                     stamp_end();
+                    if (getenv("W2X_PIXGEMM_CHECK") && pixgemm_supported(p)) {   // diagnostic: the general kernel must agree
+                        const TensorDesc& od = plan.tensors[op.g.out.t];
+                        const size_t n = (size_t)live * od.H * od.W * od.C;
+                        std::vector<uint16_t> a(n), b(n);
+                        void* tmp = nullptr;
+                        hipAssert(hipMalloc(&tmp, n * 2));
+                        hipAssert(hipStreamSynchronize(stream));
+                        hipAssert(hipMemcpy(a.data(), p.out.p, n * 2, hipMemcpyDeviceToHost));
+                        hipAssert(hipMemcpy(tmp, p.out.p, n * 2, hipMemcpyDeviceToDevice));   // pixels neither kernel writes compare equal
+                        GemmParams q = p; q.out.p = tmp;
+                        hipAssert(launch_gemm(q, stream));
+                        hipAssert(hipStreamSynchronize(stream));
+                        hipAssert(hipMemcpy(b.data(), tmp, n * 2, hipMemcpyDeviceToHost));
+                        hipAssert(hipFree(tmp));
+                        double md = 0; size_t at = 0, bad = 0;
+                        for (size_t k = 0; k < n; ++k) { const double d = std::fabs(f16_to_f32(a[k]) - f16_to_f32(b[k])); if (d > 0.01) ++bad; if (d > md) { md = d; at = k; } }
+                        log(Severity::warn, "pixgemm check op " + std::to_string(i) + " [" + op.name + "]: max|d|=" + std::to_string(md) + " at pixel " + std::to_string(at / od.C) +
+                            " ch " + std::to_string(at % od.C) + " (x=" + std::to_string(at / od.C % od.W) + ", y=" + std::to_string(at / od.C / od.W % od.H) + "), " + std::to_string(bad) + " of " + std::to_string(n) + " off by > 0.01");
+                    }
                     break;
                 }
                 case OP_ATTN: {

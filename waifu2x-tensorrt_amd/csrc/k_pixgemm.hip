@@ -387,6 +387,9 @@ bool pixgemm_supported(const GemmParams& p) {
     if (!off && p.wt_frag && p.amode == 2 && p.kh == 2 && p.kw == 2 && p.stride == 2 && p.omode == 0 && !p.ln && p.act == 0 && !p.has_clip &&
         !p.stats_out && !p.pool_out && !p.res.p && !p.res2.p && p.N == 192 && p.out.Cs == 192 && p.Kw == p.K &&
         (p.a.Cs == 96 || p.a.Cs == 192) && p.K == 4 * p.a.Cs && (long)p.out.Hs * p.out.Ws == p.Mrows && p.out.Ws == p.aW) return true;   // patch merge
+    // (cunet's 2x2 stride-2 ConvTranspose = 1x1 convolution + pixel shuffle with LeakyReLU and a cropped skip add was tried on this
+    //  kernel at K = 64 / 128: 2.3 -> 1.3 ms on config 2's largest one, but results were wrong and the cause was not found - those
+    //  launches stay on gemm_kernel)
     if (off || !p.wt_frag || p.omode != 2 || p.amode != 0 || p.ln || p.act != 0 || p.stats_out || p.pool_out || p.res2.p) return false;
     if (p.stride != 1 || p.a.y0 || p.a.x0 || p.a.Ws != p.aW || (long)p.a.Hs * p.a.Ws != p.Mrows || p.a.Cs != p.K || p.Kw != p.K) return false;
     if (p.N != p.r * p.r * p.out.Cs) return false;
