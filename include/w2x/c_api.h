@@ -57,6 +57,11 @@ int w2x_render(w2x_engine* e, const uint8_t* src, int rows, int cols, size_t src
  * `parts` = a contiguous range of the reference's column-major tile order (img2img_render.cpp:43-44) plus the output columns
  * it alone composes.  w2x_strip_plan is pure host logic: out[0..3] = first_tile, tile_count, x0, x1 (x in output pixels). */
 int w2x_render_strip(w2x_engine* e, const uint8_t* src, int rows, int cols, size_t src_step, uint8_t* dst, size_t dst_step, int part, int parts);
+/* Frame sequence with the PCIe copies overlapped (no reference counterpart: main.cpp:263-269 renders frame by frame): srcs/dsts are
+ * arrays of `count` frame pointers of one size; w2x_pin_host page-locks a caller buffer in place so its copies run by DMA. */
+int w2x_render_sequence(w2x_engine* e, const uint8_t* const* srcs, int rows, int cols, size_t src_step, uint8_t* const* dsts, size_t dst_step, int count);
+int w2x_pin_host(w2x_engine* e, void* data, size_t bytes);
+void w2x_unpin_host(w2x_engine* e, void* data);
 int w2x_strip_plan(int in_w, int in_h, int out_w, int out_h, int tile_in, int tile_out, int scaling, double overlap_x, double overlap_y,
                    int part, int parts, int* out4);
 int w2x_infer(w2x_engine* e, const float* input_nchw, float* output_nchw);

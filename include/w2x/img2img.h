@@ -38,6 +38,11 @@ public:
     // One device's share of a single frame spread over `parts` devices (tile-column strips): composes and writes only
     // the output columns of strip `part` (w2x_strip_plan); identical bytes to render() there.  render() == renderStrip(.., 0, 1).
     bool renderStrip(const Image& src, Image& dst, int part, int parts);
+    // A sequence of equally sized frames (the per-frame loop of main.cpp:263-269) with upload, compute and download overlapped on
+    // three HIP streams; outputs are the bytes render() gives.  For the copies to overlap, page-lock the buffers with pinHost().
+    bool renderSequence(const Image* srcs, Image* dsts, int count);
+    bool pinHost(void* data, size_t bytes);
+    void unpinHost(void* data);
     void setMessageCallback(MessageCallback callback);   // img2img.h:21
     void setProgressCallback(ProgressCallback callback); // img2img.h:22
 

@@ -214,6 +214,23 @@ def test_strips_reassemble_the_frame_bit_exactly(pkg, onnx_model, model, scale, 
     eng.close()
 
 
+@pytest.mark.parametrize("pin", [False, True])
+def test_frame_sequence_with_overlapped_copies_matches_render(pkg, onnx_model, pin):
+    """renderSequence: upload / compute / download of consecutive frames overlap on three streams (two device buffers, events);
+    every frame must come out exactly as from render(), also when output buffers are reused as a ring."""
+    path = onnx_model("swin_unet/art", 4, 2, 64, small=True)
+    eng = make_engine(pkg, path, 2, 64, 4)
+    frames = [smooth_frame(90, 130, 40 + k) for k in range(7)]
+    want = [eng.render(f) for f in frames]
+    got = eng.render_sequence(frames, pin=pin)
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    ring = [np.empty_like(want[0]) for _ in range(3)]                       # a writer that consumes frames in order
+    eng.render_sequence(frames, outs=[ring[k % 3] for k in range(7)], pin=pin)
+    assert np.array_equal(ring[6 % 3], want[6]) and np.array_equal(ring[5 % 3], want[5]) and np.array_equal(ring[4 % 3], want[4])
+    assert np.array_equal(eng.render(frames[2]), want[2])                    # the engine is left in a usable state
+    eng.close()
+
+
 def test_super_batching_is_bit_identical(pkg, onnx_model, monkeypatch):
     """One network pass may carry S reference batches (W2X_SUPERBATCH); frames, progress callbacks and infer() must not change."""
     path = onnx_model("swin_unet/art", 4, 2, 64, small=True)

@@ -2,6 +2,7 @@
 #include "../../include/w2x/c_api.h"
 
 #include <cstring>
+#include <vector>
 #include <string>
 
 #include "../../include/w2x/img2img.h"
@@ -72,6 +73,19 @@ int w2x_render_strip(w2x_engine* e, const uint8_t* src, int rows, int cols, size
     d.rows = rows * sc; d.cols = cols * sc;
     return e->engine.renderStrip(s, d, part, parts) ? 1 : 0;
 }
+
+int w2x_render_sequence(w2x_engine* e, const uint8_t* const* srcs, int rows, int cols, size_t src_step, uint8_t* const* dsts, size_t dst_step, int count) {
+    if (!e || count < 0) return 0;
+    const int sc = e->engine.scaling();
+    std::vector<w2x::Image> s(count), d(count);
+    for (int i = 0; i < count; ++i) {
+        s[i].data = const_cast<uint8_t*>(srcs[i]); s[i].rows = rows; s[i].cols = cols; s[i].step = src_step;
+        d[i].data = dsts[i]; d[i].rows = rows * sc; d[i].cols = cols * sc; d[i].step = dst_step;
+    }
+    return e->engine.renderSequence(s.data(), d.data(), count) ? 1 : 0;
+}
+int w2x_pin_host(w2x_engine* e, void* data, size_t bytes) { return e && e->engine.pinHost(data, bytes) ? 1 : 0; }
+void w2x_unpin_host(w2x_engine* e, void* data) { if (e) e->engine.unpinHost(data); }
 
 int w2x_strip_plan(int in_w, int in_h, int out_w, int out_h, int tile_in, int tile_out, int scaling, double overlap_x, double overlap_y,
                    int part, int parts, int* out4) {

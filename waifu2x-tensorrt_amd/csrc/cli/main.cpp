@@ -131,6 +131,30 @@ int main(int argc, char** argv) {
                 if (!single) wcmd += "-c:v " + o.codec + " -pix_fmt " + o.pixFmt + " -crf " + std::to_string(o.crf) + " ";
                 FILE* wr = popen((wcmd + shell_quote(outFile)).c_str(), "w");
                 if (!rd || !wr) throw std::runtime_error("cannot start ffmpeg for " + file);
+                if (o.devices == 1) {
+                    // one device: chunks of frames through renderSequence (upload / compute / download overlapped, buffers page-locked once)
+                    const int CH = 4;
+                    std::vector<std::vector<uint8_t>> ins(CH, std::vector<uint8_t>(inBytes)), outs(CH, std::vector<uint8_t>(outBytes));
+                    for (int k = 0; k < CH; ++k) { engines[0]->pinHost(ins[k].data(), inBytes); engines[0]->pinHost(outs[k].data(), outBytes); }
+                    bool eof = false;
+                    while (!eof) {
+                        int got = 0;
+                        for (; got < CH; ++got) if (fread(ins[got].data(), 1, inBytes, rd) != inBytes) { eof = true; break; }
+                        if (!got) break;
+                        std::vector<Image> si(got), di(got);
+                        for (int k = 0; k < got; ++k) {
+                            si[k] = Image{ins[k].data(), pr.height, pr.width, (size_t)pr.width * 3};
+                            di[k] = Image{outs[k].data(), pr.height * o.scale, pr.width * o.scale, (size_t)pr.width * o.scale * 3};
+                        }
+                        if (!engines[0]->renderSequence(si.data(), di.data(), got)) return -1;
+                        for (int k = 0; k < got; ++k) { fwrite(outs[k].data(), 1, outBytes, wr); ++frameIndex; }
+                        on_progress(1, 1, 0.0);
+                    }
+                    for (int k = 0; k < CH; ++k) { engines[0]->unpinHost(ins[k].data()); engines[0]->unpinHost(outs[k].data()); }
+                    pclose(rd); pclose(wr);
+                    ++fileIndex;
+                    continue;
+                }
                 // frames round-robin over the devices, written in order
                 const int N = o.devices;
                 std::vector<std::vector<uint8_t>> ins(N, std::vector<uint8_t>(inBytes)), outs(N, std::vector<uint8_t>(outBytes));

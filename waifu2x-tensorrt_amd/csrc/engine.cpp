@@ -145,6 +145,12 @@ struct Img2Img::Impl {
     float *d_rampx = nullptr, *d_rampy = nullptr;
     int ovx = 0, ovy = 0;
     float* d_blob_in = nullptr; float* d_blob_out = nullptr;
+    // renderSequence(): second frame/output buffer and the copy streams
+    uint8_t* d_frame2 = nullptr; size_t frame2_cap = 0;
+    uint8_t* d_out2 = nullptr; size_t out2_cap = 0;
+    hipStream_t s_up = nullptr, s_dn = nullptr;
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_dn[2] = {nullptr, nullptr};
+    std::vector<void*> pinned;
     std::vector<TileSlot> h_slots;
 
     // per-launch HIP-event profiling (profileFrame): events recorded on the compute stream around every launch
@@ -177,7 +183,13 @@ struct Img2Img::Impl {
         for (void* p : frag_blobs) if (p) hipFree(p);
         frag_blobs.clear();
         tensors.clear(); blobs.clear(); gemm.clear(); pool_tensors.clear();
-        for (void** p : {(void**)&d_frame, (void**)&d_out, &d_slab, (void**)&d_slots, (void**)&d_rampx, (void**)&d_rampy, (void**)&d_blob_in, (void**)&d_blob_out})
+        for (void* h : pinned) if (hipHostUnregister(h) != hipSuccess) (void)hipGetLastError();
+        pinned.clear();
+        for (hipEvent_t* e : {&ev_up[0], &ev_up[1], &ev_comp[0], &ev_comp[1], &ev_dn[0], &ev_dn[1]}) if (*e) { hipEventDestroy(*e); *e = nullptr; }
+        if (s_up) { hipStreamDestroy(s_up); s_up = nullptr; }
+        if (s_dn) { hipStreamDestroy(s_dn); s_dn = nullptr; }
+        frame2_cap = out2_cap = 0;
+        for (void** p : {(void**)&d_frame, (void**)&d_out, (void**)&d_frame2, (void**)&d_out2, &d_slab, (void**)&d_slots, (void**)&d_rampx, (void**)&d_rampy, (void**)&d_blob_in, (void**)&d_blob_out})
             if (*p) { hipFree(*p); *p = nullptr; }
         frame_cap = out_cap = slab_cap = slots_cap = 0;
         if (ev0) { hipEventDestroy(ev0); ev0 = nullptr; }
@@ -673,6 +685,90 @@ bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, cons
 } catch (const std::exception& e) {
     W2X_LOG_AS(who, error, "Render failed unexpectedly: " + std::string(e.what()) + ".");
     return false;
+}
+
+// A sequence of equally sized frames (a video, main.cpp:263-269) with the PCIe copies taken off the critical path: frame i+1 is
+// uploaded and frame i-1 downloaded on two copy streams while frame i runs on the compute stream (two device frame / output
+// buffers, events between the three streams).  Each frame is the same gather -> network -> compose as render(), so outputs are
+// bit-identical; the progress callback is not raised per batch here.  Copies only overlap when the host buffers are page-locked
+// (pinHost); with pageable memory the call is still correct, the runtime just serialises the copies.
+bool Img2Img::renderSequence(const Image* srcs, Image* dsts, int count) try {
+    if (!impl->loaded) { W2X_LOG(error, "Render called before a successful load."); return false; }
+    if (count <= 0) return true;
+    const RenderConfig& cfg = impl->cfg;
+    const Plan& plan = impl->plan;
+    const int rows = srcs[0].rows, cols = srcs[0].cols, s = cfg.scaling;
+    for (int i = 0; i < count; ++i) {
+        if (!srcs[i].data || srcs[i].rows != rows || srcs[i].cols != cols || srcs[i].step < (size_t)cols * 3 || rows <= 0 || cols <= 0) { W2X_LOG(error, "Input images must be non-empty and of one size."); return false; }
+        if (!dsts[i].data || dsts[i].rows != rows * s || dsts[i].cols != cols * s || dsts[i].step < (size_t)cols * s * 3) { W2X_LOG(error, "Output image has invalid size: expected " + std::to_string(cols * s) + "x" + std::to_string(rows * s) + "."); return false; }
+    }
+    hipStream_t stream = impl->stream;
+    if (!impl->s_up) {
+        hipAssert(hipStreamCreateWithFlags(&impl->s_up, hipStreamNonBlocking));
+        hipAssert(hipStreamCreateWithFlags(&impl->s_dn, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) { hipAssert(hipEventCreateWithFlags(&impl->ev_up[b], hipEventDisableTiming)); hipAssert(hipEventCreateWithFlags(&impl->ev_comp[b], hipEventDisableTiming)); hipAssert(hipEventCreateWithFlags(&impl->ev_dn[b], hipEventDisableTiming)); }
+    }
+    const size_t in_bytes = (size_t)rows * cols * 3, out_bytes = in_bytes * s * s;
+    impl->ensure(impl->d_frame, impl->frame_cap, in_bytes);   impl->ensure(impl->d_frame2, impl->frame2_cap, in_bytes);
+    impl->ensure(impl->d_out, impl->out_cap, out_bytes);      impl->ensure(impl->d_out2, impl->out2_cap, out_bytes);
+    TileGrid grid = calculate_tiles(cols, rows, cols * s, rows * s, plan.T, plan.T, plan.Tout, plan.Tout, s, cfg.overlapX, cfg.overlapY);
+    if (grid.count <= 0) { W2X_LOG(error, "Tile grid is empty."); return false; }
+    for (const Rect& r : grid.out) if (r.w <= 0 || r.h <= 0) { W2X_LOG(error, "Tile grid does not fit the output (scaling does not match the model)."); return false; }
+    const StripPlan sp = strip_plan(grid, cols * s, plan.Tout, 0, 1);
+    const int steps = cfg.tta ? 8 : 1, B = plan.B, S = plan.B / plan.userB;
+    const int batchCount = (int)std::lround(std::ceil((double)(sp.tile_count * steps) / plan.userB));
+    const int stepCount = ((batchCount + S - 1) / S) * B;
+    impl->h_slots.resize(stepCount);
+    for (int st = 0; st < stepCount; ++st) {
+        int ti = st / steps, aug = st % steps;
+        TileSlot sl{0, 0, aug, 0};
+        if (ti < sp.tile_count) { sl.x = grid.in[ti].x; sl.y = grid.in[ti].y; sl.valid = 1; }
+        impl->h_slots[st] = sl;
+    }
+    impl->ensure(impl->d_slots, impl->slots_cap, (size_t)stepCount * sizeof(TileSlot));
+    hipAssert(hipMemcpyAsync(impl->d_slots, impl->h_slots.data(), (size_t)stepCount * sizeof(TileSlot), hipMemcpyHostToDevice, stream));
+    impl->ensure(impl->d_slab, impl->slab_cap, (size_t)stepCount * plan.Tout * plan.Tout * 4 * sizeof(uint16_t));
+    hipAssert(hipStreamSynchronize(stream));
+
+    uint8_t* const frames[2] = {impl->d_frame, impl->d_frame2};
+    uint8_t* const outs[2] = {impl->d_out, impl->d_out2};
+    struct Restore { Impl* im; uint8_t* f; uint8_t* o; ~Restore() { im->d_frame = f; im->d_out = o; } } restore{impl.get(), frames[0], outs[0]};   // also on exceptions
+    for (int i = 0; i < count; ++i) {
+        const int b = i & 1;
+        if (i >= 2) hipAssert(hipStreamWaitEvent(impl->s_up, impl->ev_comp[b], 0));       // frame i-2 has been gathered out of this buffer
+        hipAssert(hipMemcpy2DAsync(frames[b], (size_t)cols * 3, srcs[i].data, srcs[i].step, (size_t)cols * 3, rows, hipMemcpyHostToDevice, impl->s_up));
+        hipAssert(hipEventRecord(impl->ev_up[b], impl->s_up));
+        hipAssert(hipStreamWaitEvent(stream, impl->ev_up[b], 0));
+        if (i >= 2) hipAssert(hipStreamWaitEvent(stream, impl->ev_dn[b], 0));             // frame i-2 has left this output buffer
+        impl->d_frame = frames[b]; impl->d_out = outs[b];
+        impl->run_frame(rows, cols, grid, false, sp);
+        hipAssert(hipEventRecord(impl->ev_comp[b], stream));
+        hipAssert(hipStreamWaitEvent(impl->s_dn, impl->ev_comp[b], 0));
+        hipAssert(hipMemcpy2DAsync(dsts[i].data, dsts[i].step, outs[b], (size_t)cols * s * 3, (size_t)cols * s * 3, rows * s, hipMemcpyDeviceToHost, impl->s_dn));
+        hipAssert(hipEventRecord(impl->ev_dn[b], impl->s_dn));
+    }
+    hipAssert(hipStreamSynchronize(impl->s_dn));
+    hipAssert(hipStreamSynchronize(stream));
+    hipAssert(hipStreamSynchronize(impl->s_up));
+    impl->last_rows = rows; impl->last_cols = cols; impl->last_grid = grid; impl->last_strip = sp;
+    return true;
+} catch (const std::exception& e) {
+    W2X_LOG(error, "Render failed unexpectedly: " + std::string(e.what()) + ".");
+    return false;
+}
+
+// Page-lock a caller-owned frame buffer in place so that renderSequence() can copy it by DMA while kernels run.
+bool Img2Img::pinHost(void* data, size_t bytes) {
+    if (!data || !bytes) return false;
+    if (hipHostRegister(data, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+    impl->pinned.push_back(data);
+    return true;
+}
+void Img2Img::unpinHost(void* data) {
+    auto it = std::find(impl->pinned.begin(), impl->pinned.end(), data);
+    if (it == impl->pinned.end()) return;
+    if (hipHostUnregister(data) != hipSuccess) (void)hipGetLastError();
+    impl->pinned.erase(it);
 }
 
 bool Img2Img::infer(const float* input, float* output) try {

@@ -104,6 +104,9 @@ def lib():
     L.w2x_load.argtypes = [vp, C.c_char_p, C.POINTER(_RenderConfig)]; L.w2x_load.restype = C.c_int
     L.w2x_render.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t]; L.w2x_render.restype = C.c_int
     L.w2x_render_strip.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_int]; L.w2x_render_strip.restype = C.c_int
+    L.w2x_render_sequence.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t, C.c_int]; L.w2x_render_sequence.restype = C.c_int
+    L.w2x_pin_host.argtypes = [vp, vp, C.c_size_t]; L.w2x_pin_host.restype = C.c_int
+    L.w2x_unpin_host.argtypes = [vp, vp]; L.w2x_unpin_host.restype = None
     L.w2x_strip_plan.argtypes = [C.c_int] * 7 + [C.c_double, C.c_double, C.c_int, C.c_int, vp]; L.w2x_strip_plan.restype = C.c_int
     L.w2x_infer.argtypes = [vp, vp, vp]; L.w2x_infer.restype = C.c_int
     L.w2x_output_tile_size.argtypes = [vp]; L.w2x_output_tile_size.restype = C.c_int
@@ -125,7 +128,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "w2x_create", "w2x_destroy", "w2x_set_message_callback", "w2x_set_progress_callback", "w2x_build", "w2x_load",
     "w2x_render", "w2x_infer", "w2x_output_tile_size", "w2x_plan_flops", "w2x_pass_tiles", "w2x_last_render_ms", "w2x_bench_resident", "w2x_profile_frame", "w2x_op_times",
-    "w2x_render_strip", "w2x_strip_plan", "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_sha256_hex", "w2x_debug_attn_stamps", "w2x_debug_mlp_stamps", "w2x_version"]
+    "w2x_render_strip", "w2x_strip_plan", "w2x_render_sequence", "w2x_pin_host", "w2x_unpin_host", "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_sha256_hex", "w2x_debug_attn_stamps", "w2x_debug_mlp_stamps", "w2x_version"]
 
 
 class Img2Img:
@@ -217,6 +220,39 @@ class Img2Img:
             raise ValueError("dst must be a packed uint8 array of the scaled size")
         return bool(self._L.w2x_render_strip(self._h, src.ctypes.data, src.shape[0], src.shape[1], src.strides[0],
                                              dst.ctypes.data, dst.strides[0], int(part), int(parts)))
+
+    def render_sequence(self, frames, outs=None, pin: bool = False):
+        """Equally sized frames with upload / compute / download overlapped (w2x_render_sequence).  outs: list of pre-allocated
+        arrays (may repeat, e.g. a ring of buffers) or None; pin=True page-locks the distinct buffers for the duration of the call."""
+        s = getattr(self, "_scaling", 0)
+        n = len(frames)
+        if n == 0:
+            return []
+        r, c = frames[0].shape[:2]
+        for f in frames:
+            if f.dtype != np.uint8 or f.shape != (r, c, 3) or f.strides != (c * 3, 3, 1):
+                raise ValueError("frames must be packed uint8 [rows, cols, 3] arrays of one size")
+        if outs is None:
+            outs = [np.empty((r * s, c * s, 3), np.uint8) for _ in range(n)]
+        for o in outs:
+            if o.dtype != np.uint8 or o.shape != (r * s, c * s, 3) or o.strides != (c * s * 3, 3, 1):
+                raise ValueError("outs must be packed uint8 arrays of the scaled size")
+        import ctypes as C
+        sp = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+        dp = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        pinned = []
+        if pin:
+            for a in {id(x): x for x in list(frames) + list(outs)}.values():
+                if self._L.w2x_pin_host(self._h, a.ctypes.data, a.nbytes):
+                    pinned.append(a)
+        try:
+            ok = bool(self._L.w2x_render_sequence(self._h, sp, r, c, c * 3, dp, c * s * 3, n))
+        finally:
+            for a in pinned:
+                self._L.w2x_unpin_host(self._h, a.ctypes.data)
+        if not ok:
+            raise W2xError(self.last_error() or "render_sequence failed")
+        return outs
 
     def infer(self, x: np.ndarray) -> np.ndarray:
         """Private trt::Img2Img::infer (img2img_infer.cpp:41-93) as a test hook: [B,3,T,T] f32 -> [B,3,T',T'] f32."""
