@@ -10,6 +10,6 @@ model, scale, tile = (sys.argv[1], int(sys.argv[2]), int(sys.argv[3])) if len(sy
 path = sm.model_path("/tmp/w2x_pixchk", model, scale, 1)
 sm.export_onnx(sm.make_model(model, scale, seed=7), path, 1, tile, dynamic=True)
 eng = pkg.Img2Img()
-eng.setMessageCallback(lambda sev, m: print(m) if "pixgemm check" in m else None)
+eng.setMessageCallback(lambda sev, m: print(m) if ("pixgemm check" in m or "probe op" in m) else None)
 assert eng.build(path, pkg.BuildConfig.fixed(1, tile)) and eng.load(path, pkg.RenderConfig(batchSize=1, height=tile, width=tile, scaling=scale)), eng.last_error()
 eng.infer(np.random.default_rng(0).random((1, 3, tile, tile), dtype=np.float32))

@@ -286,7 +286,7 @@ struct Img2Img::Impl {
             upload_frag(blob, frag_w2((const uint16_t*)d.data(), Cc));
         };
         for (const Op& op : plan.ops)   // pixel-shuffle projections served by k_pixgemm.hip
-            if (op.kind == OP_GEMM && ((op.g.omode == 2 && op.g.amode == 0) || (op.g.amode == 2 && op.g.kh == 2 && op.g.kw == 2 && op.g.stride == 2)) && op.g.K % 32 == 0 && op.g.N % 16 == 0 &&
+            if (op.kind == OP_GEMM && ((op.g.omode == 2 && (op.g.amode == 0 || (op.g.amode == 2 && op.g.kh == 1 && op.g.kw == 1))) || (op.g.amode == 2 && op.g.kh == 2 && op.g.kw == 2 && op.g.stride == 2)) && op.g.K % 32 == 0 && op.g.N % 16 == 0 &&
                 plan.blobs[op.g.w].data.size() == (size_t)op.g.N * op.g.K * 2) frag_major_blob(op.g.w, op.g.N, op.g.K);
         for (const Op& op : plan.ops)
             if (op.kind == OP_MLP && (op.m.C == 96 || op.m.C == 192)) { frag_major_blob(op.m.w1, 2 * op.m.C, op.m.C); frag_w2_blob(op.m.w2, op.m.C); }
@@ -355,6 +355,17 @@ struct Img2Img::Impl {
                         hipAssert(hipStreamSynchronize(stream));
                         hipAssert(hipMemcpy(b.data(), tmp, n * 2, hipMemcpyDeviceToHost));
                         hipAssert(hipFree(tmp));
+                        if (getenv("W2X_PIXGEMM_PROBE")) {   // host evaluation of out[b=0][0][0][0]: sub-pixel (0,0) of input pixel (0,0)
+                            std::vector<uint16_t> xr(p.K), wr(p.K); float bias0 = 0.f; uint16_t r0 = 0;
+                            hipAssert(hipMemcpy(xr.data(), (const uint16_t*)p.a.p + (size_t)(p.a.y0 * p.a.Ws + p.a.x0) * p.a.Cs, p.K * 2, hipMemcpyDeviceToHost));
+                            hipAssert(hipMemcpy(wr.data(), p.wt, p.K * 2, hipMemcpyDeviceToHost));
+                            hipAssert(hipMemcpy(&bias0, p.bias, 4, hipMemcpyDeviceToHost));
+                            if (p.res.p) hipAssert(hipMemcpy(&r0, (const uint16_t*)p.res.p + (size_t)(p.res.y0 * p.res.Ws + p.res.x0) * p.res.Cs, 2, hipMemcpyDeviceToHost));
+                            double dot = 0; for (int k = 0; k < p.K; ++k) dot += (double)f16_to_f32(xr[k]) * f16_to_f32(wr[k]);
+                            const double lin = dot + bias0, lk = lin > 0 ? lin : lin * p.alpha;
+                            log(Severity::warn, "probe op " + std::to_string(i) + ": lin=" + std::to_string(lin) + " leaky=" + std::to_string(lk) + " res=" + std::to_string(f16_to_f32(r0)) + " -> leaky+res=" + std::to_string(lk + f16_to_f32(r0)) +
+                                " streaming=" + std::to_string(f16_to_f32(a[0])) + " general=" + std::to_string(f16_to_f32(b[0])) + " x0=" + std::to_string(f16_to_f32(xr[0])) + " w0=" + std::to_string(f16_to_f32(wr[0])) + " bias0=" + std::to_string(bias0));
+                        }
                         double md = 0; size_t at = 0, bad = 0;
                         for (size_t k = 0; k < n; ++k) { const double d = std::fabs(f16_to_f32(a[k]) - f16_to_f32(b[k])); if (d > 0.01) ++bad; if (d > md) { md = d; at = k; } }
                         log(Severity::warn, "pixgemm check op " + std::to_string(i) + " [" + op.name + "]: max|d|=" + std::to_string(md) + " at pixel " + std::to_string(at / od.C) +
