@@ -391,23 +391,20 @@ bool pixgemm_supported(const GemmParams& p) {
     if (!off && p.wt_frag && p.amode == 2 && p.kh == 2 && p.kw == 2 && p.stride == 2 && p.omode == 0 && !p.ln && p.act == 0 && !p.has_clip &&
         !p.stats_out && !p.pool_out && !p.res.p && !p.res2.p && p.N == 192 && p.out.Cs == 192 && p.Kw == p.K &&
         (p.a.Cs == 96 || p.a.Cs == 192) && p.K == 4 * p.a.Cs && (long)p.out.Hs * p.out.Ws == p.Mrows && p.out.Ws == p.aW) return true;   // patch merge
-    // cunet's 2x2 stride-2 ConvTranspose (= 1x1 convolution + pixel shuffle, LeakyReLU, cropped skip add) at K = 64 / 128 runs 1.7x
-    // faster here (2.3 -> 1.3 ms on config 2's largest one) but gives WRONG results; the cause is open.  The launches stay on
-    // gemm_kernel unless W2X_PIXGEMM_CUNET=1; W2X_PIXGEMM_CHECK=1 W2X_PIXGEMM_PROBE=1 (tools/pixgemm_check.py) shows the mismatch:
-    // the host evaluation of out[0] agrees with gemm_kernel, the streaming kernel's GEMM part is off by far more than rounding.
-    static const bool exp_cunet = getenv("W2X_PIXGEMM_CUNET") != nullptr;   // experiment switch, see the note above
-    const bool rows = p.amode == 0 || (exp_cunet && p.amode == 2 && p.kh == 1 && p.kw == 1);
-    if (off || !p.wt_frag || p.omode != 2 || !rows || p.ln || (p.act != 0 && !(exp_cunet && p.act == 1)) || p.stats_out || p.pool_out || p.res2.p) return false;
+    // rows = a Linear, or a 1x1 convolution: cunet's 2x2 stride-2 ConvTranspose is lowered to 1x1 + pixel shuffle with LeakyReLU and a
+    // cropped skip add (K = 64 / 128)
+    const bool rows = p.amode == 0 || (p.amode == 2 && p.kh == 1 && p.kw == 1);
+    if (off || !p.wt_frag || p.omode != 2 || !rows || p.ln || (p.act != 0 && p.act != 1) || p.stats_out || p.pool_out || p.res2.p) return false;
     if (p.stride != 1 || p.a.y0 || p.a.x0 || p.a.Ws != p.aW || (long)p.a.Hs * p.a.Ws != p.Mrows || p.a.Cs != p.K || p.Kw != p.K) return false;
     if (p.N != p.r * p.r * p.out.Cs) return false;
-    if (p.K == 96 && p.out.Cs == 4 && p.r == 4 && p.N == 64 && !p.res.p) return true;                 // image head
+    if (p.K == 96 && p.out.Cs == 4 && p.r == 4 && p.N == 64 && !p.res.p && p.act == 0 && p.amode == 0) return true;   // image head
     if (p.has_clip || p.Cout != p.out.Cs || (p.res.p && p.res.Cs != p.out.Cs)) return false;
-    if (exp_cunet && ((p.K == 64 && p.out.Cs == 64) || (p.K == 128 && p.out.Cs == 128))) return true;
+    if ((p.K == 64 && p.out.Cs == 64) || (p.K == 128 && p.out.Cs == 128)) return true;
     return (p.K == 192 && (p.out.Cs == 96 || p.out.Cs == 192));
 }
 
 hipError_t launch_pixgemm(const GemmParams& p, hipStream_t s) {
-    if (p.amode == 2) return p.a.Cs == 96 ? launch_merge<96>(p, s) : launch_merge<192>(p, s);
+    if (p.amode == 2 && p.kh == 2) return p.a.Cs == 96 ? launch_merge<96>(p, s) : launch_merge<192>(p, s);
     if (p.out.Cs == 4) {
         constexpr int SM = 4 * 64 * 104 * 2;
         const long M = (long)p.B * p.Mrows;
