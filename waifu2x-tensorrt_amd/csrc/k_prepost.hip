@@ -128,11 +128,25 @@ __global__ void se_kernel(const SeParams p) {
     extern __shared__ float sm[];
     float* mean = sm;            // [C]
     float* mid = sm + p.C;       // [Cmid]
+    float* part = mid + p.Cmid;  // [slices][C]
     const int b = blockIdx.x;
+    // add the producing GEMM's per-workgroup partial sums: the workgroups are split into `slices` contiguous ranges (one per
+    // thread group), each summed in block order, then the slices are added in slice order - a fixed tree, so deterministic
+    const int slices = blockDim.x / p.C > 0 ? blockDim.x / p.C : 1;
+    const int per = (p.nblocks + slices - 1) / slices;
+    {
+        const int c = threadIdx.x % p.C, sl = threadIdx.x / p.C;
+        if (sl < slices) {
+            float s = 0.f;
+            const int t1 = min(p.nblocks, (sl + 1) * per);
+            for (int t = sl * per; t < t1; ++t) s += p.pool[((size_t)b * p.nblocks + t) * p.Cs + c];
+            part[sl * p.C + c] = s;
+        }
+    }
+    __syncthreads();
     for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
-        // add the producing GEMM's per-workgroup partial sums in block order (deterministic)
         float s = 0.f;
-        for (int t = 0; t < p.nblocks; ++t) s += p.pool[((size_t)b * p.nblocks + t) * p.Cs + c];
+        for (int sl = 0; sl < slices; ++sl) s += part[sl * p.C + c];
         mean[c] = s * p.inv_count;
     }
     __syncthreads();
@@ -204,7 +218,8 @@ hipError_t launch_compose(const ComposeParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_se(const SeParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(se_kernel, dim3(p.B), dim3(256), (p.C + p.Cmid) * sizeof(float), s, p);
+    const int threads = 1024, slices = threads / p.C > 0 ? threads / p.C : 1;
+    hipLaunchKernelGGL(se_kernel, dim3(p.B), dim3(threads), (p.C + p.Cmid + slices * p.C) * sizeof(float), s, p);
     return hipGetLastError();
 }
 hipError_t launch_scale(void* x, const float* scale, int B, int HW, int Cs, hipStream_t s) {
