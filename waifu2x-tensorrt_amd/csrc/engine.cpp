@@ -286,7 +286,7 @@ struct Img2Img::Impl {
             upload_frag(blob, frag_w2((const uint16_t*)d.data(), Cc));
         };
         for (const Op& op : plan.ops)   // pixel-shuffle projections served by k_pixgemm.hip
-            if (op.kind == OP_GEMM && ((op.g.omode == 2 && (op.g.amode == 0 || (op.g.amode == 2 && op.g.kh == 1 && op.g.kw == 1))) || (op.g.amode == 2 && op.g.kh == 2 && op.g.kw == 2 && op.g.stride == 2)) && op.g.K % 32 == 0 && op.g.N % 16 == 0 &&
+            if (op.kind == OP_GEMM && ((op.g.omode == 2 && (op.g.amode == 0 || (op.g.amode == 2 && op.g.kh == 1 && op.g.kw == 1))) || (op.g.amode == 2 && op.g.kh == 2 && op.g.kw == 2 && op.g.stride == 2) || (op.g.amode == 2 && op.g.kh == 3 && op.g.kw == 3 && op.g.stride == 1 && op.g.omode == 0)) && op.g.K % 32 == 0 && op.g.N % 16 == 0 &&
                 plan.blobs[op.g.w].data.size() == (size_t)op.g.N * op.g.K * 2) frag_major_blob(op.g.w, op.g.N, op.g.K);
         for (const Op& op : plan.ops)
             if (op.kind == OP_MLP && (op.m.C == 96 || op.m.C == 192)) { frag_major_blob(op.m.w1, 2 * op.m.C, op.m.C); frag_w2_blob(op.m.w2, op.m.C); }
@@ -339,9 +339,9 @@ struct Img2Img::Impl {
                     p.B = live;
                     if ((int)i == final_op && out_override) p.out.p = out_override;
                     stamp_begin(0, op.flops);
-                    hipAssert(pixgemm_supported(p) ? launch_pixgemm(p, stream) : launch_gemm(p, stream));
+                    hipAssert(pixgemm_supported(p) ? launch_pixgemm(p, stream) : conv3_supported(p) ? launch_conv3(p, stream) : launch_gemm(p, stream));
                     stamp_end();
-                    if (getenv("W2X_PIXGEMM_CHECK") && pixgemm_supported(p)) {   // diagnostic: the general kernel must agree
+                    if (getenv("W2X_PIXGEMM_CHECK") && (pixgemm_supported(p) || conv3_supported(p))) {   // diagnostic: the general kernel must agree
                         const TensorDesc& od = plan.tensors[op.g.out.t];
                         const size_t n = (size_t)live * od.H * od.W * od.C;
                         std::vector<uint16_t> a(n), b(n);

@@ -111,6 +111,8 @@ struct ComposeParams {
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 bool pixgemm_supported(const GemmParams& p);                    // k_pixgemm.hip: streaming kernel for pixel-shuffle projections
 hipError_t launch_pixgemm(const GemmParams& p, hipStream_t s);
+bool conv3_supported(const GemmParams& p);                      // k_conv3.hip: LDS-tiled direct 3x3 convolution
+hipError_t launch_conv3(const GemmParams& p, hipStream_t s);
 hipError_t launch_attn(const AttnParams& p, hipStream_t s);
 hipError_t launch_mlp(const MlpParams& p, hipStream_t s);
 hipError_t launch_swin_attn(const SwinAttnParams& p, hipStream_t s);
