@@ -132,6 +132,7 @@ struct Img2Img::Impl {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<void*> tensors, blobs;   // tensors point into one arena
     std::vector<void*> frag_blobs;       // per blob id: fragment-major copy of a weight matrix (or null)
+    std::vector<int> pool_blocks;        // per tensor id: pooling partials per image written by the last producer (0: plan default)
     void* arena_base = nullptr; size_t arena_bytes = 0;
     std::vector<GemmParams> gemm;      // per op (kind == OP_GEMM)
     std::vector<int> pool_tensors;
@@ -258,7 +259,8 @@ struct Img2Img::Impl {
             hipAssert(hipMalloc(&arena_base, arena + 256));
             hipAssert(hipMemsetAsync(arena_base, 0, arena + 256, stream));
             arena_bytes = arena;
-            tensors.assign(nt, nullptr);
+            pool_blocks.assign(nt, 0);
+        tensors.assign(nt, nullptr);
             for (int t = 0; t < nt; ++t) tensors[t] = (uint8_t*)arena_base + off[t];
         }
         blobs.assign(plan.blobs.size(), nullptr);
@@ -339,6 +341,7 @@ struct Img2Img::Impl {
                     p.B = live;
                     if ((int)i == final_op && out_override) p.out.p = out_override;
                     stamp_begin(0, op.flops);
+                    if (op.g.pool_out >= 0) pool_blocks[op.g.pool_out] = conv3_supported(p) ? conv3_tiles(p) : 0;   // partial sums per image written by this launch (0: plan default)
                     hipAssert(pixgemm_supported(p) ? launch_pixgemm(p, stream) : conv3_supported(p) ? launch_conv3(p, stream) : launch_gemm(p, stream));
                     stamp_end();
                     if (getenv("W2X_PIXGEMM_CHECK") && (pixgemm_supported(p) || conv3_supported(p))) {   // diagnostic: the general kernel must agree
@@ -350,7 +353,7 @@ struct Img2Img::Impl {
                         hipAssert(hipStreamSynchronize(stream));
                         hipAssert(hipMemcpy(a.data(), p.out.p, n * 2, hipMemcpyDeviceToHost));
                         hipAssert(hipMemcpy(tmp, p.out.p, n * 2, hipMemcpyDeviceToDevice));   // pixels neither kernel writes compare equal
-                        GemmParams q = p; q.out.p = tmp;
+                        GemmParams q = p; q.out.p = tmp; q.pool_out = nullptr;   // the pooling partials of the real launch stay
                         hipAssert(launch_gemm(q, stream));
                         hipAssert(hipStreamSynchronize(stream));
                         hipAssert(hipMemcpy(b.data(), tmp, n * 2, hipMemcpyDeviceToHost));
@@ -416,7 +419,7 @@ struct Img2Img::Impl {
                     const SeOp& s = op.se;
                     SeParams p;
                     p.pool = (const float*)tensors[s.pool]; p.scale = (float*)tensors[s.scale]; p.B = live; p.C = s.C;
-                    p.Cs = plan.tensors[s.pool].C; p.Cmid = s.Cmid; p.inv_count = s.inv_count; p.nblocks = s.nblocks; p.Mrows = s.Mrows;
+                    p.Cs = plan.tensors[s.pool].C; p.Cmid = s.Cmid; p.inv_count = s.inv_count; p.nblocks = pool_blocks[s.pool] > 0 ? pool_blocks[s.pool] : s.nblocks; p.Mrows = s.Mrows;
                     p.w1 = (const float*)blobs[s.w1]; p.b1 = (const float*)blobs[s.b1]; p.w2 = (const float*)blobs[s.w2]; p.b2 = (const float*)blobs[s.b2];
                     stamp_begin(2, 0);
                     hipAssert(launch_se(p, stream));

@@ -19,6 +19,10 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
 #define W2X_PHASE_FENCE() asm volatile("" ::: "memory")
+// sum over the four 16-lane rows of a wave (see k_swinattn.hip for why the swaps are inline asm on two registers)
+__device__ __forceinline__ void swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float rows_sum(float v) { float a = v, b = v; swap16(a, b); v = a + b; a = v; b = v; swap32(a, b); return a + b; }
 
 template <int KC, int N>
 struct Conv3Cfg {
@@ -120,6 +124,9 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
     const int oy = oy0 + wv;
     _Float16* __restrict__ Og = (_Float16*)p.out.p + ((size_t)(b * p.out.Hs + oy) * p.out.Ws + ox0) * p.out.Cs + n0;
     constexpr int PPO = N / 8, NPO = 16 * PPO / 64 > 0 ? 16 * PPO / 64 : 1;
+    float csum[NT];                       // squeeze-excite pooling: column sums of the stored (fp16-rounded) values of this wave's row
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) csum[nt] = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
@@ -128,7 +135,9 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
             for (int j = 0; j < 4; ++j) {
                 float v = acc[mt][nt][j];
                 if (p.act == 1) v = v > 0.f ? v : v * p.alpha;
-                Ot[(g * 4 + j) * (N + 8) + nt * 16 + fr] = (_Float16)v;
+                const _Float16 h = (_Float16)v;
+                Ot[(g * 4 + j) * (N + 8) + nt * 16 + fr] = h;
+                if (p.pool_out && oy < Ho && ox0 + mt * 16 + g * 4 + j < Wo) csum[nt] += (float)h;
             }
         W2X_PHASE_FENCE();
 #pragma unroll
@@ -138,6 +147,13 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
                 *(half8*)(Og + (size_t)(mt * 16 + px) * p.out.Cs + c * 8) = *(const half8*)(Ot + px * (N + 8) + c * 8);
         }
         W2X_PHASE_FENCE();
+    }
+    if (p.pool_out) {   // per-workgroup partial sums in a fixed order (rows of a wave, then waves 0..3): se_kernel adds the tiles of an image
+        float* ws = (float*)WB;                                  // [4][N]; the weight buffers are idle (last tap ended with a barrier)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { const float t = rows_sum(csum[nt]); if (g == 0) ws[wv * N + nt * 16 + fr] = t; }
+        __syncthreads();
+        for (int n = tid; n < N; n += 256) p.pool_out[(size_t)blockIdx.x * p.out.Cs + n0 + n] = ws[n] + ws[N + n] + ws[2 * N + n] + ws[3 * N + n];
     }
 }
 
@@ -157,14 +173,18 @@ hipError_t launch_c3(const GemmParams& p, int Ho, int Wo, int n0, hipStream_t s)
 
 }  // namespace
 
+int conv3_tiles(const GemmParams& p) { const int Ho = p.Mrows / p.aW, Wo = p.aW; return ((Wo + 63) / 64) * ((Ho + 3) / 4); }   // workgroups per image
+
 bool conv3_supported(const GemmParams& p) {
     static const bool off = getenv("W2X_NO_CONV3") != nullptr;   // A/B switch
     if (off || !p.wt_frag || p.amode != 2 || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.omode != 0 || p.ln || (p.act != 0 && p.act != 1) ||
-        p.has_clip || p.stats_out || p.pool_out || p.res.p || p.res2.p) return false;
+        p.has_clip || p.stats_out || p.res.p || p.res2.p) return false;
     const int Cin = p.a.Cs;
     if (p.K != 9 * Cin || p.Kw != p.K || Cin % 32 || p.out.Cs != p.N || p.aW <= 0 || p.Mrows % p.aW) return false;
     const int Ho = p.Mrows / p.aW, Wo = p.aW;
     if (p.a.y0 + Ho + 2 > p.a.Hs || p.a.x0 + Wo + 2 > p.a.Ws || p.out.Hs < Ho || p.out.Ws < Wo) return false;
+    // pooling partials: one per workgroup; the plan sized the buffer for ceil(Mrows / kGemmBM) row tiles per image
+    if (p.pool_out && conv3_tiles(p) > (p.Mrows + kGemmBM - 1) / kGemmBM) return false;
     return p.N == 64 || p.N == 128 || p.N == 256;
 }
 

@@ -113,6 +113,7 @@ bool pixgemm_supported(const GemmParams& p);                    // k_pixgemm.hip
 hipError_t launch_pixgemm(const GemmParams& p, hipStream_t s);
 bool conv3_supported(const GemmParams& p);                      // k_conv3.hip: LDS-tiled direct 3x3 convolution
 hipError_t launch_conv3(const GemmParams& p, hipStream_t s);
+int conv3_tiles(const GemmParams& p);                           // workgroups (= pooling partials) per image of launch_conv3
 hipError_t launch_attn(const AttnParams& p, hipStream_t s);
 hipError_t launch_mlp(const MlpParams& p, hipStream_t s);
 hipError_t launch_swin_attn(const SwinAttnParams& p, hipStream_t s);
