@@ -34,7 +34,8 @@ struct Conv3Cfg {
     static constexpr int NF = TS * NT * KS, NFW = NF / 4;               // weight fragments per stage / per wave
     static constexpr int WBUF = NF * 1024;
     static constexpr int OT = 16 * (N + 8) * 2;                         // per-wave output m-tile
-    static constexpr int SMEM = HALO + 2 * WBUF + 4 * OT;
+    static constexpr int SMEM = HALO + 2 * WBUF;                        // the per-wave output tiles reuse the halo area after the last tap
+    static_assert(4 * OT <= HALO, "output tiles alias the halo tile");
     static constexpr int PPP = KC / 8;                                  // 16-byte pieces per halo pixel
     static_assert(NF % 4 == 0, "fragments per wave");
 };
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, g = lane >> 4;
-    _Float16* Ot = (_Float16*)(smem + C::HALO + 2 * C::WBUF + wv * C::OT);   // [16][N+8]
+    _Float16* Ot = (_Float16*)(smem + wv * C::OT);                    // [16][N+8], over the halo tile once the last tap is done (the loop ends with a barrier)
 
     const int tpi = tiles_x * tiles_y;
     const int b = blockIdx.x / tpi, trem = blockIdx.x - b * tpi;
