@@ -45,9 +45,19 @@ __device__ __forceinline__ half8 norm8(const half8 v, float rstd, float nm) {
 }
 // see k_swinattn.hip for why the swaps are inline asm on two registers
 __device__ __forceinline__ void swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ float rows_max(float v) { float a = v, b = v; swap16(a, b); v = fmaxf(a, b); a = v; b = v; swap32(a, b); return fmaxf(a, b); }
-__device__ __forceinline__ float rows_sum(float v) { float a = v, b = v; swap16(a, b); v = a + b; a = v; b = v; swap32(a, b); return a + b; }
+// Row maximum of three independent values at once (k_swinattn96.hip): the chains fill each other's permlane wait states
+// and v_max_f32 is used as is.
+__device__ __forceinline__ void rows_max3(float& a0, float& a1, float& a2) {
+    float b0, b1, b2;
+    asm volatile(
+        "v_mov_b32 %3, %0\n\tv_mov_b32 %4, %1\n\tv_mov_b32 %5, %2\n\t"
+        "v_permlane16_swap_b32 %0, %3\n\tv_permlane16_swap_b32 %1, %4\n\tv_permlane16_swap_b32 %2, %5\n\t"
+        "v_max_f32 %0, %0, %3\n\tv_max_f32 %1, %1, %4\n\tv_max_f32 %2, %2, %5\n\t"
+        "v_mov_b32 %3, %0\n\tv_mov_b32 %4, %1\n\tv_mov_b32 %5, %2\n\t"
+        "v_permlane32_swap_b32 %0, %3\n\tv_permlane32_swap_b32 %1, %4\n\tv_permlane32_swap_b32 %2, %5\n\t"
+        "v_max_f32 %0, %0, %3\n\tv_max_f32 %1, %1, %4\n\tv_max_f32 %2, %2, %5"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "=&v"(b0), "=&v"(b1), "=&v"(b2));
+}
 // sum over aligned groups of 32 lanes: DPP inside the 16-lane rows, one row swap across
 __device__ __forceinline__ float group_sum32(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
@@ -62,7 +72,8 @@ constexpr int C = 192, HD = 32, NH = 6, NTOK = 36, G = 2, R = G * NTOK, RT = 5, 
 constexpr int SLAB = 48, RPX = G * SLAB;       // slab rows per window / in the tile
 constexpr int LDX = C + 8;                     // 200 halves: 400-byte rows, 16-byte pieces rotate over the banks
 constexpr int XS = RPX * LDX, OS = RP * LDX;
-constexpr int SMEM192 = (XS + OS) * 2;
+constexpr int PIXN = 80;                       // row -> pixel table entries (>= the rows the passes touch)
+constexpr int SMEM192 = (XS + OS) * 2 + PIXN * 4;
 constexpr int LPR = 32, PPR = C / 8, RPP = 256 / LPR, NPASS = R / RPP;   // row passes: 32 lanes per row, 8 rows per pass, 9 passes
 static_assert(R % RPP == 0, "row passes");
 
@@ -87,6 +98,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* Xs = (_Float16*)smem;              // [RPX][LDX] normalised x slabs; later the output tile [RP][LDX]
     _Float16* Os = Xs + XS;                      // [RP][LDX]  attention output, all heads, token order
+    int* Pix = (int*)(Os + OS);                  // [PIXN] source pixel of each token row (-1: none); valid to the end
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,18 +138,13 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
     }
     W2X_LOAD_W(0, 0, ahp);
 
-    // ---- gather + LayerNorm into the slabs
-    int my_pix[NPASS];
+    // ---- source pixel of every token row, worked out once per workgroup (one thread per row) and handed round in LDS
     {
-        const int li = tid & (LPR - 1);
-        half8 xr[NPASS];
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            const int r = ps * RPP + tid / LPR;          // token row 0..71
-            const int w = r >= NTOK ? 1 : 0;
-            int pix = -1;
+        int pix = -1;
+        if (tid < R) {
+            const int w = tid >= NTOK ? 1 : 0;
             if (w == 0 ? wok0 : wok1) {
-                const int t = r - w * NTOK;
+                const int t = tid - w * NTOK;
                 if (p.ry >= 0) {
                     const int ty = t / 6, tx = t - ty * 6;
                     int y = (w == 0 ? wy0 : wy1) * 6 + ty + p.ry, x = (w == 0 ? wx0 : wx1) * 6 + tx + p.rx;
@@ -145,9 +152,22 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
                     pix = (w == 0 ? pixbase0 : pixbase1) + y * p.W + x;
                 } else pix = (w == 0 ? pixbase0 : pixbase1) + p.table[(w == 0 ? wl0 : wl1) * NTOK + t];
             }
-            my_pix[ps] = pix;
-            half8 h = {};
-            if (pix >= 0 && li < PPR) h = *(const half8*)(X + (size_t)pix * C + li * 8);
+        }
+        if (tid < PIXN) Pix[tid] = pix;
+    }
+    __syncthreads();
+
+    // ---- gather + LayerNorm into the slabs
+    {
+        const int li = tid & (LPR - 1);
+        half8 xr[NPASS];
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int r = ps * RPP + tid / LPR;          // token row 0..71
+            const int pix = Pix[r];
+            // unconditional load from a clamped address (all passes in flight at once), zeroed afterwards
+            half8 h = *(const half8*)(X + (size_t)(pix < 0 ? 0 : pix) * C + (li < PPR ? li : 0) * 8);
+            if (!(pix >= 0 && li < PPR)) h = zero8;
             xr[ps] = h;
         }
 #pragma unroll
@@ -194,14 +214,17 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
 #pragma unroll
                     for (int tt = 0; tt < 3; ++tt) a[ft][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[cur][ft * 6 + ks], xf[tt], a[ft][tt], 0, 0, 0);
             }
-            const float4v b0 = *(const float4v*)(p.bqkv + m * C + h * HD + g * 4);
-            const float4v b1 = *(const float4v*)(p.bqkv + m * C + h * HD + 16 + g * 4);
-            const float sc = m == 0 ? qscale : 1.f;
+            float4v b0 = *(const float4v*)(p.bqkv + m * C + h * HD + g * 4);
+            float4v b1 = *(const float4v*)(p.bqkv + m * C + h * HD + 16 + g * 4);
+            if (m == 0) { b0 *= qscale; b1 *= qscale; }
 #pragma unroll
             for (int tt = 0; tt < 3; ++tt) {
                 half8 f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { f[j] = (_Float16)((a[0][tt][j] + b0[j]) * sc); f[4 + j] = (_Float16)((a[1][tt][j] + b1[j]) * sc); }
+                for (int j = 0; j < 4; ++j) {
+                    if (m == 0) { f[j] = (_Float16)fmaf(a[0][tt][j], qscale, b0[j]); f[4 + j] = (_Float16)fmaf(a[1][tt][j], qscale, b1[j]); }
+                    else { f[j] = (_Float16)(a[0][tt][j] + b0[j]); f[4 + j] = (_Float16)(a[1][tt][j] + b1[j]); }
+                }
                 if (m == 0) qf[tt] = f; else kf[tt] = f;
             }
         }
@@ -209,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
         // bias (+ shift mask) of this unit in load order (lower.cpp): per query tile 2 x float4 + 1 float per lane;
         // fetched under the v products, it is the initial accumulator of S^T
         float4v s[3][3];
+        float b2[3];
         {
             const float* bias = p.bias32 + ((size_t)amask * NH + h) * (3 * 576);
 #pragma unroll
@@ -216,8 +240,8 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
                 const int bl = qi < 2 ? lane : lane2;
                 s[qi][0] = *(const float4v*)(bias + qi * 576 + bl * 4);
                 s[qi][1] = *(const float4v*)(bias + qi * 576 + 256 + bl * 4);
-                float4v t = zero4; t[0] = bias[qi * 576 + 512 + bl];
-                s[qi][2] = t;
+                s[qi][2] = zero4;
+                b2[qi] = bias[qi * 576 + 512 + bl];       // key tile 2 holds one key per lane: added after the product
             }
         }
         // ---- v: rows = slab rows (A = x), columns = features (B = weights)
@@ -251,25 +275,24 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
         for (int qi = 0; qi < 3; ++qi)
 #pragma unroll
             for (int kt = 0; kt < 3; ++kt) s[qi][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt], qf[qi], s[qi][kt], 0, 0, 0);
-        float inv[3];
+        float mx[3];
+#pragma unroll
+        for (int qi = 0; qi < 3; ++qi) {
+            s[qi][2][0] += b2[qi];
+            float m = fmaxf(fmaxf(s[qi][0][0], s[qi][0][1]), fmaxf(s[qi][0][2], s[qi][0][3]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m = fmaxf(m, s[qi][1][j]);
+            mx[qi] = fmaxf(m, s[qi][2][0]);
+        }
+        rows_max3(mx[0], mx[1], mx[2]);
         half8 pf0[3], pf1[3];
 #pragma unroll
         for (int qi = 0; qi < 3; ++qi) {
-            float mx = fmaxf(fmaxf(s[qi][0][0], s[qi][0][1]), fmaxf(s[qi][0][2], s[qi][0][3]));
+            half8 f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[qi][1][j]);
-            mx = rows_max(fmaxf(mx, s[qi][2][0]));
-            float l = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { const float e = __builtin_amdgcn_exp2f(s[qi][kt][j] - mx); s[qi][kt][j] = e; l += e; }
-            { const float e = __builtin_amdgcn_exp2f(s[qi][2][0] - mx); s[qi][2][0] = e; l += e; }
-            l = rows_sum(l);
-            inv[qi] = __builtin_amdgcn_rcpf(l);
-            pf0[qi] = (half8){(_Float16)s[qi][0][0], (_Float16)s[qi][0][1], (_Float16)s[qi][0][2], (_Float16)s[qi][0][3],
-                              (_Float16)s[qi][1][0], (_Float16)s[qi][1][1], (_Float16)s[qi][1][2], (_Float16)s[qi][1][3]};
-            half8 t = zero8; t[0] = (_Float16)s[qi][2][0];
+            for (int j = 0; j < 4; ++j) { f[j] = (_Float16)__builtin_amdgcn_exp2f(s[qi][0][j] - mx[qi]); f[4 + j] = (_Float16)__builtin_amdgcn_exp2f(s[qi][1][j] - mx[qi]); }
+            pf0[qi] = f;
+            half8 t = zero8; t[0] = (_Float16)__builtin_amdgcn_exp2f(s[qi][2][0] - mx[qi]);
             pf1[qi] = t;
         }
         W2X_STAMP(3)
@@ -279,7 +302,19 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
 #pragma unroll
                 for (int ks = 0; ks < 6; ++ks) wp[t][ks] = *(const half8*)(Wproj + (size_t)(((wv * 3 + t) * 6 + ks) * 64 + lane) * 8);
         }
-        // ---- O^T = V^T P^T: rows = features, columns = queries; scaled by 1/l and parked in Os (token order)
+        // ---- O^T = V^T P^T: rows = features, columns = queries; scaled by 1/l and parked in Os (token order).  The
+        // denominators come off the matrix pipe (a ones matrix in place of V^T, see k_swinattn96.hip).
+        float inv[3];
+        {
+            const _Float16 one = (_Float16)1.f;
+            const half8 ones = {one, one, one, one, one, one, one, one};
+#pragma unroll
+            for (int qi = 0; qi < 3; ++qi) {
+                float4v l = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf0[qi], zero4, 0, 0, 0);
+                l = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf1[qi], l, 0, 0, 0);
+                inv[qi] = __builtin_amdgcn_rcpf(l[0]);
+            }
+        }
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
@@ -327,10 +362,12 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
         _Float16* __restrict__ Y = (_Float16*)p.y;
         const int li = tid & (LPR - 1);
         half8 xres[NPASS];
+        int my_pix[NPASS];
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
-            half8 h = {};
-            if (my_pix[ps] >= 0 && li < PPR) h = *(const half8*)(X + (size_t)my_pix[ps] * C + li * 8);
+            my_pix[ps] = Pix[ps * RPP + tid / LPR];
+            half8 h = *(const half8*)(X + (size_t)(my_pix[ps] < 0 ? 0 : my_pix[ps]) * C + (li < PPR ? li : 0) * 8);
+            if (!(my_pix[ps] >= 0 && li < PPR)) h = zero8;
             xres[ps] = h;
         }
 #pragma unroll

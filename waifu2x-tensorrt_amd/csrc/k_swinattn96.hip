@@ -46,17 +46,27 @@ __device__ __forceinline__ float group_sum16(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
     return v;
 }
-// max / sum over the four 16-lane rows of a wave (see k_swinattn.hip for why this is inline asm on two registers)
-__device__ __forceinline__ void swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ float rows_max(float v) { float a = v, b = v; swap16(a, b); v = fmaxf(a, b); a = v; b = v; swap32(a, b); return fmaxf(a, b); }
-__device__ __forceinline__ float rows_sum(float v) { float a = v, b = v; swap16(a, b); v = a + b; a = v; b = v; swap32(a, b); return a + b; }
+// Row maximum of three independent values at once: each chain's permlane wait states (two after the VALU write a swap
+// reads, one before a VALU reads a swap's result) are filled by the other two chains, so the sequence carries no s_nop,
+// and v_max_f32 is used as is (fmaxf() would canonicalise both swap results first).
+__device__ __forceinline__ void rows_max3(float& a0, float& a1, float& a2) {
+    float b0, b1, b2;
+    asm volatile(
+        "v_mov_b32 %3, %0\n\tv_mov_b32 %4, %1\n\tv_mov_b32 %5, %2\n\t"
+        "v_permlane16_swap_b32 %0, %3\n\tv_permlane16_swap_b32 %1, %4\n\tv_permlane16_swap_b32 %2, %5\n\t"
+        "v_max_f32 %0, %0, %3\n\tv_max_f32 %1, %1, %4\n\tv_max_f32 %2, %2, %5\n\t"
+        "v_mov_b32 %3, %0\n\tv_mov_b32 %4, %1\n\tv_mov_b32 %5, %2\n\t"
+        "v_permlane32_swap_b32 %0, %3\n\tv_permlane32_swap_b32 %1, %4\n\tv_permlane32_swap_b32 %2, %5\n\t"
+        "v_max_f32 %0, %0, %3\n\tv_max_f32 %1, %1, %4\n\tv_max_f32 %2, %2, %5"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "=&v"(b0), "=&v"(b1), "=&v"(b2));
+}
 
 constexpr int C = 96, HD = 16, NH = 6, NTOK = 36, G = 2, R = G * NTOK, RT = 5, RP = RT * 16;
 constexpr int SLAB = 48, RPX = G * SLAB;   // slab rows per window / in the tile
 constexpr int LDX = C + 8;                 // 104 halves
 constexpr int XS = RPX * LDX, OS = RP * LDX;
-constexpr int SMEM96 = (XS + OS) * 2;
+constexpr int PIXN = 80;                   // row -> pixel table entries (>= the rows the passes touch)
+constexpr int SMEM96 = (XS + OS) * 2 + PIXN * 4;
 constexpr int LPR = 16, PPR = C / 8, RPP = 256 / LPR, NPASS = (R + RPP - 1) / RPP;   // row passes: 16 lanes per row, 16 rows per pass, 5 passes
 
 __device__ __forceinline__ int slab_row(int t) { return t < 32 ? t : 32 + 4 * (t - 32); }
@@ -65,6 +75,7 @@ __global__ __launch_bounds__(256, 3) void swin_attn96_kernel(const SwinAttnParam
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* Xs = (_Float16*)smem;              // [RPX][LDX] normalised x slabs; later the output tile [RP][LDX]
     _Float16* Os = Xs + XS;                      // [RP][LDX]  attention output, all heads, token order
+    int* Pix = (int*)(Os + OS);                  // [PIXN] source pixel of each token row (-1: none); valid to the end
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,30 +113,36 @@ __global__ __launch_bounds__(256, 3) void swin_attn96_kernel(const SwinAttnParam
     }
     W2X_LOAD_W(0, ahp);
 
+    // ---- source pixel of every token row, worked out once per workgroup (one thread per row) and handed round in LDS
+    {
+        int pix = -1;
+        if (tid < R) {
+            const int w = tid >= NTOK ? 1 : 0;
+            if (w == 0 ? wok0 : wok1) {
+                const int t = tid - w * NTOK;
+                if (p.ry >= 0) {
+                    const int ty = t / 6, tx = t - ty * 6;
+                    int y = (w == 0 ? wy0 : wy1) * 6 + ty + p.ry, x = (w == 0 ? wx0 : wx1) * 6 + tx + p.rx;
+                    y -= y >= p.H ? p.H : 0; x -= x >= p.W ? p.W : 0;
+                    pix = (w == 0 ? pixbase0 : pixbase1) + y * p.W + x;
+                } else pix = (w == 0 ? pixbase0 : pixbase1) + p.table[(w == 0 ? wl0 : wl1) * NTOK + t];
+            }
+        }
+        if (tid < PIXN) Pix[tid] = pix;
+    }
+    __syncthreads();
+
     // ---- gather + LayerNorm into the slabs
-    int my_pix[NPASS];
     {
         const int li = tid & (LPR - 1);
         half8 xr[NPASS];
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int r = ps * RPP + tid / LPR;          // token row 0..71 (the last pass is half empty)
-            int pix = -1;
-            if (r < R) {
-                const int w = r >= NTOK ? 1 : 0;
-                if (w == 0 ? wok0 : wok1) {
-                    const int t = r - w * NTOK;
-                    if (p.ry >= 0) {
-                        const int ty = t / 6, tx = t - ty * 6;
-                        int y = (w == 0 ? wy0 : wy1) * 6 + ty + p.ry, x = (w == 0 ? wx0 : wx1) * 6 + tx + p.rx;
-                        y -= y >= p.H ? p.H : 0; x -= x >= p.W ? p.W : 0;
-                        pix = (w == 0 ? pixbase0 : pixbase1) + y * p.W + x;
-                    } else pix = (w == 0 ? pixbase0 : pixbase1) + p.table[(w == 0 ? wl0 : wl1) * NTOK + t];
-                }
-            }
-            my_pix[ps] = pix;
-            half8 h = {};
-            if (pix >= 0 && li < PPR) h = *(const half8*)(X + (size_t)pix * C + li * 8);
+            const int pix = Pix[r];
+            // unconditional load from a clamped address (all passes in flight at once), zeroed afterwards
+            half8 h = *(const half8*)(X + (size_t)(pix < 0 ? 0 : pix) * C + (li < PPR ? li : 0) * 8);
+            if (!(pix >= 0 && li < PPR)) h = zero8;
             xr[ps] = h;
         }
 #pragma unroll
@@ -158,6 +175,7 @@ __global__ __launch_bounds__(256, 3) void swin_attn96_kernel(const SwinAttnParam
         // bias (+ shift mask) of this unit in load order (lower.cpp): per query tile 2 x float4 + 1 float per lane;
         // it is the initial accumulator of S^T
         float4v s[3][3];
+        float b2[3];
         {
             const float* bias = p.bias32 + ((size_t)amask * NH + h) * (3 * 576);
 #pragma unroll
@@ -165,8 +183,8 @@ __global__ __launch_bounds__(256, 3) void swin_attn96_kernel(const SwinAttnParam
                 const int bl = qi < 2 ? lane : lane2;
                 s[qi][0] = *(const float4v*)(bias + qi * 576 + bl * 4);
                 s[qi][1] = *(const float4v*)(bias + qi * 576 + 256 + bl * 4);
-                float4v t = zero4; t[0] = bias[qi * 576 + 512 + bl];
-                s[qi][2] = t;
+                s[qi][2] = zero4;
+                b2[qi] = bias[qi * 576 + 512 + bl];       // key tile 2 holds one key per lane: added after the product
             }
         }
         // ---- q^T, k^T (rows = features: A = weights, B = x) and v (rows = slab rows: A = x, B = weights)
@@ -181,50 +199,57 @@ __global__ __launch_bounds__(256, 3) void swin_attn96_kernel(const SwinAttnParam
                 av[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf, wr[cur][6 + ks], av[tt], 0, 0, 0);
             }
         }
-        const float4v bq = *(const float4v*)(p.bqkv + h * HD + g * 4);
+        float4v bq = *(const float4v*)(p.bqkv + h * HD + g * 4);
         const float4v bk = *(const float4v*)(p.bqkv + C + h * HD + g * 4);
         const float bvv = p.bqkv[2 * C + h * HD + fr];
+        bq *= qscale;
         half4 qf[3], kf[3], vf[3];
 #pragma unroll
         for (int tt = 0; tt < 3; ++tt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { qf[tt][j] = (_Float16)((aq[tt][j] + bq[j]) * qscale); kf[tt][j] = (_Float16)(ak[tt][j] + bk[j]); vf[tt][j] = (_Float16)(av[tt][j] + bvv); }
+            for (int j = 0; j < 4; ++j) { qf[tt][j] = (_Float16)fmaf(aq[tt][j], qscale, bq[j]); kf[tt][j] = (_Float16)(ak[tt][j] + bk[j]); vf[tt][j] = (_Float16)(av[tt][j] + bvv); }
         // ---- S^T = K Q^T on top of the bias (k = the 16 features), softmax over the keys
 #pragma unroll
         for (int qi = 0; qi < 3; ++qi)
 #pragma unroll
             for (int kt = 0; kt < 3; ++kt) s[qi][kt] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf[kt], qf[qi], s[qi][kt], 0, 0, 0);
-        float inv[3];
+        float mx[3];
+#pragma unroll
+        for (int qi = 0; qi < 3; ++qi) {
+            s[qi][2][0] += b2[qi];
+            float m = fmaxf(fmaxf(s[qi][0][0], s[qi][0][1]), fmaxf(s[qi][0][2], s[qi][0][3]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m = fmaxf(m, s[qi][1][j]);
+            mx[qi] = fmaxf(m, s[qi][2][0]);
+        }
+        rows_max3(mx[0], mx[1], mx[2]);
         half4 pf[3][3];
 #pragma unroll
         for (int qi = 0; qi < 3; ++qi) {
-            float mx = fmaxf(fmaxf(s[qi][0][0], s[qi][0][1]), fmaxf(s[qi][0][2], s[qi][0][3]));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[qi][1][j]);
-            mx = rows_max(fmaxf(mx, s[qi][2][0]));
-            float l = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const float e = __builtin_amdgcn_exp2f(s[qi][kt][j] - mx); s[qi][kt][j] = e; l += e; }
-            { const float e = __builtin_amdgcn_exp2f(s[qi][2][0] - mx); s[qi][2][0] = e; l += e; }
-            l = rows_sum(l);
-            inv[qi] = __builtin_amdgcn_rcpf(l);
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) pf[qi][kt] = (half4){(_Float16)s[qi][kt][0], (_Float16)s[qi][kt][1], (_Float16)s[qi][kt][2], (_Float16)s[qi][kt][3]};
-            pf[qi][2] = (half4){(_Float16)s[qi][2][0], (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};   // slab row 32 + 4g = token 32 + g
+                for (int j = 0; j < 4; ++j) pf[qi][kt][j] = (_Float16)__builtin_amdgcn_exp2f(s[qi][kt][j] - mx[qi]);
+            pf[qi][2] = (half4){(_Float16)__builtin_amdgcn_exp2f(s[qi][2][0] - mx[qi]), (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};   // slab row 32 + 4g = token 32 + g
         }
-        // ---- O^T = V^T P^T: rows = features, columns = queries (k = 16 keys per product); parked in Os (token order)
+        // ---- O^T = V^T P^T: rows = features, columns = queries (k = 16 keys per product); parked in Os (token order).
+        // The softmax denominators come off the matrix pipe too: a ones matrix in place of V^T leaves the sum of the
+        // (fp16) probabilities of query fr in every row of its column - the lane that scales the column already holds it.
+        const half4 ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
 #pragma unroll
         for (int qi = 0; qi < 3; ++qi) {
             float4v o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf[0], pf[qi][0], zero4, 0, 0, 0);
+            float4v l = __builtin_amdgcn_mfma_f32_16x16x16f16(ones, pf[qi][0], zero4, 0, 0, 0);
             o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf[1], pf[qi][1], o, 0, 0, 0);
+            l = __builtin_amdgcn_mfma_f32_16x16x16f16(ones, pf[qi][1], l, 0, 0, 0);
             o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf[2], pf[qi][2], o, 0, 0, 0);
+            l = __builtin_amdgcn_mfma_f32_16x16x16f16(ones, pf[qi][2], l, 0, 0, 0);
+            const float inv = __builtin_amdgcn_rcpf(l[0]);
             const int query = qi < 2 ? qi * 16 + fr : 32 + (fr >> 2);
             if (aok && (qi < 2 || (fr & 3) == 0)) {
                 half4 oh;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) oh[j] = (_Float16)(o[j] * inv[qi]);
+                for (int j = 0; j < 4; ++j) oh[j] = (_Float16)(o[j] * inv);
                 *(half4*)(Os + (tbase + query) * LDX + h * HD + g * 4) = oh;
             }
         }
@@ -261,10 +286,12 @@ __global__ __launch_bounds__(256, 3) void swin_attn96_kernel(const SwinAttnParam
         _Float16* __restrict__ Y = (_Float16*)p.y;
         const int li = tid & (LPR - 1);
         half8 xres[NPASS];
+        int my_pix[NPASS];
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
-            half8 h = {};
-            if (my_pix[ps] >= 0 && li < PPR) h = *(const half8*)(X + (size_t)my_pix[ps] * C + li * 8);
+            my_pix[ps] = Pix[ps * RPP + tid / LPR];
+            half8 h = *(const half8*)(X + (size_t)(my_pix[ps] < 0 ? 0 : my_pix[ps]) * C + (li < PPR ? li : 0) * 8);
+            if (!(my_pix[ps] >= 0 && li < PPR)) h = zero8;
             xres[ps] = h;
         }
 #pragma unroll
