@@ -45,6 +45,20 @@ __device__ __forceinline__ half8 norm8(const half8 v, float rstd, float nm) {
 }
 // see k_swinattn.hip for why the swaps are inline asm on two registers
 __device__ __forceinline__ void swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b)); }
+// 32-lane group sums of six independent values at once (k_swinattn96.hip): four v_add_f32 steps with a DPP operand
+// inside the 16-lane rows, then one row swap across; the chains fill each other's wait states.
+#define W2X_DPP1(R, CTRL) "v_add_f32_dpp " R ", " R ", " R " " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define W2X_DPP6(CTRL) W2X_DPP1("%0", CTRL) W2X_DPP1("%1", CTRL) W2X_DPP1("%2", CTRL) W2X_DPP1("%3", CTRL) W2X_DPP1("%4", CTRL) W2X_DPP1("%5", CTRL)
+__device__ __forceinline__ void group_sum32_x6(float& a, float& b, float& c, float& d, float& e, float& f) {
+    float ta, tb, tc, td, te, tf;
+    asm volatile(
+        "s_nop 1\n\t" W2X_DPP6("quad_perm:[1,0,3,2]") W2X_DPP6("quad_perm:[2,3,0,1]") W2X_DPP6("row_half_mirror") W2X_DPP6("row_mirror")
+        "v_mov_b32 %6, %0\n\tv_mov_b32 %7, %1\n\tv_mov_b32 %8, %2\n\tv_mov_b32 %9, %3\n\tv_mov_b32 %10, %4\n\tv_mov_b32 %11, %5\n\t"
+        "v_permlane16_swap_b32 %0, %6\n\tv_permlane16_swap_b32 %1, %7\n\tv_permlane16_swap_b32 %2, %8\n\t"
+        "v_permlane16_swap_b32 %3, %9\n\tv_permlane16_swap_b32 %4, %10\n\tv_permlane16_swap_b32 %5, %11\n\t"
+        "v_add_f32 %0, %0, %6\n\tv_add_f32 %1, %1, %7\n\tv_add_f32 %2, %2, %8\n\tv_add_f32 %3, %3, %9\n\tv_add_f32 %4, %4, %10\n\tv_add_f32 %5, %5, %11"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "=&v"(ta), "=&v"(tb), "=&v"(tc), "=&v"(td), "=&v"(te), "=&v"(tf));
+}
 // Row maximum of three independent values at once (k_swinattn96.hip): the chains fill each other's permlane wait states
 // and v_max_f32 is used as is.
 __device__ __forceinline__ void rows_max3(float& a0, float& a1, float& a2) {
@@ -170,16 +184,20 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
             if (!(pix >= 0 && li < PPR)) h = zero8;
             xr[ps] = h;
         }
+        static_assert(NPASS == 9, "the row sums are reduced three passes at a time");
+        float sm[NPASS], sq[NPASS];
+#pragma unroll
+        for (int pg = 0; pg < NPASS; pg += 3) {
+#pragma unroll
+            for (int ps = pg; ps < pg + 3; ++ps) sum_sq8(xr[ps], sm[ps], sq[ps]);
+            group_sum32_x6(sm[pg], sq[pg], sm[pg + 1], sq[pg + 1], sm[pg + 2], sq[pg + 2]);
+        }
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int r = ps * RPP + tid / LPR;
             const int w = r >= NTOK ? 1 : 0;
-            float s, q;
-            sum_sq8(xr[ps], s, q);
-            s = group_sum32(s);
-            q = group_sum32(q);
-            const float mean = s * (1.f / C);
-            const float rstd = rsqrtf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps);
+            const float mean = sm[ps] * (1.f / C);
+            const float rstd = rsqrtf(fmaxf(sq[ps] * (1.f / C) - mean * mean, 0.f) + p.eps);
             if (li < PPR) *(half8*)(Xs + (w * SLAB + slab_row(r - w * NTOK)) * LDX + li * 8) = norm8(xr[ps], rstd, -mean * rstd);
         }
         // the 12 rows between tokens 32..35 of each slab are multiplied like the rest (results ignored): keep them finite

@@ -46,6 +46,19 @@ __device__ __forceinline__ float group_sum16(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
     return v;
 }
+// Row-group sums of several independent values at once: v_add_f32 with a DPP operand (the compiler emits v_mov_dpp +
+// v_add for v += dpp(v)); the chains are interleaved so that each one's two wait states between a VALU write and a
+// DPP read are filled by the others.
+#define W2X_DPP1(R, CTRL) "v_add_f32_dpp " R ", " R ", " R " " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define W2X_DPP4(CTRL) W2X_DPP1("%0", CTRL) W2X_DPP1("%1", CTRL) W2X_DPP1("%2", CTRL) W2X_DPP1("%3", CTRL)
+#define W2X_DPP6(CTRL) W2X_DPP4(CTRL) W2X_DPP1("%4", CTRL) W2X_DPP1("%5", CTRL)
+#define W2X_DPP_STEPS(N) "s_nop 1\n\t" W2X_DPP##N("quad_perm:[1,0,3,2]") W2X_DPP##N("quad_perm:[2,3,0,1]") W2X_DPP##N("row_half_mirror") W2X_DPP##N("row_mirror")
+__device__ __forceinline__ void group_sum16_x4(float& a, float& b, float& c, float& d) {
+    asm volatile(W2X_DPP_STEPS(4) : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void group_sum16_x6(float& a, float& b, float& c, float& d, float& e, float& f) {
+    asm volatile(W2X_DPP_STEPS(6) : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+}
 // Row maximum of three independent values at once: each chain's permlane wait states (two after the VALU write a swap
 // reads, one before a VALU reads a swap's result) are filled by the other two chains, so the sequence carries no s_nop,
 // and v_max_f32 is used as is (fmaxf() would canonicalise both swap results first).
@@ -145,16 +158,20 @@ __global__ __launch_bounds__(256, 3) void swin_attn96_kernel(const SwinAttnParam
             if (!(pix >= 0 && li < PPR)) h = zero8;
             xr[ps] = h;
         }
+        static_assert(NPASS == 5, "the row sums are reduced as 3 + 2 passes");
+        float sm[NPASS], sq[NPASS];
+#pragma unroll
+        for (int ps = 0; ps < 3; ++ps) sum_sq8(xr[ps], sm[ps], sq[ps]);
+        group_sum16_x6(sm[0], sq[0], sm[1], sq[1], sm[2], sq[2]);
+#pragma unroll
+        for (int ps = 3; ps < 5; ++ps) sum_sq8(xr[ps], sm[ps], sq[ps]);
+        group_sum16_x4(sm[3], sq[3], sm[4], sq[4]);
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int r = ps * RPP + tid / LPR;
             const int w = r >= NTOK ? 1 : 0;
-            float s, q;
-            sum_sq8(xr[ps], s, q);
-            s = group_sum16(s);
-            q = group_sum16(q);
-            const float mean = s * (1.f / C);
-            const float rstd = rsqrtf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps);
+            const float mean = sm[ps] * (1.f / C);
+            const float rstd = rsqrtf(fmaxf(sq[ps] * (1.f / C) - mean * mean, 0.f) + p.eps);
             if (r < R && li < PPR) *(half8*)(Xs + (w * SLAB + slab_row(r - w * NTOK)) * LDX + li * 8) = norm8(xr[ps], rstd, -mean * rstd);
         }
         // the 12 rows between tokens 32..35 of each slab are multiplied like the rest (results ignored): keep them finite
@@ -257,6 +274,19 @@ __global__ __launch_bounds__(256, 3) void swin_attn96_kernel(const SwinAttnParam
 #undef W2X_LOAD_W
     __syncthreads();      // every wave's head outputs are in Os; nobody reads the slabs any more
 
+    // the residual rows are fetched now, under the projection
+    half8 xres[NPASS];
+    int my_pix[NPASS];
+    {
+        const int li = tid & (LPR - 1);
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            my_pix[ps] = Pix[ps * RPP + tid / LPR];
+            half8 h = *(const half8*)(X + (size_t)(my_pix[ps] < 0 ? 0 : my_pix[ps]) * C + (li < PPR ? li : 0) * 8);
+            if (!(my_pix[ps] >= 0 && li < PPR)) h = zero8;
+            xres[ps] = h;
+        }
+    }
     // ---- proj: out = Os * Wproj^T + b -> tile over Xs.  10 units of (16-row tile, 3 n-tiles), weights as fragments from L2
     for (int u = wv; u < RT * 2; u += 4) {
         const int mt = u >> 1, n3 = (u & 1) * 3;
@@ -285,15 +315,6 @@ __global__ __launch_bounds__(256, 3) void swin_attn96_kernel(const SwinAttnParam
     {
         _Float16* __restrict__ Y = (_Float16*)p.y;
         const int li = tid & (LPR - 1);
-        half8 xres[NPASS];
-        int my_pix[NPASS];
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            my_pix[ps] = Pix[ps * RPP + tid / LPR];
-            half8 h = *(const half8*)(X + (size_t)(my_pix[ps] < 0 ? 0 : my_pix[ps]) * C + (li < PPR ? li : 0) * 8);
-            if (!(my_pix[ps] >= 0 && li < PPR)) h = zero8;
-            xres[ps] = h;
-        }
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int r = ps * RPP + tid / LPR;
