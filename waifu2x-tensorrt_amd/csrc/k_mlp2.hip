@@ -28,15 +28,21 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
 // GELU(x) = max(x,0) - 0.5 u 2^-q(u), u = min(|x|, 6.5): see k_mlp.hip / tools/fit_gelu.py (|err| < 3.2e-7)
-__device__ __forceinline__ float gelu_fast(float x) {
-    const float u = fminf(fabsf(x), 6.5f);
-    float q = fmaf(-2.992485764e-05f, u, 7.398797018e-04f);
-    q = fmaf(q, u, -7.977479093e-03f);
-    q = fmaf(q, u, 5.323820859e-02f);
-    q = fmaf(q, u, 4.589156733e-01f);
-    q = fmaf(q, u, 1.151147085e+00f);
-    const float e = __builtin_amdgcn_exp2f(-(q * u));
-    return fmaf(-0.5f * u, e, fmaxf(x, 0.f));
+// Two values at a time: the polynomial, the products and the final fma are v_pk_*_f32 (one issue slot for both values);
+// min / max / exp2 have no packed form.  Same operations per element as the scalar form, so the results are identical.
+typedef float float2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2v splat2(float c) { return (float2v){c, c}; }
+__device__ __forceinline__ float2v gelu_fast2(float2v x) {
+    const float2v u = {fminf(fabsf(x[0]), 6.5f), fminf(fabsf(x[1]), 6.5f)};
+    float2v q = __builtin_elementwise_fma(splat2(-2.992485764e-05f), u, splat2(7.398797018e-04f));
+    q = __builtin_elementwise_fma(q, u, splat2(-7.977479093e-03f));
+    q = __builtin_elementwise_fma(q, u, splat2(5.323820859e-02f));
+    q = __builtin_elementwise_fma(q, u, splat2(4.589156733e-01f));
+    q = __builtin_elementwise_fma(q, u, splat2(1.151147085e+00f));
+    const float2v t = q * u;
+    const float2v e = {__builtin_amdgcn_exp2f(-t[0]), __builtin_amdgcn_exp2f(-t[1])};
+    const float2v m = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+    return __builtin_elementwise_fma(splat2(-0.5f) * u, e, m);
 }
 __device__ __forceinline__ void sum_sq8(const half8 v, float& s, float& q) {
     const half2v one = {(_Float16)1.f, (_Float16)1.f};
@@ -208,9 +214,12 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (SHARE && TT <= 2 && C == 9
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt) {
                 const float4v e = acc1[0][tt], o = acc1[1][tt];
-                a2[tt] = (half8){(_Float16)gelu_fast(e[0] + be[0]), (_Float16)gelu_fast(e[1] + be[1]), (_Float16)gelu_fast(e[2] + be[2]),
-                                 (_Float16)gelu_fast(e[3] + be[3]), (_Float16)gelu_fast(o[0] + bo[0]), (_Float16)gelu_fast(o[1] + bo[1]),
-                                 (_Float16)gelu_fast(o[2] + bo[2]), (_Float16)gelu_fast(o[3] + bo[3])};
+                const float2v g0 = gelu_fast2((float2v){e[0], e[1]} + (float2v){be[0], be[1]});
+                const float2v g1 = gelu_fast2((float2v){e[2], e[3]} + (float2v){be[2], be[3]});
+                const float2v g2 = gelu_fast2((float2v){o[0], o[1]} + (float2v){bo[0], bo[1]});
+                const float2v g3 = gelu_fast2((float2v){o[2], o[3]} + (float2v){bo[2], bo[3]});
+                a2[tt] = (half8){(_Float16)g0[0], (_Float16)g0[1], (_Float16)g1[0], (_Float16)g1[1],
+                                 (_Float16)g2[0], (_Float16)g2[1], (_Float16)g3[0], (_Float16)g3[1]};
             }
         }
         // GEMM2: acc2[tt][nt] += H[tokens][chunk] * W2[16nt ..][chunk]^T

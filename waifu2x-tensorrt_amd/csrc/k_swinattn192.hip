@@ -26,6 +26,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void sum_sq8(const half8 v, float& s, float& q) {
     const half2v one = {(_Float16)1.f, (_Float16)1.f};
@@ -307,8 +308,13 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
 #pragma unroll
         for (int qi = 0; qi < 3; ++qi) {
             half8 f;
+            const float2v m2 = {mx[qi], mx[qi]};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { f[j] = (_Float16)__builtin_amdgcn_exp2f(s[qi][0][j] - mx[qi]); f[4 + j] = (_Float16)__builtin_amdgcn_exp2f(s[qi][1][j] - mx[qi]); }
+            for (int kt = 0; kt < 2; ++kt) {   // the subtractions as v_pk_add_f32
+                const float2v d0 = (float2v){s[qi][kt][0], s[qi][kt][1]} - m2, d1 = (float2v){s[qi][kt][2], s[qi][kt][3]} - m2;
+                f[4 * kt + 0] = (_Float16)__builtin_amdgcn_exp2f(d0[0]); f[4 * kt + 1] = (_Float16)__builtin_amdgcn_exp2f(d0[1]);
+                f[4 * kt + 2] = (_Float16)__builtin_amdgcn_exp2f(d1[0]); f[4 * kt + 3] = (_Float16)__builtin_amdgcn_exp2f(d1[1]);
+            }
             pf0[qi] = f;
             half8 t = zero8; t[0] = (_Float16)__builtin_amdgcn_exp2f(s[qi][2][0] - mx[qi]);
             pf1[qi] = t;
@@ -341,9 +347,9 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
                 o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf1[ft], pf1[qi], o, 0, 0, 0);
                 const int query = qi < 2 ? qi * 16 + fr : 32 + (fr >> 2);
                 if (aok && (qi < 2 || (fr & 3) == 0)) {
-                    half4 oh;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) oh[j] = (_Float16)(o[j] * inv[qi]);
+                    const float2v i2 = {inv[qi], inv[qi]};
+                    const float2v o0 = (float2v){o[0], o[1]} * i2, o1 = (float2v){o[2], o[3]} * i2;
+                    const half4 oh = {(_Float16)o0[0], (_Float16)o0[1], (_Float16)o1[0], (_Float16)o1[1]};
                     *(half4*)(Os + (tbase + query) * LDX + h * HD + ft * 16 + g * 4) = oh;
                 }
             }
