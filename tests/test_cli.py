@@ -114,3 +114,53 @@ def test_cli_build_and_render_match_the_library(pkg, tmp_path):
     ref = eng.render(np.ascontiguousarray(rgb[..., ::-1]))              # the library works on BGR
     eng.close()
     assert np.array_equal(got, ref[..., ::-1])
+
+
+FAKE_FFPROBE = """#!/usr/bin/env python3
+# stand-in for ffprobe on a raw bgr24 clip: prints width,height,r_frame_rate,nb_read_packets like `-of csv=p=0`
+import os, sys
+w, h = int(os.environ["FAKE_W"]), int(os.environ["FAKE_H"])
+print(f"{w},{h},30/1,{os.path.getsize(sys.argv[-1]) // (w * h * 3)}")
+"""
+
+FAKE_FFMPEG = """#!/usr/bin/env python3
+# stand-in for ffmpeg: `-i FILE ... -` copies the raw clip to stdout, `-i - ... OUT` copies stdin to OUT
+import shutil, sys
+a = sys.argv[1:]
+src = a[a.index("-i") + 1]
+if src == "-":
+    with open(a[-1], "wb") as f: shutil.copyfileobj(sys.stdin.buffer, f)
+else:
+    with open(src, "rb") as f: shutil.copyfileobj(f, sys.stdout.buffer)
+"""
+
+
+@pytest.mark.gpu
+def test_cli_video_path_matches_the_library(pkg, tmp_path):
+    """The video path (frames piped through ffmpeg as raw bgr24, reader / renderer / writer on their own threads) writes,
+    in order, the frames Img2Img.render gives.  ffmpeg is not in the image: two small scripts stand in for the pipes."""
+    import synth_models as sm
+    models = tmp_path / "models"
+    path = sm.model_path(str(tmp_path), "swin_unet/art", 4, 3)
+    sm.export_onnx(sm.make_model("swin_unet/art", 4, seed=5, small=True), path, 2, 64, dynamic=True)
+    W, H, N = 100, 70, 10                                               # 10 frames: two full chunks of 4 and a ragged one
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)         # BGR
+    (tmp_path / "clip.mp4").write_bytes(frames.tobytes())
+    bindir = tmp_path / "bin"; bindir.mkdir()
+    for name, text in (("ffprobe", FAKE_FFPROBE), ("ffmpeg", FAKE_FFMPEG)):
+        (bindir / name).write_text(text); (bindir / name).chmod(0o755)
+    out = tmp_path / "out"; out.mkdir()
+    common = ["--models", str(models), "--model", "swin_unet/art", "--scale", "4", "--noise", "3", "--batchSize", "2", "--tileSize", "64"]
+    env = dict(os.environ, PATH=f"{bindir}:{os.environ['PATH']}", FAKE_W=str(W), FAKE_H=str(H))
+    r = subprocess.run([W2X, *common, "build"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([W2X, *common, "render", "-i", str(tmp_path / "clip.mp4"), "-o", str(out)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    raw = (out / "clip(swin_unet_art)(noise3)(scale4).mp4").read_bytes()
+    got = np.frombuffer(raw, np.uint8).reshape(N, H * 4, W * 4, 3)
+    eng = pkg.Img2Img()
+    assert eng.load(path, pkg.RenderConfig(batchSize=2, height=64, width=64, scaling=4)), eng.last_error()
+    for k in range(N):
+        assert np.array_equal(got[k], eng.render(np.ascontiguousarray(frames[k]))), k
+    eng.close()

@@ -9,7 +9,9 @@
 #include <cstdlib>
 #include <filesystem>
 #include <iostream>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 #include "../../../include/w2x/img2img.h"
@@ -132,26 +134,59 @@ int main(int argc, char** argv) {
                 FILE* wr = popen((wcmd + shell_quote(outFile)).c_str(), "w");
                 if (!rd || !wr) throw std::runtime_error("cannot start ffmpeg for " + file);
                 if (o.devices == 1) {
-                    // one device: chunks of frames through renderSequence (upload / compute / download overlapped, buffers page-locked once)
-                    const int CH = 4;
-                    std::vector<std::vector<uint8_t>> ins(CH, std::vector<uint8_t>(inBytes)), outs(CH, std::vector<uint8_t>(outBytes));
-                    for (int k = 0; k < CH; ++k) { engines[0]->pinHost(ins[k].data(), inBytes); engines[0]->pinHost(outs[k].data(), outBytes); }
-                    bool eof = false;
-                    while (!eof) {
-                        int got = 0;
-                        for (; got < CH; ++got) if (fread(ins[got].data(), 1, inBytes, rd) != inBytes) { eof = true; break; }
-                        if (!got) break;
+                    // one device: chunks of frames through renderSequence (upload / compute / download overlapped, buffers
+                    // page-locked once).  The ffmpeg pipes run on their own threads over two chunk slots, so decoding chunk
+                    // n+1 and encoding chunk n-1 overlap with rendering chunk n (the reference serialises them, main.cpp:263-269).
+                    const int CH = 4, SLOTS = 2;
+                    struct Slot { std::vector<std::vector<uint8_t>> in, out; int frames = 0; int state = 0; };   // 0 free, 1 read, 2 rendered
+                    std::vector<Slot> slots(SLOTS);
+                    for (Slot& sl : slots) {
+                        sl.in.assign(CH, std::vector<uint8_t>(inBytes)); sl.out.assign(CH, std::vector<uint8_t>(outBytes));
+                        for (int k = 0; k < CH; ++k) { engines[0]->pinHost(sl.in[k].data(), inBytes); engines[0]->pinHost(sl.out[k].data(), outBytes); }
+                    }
+                    std::mutex mu; std::condition_variable cv;
+                    bool failed = false;
+                    std::thread reader([&] {          // slot i: free -> read; a slot with 0 frames marks the end of the stream
+                        for (int i = 0;; i = (i + 1) % SLOTS) {
+                            Slot& sl = slots[i];
+                            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return sl.state == 0 || failed; }); if (failed) return; }
+                            int got = 0;
+                            for (; got < CH; ++got) if (fread(sl.in[got].data(), 1, inBytes, rd) != inBytes) break;
+                            { std::lock_guard<std::mutex> lk(mu); sl.frames = got; sl.state = 1; }
+                            cv.notify_all();
+                            if (got < CH) return;
+                        }
+                    });
+                    std::thread writer([&] {          // slot i: rendered -> free
+                        for (int i = 0;; i = (i + 1) % SLOTS) {
+                            Slot& sl = slots[i];
+                            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return sl.state == 2 || failed; }); if (failed) return; }
+                            const int n = sl.frames;
+                            for (int k = 0; k < n; ++k) if (fwrite(sl.out[k].data(), 1, outBytes, wr) != outBytes) { std::lock_guard<std::mutex> lk(mu); failed = true; }
+                            { std::lock_guard<std::mutex> lk(mu); sl.state = 0; }
+                            cv.notify_all();
+                            if (n < CH) return;
+                        }
+                    });
+                    for (int i = 0;; i = (i + 1) % SLOTS) {
+                        Slot& sl = slots[i];
+                        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return sl.state == 1 || failed; }); if (failed) break; }
+                        const int got = sl.frames;
                         std::vector<Image> si(got), di(got);
                         for (int k = 0; k < got; ++k) {
-                            si[k] = Image{ins[k].data(), pr.height, pr.width, (size_t)pr.width * 3};
-                            di[k] = Image{outs[k].data(), pr.height * o.scale, pr.width * o.scale, (size_t)pr.width * o.scale * 3};
+                            si[k] = Image{sl.in[k].data(), pr.height, pr.width, (size_t)pr.width * 3};
+                            di[k] = Image{sl.out[k].data(), pr.height * o.scale, pr.width * o.scale, (size_t)pr.width * o.scale * 3};
                         }
-                        if (!engines[0]->renderSequence(si.data(), di.data(), got)) return -1;
-                        for (int k = 0; k < got; ++k) { fwrite(outs[k].data(), 1, outBytes, wr); ++frameIndex; }
-                        on_progress(1, 1, 0.0);
+                        const bool ok = got == 0 || engines[0]->renderSequence(si.data(), di.data(), got);
+                        { std::lock_guard<std::mutex> lk(mu); if (!ok) failed = true; sl.state = 2; frameIndex += got; }
+                        cv.notify_all();
+                        if (got) on_progress(1, 1, 0.0);
+                        if (!ok || got < CH) break;
                     }
-                    for (int k = 0; k < CH; ++k) { engines[0]->unpinHost(ins[k].data()); engines[0]->unpinHost(outs[k].data()); }
+                    reader.join(); writer.join();
+                    for (Slot& sl : slots) for (int k = 0; k < CH; ++k) { engines[0]->unpinHost(sl.in[k].data()); engines[0]->unpinHost(sl.out[k].data()); }
                     pclose(rd); pclose(wr);
+                    if (failed) return -1;
                     ++fileIndex;
                     continue;
                 }
