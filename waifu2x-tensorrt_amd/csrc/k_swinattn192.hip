@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (m == 0) { f[j] = (_Float16)fmaf(a[0][tt][j], qscale, b0[j]); f[4 + j] = (_Float16)fmaf(a[1][tt][j], qscale, b1[j]); }
-                    else { f[j] = (_Float16)(a[0][tt][j] + b0[j]); f[4 + j] = (_Float16)(a[1][tt][j] + b1[j]); }
+                    else { f[j] = (_Float16)a[0][tt][j]; f[4 + j] = (_Float16)a[1][tt][j]; }   // no k bias: q.bk is the same for every key of a query
                 }
                 if (m == 0) qf[tt] = f; else kf[tt] = f;
             }
@@ -280,11 +280,10 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
             }
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) {
-                const float bvv = p.bqkv[2 * C + h * HD + ft * 16 + fr];
                 half8 f0, f1 = zero8;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { f0[j] = (_Float16)(a[0][ft][j] + bvv); f0[4 + j] = (_Float16)(a[1][ft][j] + bvv); }
-                f1[0] = (_Float16)(a[2][ft][0] + bvv);                          // slab row 32 + 4g = token 32 + g
+                for (int j = 0; j < 4; ++j) { f0[j] = (_Float16)a[0][ft][j]; f0[4 + j] = (_Float16)a[1][ft][j]; }   // the v bias is added to the normalised output
+                f1[0] = (_Float16)a[2][ft][0];                          // slab row 32 + 4g = token 32 + g
                 vf0[ft] = f0; vf1[ft] = f1;
             }
         }
@@ -329,6 +328,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
         // ---- O^T = V^T P^T: rows = features, columns = queries; scaled by 1/l and parked in Os (token order).  The
         // denominators come off the matrix pipe (a ones matrix in place of V^T, see k_swinattn96.hip).
         float inv[3];
+        const float4v bv[2] = {*(const float4v*)(p.bqkv + 2 * C + h * HD + g * 4), *(const float4v*)(p.bqkv + 2 * C + h * HD + 16 + g * 4)};
         {
             const _Float16 one = (_Float16)1.f;
             const half8 ones = {one, one, one, one, one, one, one, one};
@@ -348,7 +348,8 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
                 const int query = qi < 2 ? qi * 16 + fr : 32 + (fr >> 2);
                 if (aok && (qi < 2 || (fr & 3) == 0)) {
                     const float2v i2 = {inv[qi], inv[qi]};
-                    const float2v o0 = (float2v){o[0], o[1]} * i2, o1 = (float2v){o[2], o[3]} * i2;
+                    const float2v o0 = __builtin_elementwise_fma((float2v){o[0], o[1]}, i2, (float2v){bv[ft][0], bv[ft][1]});
+                    const float2v o1 = __builtin_elementwise_fma((float2v){o[2], o[3]}, i2, (float2v){bv[ft][2], bv[ft][3]});
                     const half4 oh = {(_Float16)o0[0], (_Float16)o0[1], (_Float16)o1[0], (_Float16)o1[1]};
                     *(half4*)(Os + (tbase + query) * LDX + h * HD + ft * 16 + g * 4) = oh;
                 }

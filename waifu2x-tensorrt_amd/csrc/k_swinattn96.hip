@@ -218,14 +218,15 @@ __global__ __launch_bounds__(256, 3) void swin_attn96_kernel(const SwinAttnParam
             }
         }
         float4v bq = *(const float4v*)(p.bqkv + h * HD + g * 4);
-        const float4v bk = *(const float4v*)(p.bqkv + C + h * HD + g * 4);
-        const float bvv = p.bqkv[2 * C + h * HD + fr];
+        // The k bias adds the same q.bk to every key of a query and drops out of the softmax; the v bias commutes with the
+        // weighted mean (sum p (v + bv) / sum p = sum p v / sum p + bv) and is added to the normalised output instead.
+        const float4v bv = *(const float4v*)(p.bqkv + 2 * C + h * HD + g * 4);
         bq *= qscale;
         half4 qf[3], kf[3], vf[3];
 #pragma unroll
         for (int tt = 0; tt < 3; ++tt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { qf[tt][j] = (_Float16)fmaf(aq[tt][j], qscale, bq[j]); kf[tt][j] = (_Float16)(ak[tt][j] + bk[j]); vf[tt][j] = (_Float16)(av[tt][j] + bvv); }
+            for (int j = 0; j < 4; ++j) { qf[tt][j] = (_Float16)fmaf(aq[tt][j], qscale, bq[j]); kf[tt][j] = (_Float16)ak[tt][j]; vf[tt][j] = (_Float16)av[tt][j]; }
         // ---- S^T = K Q^T on top of the bias (k = the 16 features), softmax over the keys
 #pragma unroll
         for (int qi = 0; qi < 3; ++qi)
@@ -269,7 +270,8 @@ __global__ __launch_bounds__(256, 3) void swin_attn96_kernel(const SwinAttnParam
             const int query = qi < 2 ? qi * 16 + fr : 32 + (fr >> 2);
             if (aok && (qi < 2 || (fr & 3) == 0)) {
                 const float2v i2 = {inv, inv};
-                const float2v o0 = (float2v){o[0], o[1]} * i2, o1 = (float2v){o[2], o[3]} * i2;
+                const float2v o0 = __builtin_elementwise_fma((float2v){o[0], o[1]}, i2, (float2v){bv[0], bv[1]});
+                const float2v o1 = __builtin_elementwise_fma((float2v){o[2], o[3]}, i2, (float2v){bv[2], bv[3]});
                 const half4 oh = {(_Float16)o0[0], (_Float16)o0[1], (_Float16)o1[0], (_Float16)o1[1]};
                 *(half4*)(Os + (tbase + query) * LDX + h * HD + g * 4) = oh;
             }
