@@ -10,7 +10,8 @@
 //     S^T after the softmax      -> B operand of O^T                   (as in the other variants),
 // and q, k, v, S, P never touch LDS.  LDS only holds the normalised x slab (MFMA operand of the q/k/v products, read by
 // both waves of a window) and the head outputs (operand of proj).  Weights come from L2 as fragments, one 32x192 matrix
-// (12 fragments) ahead of its use.  Three workgroup barriers in the whole kernel.
+// (12 fragments) ahead of its use.  Four workgroup barriers in the whole kernel; the vector work around the products is
+// trimmed as in k_swinattn96.hip (ones-operand MFMA for the softmax denominators, folded k / v biases, packed fp32).
 //
 // Window slab: 48 rows; tokens 0..31 on rows 0..31, tokens 32..35 on rows 32, 36, 40, 44, zero rows between.  That puts
 // key 32+g on row 4g of the third key tile (one per lane group, register j = 0: the softmax touches 9 instead of 12

@@ -11,7 +11,11 @@
 // need no LDS round trip and no permutation.  The q/k/v products use v_mfma_f32_16x16x32_f16 over the 96 channels.
 // LDS holds the normalised x slabs (48 rows per window: tokens 0..31, then tokens 32..35 on rows 32, 36, 40, 44 so that
 // key 32+g sits on row 4g of the third key tile - see k_swinattn192.hip) and the head outputs for proj.
-// Three workgroup barriers in the whole kernel.
+// Four workgroup barriers in the whole kernel.
+// The kernel is VALU-issue bound (SQ counters: 11 VALU instructions per MFMA before, MFMA pipe < 25 % busy), so the vector
+// work around the products is kept minimal: softmax denominators from a ones-operand MFMA, k bias dropped / v bias after the
+// normalisation, packed fp32 (v_pk_*) where two values share an operation, interleaved permlane / DPP chains without wait
+// states, the row -> pixel map computed once per workgroup, all row loads unconditional from clamped addresses.
 #include "kernels.h"
 
 namespace w2x {
