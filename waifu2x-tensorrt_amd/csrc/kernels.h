@@ -112,6 +112,9 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 bool pixgemm_supported(const GemmParams& p);                    // k_pixgemm.hip: streaming kernel for pixel-shuffle projections
 hipError_t launch_pixgemm(const GemmParams& p, hipStream_t s);
 bool conv3_supported(const GemmParams& p);                      // k_conv3.hip: LDS-tiled direct 3x3 convolution
+// k_stem.hip: first 3x3 convolution on the 4-halves-per-pixel input tile (no LDS, weights in registers)
+bool stem_supported(const GemmParams& p);
+hipError_t launch_stem(const GemmParams& p, hipStream_t s);
 hipError_t launch_conv3(const GemmParams& p, hipStream_t s);
 int conv3_tiles(const GemmParams& p);                           // workgroups (= pooling partials) per image of launch_conv3
 hipError_t launch_attn(const AttnParams& p, hipStream_t s);
