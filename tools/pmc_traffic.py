@@ -17,7 +17,7 @@ def symbol(name):
     if m: return m.group(1)
     m = re.search(r"mlp2_kernel<(\d+), (\d+)[^>]*>", name)
     if m: return f"mlp2_kernel<{m.group(1)},{m.group(2)}>"
-    m = re.search(r"(pixgemm_kernel<[^>]*>|merge_kernel<[^>]*>|gemm_kernel<[^>]*>|mlp_kernel<[^>]*>|swin_attn_kernel<[^>]*>)", name)
+    m = re.search(r"(pixgemm_kernel<[^>]*>|merge_kernel<[^>]*>|stem_kernel<[^>]*>|conv3_kernel<[^>]*>|gemm_kernel<[^>]*>|mlp_kernel<[^>]*>|swin_attn_kernel<[^>]*>)", name)
     return m.group(1) if m else None
 
 root, out, tag = sys.argv[1], sys.argv[2], sys.argv[3]
