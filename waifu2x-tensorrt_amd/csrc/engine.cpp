@@ -179,23 +179,23 @@ struct Img2Img::Impl {
 
     void release() {
         // img2img_base.cpp:6-10 frees the IO buffers; here everything the engine owns
-        if (arena_base) { hipFree(arena_base); arena_base = nullptr; }
-        for (void* p : blobs) if (p) hipFree(p);
-        for (void* p : frag_blobs) if (p) hipFree(p);
+        if (arena_base) { (void)hipFree(arena_base); arena_base = nullptr; }
+        for (void* p : blobs) if (p) (void)hipFree(p);
+        for (void* p : frag_blobs) if (p) (void)hipFree(p);
         frag_blobs.clear();
         tensors.clear(); blobs.clear(); gemm.clear(); pool_tensors.clear();
         for (void* h : pinned) if (hipHostUnregister(h) != hipSuccess) (void)hipGetLastError();
         pinned.clear();
-        for (hipEvent_t* e : {&ev_up[0], &ev_up[1], &ev_comp[0], &ev_comp[1], &ev_dn[0], &ev_dn[1]}) if (*e) { hipEventDestroy(*e); *e = nullptr; }
-        if (s_up) { hipStreamDestroy(s_up); s_up = nullptr; }
-        if (s_dn) { hipStreamDestroy(s_dn); s_dn = nullptr; }
+        for (hipEvent_t* e : {&ev_up[0], &ev_up[1], &ev_comp[0], &ev_comp[1], &ev_dn[0], &ev_dn[1]}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+        if (s_up) { (void)hipStreamDestroy(s_up); s_up = nullptr; }
+        if (s_dn) { (void)hipStreamDestroy(s_dn); s_dn = nullptr; }
         frame2_cap = out2_cap = 0;
         for (void** p : {(void**)&d_frame, (void**)&d_out, (void**)&d_frame2, (void**)&d_out2, &d_slab, (void**)&d_slots, (void**)&d_rampx, (void**)&d_rampy, (void**)&d_blob_in, (void**)&d_blob_out})
-            if (*p) { hipFree(*p); *p = nullptr; }
+            if (*p) { (void)hipFree(*p); *p = nullptr; }
         frame_cap = out_cap = slab_cap = slots_cap = 0;
-        if (ev0) { hipEventDestroy(ev0); ev0 = nullptr; }
-        if (ev1) { hipEventDestroy(ev1); ev1 = nullptr; }
-        if (stream) { hipStreamDestroy(stream); stream = nullptr; }
+        if (ev0) { (void)hipEventDestroy(ev0); ev0 = nullptr; }
+        if (ev1) { (void)hipEventDestroy(ev1); ev1 = nullptr; }
+        if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
         loaded = false;
     }
 
@@ -848,7 +848,7 @@ bool Img2Img::profileFrame(double* out, int cap) try {
         out[5 * st.kind] += ms; out[5 * st.kind + 1] += 1; out[5 * st.kind + 2] += st.flops;
     }
     if (!impl->stamps.empty()) { float ms = 0.f; hipAssert(hipEventElapsedTime(&ms, impl->stamps.front().a, impl->stamps.back().b)); out[30] = ms; }
-    for (auto& st : impl->stamps) { hipEventDestroy(st.a); hipEventDestroy(st.b); }
+    for (auto& st : impl->stamps) { (void)hipEventDestroy(st.a); (void)hipEventDestroy(st.b); }
     impl->stamps.clear();
     return true;
 } catch (const std::exception& e) {
