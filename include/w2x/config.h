@@ -1,50 +1,40 @@
-// Configuration structs of the engine interface.
-// Mirrors /root/reference/src/tensorrt/config.h:7-43 (trt::Precision, trt::BuildConfig, trt::RenderConfig):
-// same fields, same defaults.  cv::Point2d overlap becomes two doubles (OpenCV is not a dependency here).
+// Configuration structs of the engine interface: the members, member order and defaults of trt::Precision,
+// trt::BuildConfig and trt::RenderConfig (/root/reference/src/tensorrt/config.h:7-43), so that code written against the
+// reference's structs compiles against these.  cv::Point2d overlap becomes two doubles (OpenCV is not a dependency here).
 #ifndef W2X_CONFIG_H
 #define W2X_CONFIG_H
 
 namespace w2x {
 
-enum class Precision {
-    TF32,   // config.h:8.  gfx950 has no TF32/xf32 MFMA: accepted by the parser, rejected by build()/load() with a message.
-    FP16    // config.h:9
-};
+// Arithmetic of the network.  gfx950 has no TF32 / xf32 matrix instructions: TF32 is accepted by the command line for
+// compatibility and refused by build() / load() with a message (the reference's own error convention).
+enum class Precision { TF32, FP16 };
 
-struct BuildConfig {      // config.h:12-31
-    int deviceId = 0;
+// What build() specialises a plan for.  The reference hands TensorRT a min / opt / max optimisation profile per
+// dimension (img2img_build.cpp:102-116) and its command line always sets the three equal (main.cpp:276-291); this engine
+// requires them equal (static shapes) and keys the plan cache on all of them, like the reference's JSON side file.
+struct BuildConfig {
+    int deviceId = 0;                                             // HIP device ordinal
     Precision precision = Precision::FP16;
-
-    int minBatchSize = 1;
-    int optBatchSize = 1;
-    int maxBatchSize = 4;
-
-    int minChannels = 3;
-    int optChannels = 3;
-    int maxChannels = 3;
-
-    int minWidth = 64;
-    int optWidth = 256;
-    int maxWidth = 640;
-
-    int minHeight = 64;
-    int optHeight = 256;
-    int maxHeight = 640;
+    int minBatchSize = 1, optBatchSize = 1, maxBatchSize = 4;     // tiles per network call
+    int minChannels = 3, optChannels = 3, maxChannels = 3;        // always RGB
+    int minWidth = 64, optWidth = 256, maxWidth = 640;            // tile width in pixels
+    int minHeight = 64, optHeight = 256, maxHeight = 640;         // tile height in pixels
 };
 
-struct RenderConfig {     // config.h:33-43
+// What load() prepares render() for: one plan (batch, tile size), the scale the caller expects, the blend overlap as a
+// fraction of the tile, and test-time augmentation.
+struct RenderConfig {
     int deviceId = 0;
     Precision precision = Precision::FP16;
     int batchSize = 1;
     int channels = 3;
-    int height = 256;
-    int width = 256;
-    int scaling = 4;
-    double overlapX = 0.0625;   // cv::Point2d overlap = (0.0625, 0.0625)
-    double overlapY = 0.0625;
+    int height = 256, width = 256;                                // tile size
+    int scaling = 4;                                              // comes from the caller, not from the graph
+    double overlapX = 0.0625, overlapY = 0.0625;                  // the reference's cv::Point2d overlap
     bool tta = false;
-    // extension (not in the reference): reproduce quirk Q1 (img2img_render.cpp:313-316, the TTA mean is computed and
-    // then the last de-augmented output is blended instead).  Default false = the intended mean.
+    // Not in the reference: reproduce its quirk Q1 (img2img_render.cpp:313-316 computes the TTA mean and then blends the
+    // last de-augmented output instead).  false = the intended mean.
     bool ttaBugCompat = false;
 };
 
