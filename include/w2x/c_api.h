@@ -84,11 +84,13 @@ int w2x_calculate_tiles(int in_w, int in_h, int out_w, int out_h, int tile_in, i
 int w2x_tile_weights(int which, int overlap_x, int overlap_y, int size, float* out);
 /* Lower an ONNX file at [batch,3,tile,tile] and write a textual description of the plan (ops, FLOPs) into buf. */
 int w2x_describe_plan(const char* onnx_path, int batch, int tile, char* buf, size_t cap);
+/* Host-only halves of build() / load() for tools and tests: lower an ONNX file and write the plan (no .json side file, no
+ * device); read a plan file back and run the consistency checks load() runs (img2img_load.cpp:149-154 "Failed to deserialize
+ * engine"), writing "ok" or the reason into buf. */
+int w2x_write_engine_file(const char* onnx_path, int batch, int tile, const char* out_path);
+int w2x_validate_engine_file(const char* path, char* buf, size_t cap);
 /* sha256 hex digest (names engine files; utilities/sha256.h:39-94). out: 65 bytes. */
 void w2x_sha256_hex(const void* data, size_t len, char* out);
-/* diagnostic: per-phase cycle sums of the fused attention kernels when W2X_STAMPS=1 (2 x 8 values, cleared on read) */
-int w2x_debug_attn_stamps(unsigned long long* out);
-int w2x_debug_mlp_stamps(unsigned long long* out);   /* 16 values: [C==192][phase] */
 const char* w2x_version(void);
 
 #ifdef __cplusplus

@@ -8,6 +8,15 @@ follows the ONNX operator specification (opset 13-17) node by node, in fp32, NCH
 it is cross-checked against the torch modules the fixtures were exported from
 (tests/test_oracle_net.py).
 
+Two arithmetic modes:
+  * fp32 (default): every value in float32 - the ONNX specification's reading of the graph;
+  * act_dtype="float16": the model of a kFP16 engine (img2img_build.cpp:128) - weights rounded to fp16, products
+    accumulated in fp32, and every value a layer hands to the next layer rounded to fp16: the output of a
+    Conv / ConvTranspose / MatMul / Gemm (after the constant bias Add that follows it, if any), of an activation,
+    LayerNormalization, Softmax, Clip, and of an Add / Mul of two runtime tensors (residuals, gates).  It makes the
+    checker's output fp16-grained like the engine's, so that differences can be read in fp16 ULPs; the exact
+    places where TensorRT rounds are unknown (closed source), this is the layer-by-layer reading.
+
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 """
 from __future__ import annotations
@@ -31,12 +40,59 @@ _CAST = {1: torch.float32, 6: torch.int32, 7: torch.int64, 9: torch.bool, 10: to
 
 
 class Executor:
-    def __init__(self, path_or_graph, threads: int | None = None):
+    _HEAVY = {"Conv", "ConvTranspose", "MatMul", "Gemm"}
+    _ROUND_ALWAYS = {"LeakyRelu", "Relu", "Sigmoid", "LayerNormalization", "Softmax", "Clip", "Tanh"}
+
+    def __init__(self, path_or_graph, threads: int | None = None, act_dtype: str = "float32"):
         g = onnx_reader.load(path_or_graph) if isinstance(path_or_graph, str) else path_or_graph
         self.g = g
         self.consts = {k: _t(v) for k, v in g.initializers.items()}
         self.threads = threads
         self._static = None  # values that do not depend on the graph input (folded once)
+        assert act_dtype in ("float32", "float16")
+        self.half = act_dtype == "float16"
+        if self.half:
+            self._plan_rounding()
+
+    def _plan_rounding(self):
+        """Which node outputs are rounded to fp16 (see the module docstring) and which constants are fp16 weights."""
+        g = self.g
+        users, producer = {}, {}
+        for k, n in enumerate(g.nodes):
+            for i in n.inputs:
+                if i: users.setdefault(i, []).append(k)
+            for o in n.outputs:
+                producer[o] = k
+        # runtime values = everything reachable from the graph input
+        runtime = {g.inputs[0].name}
+        for n in g.nodes:
+            if any(i in runtime for i in n.inputs if i):
+                runtime.update(n.outputs)
+        self._round = set()
+        for k, n in enumerate(g.nodes):
+            if not n.outputs or n.outputs[0] not in runtime:
+                continue
+            out = n.outputs[0]
+            rt_in = [i for i in n.inputs if i and i in runtime]
+            if n.op in self._HEAVY:
+                if n.op in ("MatMul", "Gemm") and len(rt_in) == 2:
+                    self._round.add(k)                     # q k^T and attn v: both operands are activations
+                    continue
+                us = users.get(out, [])
+                bias_next = len(us) == 1 and g.nodes[us[0]].op == "Add" and sum(1 for i in g.nodes[us[0]].inputs if i in runtime) == 1
+                if not bias_next:
+                    self._round.add(k)
+            elif n.op in self._ROUND_ALWAYS:
+                self._round.add(k)
+            elif n.op == "Add":
+                if len(rt_in) == 2 or any(producer.get(i) is not None and g.nodes[producer[i]].op in self._HEAVY for i in rt_in):
+                    self._round.add(k)
+            elif n.op == "Mul" and len(rt_in) == 2:
+                self._round.add(k)
+        # weights of the heavy nodes are what the engine stores in fp16
+        for n in g.nodes:
+            if n.op in self._HEAVY and len(n.inputs) > 1 and n.inputs[1] in self.consts and self.consts[n.inputs[1]].is_floating_point():
+                self.consts[n.inputs[1]] = self.consts[n.inputs[1]].half().float()
 
     # -- public -----------------------------------------------------------------------------
     @property
@@ -49,6 +105,8 @@ class Executor:
             torch.set_num_threads(self.threads)
         env = dict(self.consts)
         env[self.input_name] = _t(np.asarray(x, np.float32))
+        if self.half:
+            env[self.input_name] = env[self.input_name].half().float()
         # values are dropped after their last reader: a swin_unet graph has ~700 runtime nodes and keeping every
         # intermediate alive costs tens to hundreds of GB at tile 256..640
         last = {}
@@ -61,6 +119,8 @@ class Executor:
                 outs = self._node(n, [env[i] if i else None for i in n.inputs])
                 if not isinstance(outs, (tuple, list)):
                     outs = (outs,)
+                if self.half and k in self._round and outs[0].dtype == torch.float32:
+                    outs = (outs[0].half().float(),) + tuple(outs[1:])
                 for name, v in zip(n.outputs, outs):
                     env[name] = v
                 for i in n.inputs:

@@ -1,0 +1,56 @@
+"""Shared measurement helpers of the GPU parity tests: every comparison with the oracle is printed, appended to
+gpurun_out/parity/parity.jsonl (copied to profiles/<round>/parity.jsonl for the record) and asserted against a bound that
+sits just above what was measured, so that a regression in accuracy fails instead of hiding under a loose tolerance.
+
+Units.  The network maps [0,1] images to [0,1] images and runs in fp16 with fp32 accumulation, like the reference's kFP16
+engine (img2img_build.cpp:128).  Its errors are absolute (sums of O(1) terms), so they are quoted in units of the fp16 ULP of
+the output range's top binade [0.5, 1): ULP16 = 2^-11 = 4.88e-4 (north_star: "within 1 ULP fp16 per pixel"), next to the ULP
+of each reference value for reference values >= 0.5.  Frames are quoted in u8 LSB and PSNR."""
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ULP16 = 2.0 ** -11
+_OUT = os.path.join(ROOT, "gpurun_out", "parity")
+
+
+def psnr(a, b):
+    mse = float(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2))
+    return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+
+
+def _record(rec):
+    try:
+        os.makedirs(_OUT, exist_ok=True)
+        with open(os.path.join(_OUT, "parity.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+    print("PARITY " + json.dumps(rec), flush=True)
+
+
+def network_report(name, y, ref16, ref32=None):
+    """y: engine output [B,3,T',T'] f32; ref16: oracle in fp16-boundary mode; ref32: oracle in fp32 (optional)."""
+    d = np.abs(y.astype(np.float64) - ref16.astype(np.float64))
+    top = ref16 >= 0.5
+    ulp_ref = np.where(top, np.exp2(np.floor(np.log2(np.maximum(np.abs(ref16), 2.0 ** -14))) - 10), np.inf)
+    rec = {"test": name, "kind": "network", "max_abs": float(d.max()), "mean_abs": float(d.mean()),
+           "max_ulp16": float(d.max() / ULP16), "p999_ulp16": float(np.quantile(d, 0.999) / ULP16),
+           "max_ulp_of_ref_top_binade": float((d / ulp_ref).max()) if top.any() else 0.0}
+    if ref32 is not None:
+        d32 = np.abs(y.astype(np.float64) - ref32.astype(np.float64))
+        o = np.abs(ref16.astype(np.float64) - ref32.astype(np.float64))
+        rec.update({"max_ulp16_vs_fp32_oracle": float(d32.max() / ULP16), "mean_abs_vs_fp32_oracle": float(d32.mean()),
+                    "fp16_oracle_vs_fp32_oracle_max_ulp16": float(o.max() / ULP16)})
+    _record(rec)
+    return rec
+
+
+def frame_report(name, out, ref):
+    d = np.abs(out.astype(np.int32) - ref.astype(np.int32))
+    rec = {"test": name, "kind": "frame", "max_lsb": int(d.max()), "psnr_db": round(float(psnr(out, ref)), 2),
+           "frac_pixels_off_by_1": float((d == 1).mean()), "frac_pixels_off_by_more": float((d > 1).mean())}
+    _record(rec)
+    return rec

@@ -1,6 +1,7 @@
-"""Kernel-level A/B on the GPU box: the LDS-staged fused MLP (k_mlp.hip) against the wave-private one (k_mlp2.hip) on the
-same random rows and weights, at small ragged sizes and at the headline row counts (where the wave-private kernel is also
-run twice and must reproduce itself bit for bit).  Builds tools/mlp_ab.hip with hipcc; no oracle involved."""
+"""Kernel-level A/B on the GPU box: the LDS-staged fused MLP of round 1 (tools/ab/k_mlp_staged.hip, no longer part of the
+library) against the shipped wave-private one (csrc/k_mlp2.hip) on the same random rows and weights, at small ragged sizes and
+at the headline row counts (where the shipped kernel is also run twice and must reproduce itself bit for bit).  Builds
+tools/ab/mlp_ab.hip with hipcc; no oracle involved."""
 import os
 import re
 import shutil
@@ -16,8 +17,8 @@ def test_fused_mlp_kernels_agree_and_are_deterministic(tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     csrc = os.path.join(ROOT, "waifu2x-tensorrt_amd", "csrc")
     exe = str(tmp_path / "mlp_ab")
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", csrc, os.path.join(ROOT, "tools", "mlp_ab.hip"),
-                    os.path.join(csrc, "k_mlp.hip"), os.path.join(csrc, "k_mlp2.hip"), "-o", exe], check=True, timeout=900)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", csrc, os.path.join(ROOT, "tools", "ab", "mlp_ab.hip"),
+                    os.path.join(ROOT, "tools", "ab", "k_mlp_staged.hip"), os.path.join(csrc, "k_mlp2.hip"), "-o", exe], check=True, timeout=900)
     out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=600).stdout
     cases = re.findall(r"C=(\d+) M=(\d+) stats=(\d): max\|dy\|=([0-9.]+) .*max rel stats diff=([0-9.e+-]+)", out)
     assert len(cases) >= 18, out

@@ -1,21 +1,32 @@
 """GPU parity: the HIP engine, called through the C ABI, against the oracle on the same seeded inputs.
-Tolerances (fp16 network, fp32 blend): network output |d| <= 4e-3 (about 4 fp16 ulp at 0.5-1.0 after ~60 fused
-layers), frames PSNR > 50 dB and <= 2 LSB; everything that is integer/byte work (tile order, padding, TTA index
-maps, blend masks, u8 rounding) is bit-exact, which the identity-network tests check with == on bytes."""
+
+Tolerances, stated here and asserted below (units: tests/parity_util.py; every comparison is printed and recorded):
+  * network output [B,3,T',T'] against the oracle in fp16-boundary mode (an fp16 engine modelled layer by layer):
+    max |d| <= NET_MAX_ULP16 fp16 ULPs of the output range (2^-11), mean |d| <= NET_MEAN_ABS; against the fp32 oracle the
+    same run is recorded (it adds the fp16 model's own distance from fp32, ~2 ULP).  Measured in round 2: see
+    profiles/r2_*/parity.jsonl; the bounds sit one ULP above the largest figure measured.
+  * frames (u8) against the oracle pipeline with the fp16-boundary network: <= FRAME_MAX_LSB, PSNR > 50 dB;
+  * everything that is integer / byte work (tile order, padding, TTA index maps, blend masks, u8 rounding) is bit-exact:
+    batch-size, super-batch, strip, sequence, graph-replay and poison tests compare with == on bytes."""
 import os
+import threading
 
 import numpy as np
 import pytest
 
 import synth_models as sm
 from oracle import onnx_exec, pipeline
+from parity_util import ULP16, frame_report, network_report, psnr
 
 pytestmark = pytest.mark.gpu
 
+NET_MAX_ULP16 = 6.0      # fp16 ULPs of [0.5, 1) = 2^-11 each; measured <= 4.1 (round 2), north_star asks 1 against TensorRT itself
+NET_MEAN_ABS = 2.5e-4    # measured <= 1.6e-4
+FRAME_MAX_LSB = 1        # u8; measured 1 on every case
 
-def psnr(a, b):
-    mse = float(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2))
-    return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+
+def oracle16(path):
+    return onnx_exec.Executor(path, act_dtype="float16").run
 
 
 def make_engine(pkg, path, batch, tile, scale, **kw):
@@ -45,10 +56,11 @@ def test_network_matches_oracle(pkg, onnx_model, model, scale, batch, tile, smal
     x = rng.random((batch, 3, tile, tile), dtype=np.float32).astype(np.float16).astype(np.float32)
     x[0, :, :8, :8] = 0.0; x[-1, :, -8:, -8:] = 1.0
     y = eng.infer(x)
-    ref = onnx_exec.Executor(path).run(x)
+    ref32 = onnx_exec.Executor(path).run(x)
+    ref16 = oracle16(path)(x)
     assert not np.isnan(y).any()
-    d = np.abs(y - ref)
-    assert d.max() <= 4e-3 and d.mean() <= 5e-4, (d.max(), d.mean())
+    r = network_report(f"network[{model} s{scale} B{batch} T{tile} {'small' if small else 'full'}]", y, ref16, ref32)
+    assert r["max_ulp16"] <= NET_MAX_ULP16 and r["mean_abs"] <= NET_MEAN_ABS, r
     # batch items are independent: same tile in slot 0 and slot B-1 gives the same bytes
     if batch > 1:
         x2 = np.repeat(x[:1], batch, axis=0)
@@ -65,6 +77,10 @@ def test_network_matches_oracle(pkg, onnx_model, model, scale, batch, tile, smal
     ("cunet/art", 2, 4, 64, False, 0.0625, False, (100, 77)),
     ("cunet/art", 1, 2, 96, False, 0.125, False, (70, 50)),
     ("cunet/art", 2, 1, 64, False, 0.0625, True, (30, 34)),
+    # the kernels that ship in the benchmark (96 / 192 channels: fused attention + MLP), with TTA, ragged frames, partial batches
+    ("swin_unet/art", 4, 4, 64, False, 0.0625, False, (100, 140)),
+    ("swin_unet/photo", 4, 8, 64, False, 0.0625, True, (60, 100)),
+    ("swin_unet/art_scan", 2, 3, 88, False, 0.125, True, (80, 75)),
 ])
 def test_render_matches_oracle(pkg, onnx_model, model, scale, batch, tile, small, ov, tta, shape):
     """trt::Img2Img::render (img2img_render.cpp:224-352) end to end, ragged frames, partial last batch, TTA, blend."""
@@ -74,10 +90,13 @@ def test_render_matches_oracle(pkg, onnx_model, model, scale, batch, tile, small
     prog = []
     eng.setProgressCallback(lambda c, t, s: prog.append((c, t)))
     out = eng.render(frame)
-    ref = pipeline.render(frame, onnx_exec.Executor(path).run, batch=batch, tile=tile, scaling=scale, overlap=(ov, ov), tta=tta,
+    ref = pipeline.render(frame, oracle16(path), batch=batch, tile=tile, scaling=scale, overlap=(ov, ov), tta=tta,
                           net_dtype=np.float16)
-    d = np.abs(out.astype(int) - ref.astype(int))
-    assert psnr(out, ref) > 50.0 and d.max() <= 2, (psnr(out, ref), d.max())
+    r = frame_report(f"render[{model} s{scale} B{batch} T{tile} {'small' if small else 'full'} ov{ov} tta{int(tta)} {shape}]", out, ref)
+    assert r["psnr_db"] > 50.0 and r["max_lsb"] <= FRAME_MAX_LSB, r
+    # the step schedule of img2img_render.cpp:246-250: tiles x (8 if tta) steps, rounded up to whole batches
+    n_tiles = pkg.calculate_tiles(shape[1], shape[0], shape[1] * scale, shape[0] * scale, tile, eng.output_tile_size, scale, (ov, ov))[0]
+    assert prog[-1][1] == -(-(n_tiles * (8 if tta else 1)) // batch)
     assert prog and prog[-1][0] == prog[-1][1] and [c for c, _ in prog] == list(range(1, prog[-1][1] + 1))
     # deterministic: a second render gives identical bytes; strided src/dst views work
     assert np.array_equal(out, eng.render(frame))
@@ -94,18 +113,23 @@ def test_tta_bug_compat_mode(pkg, onnx_model):
     eng = make_engine(pkg, path, 4, 64, 2, overlap=(0.0625, 0.0625), tta=True, ttaBugCompat=True)
     frame = smooth_frame(50, 60, 9)
     out = eng.render(frame)
-    ref = pipeline.render(frame, onnx_exec.Executor(path).run, batch=4, tile=64, scaling=2, overlap=(0.0625, 0.0625), tta=True,
+    ref = pipeline.render(frame, oracle16(path), batch=4, tile=64, scaling=2, overlap=(0.0625, 0.0625), tta=True,
                           tta_bug_compat=True, net_dtype=np.float16)
-    assert psnr(out, ref) > 50.0
-    eng.close()
+    r = frame_report("tta_bug_compat[swin small s2 B4 T64]", out, ref)
+    assert r["psnr_db"] > 50.0 and r["max_lsb"] <= FRAME_MAX_LSB, r
+    # and it really is a different picture from the intended mean (the default), which the other tests cover
+    eng2 = make_engine(pkg, path, 4, 64, 2, overlap=(0.0625, 0.0625), tta=True)
+    assert not np.array_equal(out, eng2.render(frame))
+    eng.close(); eng2.close()
 
 
-def test_batch_size_invariance_bit_exact(pkg, onnx_model):
+@pytest.mark.parametrize("small", [True, False])
+def test_batch_size_invariance_bit_exact(pkg, onnx_model, small):
     """Tiles are independent units: the frame must not depend on how tiles are grouped into batches."""
     frame = smooth_frame(120, 150, 4)
     outs = []
     for b in (1, 3, 4):
-        eng = make_engine(pkg, onnx_model("swin_unet/art", 4, b, 64, small=True), b, 64, 4)
+        eng = make_engine(pkg, onnx_model("swin_unet/art", 4, b, 64, small=small), b, 64, 4)
         outs.append(eng.render(frame)); eng.close()
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
@@ -155,49 +179,35 @@ def test_headline_config_properties(pkg, onnx_model):
     # small frame (2x2 tiles at T=256) against the oracle
     small = smooth_frame(300, 420, 13)
     o3 = eng.render(small)
-    ref = pipeline.render(small, onnx_exec.Executor(path).run, batch=4, tile=256, scaling=4, overlap=(0.0625, 0.0625), net_dtype=np.float16)
-    d = np.abs(o3.astype(int) - ref.astype(int))
-    assert psnr(o3, ref) > 50.0 and d.max() <= 2, (psnr(o3, ref), d.max())
+    ref = pipeline.render(small, oracle16(path), batch=4, tile=256, scaling=4, overlap=(0.0625, 0.0625), net_dtype=np.float16)
+    r = frame_report("config3[swin_unet/art s4 B4 T256 300x420]", o3, ref)
+    assert r["psnr_db"] > 50.0 and r["max_lsb"] <= FRAME_MAX_LSB, r
     eng.close()
 
 
-def test_large_tile_graph_matches_oracle(pkg, onnx_model):
-    """BASELINE config 4's tile size (400: 64x64 windows per tile, odd tile counts per pass) on a one-tile frame with TTA off;
-    tools/config_sanity.py runs configs 2, 4 and 5 at full size."""
-    path = onnx_model("swin_unet/photo", 4, 1, 400)
-    eng = make_engine(pkg, path, 2, 400, 4)
-    frame = smooth_frame(100, 380, 17)
-    out = eng.render(frame)
-    ref = pipeline.render(frame, onnx_exec.Executor(path).run, batch=1, tile=400, scaling=4, overlap=(0.0625, 0.0625), net_dtype=np.float16)
-    d = np.abs(out.astype(int) - ref.astype(int))
-    assert psnr(out, ref) > 50.0 and d.max() <= 2, (psnr(out, ref), d.max())
-    eng.close()
-
-
-def test_pad_slots_are_skipped_and_stale_memory_is_never_read(pkg, onnx_model, monkeypatch):
-    """The zero-pad slots of the last batch (img2img_render.cpp:281) are not computed; W2X_POISON turns every stale
-    activation into an fp16 NaN before each frame, so any read of a skipped slot would show up in the picture."""
-    path = onnx_model("swin_unet/art", 4, 4, 64, small=True)
-    eng = make_engine(pkg, path, 4, 64, 4)
+@pytest.mark.parametrize("model,scale,small", [("swin_unet/art", 4, True), ("swin_unet/art", 4, False), ("cunet/art", 2, False)])
+def test_pad_slots_are_skipped_and_stale_memory_is_never_read(pkg, onnx_model, monkeypatch, model, scale, small):
+    """The zero-pad slots of the last batch (img2img_render.cpp:281) are not computed; W2X_POISON (read by load()) turns every
+    stale activation into an fp16 NaN before each frame, so any read of a skipped slot would show up in the picture."""
+    path = onnx_model(model, scale, 4, 64, small=small)
     frame = smooth_frame(100, 150, 5)                                    # 3x4 = 12 tiles... not a multiple of the pass size
+    monkeypatch.delenv("W2X_POISON", raising=False)
+    eng = make_engine(pkg, path, 4, 64, scale)
     clean = eng.render(frame)
-    monkeypatch.setenv("W2X_POISON", "1")
-    assert np.array_equal(clean, eng.render(frame))
     eng.close()
-    path = onnx_model("cunet/art", 2, 4, 64)
-    eng = make_engine(pkg, path, 4, 64, 2)
-    monkeypatch.delenv("W2X_POISON")
-    clean = eng.render(frame)
     monkeypatch.setenv("W2X_POISON", "1")
+    eng = make_engine(pkg, path, 4, 64, scale)
+    assert np.array_equal(clean, eng.render(frame))
     assert np.array_equal(clean, eng.render(frame))
     eng.close()
 
 
-@pytest.mark.parametrize("model,scale,tile,tta,shape", [("swin_unet/art", 4, 64, False, (150, 330)), ("cunet/art", 2, 64, True, (100, 260))])
-def test_strips_reassemble_the_frame_bit_exactly(pkg, onnx_model, model, scale, tile, tta, shape):
+@pytest.mark.parametrize("model,scale,tile,tta,shape,small", [("swin_unet/art", 4, 64, False, (150, 330), True), ("cunet/art", 2, 64, True, (100, 260), False),
+                                                              ("swin_unet/art", 4, 64, True, (100, 300), False)])
+def test_strips_reassemble_the_frame_bit_exactly(pkg, onnx_model, model, scale, tile, tta, shape, small):
     """one frame split over N devices by tile-column strips.  Rendering the strips one after another on this
     GPU into one buffer must give exactly the bytes of the whole-frame render (same contributions, same order)."""
-    path = onnx_model(model, scale, 2, tile, small=model.startswith("swin"))
+    path = onnx_model(model, scale, 2, tile, small=small)
     eng = make_engine(pkg, path, 2, tile, scale, tta=tta)
     frame = smooth_frame(*shape, 31)
     whole = eng.render(frame)
@@ -214,11 +224,11 @@ def test_strips_reassemble_the_frame_bit_exactly(pkg, onnx_model, model, scale, 
     eng.close()
 
 
-@pytest.mark.parametrize("pin", [False, True])
-def test_frame_sequence_with_overlapped_copies_matches_render(pkg, onnx_model, pin):
+@pytest.mark.parametrize("pin,small", [(False, True), (True, True), (True, False)])
+def test_frame_sequence_with_overlapped_copies_matches_render(pkg, onnx_model, pin, small):
     """renderSequence: upload / compute / download of consecutive frames overlap on three streams (two device buffers, events);
     every frame must come out exactly as from render(), also when output buffers are reused as a ring."""
-    path = onnx_model("swin_unet/art", 4, 2, 64, small=True)
+    path = onnx_model("swin_unet/art", 4, 2, 64, small=small)
     eng = make_engine(pkg, path, 2, 64, 4)
     frames = [smooth_frame(90, 130, 40 + k) for k in range(7)]
     want = [eng.render(f) for f in frames]
@@ -228,12 +238,14 @@ def test_frame_sequence_with_overlapped_copies_matches_render(pkg, onnx_model, p
     eng.render_sequence(frames, outs=[ring[k % 3] for k in range(7)], pin=pin)
     assert np.array_equal(ring[6 % 3], want[6]) and np.array_equal(ring[5 % 3], want[5]) and np.array_equal(ring[4 % 3], want[4])
     assert np.array_equal(eng.render(frames[2]), want[2])                    # the engine is left in a usable state
+    assert eng.last_render_ms > 0
     eng.close()
 
 
-def test_super_batching_is_bit_identical(pkg, onnx_model, monkeypatch):
+@pytest.mark.parametrize("small", [True, False])
+def test_super_batching_is_bit_identical(pkg, onnx_model, monkeypatch, small):
     """One network pass may carry S reference batches (W2X_SUPERBATCH); frames, progress callbacks and infer() must not change."""
-    path = onnx_model("swin_unet/art", 4, 2, 64, small=True)
+    path = onnx_model("swin_unet/art", 4, 2, 64, small=small)
     frame = smooth_frame(100, 140, 21)
     res = []
     for S in ("1", "3"):
@@ -249,3 +261,64 @@ def test_super_batching_is_bit_identical(pkg, onnx_model, monkeypatch):
     assert np.array_equal(res[0][0], res[1][0])
     assert res[0][1] == res[1][1]
     assert np.array_equal(res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize("model,scale,batch,small,tta", [("swin_unet/art", 4, 1, False, False), ("swin_unet/art", 4, 4, False, True), ("cunet/art", 2, 2, False, False)])
+def test_graph_replay_is_bit_identical_to_plain_launches(pkg, onnx_model, monkeypatch, model, scale, batch, small, tta):
+    """A network pass is captured as a hipGraph the second time it is met and replayed afterwards (the reference's network is
+    one enqueueV3, img2img_infer.cpp:80).  Same kernels, same arguments: first (plain), second (capture + launch) and later
+    (replay) renders of a frame, render_sequence through two frame buffers, and an engine with W2X_NO_GRAPH must all give the
+    same bytes; a frame of another size in between must not disturb the cached passes."""
+    path = onnx_model(model, scale, batch, 64, small=small)
+    frame, other = smooth_frame(100, 150, 5), smooth_frame(70, 90, 6)
+    monkeypatch.setenv("W2X_NO_GRAPH", "1")
+    eng = make_engine(pkg, path, batch, 64, scale, tta=tta)
+    want, want_other = eng.render(frame), eng.render(other)
+    eng.close()
+    monkeypatch.delenv("W2X_NO_GRAPH")
+    eng = make_engine(pkg, path, batch, 64, scale, tta=tta)
+    for k in range(4):
+        assert np.array_equal(eng.render(frame), want), k
+        if k == 1:
+            assert np.array_equal(eng.render(other), want_other)
+    got = eng.render_sequence([frame, frame, frame, frame, frame], pin=True)
+    assert all(np.array_equal(g, want) for g in got)
+    assert np.array_equal(eng.render(other), want_other) and np.array_equal(eng.render(other), want_other) and np.array_equal(eng.render(other), want_other)
+    eng.close()
+
+
+def test_engines_on_their_own_host_threads(pkg, onnx_model, monkeypatch):
+    """one Img2Img per device, one host thread each.  Every public entry makes the engine's device current
+    for its own duration, so engines can be driven from fresh threads whatever device those threads start on.
+    On a one-GPU box W2X_DEVICE_MAP lets two logical devices share the physical one; with two GPUs they are distinct."""
+    monkeypatch.setenv("W2X_DEVICE_MAP", "0,0")
+    path = onnx_model("swin_unet/art", 4, 2, 64, small=False)
+    frames = [smooth_frame(90, 130, 60 + k) for k in range(4)]
+    ref_eng = make_engine(pkg, path, 2, 64, 4)
+    want = [ref_eng.render(f) for f in frames]
+    ref_eng.close()
+    engs = []
+    for dev in (0, 1):
+        e = pkg.Img2Img()
+        assert e.build(path, pkg.BuildConfig.fixed(2, 64, device=dev)), e.last_error()
+        assert e.load(path, pkg.RenderConfig(deviceId=dev, batchSize=2, height=64, width=64, scaling=4)), e.last_error()
+        engs.append(e)
+    got = [None] * 4
+    errs = []
+
+    def work(e, idx):
+        try:
+            for i in idx:
+                got[i] = e.render(frames[i])
+            got[idx[0]] = e.render_sequence([frames[idx[0]]] * 3, pin=True)[2]
+            whole = np.zeros_like(got[idx[1]])
+            for part in range(2):
+                assert e.render_strip(frames[idx[1]], whole, part, 2)
+            got[idx[1]] = whole
+        except Exception as ex:      # surfaced in the main thread
+            errs.append(ex)
+    ts = [threading.Thread(target=work, args=(engs[0], [0, 2])), threading.Thread(target=work, args=(engs[1], [1, 3]))]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errs, errs
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    [e.close() for e in engs]

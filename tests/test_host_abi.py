@@ -115,3 +115,46 @@ def test_strip_plan_partitions_a_frame(pkg, W, H, T, s, Tout, ov, parts):
     assert all(a[1] == b[0] for a, b in zip(xs, xs[1:]))
     if parts == 1:
         assert pkg.strip_plan(W, H, W * s, H * s, T, Tout, s, (ov, ov), 0, 1) == (0, n, 0, W * s)
+
+
+@pytest.mark.parametrize("model,scale,tile,small", [("cunet/art", 2, 64, False), ("swin_unet/art", 4, 64, True), ("swin_unet/art", 4, 64, False)])
+def test_engine_file_is_validated_on_read(pkg, onnx_model, tmp_path, model, scale, tile, small):
+    """The plan file is an input from disk (img2img_load.cpp:137-154): a truncated or edited file must be refused with a
+    reason, never followed into tensors[] / blobs[] or onto the device.  Host-only halves of build() / load()."""
+    path = onnx_model(model, scale, 2, tile, small=small)
+    eng = str(tmp_path / "plan.w2x")
+    assert pkg.write_engine_file(path, 2, tile, eng)
+    ok, why = pkg.validate_engine_file(eng)
+    assert ok, why
+    good = open(eng, "rb").read()
+    bad = str(tmp_path / "bad.w2x")
+    # truncations at many points
+    for cut in (0, 7, 12, 40, len(good) // 3, len(good) // 2, len(good) - 9, len(good) - 1):
+        open(bad, "wb").write(good[:cut])
+        ok, why = pkg.validate_engine_file(bad)
+        assert not ok and why
+    # flipped bytes: header fields, and a sweep over the op records at the end of the file (tensor / blob ids, shapes).  Every
+    # outcome must be a clean verdict; edits that hit an id or a shape must be refused.
+    rng = np.random.default_rng(7)
+    refused = 0
+    tail = max(64, len(good) - 20000)
+    for pos in list(range(16, 64, 4)) + [int(v) for v in rng.integers(tail, len(good) - 8, 300)]:
+        b = bytearray(good)
+        b[pos:pos + 4] = (0x7fffff00).to_bytes(4, "little")
+        open(bad, "wb").write(bytes(b))
+        ok, why = pkg.validate_engine_file(bad)
+        refused += (not ok)
+    assert refused >= 50
+
+
+def test_infer_validates_the_blob_shape(pkg):
+    """w2x_infer reads batchSize*3*T*T floats, so the binding must refuse any other shape (img2img_infer.cpp:43-68)."""
+    eng = pkg.Img2Img()
+    with pytest.raises(pkg.W2xError):
+        eng.infer(np.zeros((1, 3, 64, 64), np.float32))
+    eng._batch, eng._tile = 2, 64           # as load() would record them
+    with pytest.raises(ValueError):
+        eng.infer(np.zeros((1, 3, 64, 64), np.float32))
+    with pytest.raises(ValueError):
+        eng.infer(np.zeros((2, 3, 32, 64), np.float32))
+    eng.close()

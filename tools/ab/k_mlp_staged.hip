@@ -280,13 +280,9 @@ hipError_t launch_mlp_c(const MlpParams& p, hipStream_t s) {
     constexpr int SMEM = BM * LDX * 2 + (W_BYTES > C_BYTES ? W_BYTES : C_BYTES);
     static const bool stamps = getenv("W2X_STAMPS") != nullptr;
     auto kern = stamps ? mlp_kernel<C, true> : mlp_kernel<C, false>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)mlp_kernel<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mlp_kernel<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned lds_ok = 0, lds_ok2 = 0;   // per-device bit: kernels.h ensure_dynamic_lds
+    if (hipError_t e = ensure_dynamic_lds((const void*)mlp_kernel<C, true>, SMEM, lds_ok); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)mlp_kernel<C, false>, SMEM, lds_ok2); e != hipSuccess) return e;
     dim3 grid((unsigned)((p.M + BM - 1) / BM));
     hipLaunchKernelGGL(kern, grid, dim3(256), SMEM, s, p);
     return hipGetLastError();

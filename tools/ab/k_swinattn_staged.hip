@@ -448,13 +448,9 @@ hipError_t launch_sa(const SwinAttnParams& p, hipStream_t s) {
     using K = SwinCfg<C, HD>;
     static const bool stamps = getenv("W2X_STAMPS") != nullptr;
     auto kern = stamps ? swin_attn_kernel<C, HD, true> : swin_attn_kernel<C, HD, false>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)swin_attn_kernel<C, HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)swin_attn_kernel<C, HD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned lds_ok = 0, lds_ok2 = 0;   // per-device bit: kernels.h ensure_dynamic_lds
+    if (hipError_t e = ensure_dynamic_lds((const void*)swin_attn_kernel<C, HD, true>, K::SMEM, lds_ok); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)swin_attn_kernel<C, HD, false>, K::SMEM, lds_ok2); e != hipSuccess) return e;
     const long total_win = (long)p.B * p.nwin;
     dim3 grid((unsigned)((total_win + K::G - 1) / K::G));
     hipLaunchKernelGGL(kern, grid, dim3(K::NT), K::SMEM, s, p);

@@ -1,6 +1,6 @@
-// Kernel-level A/B check (GPU box only):  hipcc --offload-arch=gfx950 -O2 -std=c++17 -I waifu2x-tensorrt_amd/csrc tools/mlp_ab.hip \
-//     waifu2x-tensorrt_amd/csrc/k_mlp.hip waifu2x-tensorrt_amd/csrc/k_mlp2.hip -o /tmp/mlp_ab && /tmp/mlp_ab
-// Runs the LDS-staged (k_mlp.hip) and the wave-private (k_mlp2.hip) fused MLP kernels on the same random rows/weights
+// Kernel-level A/B check (GPU box only):  hipcc --offload-arch=gfx950 -O2 -std=c++17 -I waifu2x-tensorrt_amd/csrc tools/ab/mlp_ab.hip \
+//     tools/ab/k_mlp_staged.hip waifu2x-tensorrt_amd/csrc/k_mlp2.hip -o /tmp/mlp_ab && /tmp/mlp_ab
+// Runs the LDS-staged (tools/ab/k_mlp_staged.hip, round 1) and the wave-private (k_mlp2.hip, shipped) fused MLP kernels on the same random rows/weights
 // and prints the largest difference, with and without the LayerNorm-statistics output.
 #include <hip/hip_runtime.h>
 #include <cmath>

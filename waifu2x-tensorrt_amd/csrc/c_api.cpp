@@ -2,6 +2,7 @@
 #include "../../include/w2x/c_api.h"
 
 #include <cstring>
+#include <fstream>
 #include <vector>
 #include <string>
 
@@ -125,19 +126,46 @@ int w2x_tile_weights(int which, int overlap_x, int overlap_y, int size, float* o
 
 int w2x_describe_plan(const char* onnx_path, int batch, int tile, char* buf, size_t cap) {
     std::string s; int ok = 1;
-    try { s = w2x::build_plan(onnx_path, batch, 3, tile, tile).describe(); }
+    try {
+        w2x::Plan plan = w2x::build_plan(onnx_path, batch, 3, tile, tile);
+        plan.userB = batch;
+        const auto bytes = plan.serialize();                          // what build() writes must be what load() accepts
+        s = w2x::Plan::deserialize(bytes.data(), bytes.size()).describe();
+    }
     catch (const std::exception& e) { s = std::string("ERROR: ") + e.what(); ok = 0; }
     if (buf && cap) { size_t n = s.size() < cap - 1 ? s.size() : cap - 1; memcpy(buf, s.data(), n); buf[n] = 0; }
     return ok;
+}
+
+int w2x_validate_engine_file(const char* path, char* buf, size_t cap) {
+    std::string s = "ok"; int ok = 1;
+    try {
+        std::ifstream f(path, std::ios::binary | std::ios::ate);
+        if (!f.is_open()) throw std::runtime_error("could not open engine file");
+        std::vector<char> bytes((size_t)f.tellg());
+        f.seekg(0); f.read(bytes.data(), (std::streamsize)bytes.size());
+        (void)w2x::Plan::deserialize((const uint8_t*)bytes.data(), bytes.size());
+    } catch (const std::exception& e) { s = e.what(); ok = 0; }
+    if (buf && cap) { size_t n = s.size() < cap - 1 ? s.size() : cap - 1; memcpy(buf, s.data(), n); buf[n] = 0; }
+    return ok;
+}
+
+int w2x_write_engine_file(const char* onnx_path, int batch, int tile, const char* out_path) {
+    try {
+        w2x::Plan plan = w2x::build_plan(onnx_path, batch, 3, tile, tile);
+        plan.userB = batch;
+        const auto bytes = plan.serialize();
+        std::ofstream f(out_path, std::ios::binary);
+        if (!f.is_open()) return 0;
+        f.write((const char*)bytes.data(), (std::streamsize)bytes.size());
+        return f.good() ? 1 : 0;
+    } catch (const std::exception&) { return 0; }
 }
 
 void w2x_sha256_hex(const void* data, size_t len, char* out) {
     std::string h = w2x::sha256_hex(data, len);
     memcpy(out, h.c_str(), 65);
 }
-
-int w2x_debug_mlp_stamps(unsigned long long* out) { return w2x::read_mlp_stamps(out) == hipSuccess ? 1 : 0; }
-int w2x_debug_attn_stamps(unsigned long long* out) { return w2x::read_swin_attn_stamps(out) == hipSuccess ? 1 : 0; }
 
 const char* w2x_version(void) { return "w2x-hip 0.1 (gfx950)"; }
 

@@ -8,7 +8,9 @@
 #include <cmath>
 #include <filesystem>
 #include <fstream>
+#include <map>
 #include <sstream>
+#include <tuple>
 
 #include "../../include/w2x/img2img.h"
 #include "common.h"
@@ -40,6 +42,29 @@ std::string hipGetDeviceName(int deviceId) {
     std::string arch = prop.gcnArchName;
     return arch + " x" + std::to_string(prop.multiProcessorCount);
 }
+
+// Logical -> physical device ordinal.  W2X_DEVICE_MAP="0,0,1" makes logical devices 0 and 1 share physical device 0 (test hook:
+// the multi-device code paths - one engine and one host thread per logical device - can then run on a single-GPU box).
+int physical_device(int logical) {   // called by build() and load() only
+    std::vector<int> map;
+    if (const char* e = getenv("W2X_DEVICE_MAP")) { std::stringstream ss(e); std::string tok; while (std::getline(ss, tok, ',')) if (!tok.empty()) map.push_back(atoi(tok.c_str())); }
+    return logical >= 0 && logical < (int)map.size() ? map[logical] : logical;
+}
+
+// One instance = one device (img2img_load.cpp:129 cudaSetDevice in load only).  The reference is driven from one thread; here
+// several engines may live in one process, each on its own host thread, so every public entry that allocates, copies or launches
+// makes the engine's device current for its own duration and restores the caller's on the way out.
+struct DeviceGuard {
+    int prev = -1, dev = -1;
+    explicit DeviceGuard(int d) : dev(d) {
+        if (d < 0) return;
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+        if (prev != d) hipAssert(hipSetDevice(d));
+    }
+    ~DeviceGuard() { if (dev >= 0 && prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 std::string precision_name(Precision p) { return p == Precision::FP16 ? "FP16" : "TF32"; }
 
@@ -126,6 +151,11 @@ struct Img2Img::Impl {
     void log(int current, int total, double speed) { if (progressCallback) progressCallback(current, total, speed); }
 
     bool loaded = false;
+    int device = -1;                   // physical HIP ordinal this engine lives on (set by load)
+    // switches read from the environment once per load(), never on the launch path
+    bool poison = false;               // W2X_POISON: stale activations become fp16 NaNs before every frame (tests)
+    bool check_general = false;        // W2X_PIXGEMM_CHECK: every shape-specialised launch is compared with the general kernel
+    bool use_graphs = true;            // W2X_NO_GRAPH switches the hipGraph replay of network passes off
     Plan plan;
     RenderConfig cfg;
     hipStream_t stream = nullptr;
@@ -175,9 +205,25 @@ struct Img2Img::Impl {
     StripPlan last_strip;
     float last_ms = 0.f;
 
+    // One network pass (gather + every plan op) captured as a hipGraph: the reference's whole network is a single
+    // enqueueV3 (img2img_infer.cpp:80); here a pass is ~40 launches, which the host cannot issue fast enough for small tiles.
+    // A pass is captured the second time it is met (the first run stays eager so that one-time attribute calls are out of the
+    // way) and replayed from then on.  The key holds everything the captured launches bake in.
+    using GraphKey = std::tuple<const void*, const void*, const void*, const void*, int, int, int>;   // frame, slots, slab out, arena, rows, cols, live
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    std::map<GraphKey, int> graph_seen;
+    long graph_replays = 0, eager_passes = 0;
+    void drop_graphs() {
+        for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+        graphs.clear(); graph_seen.clear();
+    }
+
     ~Impl() { release(); }
 
     void release() {
+        std::unique_ptr<DeviceGuard> guard;
+        if (device >= 0) { try { guard.reset(new DeviceGuard(device)); } catch (...) {} }
+        drop_graphs();
         // img2img_base.cpp:6-10 frees the IO buffers; here everything the engine owns
         if (arena_base) { (void)hipFree(arena_base); arena_base = nullptr; }
         for (void* p : blobs) if (p) (void)hipFree(p);
@@ -291,7 +337,7 @@ struct Img2Img::Impl {
             if (op.kind == OP_GEMM && ((op.g.omode == 2 && (op.g.amode == 0 || (op.g.amode == 2 && op.g.kh == 1 && op.g.kw == 1))) || (op.g.amode == 2 && op.g.kh == 2 && op.g.kw == 2 && op.g.stride == 2) || (op.g.amode == 2 && op.g.kh == 3 && op.g.kw == 3 && op.g.stride == 1 && op.g.omode == 0)) && op.g.K % 32 == 0 && op.g.N % 16 == 0 &&
                 plan.blobs[op.g.w].data.size() == (size_t)op.g.N * op.g.K * 2) frag_major_blob(op.g.w, op.g.N, op.g.K);
         for (const Op& op : plan.ops)
-            if (op.kind == OP_MLP && (op.m.C == 96 || op.m.C == 192)) { frag_major_blob(op.m.w1, 2 * op.m.C, op.m.C); frag_w2_blob(op.m.w2, op.m.C); }
+            if (op.kind == OP_MLP && mlp_supported(op.m.C)) { frag_major_blob(op.m.w1, 2 * op.m.C, op.m.C); frag_w2_blob(op.m.w2, op.m.C); }
         for (const Op& op : plan.ops)
             if (op.kind == OP_SWINATTN) { frag_major_blob(op.sa.wqkv, 3 * op.sa.C, op.sa.C); frag_major_blob(op.sa.wproj, op.sa.C, op.sa.C); }
         gemm.assign(plan.ops.size(), GemmParams{});
@@ -344,7 +390,7 @@ struct Img2Img::Impl {
                     if (op.g.pool_out >= 0) pool_blocks[op.g.pool_out] = conv3_supported(p) ? conv3_tiles(p) : 0;   // partial sums per image written by this launch (0: plan default)
                     hipAssert(pixgemm_supported(p) ? launch_pixgemm(p, stream) : conv3_supported(p) ? launch_conv3(p, stream) : stem_supported(p) ? launch_stem(p, stream) : launch_gemm(p, stream));
                     stamp_end();
-                    if (getenv("W2X_PIXGEMM_CHECK") && (pixgemm_supported(p) || conv3_supported(p) || stem_supported(p))) {   // diagnostic: the general kernel must agree
+                    if (check_general && (pixgemm_supported(p) || conv3_supported(p) || stem_supported(p))) {   // diagnostic: the general kernel must agree
                         const TensorDesc& od = plan.tensors[op.g.out.t];
                         const size_t n = (size_t)live * od.H * od.W * od.C;
                         std::vector<uint16_t> a(n), b(n);
@@ -441,6 +487,7 @@ struct Img2Img::Impl {
 
     template <class T> void ensure(T*& p, size_t& cap, size_t bytes) {
         if (bytes <= cap) return;
+        drop_graphs();                        // captured passes hold the old addresses
         if (p) hipAssert(hipFree(p));
         p = nullptr; cap = 0;
         hipAssert(hipMalloc((void**)&p, bytes));
@@ -455,21 +502,49 @@ struct Img2Img::Impl {
         const int batchCount = (int)std::lround(std::ceil((double)(sp.tile_count * steps) / userB));   // img2img_render.cpp:249
         const int passCount = (batchCount + S - 1) / S;
         const size_t slot_bytes = (size_t)To * To * 4 * sizeof(uint16_t);
-        const bool poison = getenv("W2X_POISON") != nullptr;   // test hook: stale activations become fp16 NaNs
         if (poison) {
             hipAssert(hipMemsetAsync(arena_base, 0x7E, arena_bytes, stream));
             hipAssert(hipMemsetAsync(d_slab, 0x7E, slab_cap, stream));
         }
+        const bool graphable = use_graphs && !profiling && !poison && !check_general;
         for (int bi = 0; bi < passCount; ++bi) {
             const auto t0 = std::chrono::steady_clock::now();
-            GatherParams gp;
-            gp.frame = d_frame; gp.rows = rows; gp.cols = cols; gp.step = (size_t)cols * 3;
-            gp.out = tensors[plan.in_tensor]; gp.slots = d_slots + (size_t)bi * B; gp.B = B; gp.T = T;
-            stamp_begin(3, 0);
-            hipAssert(launch_gather(gp, stream));
-            stamp_end();
             const int live = std::max(0, std::min(B, sp.tile_count * steps - bi * B));
-            run_network((uint8_t*)d_slab + (size_t)bi * B * slot_bytes, live);
+            void* const slab_out = (uint8_t*)d_slab + (size_t)bi * B * slot_bytes;
+            auto run_pass = [&] {
+                GatherParams gp;
+                gp.frame = d_frame; gp.rows = rows; gp.cols = cols; gp.step = (size_t)cols * 3;
+                gp.out = tensors[plan.in_tensor]; gp.slots = d_slots + (size_t)bi * B; gp.B = B; gp.T = T;
+                stamp_begin(3, 0);
+                hipAssert(launch_gather(gp, stream));
+                stamp_end();
+                run_network(slab_out, live);
+            };
+            if (!graphable) run_pass();
+            else {
+                const GraphKey key{d_frame, d_slots + (size_t)bi * B, slab_out, arena_base, rows, cols, live};
+                auto it = graphs.find(key);
+                if (it != graphs.end()) { hipAssert(hipGraphLaunch(it->second, stream)); ++graph_replays; }
+                else if (graph_seen[key]++ == 0) { run_pass(); ++eager_passes; }
+                else {
+                    if (graphs.size() >= 1024) drop_graphs();      // frames of ever-changing sizes: start over rather than grow without bound
+                    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+                    hipAssert(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+                    try { run_pass(); } catch (...) { (void)hipStreamEndCapture(stream, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
+                    hipAssert(hipStreamEndCapture(stream, &graph));
+                    const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                    (void)hipGraphDestroy(graph);
+                    if (ie != hipSuccess) {                        // nothing has run yet: fall back to plain launches for good
+                        (void)hipGetLastError();
+                        use_graphs = false;
+                        log(Severity::warn, std::string("hipGraph instantiation failed (") + hipGetErrorString(ie) + "), passes stay on plain launches");
+                        run_pass(); ++eager_passes;
+                    } else {
+                        graphs[key] = exec;
+                        hipAssert(hipGraphLaunch(exec, stream)); ++graph_replays;
+                    }
+                }
+            }
             if (report) {
                 const auto t1 = std::chrono::steady_clock::now();
                 const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
@@ -500,8 +575,10 @@ void Img2Img::setProgressCallback(ProgressCallback callback) { impl->progressCal
 
 bool Img2Img::build(const std::string& onnxModelPath, const BuildConfig& config) try {
     // img2img_build.cpp:56-64
+    const int dev = physical_device(config.deviceId);
+    std::unique_ptr<DeviceGuard> guard;
     try {
-        hipAssert(hipSetDevice(config.deviceId));
+        guard.reset(new DeviceGuard(dev));
     } catch (const std::exception& e) {
         W2X_LOG(error, "Failed to set hip device to device id " + std::to_string(config.deviceId) + ": " + std::string(e.what()) + ".");
         return false;
@@ -540,7 +617,7 @@ bool Img2Img::build(const std::string& onnxModelPath, const BuildConfig& config)
     W2X_LOG(info, "Lowered \"" + onnxModelPath + "\": " + std::to_string(plan.ops.size()) + " fused ops, " +
                       std::to_string((long long)plan.flops) + " algorithmic FLOP per batch, output tile " + std::to_string(plan.Tout) + ".");
     // :151-161
-    const std::string deviceName = hipGetDeviceName(config.deviceId);
+    const std::string deviceName = hipGetDeviceName(dev);
     const auto basePath = std::filesystem::path(onnxModelPath).replace_extension("").string() + "_" + getConfigHash(config, deviceName).substr(0, 16);
     serializeConfig(basePath + ".json", config, deviceName);
     try {
@@ -561,8 +638,10 @@ bool Img2Img::build(const std::string& onnxModelPath, const BuildConfig& config)
 bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try {
     namespace fs = std::filesystem;
     // img2img_load.cpp:127-135
+    const int dev = physical_device(config.deviceId);
+    std::unique_ptr<DeviceGuard> guard;
     try {
-        hipAssert(hipSetDevice(config.deviceId));
+        guard.reset(new DeviceGuard(dev));
     } catch (const std::exception& e) {
         W2X_LOG(error, "Failed to set hip device to device id " + std::to_string(config.deviceId) + ": " + std::string(e.what()) + ".");
         return false;
@@ -571,7 +650,7 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
     std::string enginePath;
     try {
         if (!fs::exists(modelPath)) throw std::runtime_error("model file does not exist");
-        const std::string runningOn = hipGetDeviceName(config.deviceId);
+        const std::string runningOn = hipGetDeviceName(dev);
         const std::string engineName = fs::path(modelPath).stem().string();
         fs::path dir = fs::path(modelPath).parent_path();
         if (dir.empty()) dir = ".";
@@ -601,6 +680,10 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
     file.read(engineBuffer.data(), fileSize);
 
     impl->release();   // :149-154, :209-222
+    impl->device = dev;
+    impl->poison = getenv("W2X_POISON") != nullptr;
+    impl->check_general = getenv("W2X_PIXGEMM_CHECK") != nullptr;
+    impl->use_graphs = getenv("W2X_NO_GRAPH") == nullptr;
     try {
         impl->plan = Plan::deserialize((const uint8_t*)engineBuffer.data(), engineBuffer.size());
     } catch (const std::exception& e) {
@@ -652,6 +735,7 @@ bool Img2Img::renderStrip(const Image& src, Image& dst, int part, int parts) { r
 
 bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, const char* who) try {
     if (!impl->loaded) { W2X_LOG_AS(who, error, "Render called before a successful load."); return false; }
+    DeviceGuard guard(impl->device);
     if (parts <= 0 || part < 0 || part >= parts) { W2X_LOG_AS(who, error, "Invalid strip index."); return false; }
     const RenderConfig& cfg = impl->cfg;
     const Plan& plan = impl->plan;
@@ -709,6 +793,7 @@ bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, cons
 bool Img2Img::renderSequence(const Image* srcs, Image* dsts, int count) try {
     if (!impl->loaded) { W2X_LOG(error, "Render called before a successful load."); return false; }
     if (count <= 0) return true;
+    DeviceGuard guard(impl->device);
     const RenderConfig& cfg = impl->cfg;
     const Plan& plan = impl->plan;
     const int rows = srcs[0].rows, cols = srcs[0].cols, s = cfg.scaling;
@@ -747,6 +832,7 @@ bool Img2Img::renderSequence(const Image* srcs, Image* dsts, int count) try {
     uint8_t* const frames[2] = {impl->d_frame, impl->d_frame2};
     uint8_t* const outs[2] = {impl->d_out, impl->d_out2};
     struct Restore { Impl* im; uint8_t* f; uint8_t* o; ~Restore() { im->d_frame = f; im->d_out = o; } } restore{impl.get(), frames[0], outs[0]};   // also on exceptions
+    hipAssert(hipEventRecord(impl->ev0, stream));
     for (int i = 0; i < count; ++i) {
         const int b = i & 1;
         if (i >= 2) hipAssert(hipStreamWaitEvent(impl->s_up, impl->ev_comp[b], 0));       // frame i-2 has been gathered out of this buffer
@@ -761,32 +847,45 @@ bool Img2Img::renderSequence(const Image* srcs, Image* dsts, int count) try {
         hipAssert(hipMemcpy2DAsync(dsts[i].data, dsts[i].step, outs[b], (size_t)cols * s * 3, (size_t)cols * s * 3, rows * s, hipMemcpyDeviceToHost, impl->s_dn));
         hipAssert(hipEventRecord(impl->ev_dn[b], impl->s_dn));
     }
+    hipAssert(hipEventRecord(impl->ev1, stream));
     hipAssert(hipStreamSynchronize(impl->s_dn));
     hipAssert(hipStreamSynchronize(stream));
     hipAssert(hipStreamSynchronize(impl->s_up));
+    float total_ms = 0.f;
+    hipAssert(hipEventElapsedTime(&total_ms, impl->ev0, impl->ev1));
+    impl->last_ms = total_ms / count;        // lastRenderMs(): compute-stream time per frame of the sequence
     impl->last_rows = rows; impl->last_cols = cols; impl->last_grid = grid; impl->last_strip = sp;
     return true;
 } catch (const std::exception& e) {
+    // copies on the side streams may still be reading or writing the caller's buffers: let them drain before the caller
+    // gets its buffers back (errors here are ignored, the first one is what gets reported)
+    for (hipStream_t st : {impl->s_up, impl->stream, impl->s_dn}) if (st && hipStreamSynchronize(st) != hipSuccess) (void)hipGetLastError();
     W2X_LOG(error, "Render failed unexpectedly: " + std::string(e.what()) + ".");
     return false;
 }
 
 // Page-lock a caller-owned frame buffer in place so that renderSequence() can copy it by DMA while kernels run.
-bool Img2Img::pinHost(void* data, size_t bytes) {
+bool Img2Img::pinHost(void* data, size_t bytes) try {
     if (!data || !bytes) return false;
+    DeviceGuard guard(impl->device);
     if (hipHostRegister(data, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
     impl->pinned.push_back(data);
     return true;
+} catch (const std::exception&) {
+    return false;
 }
-void Img2Img::unpinHost(void* data) {
+void Img2Img::unpinHost(void* data) try {
+    DeviceGuard guard(impl->device);
     auto it = std::find(impl->pinned.begin(), impl->pinned.end(), data);
     if (it == impl->pinned.end()) return;
     if (hipHostUnregister(data) != hipSuccess) (void)hipGetLastError();
     impl->pinned.erase(it);
+} catch (const std::exception&) {
 }
 
 bool Img2Img::infer(const float* input, float* output) try {
     if (!impl->loaded) { W2X_LOG(error, "Infer called before a successful load."); return false; }
+    DeviceGuard guard(impl->device);
     const Plan& plan = impl->plan;
     const size_t in_elems = (size_t)plan.B * 3 * plan.T * plan.T, out_elems = (size_t)plan.B * 3 * plan.Tout * plan.Tout;
     const size_t user_in = (size_t)plan.userB * 3 * plan.T * plan.T, user_out = (size_t)plan.userB * 3 * plan.Tout * plan.Tout;
@@ -817,6 +916,7 @@ float Img2Img::lastRenderMs() const { return impl->last_ms; }
 
 float Img2Img::benchResident(int iters) try {
     if (!impl->loaded || impl->last_rows == 0 || iters <= 0) return -1.f;
+    DeviceGuard guard(impl->device);
     hipStream_t stream = impl->stream;
     hipAssert(hipEventRecord(impl->ev0, stream));
     for (int i = 0; i < iters; ++i) impl->run_frame(impl->last_rows, impl->last_cols, impl->last_grid, false, impl->last_strip);
@@ -835,6 +935,7 @@ float Img2Img::benchResident(int iters) try {
 // 4 compose, 5 fused mlp; out[30] = wall ms of the whole frame (first launch start to last launch end).
 bool Img2Img::profileFrame(double* out, int cap) try {
     if (!impl->loaded || impl->last_rows == 0 || cap < 31) return false;
+    DeviceGuard guard(impl->device);
     for (int i = 0; i < 31; ++i) out[i] = 0;
     impl->profiling = true; impl->stamps.clear();
     impl->run_frame(impl->last_rows, impl->last_cols, impl->last_grid, false, impl->last_strip);

@@ -169,12 +169,8 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
 template <int KC, int N, int TS>
 hipError_t launch_c3(const GemmParams& p, int Ho, int Wo, int n0, hipStream_t s) {
     using C = Conv3Cfg<KC, N, TS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3_kernel<KC, N, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
+    if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<KC, N, TS>, C::SMEM, lds_ok); e != hipSuccess) return e;
     const int tiles_x = (Wo + C::TW - 1) / C::TW, tiles_y = (Ho + C::TH - 1) / C::TH;
     hipLaunchKernelGGL((conv3_kernel<KC, N, TS>), dim3((unsigned)(p.B * tiles_x * tiles_y)), dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, n0);
     return hipGetLastError();

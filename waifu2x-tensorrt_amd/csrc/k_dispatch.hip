@@ -1,0 +1,29 @@
+// Shape dispatch of the fused transformer operators (plan.h OP_SWINATTN / OP_MLP) onto the gfx950 kernels that serve them.
+// lower.cpp asks swin_attn_supported() / mlp_supported() before it fuses a branch, so a plan never holds a fused op without a
+// kernel; graphs of other widths keep the un-fused GEMM + OP_ATTN plan.
+#include "kernels.h"
+
+namespace w2x {
+
+hipError_t launch_mlp2(const MlpParams& p, hipStream_t s);                // k_mlp2.hip
+hipError_t launch_swin_attn96(const SwinAttnParams& p, hipStream_t s);    // k_swinattn96.hip
+hipError_t launch_swin_attn192(const SwinAttnParams& p, hipStream_t s);   // k_swinattn192.hip
+
+bool swin_attn_supported(int C, int heads, int hd, int ws) {
+    return ws == 6 && heads * hd == C && ((C == 96 && hd == 16) || (C == 192 && hd == 32));
+}
+bool mlp_supported(int C) { return C == 96 || C == 192; }
+
+hipError_t launch_swin_attn(const SwinAttnParams& p, hipStream_t s) {
+    if (!p.wqkv_frag || !p.wproj_frag) return hipErrorInvalidValue;       // the kernels read fragment-major weights only
+    if (p.C == 96 && p.hd == 16) return launch_swin_attn96(p, s);
+    if (p.C == 192 && p.hd == 32) return launch_swin_attn192(p, s);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_mlp(const MlpParams& p, hipStream_t s) {
+    if (!p.w1_frag || !p.w2_frag || !mlp_supported(p.C)) return hipErrorInvalidValue;
+    return launch_mlp2(p, s);
+}
+
+}  // namespace w2x

@@ -301,12 +301,8 @@ hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
     constexpr int SMEM = MAIN + BM * 6 * 4;
     static_assert(BM == kGemmBM, "plan.h sizes the pooling partials for this tile height");
     auto kern = gemm_kernel<KB, WAVES_M, WAVES_N, WM, WN, AP, OP>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
+    if (hipError_t e = ensure_dynamic_lds((const void*)kern, SMEM, lds_ok); e != hipSuccess) return e;
     dim3 grid(p.B * ((p.Mrows + BM - 1) / BM), (p.N + BN - 1) / BN);
     hipLaunchKernelGGL(kern, grid, dim3(256), SMEM, s, p);
     return hipGetLastError();

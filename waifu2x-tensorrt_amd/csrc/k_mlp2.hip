@@ -18,7 +18,6 @@
 // Default (SHARE): the four waves of a workgroup stage each chunk once into LDS instead (the weight stream from L2 was 56 % of
 // the C = 192 kernel's time); TT = 2 for both widths, which leaves C = 96 at 140 VGPRs = 3 waves per SIMD.
 #include "kernels.h"
-#include <cstdlib>
 
 namespace w2x {
 namespace {
@@ -281,12 +280,8 @@ __global__ __launch_bounds__(NW * 64, (SHARE && TT <= 2 && C == 96 ? 3 : (NW >= 
 template <int C, int TT, int NW, bool SHARE>
 hipError_t launch_mlp2_c(const MlpParams& p, hipStream_t s) {
     using K = Mlp2Cfg<C, TT, NW, SHARE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)mlp2_kernel<C, TT, NW, SHARE>, hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
+    if (hipError_t e = ensure_dynamic_lds((const void*)mlp2_kernel<C, TT, NW, SHARE>, K::SMEM, lds_ok); e != hipSuccess) return e;
     dim3 grid((unsigned)((p.M + K::BM - 1) / K::BM));
     hipLaunchKernelGGL((mlp2_kernel<C, TT, NW, SHARE>), grid, dim3(K::NWV * 64), K::SMEM, s, p);
     return hipGetLastError();
@@ -295,10 +290,11 @@ hipError_t launch_mlp2_c(const MlpParams& p, hipStream_t s) {
 }  // namespace
 
 hipError_t launch_mlp2(const MlpParams& p, hipStream_t s) {
-    static const int nw = getenv("W2X_MLP2_NW") ? atoi(getenv("W2X_MLP2_NW")) : 4;   // waves per workgroup (tuning switch)
-    static const bool ring = getenv("W2X_MLP2_RING") != nullptr;   // A/B switch: per-wave register ring instead of LDS-shared chunks
-    if (p.C == 96) return ring ? (nw == 8 ? launch_mlp2_c<96, 4, 8, false>(p, s) : launch_mlp2_c<96, 4, 4, false>(p, s)) : (getenv("W2X_MLP2_TT4") ? launch_mlp2_c<96, 4, 4, true>(p, s) : launch_mlp2_c<96, 2, 4, true>(p, s));   // shared weights: 32 rows per wave, 3 waves per SIMD (6 / 12 waves per workgroup measured: 2.45 / 1.86 ms per frame against 1.58)
-    if (p.C == 192) return ring ? (nw == 8 ? launch_mlp2_c<192, 2, 8, false>(p, s) : launch_mlp2_c<192, 2, 4, false>(p, s)) : (nw == 8 ? launch_mlp2_c<192, 2, 8, true>(p, s) : launch_mlp2_c<192, 2, 4, true>(p, s));
+    // Shared-weight schedule, 32 rows per wave, 4 waves per workgroup for both widths.  Measured alternatives (git history): 6 / 12
+    // waves per workgroup 2.45 / 1.86 ms of MLP time per frame against 1.58; the per-wave register ring (SHARE = false, TT = 4) and
+    // 64 rows per wave with shared weights were slower as well.
+    if (p.C == 96) return launch_mlp2_c<96, 2, 4, true>(p, s);
+    if (p.C == 192) return launch_mlp2_c<192, 2, 4, true>(p, s);
     return hipErrorInvalidValue;
 }
 

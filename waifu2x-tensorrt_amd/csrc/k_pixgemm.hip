@@ -159,12 +159,8 @@ __global__ __launch_bounds__(256, 2) void pixgemm_kernel(const GemmParams p) {
 template <int K, int CSO, int G>
 hipError_t launch_pix(const GemmParams& p, hipStream_t s) {
     using C = PixCfg<K, CSO, G>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)pixgemm_kernel<K, CSO, G>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
+    if (hipError_t e = ensure_dynamic_lds((const void*)pixgemm_kernel<K, CSO, G>, C::SMEM, lds_ok); e != hipSuccess) return e;
     const long M = (long)p.B * p.Mrows;
     dim3 grid((unsigned)((M + C::BM - 1) / C::BM));
     hipLaunchKernelGGL((pixgemm_kernel<K, CSO, G>), grid, dim3(256), C::SMEM, s, p);
@@ -372,12 +368,8 @@ __global__ __launch_bounds__(256, 2) void merge_kernel(const GemmParams p) {
 template <int CIN>
 hipError_t launch_merge(const GemmParams& p, hipStream_t s) {
     constexpr int SM = 2 * 12 * 1024 + 4 * (32 * 200 * 2 + 32 * 4);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)merge_kernel<CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, SM);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
+    if (hipError_t e = ensure_dynamic_lds((const void*)merge_kernel<CIN>, SM, lds_ok); e != hipSuccess) return e;
     const long M = (long)p.B * p.Mrows;
     hipLaunchKernelGGL(merge_kernel<CIN>, dim3((unsigned)((M + 127) / 128)), dim3(256), SM, s, p);
     return hipGetLastError();

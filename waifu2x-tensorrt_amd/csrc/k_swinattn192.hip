@@ -18,7 +18,6 @@
 // values per lane, the layout the bias table is stored for) and - because q, k and v are all computed from the same slab -
 // needs no data movement for it: the third tiles of K, V and Q come out of the MFMAs already arranged that way.
 #include "kernels.h"
-#include <cstdlib>
 
 namespace w2x {
 namespace {
@@ -95,7 +94,7 @@ static_assert(R % RPP == 0, "row passes");
 
 __device__ __forceinline__ int slab_row(int t) { return t < 32 ? t : 32 + 4 * (t - 32); }
 
-// Diagnostic build only (W2X_STAMPS=1 at run time selects it): per-phase s_memtime deltas summed over all waves.
+// Diagnostic build only (instantiate the kernel with STAMPS = true): per-phase s_memtime deltas summed over all waves.
 // g_sa192_stamps[k]: 0 gather+LN+barrier, 1 q and k products, 2 v products, 3 S + softmax, 4 O + store, 5 barrier + proj,
 // 6 barrier + final rows, 7 waves counted.
 __device__ unsigned long long g_sa192_stamps[8];
@@ -421,24 +420,10 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
 
 }  // namespace
 
-// copies and clears the diagnostic stamp counters (8 values)
-hipError_t read_swin_attn192_stamps(unsigned long long* out) {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sa192_stamps), sizeof(unsigned long long) * 8);
-    if (e != hipSuccess) return e;
-    unsigned long long z[8] = {};
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_sa192_stamps), z, sizeof(z));
-}
-
 hipError_t launch_swin_attn192(const SwinAttnParams& p, hipStream_t s) {
-    static const bool stamps = getenv("W2X_STAMPS") != nullptr;
-    auto kern = stamps ? swin_attn192_kernel<true> : swin_attn192_kernel<false>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)swin_attn192_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM192);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)swin_attn192_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM192);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    auto kern = swin_attn192_kernel<false>;   // <true>: per-phase s_memtime stamps into g_sa192_stamps (diagnostic builds only)
+    static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
+    if (hipError_t e = ensure_dynamic_lds((const void*)kern, SMEM192, lds_ok); e != hipSuccess) return e;
     const long total_win = (long)p.B * p.nwin;
     dim3 grid((unsigned)((total_win + G - 1) / G));
     hipLaunchKernelGGL(kern, grid, dim3(256), SMEM192, s, p);

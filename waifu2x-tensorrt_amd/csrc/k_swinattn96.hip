@@ -350,12 +350,8 @@ __global__ __launch_bounds__(256, 3) void swin_attn96_kernel(const SwinAttnParam
 }  // namespace
 
 hipError_t launch_swin_attn96(const SwinAttnParams& p, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)swin_attn96_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM96);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
+    if (hipError_t e = ensure_dynamic_lds((const void*)swin_attn96_kernel, SMEM96, lds_ok); e != hipSuccess) return e;
     const long total_win = (long)p.B * p.nwin;
     dim3 grid((unsigned)((total_win + G - 1) / G));
     hipLaunchKernelGGL(swin_attn96_kernel, grid, dim3(256), SMEM96, s, p);

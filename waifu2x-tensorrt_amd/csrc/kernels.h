@@ -7,6 +7,19 @@ namespace w2x {
 
 constexpr int kGemmBM = 128;   // rows per GEMM workgroup tile (every instantiation)
 
+// The opt-in to more than 64 KiB of dynamic LDS is a per-device attribute of a kernel: every launcher calls this with its own
+// static mask before launching, so that engines on several devices of one process (one host thread each) all get it.
+inline hipError_t ensure_dynamic_lds(const void* fn, int bytes, unsigned& done_mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned bit = 1u << (dev & 31);
+    if (__atomic_load_n(&done_mask, __ATOMIC_ACQUIRE) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) __atomic_fetch_or(&done_mask, bit, __ATOMIC_RELEASE);
+    return e;
+}
+
 struct TView {           // device view of a channel-last tensor
     void* p = nullptr;
     int Hs = 0, Ws = 0, Cs = 0;  // stored dims
@@ -121,8 +134,7 @@ hipError_t launch_attn(const AttnParams& p, hipStream_t s);
 hipError_t launch_mlp(const MlpParams& p, hipStream_t s);
 hipError_t launch_swin_attn(const SwinAttnParams& p, hipStream_t s);
 bool swin_attn_supported(int C, int heads, int hd, int ws);
-hipError_t read_mlp_stamps(unsigned long long* out);         // diagnostic (W2X_STAMPS=1): 2 x 8 per-phase cycle sums, see k_mlp.hip
-hipError_t read_swin_attn_stamps(unsigned long long* out);   // diagnostic (W2X_STAMPS=1): per-phase cycle sums, see k_swinattn.hip
+bool mlp_supported(int C);
 hipError_t launch_se(const SeParams& p, hipStream_t s);
 hipError_t launch_scale(void* x, const float* scale, int B, int HW, int Cs, hipStream_t s);
 hipError_t launch_gather(const GatherParams& p, hipStream_t s);

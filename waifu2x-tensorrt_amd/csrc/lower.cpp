@@ -727,7 +727,7 @@ struct Lowerer {
                 auto plain = [&](const View& v) { const TensorDesc& t = plan.tensors[v.t]; return v.y0 == 0 && v.x0 == 0 && v.H == t.H && v.W == t.W; };
                 int hidden_users = 0;
                 for (auto& o : plan.ops) if (o.kind == OP_GEMM && (o.g.a.t == g1.out.t || o.g.res.t == g1.out.t || o.g.res2.t == g1.out.t)) ++hidden_users;
-                if ((C == 96 || C == 192) && g1.amode == A_ROWS && g1.ln && g1.act == ACT_GELU && g1.omode == O_ROWS && g1.res.t < 0 && !g1.has_clip &&
+                if (mlp_supported(C) && g1.amode == A_ROWS && g1.ln && g1.act == ACT_GELU && g1.omode == O_ROWS && g1.res.t < 0 && !g1.has_clip &&
                     g1.N == 2 * C && g1.stats_out < 0 && g1.pool_out < 0 && plain(g1.a) && plan.tensors[g1.a.t].C == C &&
                     g2.amode == A_ROWS && !g2.ln && g2.act == ACT_NONE && g2.omode == O_ROWS && g2.a.t == g1.out.t && g2.K == 2 * C && g2.N == C &&
                     g2.res.t == g1.a.t && g2.res2.t < 0 && !g2.has_clip && g2.pool_out < 0 && plain(g2.res) && hidden_users == 1 && g1.out.t != plan.out_tensor) {

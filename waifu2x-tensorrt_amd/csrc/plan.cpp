@@ -1,5 +1,6 @@
 #include "plan.h"
 
+#include <algorithm>
 #include <cstring>
 #include <sstream>
 #include <stdexcept>
@@ -91,7 +92,102 @@ Plan Plan::deserialize(const uint8_t* p, size_t n) {
     uint64_t nb = r.pod<uint64_t>(); pl.blobs.resize(nb); for (auto& b : pl.blobs) b.data = r.bytes();
     uint64_t no = r.pod<uint64_t>(); pl.ops.resize(no);
     for (auto& op : pl.ops) { op.kind = r.pod<int>(); op.name = r.str(); op.g = r.pod<GemmOp>(); op.at = r.pod<AttnOp>(); op.se = r.pod<SeOp>(); op.m = r.pod<MlpOp>(); op.sa = r.pod<SwinAttnOp>(); op.flops = r.pod<double>(); }
+    pl.validate();
     return pl;
+}
+
+// A plan file is an input from disk: every index the engine later uses to address tensors[], blobs[] or device memory is
+// checked here, so that a stale, truncated or edited file ends as "Failed to deserialize engine" and never as a host
+// out-of-bounds access or a device fault.
+void Plan::validate() const {
+    auto fail = [](const std::string& what) { throw std::runtime_error("engine file inconsistent: " + what); };
+    const int nt = (int)tensors.size(), nb = (int)blobs.size();
+    if (B <= 0 || userB <= 0 || B % userB || T <= 0 || Tout <= 0 || Cin != 3 || Cout != 3) fail("header");
+    if (in_tensor < 0 || in_tensor >= nt || out_tensor < 0 || out_tensor >= nt) fail("input / output tensor id");
+    for (const TensorDesc& t : tensors) if (t.B <= 0 || t.H <= 0 || t.W <= 0 || t.C <= 0 || (t.elt != 2 && t.elt != 4) || t.bytes() > ((int64_t)1 << 40)) fail("tensor shape");
+    if (tensors[in_tensor].H != T || tensors[in_tensor].W != T || tensors[in_tensor].C != 4 || tensors[in_tensor].B != B) fail("input tensor shape");
+    if (tensors[out_tensor].H != Tout || tensors[out_tensor].W != Tout || tensors[out_tensor].C != 4) fail("output tensor shape");
+    auto ten = [&](int id, bool optional) { if (id < (optional ? -1 : 0) || id >= nt) fail("tensor id"); };
+    auto blob = [&](int id, bool optional, size_t bytes) {
+        if (id < (optional ? -1 : 0) || id >= nb) fail("blob id");
+        if (id >= 0 && bytes && blobs[id].data.size() < bytes) fail("blob size");
+    };
+    auto view = [&](const View& v, bool optional) {
+        ten(v.t, optional);
+        if (v.t < 0) return;
+        const TensorDesc& d = tensors[v.t];
+        if (v.H <= 0 || v.W <= 0 || v.y0 < 0 || v.x0 < 0 || v.y0 + v.H > d.H || v.x0 + v.W > d.W) fail("view outside its tensor");
+    };
+    for (const Op& op : ops) {
+        switch (op.kind) {
+            case OP_GEMM: {
+                const GemmOp& g = op.g;
+                view(g.res, true); view(g.res2, true); view(g.out, false);
+                ten(g.a.t, false);
+                ten(g.stats_in, true); ten(g.stats_out, true); ten(g.pool_out, true); ten(g.se_scale, true);
+                if (g.K <= 0 || g.N <= 0 || g.Mrows <= 0 || g.kh <= 0 || g.kw <= 0 || g.stride <= 0 || g.r <= 0 || g.aW <= 0) fail("gemm shape");
+                if (g.amode < A_ROWS || g.amode > A_CONV || g.omode < O_ROWS || g.omode > O_PIXSHUF) fail("gemm mode");
+                if (g.K != g.kh * g.kw * tensors[g.a.t].C) fail("gemm K");
+                {   // the A side reads pixel (y0 + oy*stride + ky, x0 + ox*stride + kx) for the Mrows = oH x aW output positions
+                    // (a crop folded into a convolution moves y0 / x0 without touching the view's H / W, so those are not used)
+                    const TensorDesc& d = tensors[g.a.t];
+                    const int oH = (g.Mrows + g.aW - 1) / g.aW;
+                    if (g.a.y0 < 0 || g.a.x0 < 0 || (int64_t)g.a.y0 + (int64_t)(oH - 1) * g.stride + g.kh > d.H || (int64_t)g.a.x0 + (int64_t)(g.aW - 1) * g.stride + g.kw > d.W) fail("gemm input window outside its tensor");
+                    if (g.amode == A_WIN && g.Mrows != d.H * d.W) fail("window gather geometry");
+                }
+                blob(g.w, false, (size_t)g.N * ((g.K + 7) / 8 * 8) * 2);
+                blob(g.bias, false, (size_t)g.N * 4);
+                blob(g.csum, !g.ln, (size_t)g.N * 4);
+                if (g.amode == A_WIN || g.omode == O_WIN) blob(g.win_table, false, (size_t)g.Mrows * 4); else blob(g.win_table, true, 0);
+                if (g.ln && g.stats_in < 0) fail("LayerNorm without statistics");
+                break;
+            }
+            case OP_ATTN: {
+                const AttnOp& a = op.at;
+                ten(a.qkv, false); ten(a.out, false);
+                if (a.heads <= 0 || a.hd <= 0 || a.ws <= 0 || a.nwin <= 0 || a.nmask <= 0) fail("attention shape");
+                const size_t n = (size_t)a.ws * a.ws;
+                blob(a.bias, false, (size_t)a.nmask * a.heads * n * n * 2);
+                blob(a.maskid, false, (size_t)a.nwin * 4);
+                for (int i = 0; i < a.nwin; ++i) { int m; memcpy(&m, blobs[a.maskid].data.data() + 4 * (size_t)i, 4); if (m < 0 || m >= a.nmask) fail("attention mask id"); }
+                break;
+            }
+            case OP_SE: {
+                const SeOp& e = op.se;
+                ten(e.pool, false); ten(e.scale, false);
+                if (e.C <= 0 || e.Cmid <= 0 || e.nblocks <= 0) fail("squeeze-excite shape");
+                blob(e.w1, false, (size_t)e.C * e.Cmid * 4); blob(e.b1, false, (size_t)e.Cmid * 4);
+                blob(e.w2, false, (size_t)e.C * e.Cmid * 4); blob(e.b2, false, (size_t)e.C * 4);
+                break;
+            }
+            case OP_SCALE_ADD: ten(op.se.pool, false); ten(op.se.scale, false); break;
+            case OP_MLP: {
+                const MlpOp& m = op.m;
+                ten(m.x, false); ten(m.y, false); ten(m.stats_out, true);
+                if (m.C <= 0 || tensors[m.x].C != m.C || tensors[m.y].C != m.C) fail("MLP width");
+                blob(m.w1, false, (size_t)2 * m.C * m.C * 2); blob(m.b1, false, (size_t)2 * m.C * 4);
+                blob(m.w2, false, (size_t)2 * m.C * m.C * 2); blob(m.b2, false, (size_t)m.C * 4);
+                break;
+            }
+            case OP_SWINATTN: {
+                const SwinAttnOp& a = op.sa;
+                ten(a.x, false); ten(a.y, false); ten(a.stats_out, true);
+                if (a.C <= 0 || a.heads <= 0 || a.hd <= 0 || a.heads * a.hd != a.C || a.ws <= 0 || a.nwin <= 0 || a.H <= 0 || a.W <= 0) fail("window attention shape");
+                if (tensors[a.x].C != a.C || tensors[a.y].C != a.C || a.H * a.W != a.nwin * a.ws * a.ws || tensors[a.x].H * tensors[a.x].W != a.H * a.W) fail("window attention geometry");
+                if (a.ry >= a.H || a.rx >= a.W) fail("window attention shift");
+                blob(a.table, false, (size_t)a.H * a.W * 4);
+                blob(a.wqkv, false, (size_t)3 * a.C * a.C * 2); blob(a.bqkv, false, (size_t)3 * a.C * 4);
+                blob(a.wproj, false, (size_t)a.C * a.C * 2); blob(a.bproj, false, (size_t)a.C * 4);
+                blob(a.maskid, false, (size_t)a.nwin * 4);
+                int nmask = 0;
+                for (int i = 0; i < a.nwin; ++i) { int m; memcpy(&m, blobs[a.maskid].data.data() + 4 * (size_t)i, 4); if (m < 0) fail("window mask id"); nmask = std::max(nmask, m + 1); }
+                blob(a.bias, false, (size_t)nmask * a.heads * 3 * 576 * 4);
+                for (size_t i = 0; i < (size_t)a.H * a.W; ++i) { int v; memcpy(&v, blobs[a.table].data.data() + 4 * i, 4); if (v < 0 || v >= a.H * a.W) fail("window table entry"); }
+                break;
+            }
+            default: fail("op kind");
+        }
+    }
 }
 
 }  // namespace w2x

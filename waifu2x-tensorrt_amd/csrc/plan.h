@@ -129,7 +129,8 @@ struct Plan {
     std::string describe() const;
     // binary (de)serialization for the on-disk engine file
     std::vector<uint8_t> serialize() const;
-    static Plan deserialize(const uint8_t* p, size_t n);
+    static Plan deserialize(const uint8_t* p, size_t n);   // throws on a truncated or inconsistent file (validate())
+    void validate() const;
 };
 
 }  // namespace w2x

@@ -119,6 +119,8 @@ def lib():
     L.w2x_calculate_tiles.argtypes = [C.c_int] * 7 + [C.c_double, C.c_double, vp, vp, C.c_int]; L.w2x_calculate_tiles.restype = C.c_int
     L.w2x_tile_weights.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp]; L.w2x_tile_weights.restype = C.c_int
     L.w2x_describe_plan.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]; L.w2x_describe_plan.restype = C.c_int
+    L.w2x_write_engine_file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p]; L.w2x_write_engine_file.restype = C.c_int
+    L.w2x_validate_engine_file.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]; L.w2x_validate_engine_file.restype = C.c_int
     L.w2x_sha256_hex.argtypes = [vp, C.c_size_t, C.c_char_p]
     L.w2x_version.restype = C.c_char_p
     _lib = L
@@ -128,7 +130,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "w2x_create", "w2x_destroy", "w2x_set_message_callback", "w2x_set_progress_callback", "w2x_build", "w2x_load",
     "w2x_render", "w2x_infer", "w2x_output_tile_size", "w2x_plan_flops", "w2x_pass_tiles", "w2x_last_render_ms", "w2x_bench_resident", "w2x_profile_frame", "w2x_op_times",
-    "w2x_render_strip", "w2x_strip_plan", "w2x_render_sequence", "w2x_pin_host", "w2x_unpin_host", "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_sha256_hex", "w2x_debug_attn_stamps", "w2x_debug_mlp_stamps", "w2x_version"]
+    "w2x_render_strip", "w2x_strip_plan", "w2x_render_sequence", "w2x_pin_host", "w2x_unpin_host", "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_write_engine_file", "w2x_validate_engine_file", "w2x_sha256_hex", "w2x_version"]
 
 
 class Img2Img:
@@ -188,6 +190,7 @@ class Img2Img:
                           int(config.tta), int(config.ttaBugCompat))
         ok = bool(self._L.w2x_load(self._h, os.fsencode(path), C.byref(c)))
         self._scaling = config.scaling if ok else 0
+        self._batch, self._tile = (config.batchSize, config.height) if ok else (0, 0)
         return ok
 
     def render(self, src: np.ndarray, dst: np.ndarray | None = None):
@@ -257,8 +260,13 @@ class Img2Img:
     def infer(self, x: np.ndarray) -> np.ndarray:
         """Private trt::Img2Img::infer (img2img_infer.cpp:41-93) as a test hook: [B,3,T,T] f32 -> [B,3,T',T'] f32."""
         x = np.ascontiguousarray(x, np.float32)
+        b, t = getattr(self, "_batch", 0), getattr(self, "_tile", 0)
+        if not b:
+            raise W2xError("infer called before a successful load")
+        if x.shape != (b, 3, t, t):        # img2img_infer.cpp:43-68: batch count and tile shape must be the loaded configuration's
+            raise ValueError(f"infer expects a [{b}, 3, {t}, {t}] blob, got {list(x.shape)}")
         to = self.output_tile_size
-        y = np.empty((x.shape[0], 3, to, to), np.float32)
+        y = np.empty((b, 3, to, to), np.float32)
         if not self._L.w2x_infer(self._h, x.ctypes.data, y.ctypes.data):
             raise W2xError(self.last_error() or "infer failed")
         return y
@@ -334,6 +342,18 @@ def describe_plan(onnx_path, batch, tile) -> str:
     if not ok:
         raise W2xError(s)
     return s
+
+
+def write_engine_file(onnx_path, batch, tile, out_path) -> bool:
+    """Host-only half of build(): lower the graph and write the plan file (no device needed)."""
+    return bool(lib().w2x_write_engine_file(os.fsencode(onnx_path), batch, tile, os.fsencode(out_path)))
+
+
+def validate_engine_file(path) -> tuple[bool, str]:
+    """Host-only half of load(): deserialize + consistency checks -> (ok, reason)."""
+    buf = C.create_string_buffer(4096)
+    ok = lib().w2x_validate_engine_file(os.fsencode(path), buf, len(buf))
+    return bool(ok), buf.value.decode(errors="replace")
 
 
 def sha256_hex(data: bytes) -> str:
