@@ -8,6 +8,17 @@ batch 4, tile 256, blend 1/16 (BASELINE.json configs[2]) on N MI355X.
 A step = one pass of the hot path (gather -> network on every tile batch -> blend/compose) over one synthetic
 1920x1080 frame that is already resident in HBM; frames are independent, so ranks shard frames with no data-path
 collective (weak scaling: every rank renders K frames).  Rank 0 prints ONE JSON line.
+
+`value` is the resident figure (inputs in HBM when the timed region starts).  The same K frames are then rendered by every
+rank through the reference's whole render() contract - host frame in, host frame out (img2img_render.cpp:226,344; caller
+loop main.cpp:263-269) - as a renderSequence over page-locked buffers with the copies on side streams; that PCIe-inclusive
+figure is reported next to it as config.full_path_* (max over ranks, same barriers), never as `value`.
+
+Ranks never touch torch.cuda: libw2x.so links /opt/rocm's HIP runtime and PyTorch bundles its own, so the timing barrier
+and the max-reduction run over gloo on CPU tensors (there is no data-path collective to put on RCCL).  With --gpus N > 1
+and no launcher environment the script starts the N ranks itself (child processes, spawned before any GPU call).
+--mode strips times the other multi-GPU mode: ONE frame split into tile-column strips, rank r renders strip r of N
+(renderStrip), strong scaling.
 """
 from __future__ import annotations
 
@@ -72,21 +83,47 @@ def cpu_baseline(work: str, threads: int) -> dict:
                       f"extrapolated to {n} tiles/frame ({frame_s:.0f} s/frame)"}
 
 
+def spawn_ranks(a) -> int:
+    """--gpus N without a launcher: start the N ranks as child processes (this parent never touches the GPU) and pass rank 0's
+    JSON line through.  Children rendezvous over gloo on 127.0.0.1."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()                 # counting devices does not initialise the GPU
+    if have < a.gpus and not os.environ.get("W2X_DEVICE_MAP"):
+        raise SystemExit(f"--gpus {a.gpus} but this node shows {have} GPU(s); refusing to report n_gpus != requested")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = rc or p.wait()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", choices=["frames", "strips"], default="frames",
+                    help="frames: every rank renders K whole frames (weak scaling, the headline); strips: rank r renders strip r of N of the same frame K times (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--op-times", action="store_true", help="print HIP-event time per plan op (one frame) to stderr")
     ap.add_argument("--work", default=os.environ.get("W2X_BENCH_WORK", "/tmp/w2x_bench"))
     a = ap.parse_args()
 
+    if a.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: refusing to report n_gpus != requested")
 
     import torch
     import __graft_entry__ as g
@@ -96,8 +133,8 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")              # CPU tensors only: PyTorch's HIP runtime is never initialised beside /opt/rocm's
 
     work = os.path.join(a.work, f"rank{rank}")
     path = sm.model_path(work, MODEL, SCALE, NOISE)
@@ -115,34 +152,23 @@ def main():
             print("[w2x] " + m, file=sys.stderr)
 
     import shard
-    my_frames = shard.frames_for_rank(a.steps * world, rank, world)       # frame f -> rank f mod N; each rank renders K frames
+    strips = a.mode == "strips"
+    my_frames = [0] if strips else shard.frames_for_rank(a.steps * world, rank, world)   # frame f -> rank f mod N; each rank renders K frames
     frame = synthetic_frame(my_frames[0])
     out = np.empty((FRAME_H * SCALE, FRAME_W * SCALE, 3), np.uint8)
-    if not eng.render(frame, out):           # uploads the frame; it stays resident for the timed steps
-        raise SystemExit("render failed: " + eng.last_error())
-    pcie_ms_one = None
-    t0 = time.perf_counter(); eng.render(frame, out); pcie_ms_one = (time.perf_counter() - t0) * 1e3
+    part, parts = (rank, world) if strips else (0, 1)
 
-    # the same frames as a sequence with the PCIe copies overlapped (renderSequence, page-locked ring of 3 output buffers)
-    pipelined_ms = None
-    if rank == 0:
-        try:
-            ring = [out] + [np.empty_like(out) for _ in range(2)]
-            n_seq = 12
-            for hb in [frame] + ring:
-                eng._L.w2x_pin_host(eng._h, hb.ctypes.data, hb.nbytes)
-            eng.render_sequence([frame] * 3, outs=ring)
-            t0 = time.perf_counter(); eng.render_sequence([frame] * n_seq, outs=[ring[k % 3] for k in range(n_seq)]); pipelined_ms = (time.perf_counter() - t0) * 1e3 / n_seq
-            for hb in [frame] + ring:
-                eng._L.w2x_unpin_host(eng._h, hb.ctypes.data)
-        except Exception as e:                   # informational figure only
-            print(f"[w2x] pipelined measurement skipped: {e}", file=sys.stderr)
+    def render_once():                       # uploads the frame (it stays resident for the timed steps) and sets the strip
+        ok = eng.render_strip(frame, out, part, parts) if strips else eng.render(frame, out)
+        if not ok:
+            raise SystemExit("render failed: " + eng.last_error())
+    render_once()
+    t0 = time.perf_counter(); render_once(); pcie_ms_one = (time.perf_counter() - t0) * 1e3
 
-    def sync_all():
+    def sync_all():                          # every engine call returns after its stream has drained, so the device is idle here
         shard.barrier(dist)
-        if dist is not None:
-            torch.cuda.synchronize()
 
+    # ---- the timed region of `value`: K resident steps on every rank
     eng.bench_resident(max(a.warmup, 1))
     sync_all()
     t0 = time.perf_counter()
@@ -151,7 +177,29 @@ def main():
     wall = time.perf_counter() - t0
     if ms <= 0:
         raise SystemExit("bench failed: " + eng.last_error())
-    wall_max = shard.max_over_ranks(wall, dist, device=torch.device("cuda", local_rank) if dist is not None else None)
+    wall_max = shard.max_over_ranks(wall, dist)
+
+    # ---- the same K frames through the whole render() contract (host buffer in, host buffer out), copies overlapped on side
+    # streams (renderSequence over page-locked buffers, a ring of 3 output frames); every rank, same barriers, max over ranks
+    full_wall_max = None
+    if not strips:
+        try:
+            ring = [out] + [np.empty_like(out) for _ in range(2)]
+            for hb in [frame] + ring:
+                eng._L.w2x_pin_host(eng._h, hb.ctypes.data, hb.nbytes)
+            eng.render_sequence([frame] * max(a.warmup, 3), outs=[ring[k % 3] for k in range(max(a.warmup, 3))])
+            sync_all()
+            t0 = time.perf_counter()
+            eng.render_sequence([frame] * a.steps, outs=[ring[k % 3] for k in range(a.steps)])
+            sync_all()
+            full_wall_max = shard.max_over_ranks(time.perf_counter() - t0, dist)
+            for hb in [frame] + ring:
+                eng._L.w2x_unpin_host(eng._h, hb.ctypes.data)
+        except Exception as e:
+            if world > 1:
+                raise
+            print(f"[w2x] full-path measurement skipped: {e}", file=sys.stderr)
+        render_once()                        # restore the single-frame state profile_frame() works on
 
     prof = eng.profile_frame()
     desc = pkg.describe_plan(path, eng.pass_tiles, TILE).splitlines()[2:]
@@ -161,8 +209,11 @@ def main():
             print(f"{t:8.3f} ms  {line[:150]}", file=sys.stderr)
     if rank == 0:
         import re
-        fps = a.steps * world / wall_max
+        fps = a.steps * (1 if strips else world) / wall_max       # strips: the N ranks together produce each frame
         n_tiles = pkg.calculate_tiles(FRAME_W, FRAME_H, FRAME_W * SCALE, FRAME_H * SCALE, TILE, eng.output_tile_size, SCALE, (BLEND, BLEND))[0]
+        frame_tiles = n_tiles
+        if strips:                               # the kernel figures below are rank 0's: its strip's tiles
+            n_tiles = pkg.strip_plan(FRAME_W, FRAME_H, FRAME_W * SCALE, FRAME_H * SCALE, TILE, eng.output_tile_size, SCALE, (BLEND, BLEND), 0, world)[1]
         live = n_tiles / eng.pass_tiles          # the zero-pad slots of the last batch are not computed (plan FLOPs are per pass of pass_tiles)
         # dominant kernel of the frame: plan ops grouped by the kernel that serves them, by summed HIP-event time
         # (measured on the compute stream by w2x_profile_frame / w2x_op_times)
@@ -208,14 +259,18 @@ def main():
         line = {
             "metric": "upscaled MPix/s, 1080p->4K swin_unet/art fp16",
             "value": round(fps * OUT_MPIX, 2), "unit": "MPix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(wall_max * 1e3 / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(wall_max * 1e3 / a.steps, 3), "higher_is_better": True, "scaling": "strong" if strips else "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": "configs[2]: swin_unet/art scale4 noise3 batch4 tile256 fp16, 1920x1080 frame, blend=0.0625 "
-                                   f"({n_tiles} tiles, 12 batches); synthetic-weight graph of that architecture, frame resident in HBM",
+                                   f"({frame_tiles} tiles, 12 batches); synthetic-weight graph of that architecture, frame resident in HBM",
                        "frames_per_s": round(fps, 3), "device_ms_per_frame": round(ms, 3), "frames_per_rank": a.steps,
-                       "parallelism": f"frame-sharded x{world}, no collectives",
-                       "pcie_inclusive_ms_per_frame": round(pcie_ms_one, 2),
-                       "pcie_pipelined_ms_per_frame": None if pipelined_ms is None else round(pipelined_ms, 2),
+                       "parallelism": (f"one frame in {world} tile-column strips (renderStrip), no collectives" if strips else f"frame-sharded x{world}, no collectives") + "; timing barrier over gloo",
+                       "mode": a.mode,
+                       "render_call_ms_pageable": round(pcie_ms_one, 2),
+                       "full_path_ms_per_frame": None if full_wall_max is None else round(full_wall_max * 1e3 / a.steps, 3),
+                       "full_path_frames_per_s": None if full_wall_max is None else round(a.steps * world / full_wall_max, 3),
+                       "full_path_mpix_per_s": None if full_wall_max is None else round(a.steps * world / full_wall_max * OUT_MPIX, 2),
+                       "full_path_note": "host frame in -> host frame out for all K frames on every rank (renderSequence, page-locked buffers, H2D/D2H on side streams); max over ranks",
                        "tiles_per_network_pass": eng.pass_tiles,
                        "algorithmic_tflop_per_frame": round(eng.plan_flops * live / 1e12, 4),
                        "families_ms_per_frame": {k: round(v[0], 3) for k, v in prof.items() if k != "frame_ms"}},

@@ -174,7 +174,7 @@ def to_u8(canvas_f32: np.ndarray) -> np.ndarray:
 
 
 def render(frame_bgr: np.ndarray, net, *, batch, tile, scaling, overlap, tta=False,
-           tta_bug_compat=False, net_dtype=None, progress=None) -> np.ndarray:
+           tta_bug_compat=False, net_dtype=None, progress=None, tile_out=None) -> np.ndarray:
     """trt::Img2Img::render, img2img_render.cpp:224-352.
 
     frame_bgr: HxWx3 u8 (ffmpeg bgr24, capture.cpp:99).  net(x[B,3,T,T] f32) -> [B,3,T',T'] f32.
@@ -188,9 +188,9 @@ def render(frame_bgr: np.ndarray, net, *, batch, tile, scaling, overlap, tta=Fal
     rgb = frame_bgr[..., ::-1]                                        # :227
     out_h, out_w = H * scaling, W * scaling
     canvas = np.zeros((out_h, out_w, 3), np.float32)                  # :228-229
-    # T' is discovered from the engine (img2img_load.cpp:203)
-    probe = net(np.zeros((batch, 3, tile, tile), np.float32))
-    tout = probe.shape[-1]
+    # T' is discovered from the engine's output tensor shape (img2img_load.cpp:203); callers that know it pass tile_out,
+    # otherwise one zero batch is pushed through the network to read it off
+    tout = int(tile_out) if tile_out else net(np.zeros((batch, 3, tile, tile), np.float32)).shape[-1]
     count, in_rects, out_rects = calculate_tiles(W, H, out_w, out_h, (tile, tile), (tout, tout),
                                                  scaling, overlap)
     overlapping = overlap[0] != 0 or overlap[1] != 0                  # :244

@@ -16,6 +16,25 @@ from test_gpu_parity import FRAME_MAX_LSB, make_engine, oracle16, smooth_frame
 pytestmark = pytest.mark.gpu
 
 
+def live_oracle16(path):
+    """The fp16-boundary oracle applied tile by tile to the slots that carry image data.  Batch items never interact (the ONNX batch
+    axis is a plain batch), and the zero tiles the reference appends to its last batch are dropped unread
+    (img2img_render.cpp:281,298-299), so skipping them changes nothing but the CPU time (14 of 16 slots at config 5)."""
+    run = oracle16(path)
+
+    def net(x):
+        y = None
+        for i in range(x.shape[0]):
+            if not x[i].any():
+                continue
+            yi = run(x[i:i + 1])
+            if y is None:
+                y = np.zeros((x.shape[0],) + yi.shape[1:], yi.dtype)
+            y[i] = yi[0]
+        return y
+    return net
+
+
 def full_size_properties(pkg, eng, tag, hw, scale, tile, batch, tta, stride):
     rows, cols = hw
     frame = smooth_frame(rows, cols, 7)
@@ -56,7 +75,7 @@ def test_config2_cunet_art_s2_n1_b4_t256_1080p(pkg, onnx_model):
     full_size_properties(pkg, eng, "configs[1] cunet/art s2 n1 B4 T256", (1080, 1920), 2, 256, 4, False, 220 - 16)
     small = smooth_frame(300, 420, 13)                                     # 2 x 2 tiles
     out = eng.render(small)
-    ref = pipeline.render(small, oracle16(path), batch=4, tile=256, scaling=2, overlap=(0.0625, 0.0625), net_dtype=np.float16)
+    ref = pipeline.render(small, live_oracle16(path), batch=4, tile=256, scaling=2, overlap=(0.0625, 0.0625), net_dtype=np.float16, tile_out=eng.output_tile_size)
     r = frame_report("config2[cunet/art s2 n1 B4 T256 300x420]", out, ref)
     assert r["psnr_db"] > 50.0 and r["max_lsb"] <= FRAME_MAX_LSB, r
     eng.close()
@@ -70,7 +89,7 @@ def test_config4_swin_photo_s4_n3_b8_t400_tta_1080p(pkg, onnx_model):
     full_size_properties(pkg, eng, "configs[3] swin_unet/photo s4 n3 B8 T400 +TTA", (1080, 1920), 4, 400, 8, True, 384 - 25)
     small = smooth_frame(120, 700, 17)                                     # 2 x 1 tiles, 16 steps = 2 batches of 8
     out = eng.render(small)
-    ref = pipeline.render(small, oracle16(path), batch=8, tile=400, scaling=4, overlap=(0.0625, 0.0625), tta=True, net_dtype=np.float16)
+    ref = pipeline.render(small, live_oracle16(path), batch=8, tile=400, scaling=4, overlap=(0.0625, 0.0625), tta=True, net_dtype=np.float16, tile_out=eng.output_tile_size)
     r = frame_report("config4[swin_unet/photo s4 n3 B8 T400 tta 120x700]", out, ref)
     assert r["psnr_db"] > 50.0 and r["max_lsb"] <= FRAME_MAX_LSB, r
     eng.close()
@@ -85,7 +104,7 @@ def test_config5_swin_art_scan_s4_n3_b16_t640_4k(pkg, onnx_model):
     full_size_properties(pkg, eng, "configs[4] swin_unet/art_scan s4 n3 B16 T640", (2160, 3840), 4, 640, 16, False, 624 - 40)
     small = smooth_frame(200, 1100, 19)                                    # 2 x 1 tiles
     out = eng.render(small)
-    ref = pipeline.render(small, oracle16(path), batch=16, tile=640, scaling=4, overlap=(0.0625, 0.0625), net_dtype=np.float16)
+    ref = pipeline.render(small, live_oracle16(path), batch=16, tile=640, scaling=4, overlap=(0.0625, 0.0625), net_dtype=np.float16, tile_out=eng.output_tile_size)
     r = frame_report("config5[swin_unet/art_scan s4 n3 B16 T640 200x1100]", out, ref)
     assert r["psnr_db"] > 50.0 and r["max_lsb"] <= FRAME_MAX_LSB, r
     eng.close()

@@ -27,3 +27,26 @@ def test_fused_mlp_kernels_agree_and_are_deterministic(tmp_path):
         assert float(ds) <= 5e-2, (C, M, stats, ds)
     twice = re.findall(r"run twice: (\d+) elements differ", out)
     assert len(twice) == 2 and all(int(n) == 0 for n in twice), out
+
+
+@pytest.mark.gpu
+def test_fused_attention96_schedules_agree_with_each_other_and_with_fp32(tmp_path):
+    """tools/ab/attn_ab.hip: the round-1 schedule of the C = 96 fused attention (2 windows per workgroup, a wave = 3 heads) against the
+    shipped one (4 windows per workgroup, a wave = a head, left-over queries of the four windows in one tile) on random token maps,
+    shifted and unshifted windows, several mask classes, window counts that do not fill the last workgroup - and both against a
+    plain fp32 host evaluation of y = x + proj(W-MSA(LN(x)))."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    csrc = os.path.join(ROOT, "waifu2x-tensorrt_amd", "csrc")
+    exe = str(tmp_path / "attn_ab")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", csrc, os.path.join(ROOT, "tools", "ab", "attn_ab.hip"),
+                    os.path.join(ROOT, "tools", "ab", "k_swinattn96_g2.hip"), os.path.join(csrc, "k_swinattn96.hip"), "-o", exe], check=True, timeout=900)
+    out = subprocess.run([exe, "timing"], check=True, capture_output=True, text=True, timeout=600).stdout   # + the headline size, timed, run twice
+    print(out)
+    ab = re.findall(r"g2 vs shipped max\|dy\|=([0-9.]+) .* nan=(\d+)", out)
+    host = re.findall(r"fp32 host evaluation: g2 max\|d\|=([0-9.]+) shipped max\|d\|=([0-9.]+)", out)
+    assert len(ab) == 5 and len(host) >= 3, out
+    assert re.search(r"shipped kernel run twice: 0 elements differ", out), out
+    for dy, nan in ab:
+        assert float(dy) <= 8e-3 and int(nan) == 0, out      # |y| is O(3): one fp16 ULP there is 2e-3; the two differ in summation order only
+    for a, b in host:
+        assert float(b) <= 1.2e-2 and float(b) <= float(a) + 4e-3, out

@@ -1,22 +1,20 @@
-// Fused transformer MLP branch for gfx950, wave-private variant:   y = x + W2 * gelu(W1 * LayerNorm(x) + b1) + b2
-// Same math and parameters as k_mlp.hip (which stages weight chunks through LDS behind workgroup barriers); here
-// every wave owns 16*TT token rows from the first load to the last store and there is no workgroup barrier at all:
-//   * x rows arrive as one flat, fully coalesced stream into the wave's LDS slab; each lane then reads the 16-byte pieces
-//     it will later use as MFMA fragments, LayerNorm statistics are the lane's own sums plus two row swaps, and the
-//     normalised pieces go back in place (piece (row, 8 channels) is touched by exactly one lane; LDS program order is
-//     the only ordering needed, see W2X_PHASE_FENCE);
-//   * weights are read straight from L2 as MFMA fragments in fragment-major order (engine.cpp: one contiguous KiB per
-//     wave load).  The fragment registers form a ring: right after the last MFMA that uses a fragment of hidden chunk c,
-//     the same registers are refilled with that fragment of chunk c+1, i.e. a prefetch distance of one whole chunk
-//     (2*KS + NT fragments) without a second register set;
-//   * GEMM1 is computed transposed (rows = 32 hidden units of the chunk, columns = tokens) so that the GELU'd
-//     accumulators are, as they stand, the A fragments of GEMM2 with a permuted k order (W2 is stored with the same
-//     permutation) - no LDS round trip between the two products;
-//   * the result tile goes through the slab once so that residual add and stores are flat 16-byte pieces again.
-// Register-ring mode (W2X_MLP2_RING=1): TT = 4 (64 rows per wave) for C = 96 and TT = 2 for C = 192 - a weight fragment feeds
-// TT MFMAs, and the 64 B/clk L1 -> register path sustains 4 SIMDs of MFMAs only from about 4 uses per fragment on.
-// Default (SHARE): the four waves of a workgroup stage each chunk once into LDS instead (the weight stream from L2 was 56 % of
-// the C = 192 kernel's time); TT = 2 for both widths, which leaves C = 96 at 140 VGPRs = 3 waves per SIMD.
+// Fused transformer MLP branch for gfx950, wave-private rows:   y = x + W2 * gelu(W1 * LayerNorm(x) + b1) + b2
+// Every wave owns 16*TT token rows from the first load to the last store:
+//   * x rows arrive as one flat, fully coalesced stream into the wave's LDS slab; each lane then reads the 16-byte pieces it
+//     uses as MFMA fragments, LayerNorm statistics are the lane's own sums plus two row swaps, and the normalised pieces are
+//     the operand registers of GEMM1 as they stand (LDS program order is the only ordering needed inside a wave, see
+//     W2X_PHASE_FENCE);
+//   * weights (SHARE, the shipped schedule): the four waves of a workgroup stage each 32-hidden-unit chunk once into LDS,
+//     fragment-major (engine.cpp: one contiguous KiB per wave load), double-buffered, one workgroup barrier per chunk - the
+//     per-wave weight stream from L2 was 56 % of the C = 192 kernel's time.  (!SHARE: a per-wave register ring straight from L2,
+//     kept for A/B runs);
+//   * GEMM1 is computed transposed (rows = 32 hidden units of the chunk, columns = tokens) so that the GELU'd accumulators
+//     are, as they stand, the B fragments of GEMM2 with a permuted k order (W2 is stored with the same permutation) - no LDS
+//     round trip between the two products; GEMM2 is transposed too (rows = output channels), so a lane ends with 4 consecutive
+//     channels of a token: b2 is the initial accumulator and the tile reaches the slab in 8-byte stores;
+//   * the result tile goes through the slab once so that residual add and stores are flat 16-byte pieces again; at C = 96 the
+//     raw x rows are still in the slab at that point (the weight buffers sit behind the slabs), so x is read from HBM once.
+// TT = 2 for both widths, which leaves C = 96 at 3 waves per SIMD.
 #include "kernels.h"
 
 namespace w2x {
@@ -56,11 +54,19 @@ __device__ __forceinline__ void sum_sq8(const half8 v, float& s, float& q) {
 __device__ __forceinline__ void swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ float rows_sum(float v) { float a = v, b = v; swap16(a, b); v = a + b; a = v; b = v; swap32(a, b); return a + b; }
+// (x * rstd + nm) on 8 halves with fp32 arithmetic: v_fma_mixlo / mixhi read the f16 halves directly and write f16 (one instruction
+// per element; the compiler's own lowering converts both ways around a packed fp32 fma)
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ half8 norm8(const half8 v, float rstd, float nm) {
-    half8 o;
+    uint4v x = __builtin_bit_cast(uint4v, v), o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (_Float16)fmaf((float)v[e], rstd, nm);
-    return o;
+    for (int d = 0; d < 4; ++d) {
+        unsigned r;
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(x[d]), "v"(rstd), "v"(nm));
+        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(x[d]), "v"(rstd), "v"(nm));
+        o[d] = r;
+    }
+    return __builtin_bit_cast(half8, o);
 }
 
 // The phases below hand data from lane to lane through the wave's own LDS slab.  The hardware executes a wave's LDS
@@ -85,8 +91,12 @@ struct Mlp2Cfg {
     static constexpr int NP = RW * PPR / 64;     // flat 16-byte pieces per lane
     static constexpr int SLAB = RW * LDX * 2;    // bytes per wave
     static constexpr int NF = 2 * KS + NT;       // weight fragments (KiB) per hidden chunk
-    static constexpr int WBUF = NF * 1024;       // SHARE: one staged chunk; two of them alias the slabs (x lives in registers by then)
-    static constexpr int SMEM = SHARE ? (NWV * SLAB > 2 * WBUF ? NWV * SLAB : 2 * WBUF) : NWV * SLAB;
+    static constexpr int WBUF = NF * 1024;       // SHARE: one staged chunk, two buffers
+    // KEEP (C = 96): the weight buffers sit behind the slabs (50.6 KB per workgroup, still 3 workgroups per CU), so the raw x rows stay
+    // in the slab and serve the residual add - x is read from HBM once.  Otherwise the buffers alias the slabs (x lives in
+    // registers by then) and the residual rows are fetched a second time.
+    static constexpr bool KEEP = SHARE && C == 96;
+    static constexpr int SMEM = KEEP ? NWV * SLAB + 2 * WBUF : SHARE ? (NWV * SLAB > 2 * WBUF ? NWV * SLAB : 2 * WBUF) : NWV * SLAB;
     static_assert(!SHARE || NF % NWV == 0, "fragments per wave");
     static_assert(RW * PPR % 64 == 0, "flat piece count");
 };
@@ -115,7 +125,7 @@ __global__ __launch_bounds__(NW * 64, (SHARE && TT <= 2 && C == 96 ? 3 : (NW >= 
     constexpr int NF = K::NF, NFW = NF / K::NWV;
     half8 w1r[2 * KS], w2r[NT];
     half8 stg[NFW];
-    _Float16* WB = (_Float16*)smem;
+    _Float16* WB = (_Float16*)(smem + (K::KEEP ? K::NWV * K::SLAB : 0));
     auto frag_src = [&](int ch, int f) { return f < 2 * KS ? W1 + (size_t)(ch * 2 * KS + f) * 512 : W2 + (size_t)(ch * NT + (f - 2 * KS)) * 512; };
     if (SHARE) {
 #pragma unroll
@@ -145,8 +155,9 @@ __global__ __launch_bounds__(NW * 64, (SHARE && TT <= 2 && C == 96 ? 3 : (NW >= 
     }
     W2X_PHASE_FENCE();
     // ---- LayerNorm in fragment layout: lane (fr, g) holds channels ks*32 + 8g .. +7 of row 16tt + fr, so the row sums are the
-    //      lane's own KS pieces plus the three other lane groups (two row swaps); normalised pieces go back in place
-    //      (rows without data hold zeros: 0 * rstd - 0)
+    //      lane's own KS pieces plus the three other lane groups (two row swaps).  SHARE: the normalised pieces are the operand
+    //      registers of GEMM1 as they stand; otherwise they go back in place (rows without data hold zeros: 0 * rstd - 0)
+    half8 xreg[TT][KS];
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
         half8 raw[KS];
@@ -159,25 +170,27 @@ __global__ __launch_bounds__(NW * 64, (SHARE && TT <= 2 && C == 96 ? 3 : (NW >= 
         const float rstd = rsqrtf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps);
         const float nm = -mean * rstd;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) *(half8*)(Xw + (tt * 16 + fr) * LDX + ks * 32 + g * 8) = norm8(raw[ks], rstd, nm);
+        for (int ks = 0; ks < KS; ++ks) {
+            if (SHARE) xreg[tt][ks] = norm8(raw[ks], rstd, nm);
+            else *(half8*)(Xw + (tt * 16 + fr) * LDX + ks * 32 + g * 8) = norm8(raw[ks], rstd, nm);
+        }
     }
     W2X_PHASE_FENCE();
-    half8 xreg[TT][KS];
     if (SHARE) {
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) xreg[tt][ks] = *(const half8*)(Xw + (tt * 16 + fr) * LDX + ks * 32 + g * 8);
-        __syncthreads();                       // every wave holds its rows in registers: the slab area becomes weight buffers
+        if (!K::KEEP) __syncthreads();         // every wave holds its rows in registers: the slab area becomes weight buffers
 #pragma unroll
         for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[i];
         __syncthreads();
     }
+    // GEMM2 is computed transposed as well (rows = output channels, columns = tokens): a lane ends with 4 consecutive channels of
+    // one token (8-byte slab stores) and b2 is the initial accumulator
     float4v acc2[TT][NT];
 #pragma unroll
-    for (int i = 0; i < TT; ++i)
+    for (int j = 0; j < NT; ++j) {
+        const float4v b2v = *(const float4v*)(p.b2 + j * 16 + g * 4);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc2[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < TT; ++i) acc2[i][j] = b2v;
+    }
 
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {   // fully unrolled: the ring registers are renamed statically
@@ -205,7 +218,7 @@ __global__ __launch_bounds__(NW * 64, (SHARE && TT <= 2 && C == 96 ? 3 : (NW >= 
                 if (!SHARE && ch + 1 < NCH) w1r[ht * KS + ks] = *(const half8*)(W1 + (size_t)(((ch + 1) * 2 + ht) * KS + ks) * 512);
             }
         }
-        // bias + GELU in place; lane holds hidden rows 16ht + 4g + j of token column fr -> A fragment of GEMM2 for the
+        // bias + GELU in place; lane holds hidden rows 16ht + 4g + j of token column fr -> B fragment of GEMM2 for the
         // k order (ht 0: slots 0..3, ht 1: slots 4..7)
         half8 a2[TT];
         {
@@ -222,12 +235,12 @@ __global__ __launch_bounds__(NW * 64, (SHARE && TT <= 2 && C == 96 ? 3 : (NW >= 
                                  (_Float16)g2[0], (_Float16)g2[1], (_Float16)g3[0], (_Float16)g3[1]};
             }
         }
-        // GEMM2: acc2[tt][nt] += H[tokens][chunk] * W2[16nt ..][chunk]^T
+        // GEMM2 (transposed): acc2[tt][nt] += W2[16nt ..][chunk] * H[tokens][chunk]^T
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const half8 wb = SHARE ? *(const half8*)(wcur + (size_t)(2 * KS + nt) * 512) : w2r[nt];
 #pragma unroll
-            for (int tt = 0; tt < TT; ++tt) acc2[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[tt], wb, acc2[tt][nt], 0, 0, 0);
+            for (int tt = 0; tt < TT; ++tt) acc2[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, a2[tt], acc2[tt][nt], 0, 0, 0);
             if (!SHARE && ch + 1 < NCH) w2r[nt] = *(const half8*)(W2 + (size_t)((ch + 1) * NT + nt) * 512);
         }
         if (SHARE) {   // hand the next chunk over: the other buffer was last read one iteration ago, before the previous barrier
@@ -240,23 +253,24 @@ __global__ __launch_bounds__(NW * 64, (SHARE && TT <= 2 && C == 96 ? 3 : (NW >= 
     }
 
     W2X_PHASE_FENCE();
-    // ---- epilogue: residual pieces are requested first, accumulators + b2 -> fp16 tile in the slab, then flat pieces
+    // ---- epilogue: residual pieces first (KEEP: from the slab, which still holds the raw rows; otherwise a second fetch),
+    //      accumulators -> fp16 tile in the slab, then flat pieces
     half8 xres[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-        const int idx = k * 64 + lane;
+        const int idx = k * 64 + lane, r = idx / PPR, c = idx - r * PPR;
         half8 h = {};
-        if (idx < npieces) h = *(const half8*)(X + (size_t)idx * 8);
+        if (K::KEEP) h = *(const half8*)(Xw + r * LDX + c * 8);
+        else if (idx < npieces) h = *(const half8*)(X + (size_t)idx * 8);
         xres[k] = h;
     }
+    W2X_PHASE_FENCE();
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const float b2 = p.b2[nt * 16 + fr];
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) Xw[(tt * 16 + g * 4 + j) * LDX + nt * 16 + fr] = (_Float16)(acc2[tt][nt][j] + b2);
-    }
+            *(half4*)(Xw + (tt * 16 + fr) * LDX + nt * 16 + g * 4) = (half4){(_Float16)acc2[tt][nt][0], (_Float16)acc2[tt][nt][1], (_Float16)acc2[tt][nt][2], (_Float16)acc2[tt][nt][3]};
     W2X_PHASE_FENCE();
     _Float16* __restrict__ Y = (_Float16*)p.y + row0 * C;
 #pragma unroll
