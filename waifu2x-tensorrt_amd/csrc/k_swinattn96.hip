@@ -26,6 +26,8 @@
 // initial accumulator, 8-byte LDS stores).
 #include "kernels.h"
 
+#include <algorithm>
+
 namespace w2x {
 namespace {
 
@@ -37,7 +39,14 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 typedef int int2v __attribute__((ext_vector_type(2)));
 typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 
-__device__ __attribute__((aligned(16))) unsigned kZeroPage[4] = {0u, 0u, 0u, 0u};   // source of rows that do not exist
+// Rows are fetched and stored through buffer resources over x / y: an offset at or beyond num_records reads zeros and drops
+// stores, so rows that do not exist (and the four idle lanes of a 16-lane row) need neither a predicate nor masking of the data.
+// Offsets are 32 bits: the launcher cuts passes of more than kMaxBufBytes into runs of whole images.
+constexpr unsigned kNoRow = 0xFFFFFFFFu;     // saturating adds keep it there
+constexpr size_t kMaxBufBytes = 0xFFFFFF00u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);   // raw buffer, 32-bit offsets, bounds-checked
+}
 
 __device__ __forceinline__ void sum_sq8(const half8 v, float& s, float& q) {
     const half2v one = {(_Float16)1.f, (_Float16)1.f};
@@ -120,7 +129,9 @@ constexpr int NTHR = 256, NU = 3;          // 4 waves, 3 (window, head) units pe
 constexpr int SLAB = 48, RPX = G * SLAB;   // slab rows per window (tokens 0..31, then 32..35 on rows 32, 36, 40, 44) / per workgroup
 constexpr int LDX = C + 8;                 // 104 halves
 constexpr int XS = RPX * LDX, OS = RP * LDX;
-constexpr int SMEM96 = (XS + OS) * 2 + RP * 8 + 16;
+constexpr int NPAD = G * 12;                // slab rows between the left-over tokens (kept at zero)
+constexpr int SMEM96 = (XS + OS) * 2 + (RP + NPAD) * 8 + 16;
+constexpr int DUMMY = XS * 2;              // byte offset of a row nobody reads at that point (first row of Os): target of the stores of lanes / rows without data
 constexpr int LPR = 16, PPR = C / 8, RPP = NTHR / LPR, NPASS = RP / RPP;   // row passes: 16 lanes per row (12 carry data), 16 rows per pass, 5 passes
 static_assert(NPASS == 5, "the row sums are reduced as 3 + 2 passes");
 
@@ -136,12 +147,12 @@ __device__ __forceinline__ void probs(const float4v s0, const float4v s1, float 
     p2 = (half4){(_Float16)__builtin_amdgcn_exp2f(s2 - mx), (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};   // slab row 32 + 4g = token 32 + g
 }
 
-__global__ __launch_bounds__(NTHR, 3) void swin_attn96_kernel(const SwinAttnParams p) {
+__global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* Xs = (_Float16*)smem;              // [RPX][LDX] normalised x slabs; later the output tile [RP][LDX] (token order)
     _Float16* Os = Xs + XS;                      // [RP][LDX]  attention output, all heads, token order
-    int2v* Pix = (int2v*)(Os + OS);              // [RP] {source pixel of the token row (-1: none), its slab row}
-    int* Cls = (int*)(Pix + RP);                 // [G] shift-mask class of each window
+    int2v* Pix = (int2v*)(Os + OS);              // [RP] {byte offset of the token row's pixel in x / y (kNoRow: none), byte offset of its slab row}, then [NPAD] {-, offset of a pad row}
+    int* Cls = (int*)(Pix + RP + NPAD);          // [G] shift-mask class of each window
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -149,7 +160,8 @@ __global__ __launch_bounds__(NTHR, 3) void swin_attn96_kernel(const SwinAttnPara
 
     const int iw0 = blockIdx.x * G, itotal = p.B * p.nwin;
     const int HW = p.nwin * NTOK;
-    const _Float16* __restrict__ X = (const _Float16*)p.x;
+    const unsigned xbytes = (unsigned)p.B * (unsigned)HW * (C * 2);
+    const __amdgpu_buffer_rsrc_t X = make_rsrc(p.x, xbytes), Y = make_rsrc(p.y, xbytes);
     const _Float16* __restrict__ Wqkv = (const _Float16*)p.wqkv_frag;    // [18 row tiles][3 k-steps][64 lanes][8] (engine.cpp frag_major)
     const _Float16* __restrict__ Wproj = (const _Float16*)p.wproj_frag;  // [6 row tiles][3 k-steps][64 lanes][8]
     const float4v zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -171,12 +183,15 @@ __global__ __launch_bounds__(NTHR, 3) void swin_attn96_kernel(const SwinAttnPara
     W2X_LOAD_W(hA)
 
     // ---- source pixel and slab row of every token row, worked out once per workgroup (one thread per row)
-    if (tid < RP) {
-        int pix = -1, srow = -1;
-        if (tid < R) {
+    if (tid < RP + NPAD) {
+        int pix = -1, srow = DUMMY;                      // pix: pixel index, stored as a byte offset
+        if (tid >= RP) {            // the 12 rows between tokens 32..35 of each slab
+            const int k = tid - RP, w = k >= 12 ? 1 : 0, kk = k - 12 * w;
+            srow = (w * SLAB + 33 + (kk / 3) * 4 + (kk % 3)) * LDX * 2;
+        } else if (tid < R) {
             const int w = tid >= NTOK ? 1 : 0, t = tid - w * NTOK;
             const int iw = iw0 + w;
-            srow = w * SLAB + slab_row(t);
+            srow = (w * SLAB + slab_row(t)) * LDX * 2;
             if (iw < itotal) {
                 const int wb = iw / p.nwin, wl = iw - wb * p.nwin;
                 if (p.ry >= 0) {
@@ -190,22 +205,22 @@ __global__ __launch_bounds__(NTHR, 3) void swin_attn96_kernel(const SwinAttnPara
                 if (t == 0) Cls[w] = p.maskid[wl];
             } else if (t == 0) Cls[w] = 0;
         }
-        Pix[tid] = (int2v){pix, srow};
+        Pix[tid] = (int2v){pix < 0 ? (int)kNoRow : pix * (C * 2), srow};
     }
     __syncthreads();
 
     // ---- gather + LayerNorm into the slabs
     {
         const int li = tid & (LPR - 1), rsub = tid / LPR;
+        const unsigned lane_off = li < PPR ? li * 16u : kNoRow;
         half8 xr[NPASS];
         int srow[NPASS];
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int2v pr = Pix[ps * RPP + rsub];
             srow[ps] = pr[1];
-            // rows that do not exist and the four idle lanes of a row read zeros (no masking of the data afterwards)
-            const _Float16* src = (pr[0] >= 0 && li < PPR) ? X + (size_t)pr[0] * C + li * 8 : (const _Float16*)kZeroPage;
-            xr[ps] = *(const half8*)src;
+            // rows that do not exist and the four idle lanes of a row read zeros
+            xr[ps] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(X, __builtin_elementwise_add_sat((unsigned)pr[0], lane_off), 0, 0));
         }
         float sm[NPASS], sq[NPASS];
 #pragma unroll
@@ -217,13 +232,15 @@ __global__ __launch_bounds__(NTHR, 3) void swin_attn96_kernel(const SwinAttnPara
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const float mean = sm[ps] * (1.f / C);
-            const float rstd = rsqrtf(fmaxf(sq[ps] * (1.f / C) - mean * mean, 0.f) + p.eps);
-            if (li < PPR && srow[ps] >= 0) *(half8*)(Xs + srow[ps] * LDX + li * 8) = norm8(xr[ps], rstd, -mean * rstd);
+            const float rstd = __builtin_amdgcn_rsqf(fmaxf(sq[ps] * (1.f / C) - mean * mean, 0.f) + p.eps);   // the argument is >= eps: no denormal scaling needed
+            // unconditional store: the four idle lanes of a row and rows without a token write to the dummy row
+            *(half8*)(smem + (li < PPR ? srow[ps] + li * 16 : DUMMY)) = norm8(xr[ps], rstd, -mean * rstd);
         }
         // the 12 rows between tokens 32..35 of each slab are multiplied like the rest (results ignored): keep them finite
-        for (int i = tid; i < G * 12 * PPR; i += NTHR) {
-            const int rr = i / PPR, c = i - rr * PPR, w = rr / 12, k = rr - w * 12;
-            *(half8*)(Xs + (w * SLAB + 33 + (k / 3) * 4 + (k % 3)) * LDX + c * 8) = zero8;
+#pragma unroll
+        for (int k = 0; k < (NPAD + RPP - 1) / RPP; ++k) {
+            const int pr = k * RPP + rsub;
+            if (pr < NPAD) *(half8*)(smem + (li < PPR ? Pix[RP + pr][1] + li * 16 : DUMMY)) = zero8;
         }
     }
     __syncthreads();
@@ -301,7 +318,8 @@ __global__ __launch_bounds__(NTHR, 3) void swin_attn96_kernel(const SwinAttnPara
                 av[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf, wv_[ks], av[tt], 0, 0, 0);
             }
         }
-        if (u == 1) { W2X_LOAD_W(hC) }   // the second head's fragments take over the registers
+        if (u == 1) { W2X_LOAD_W(hC) }   // the second head's fragments take over the registers (reloading each register right after its
+                                         // last use inside the loop above measured no faster and cost a spill)
         half4 qf[2], kf[3];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
@@ -377,14 +395,14 @@ __global__ __launch_bounds__(NTHR, 3) void swin_attn96_kernel(const SwinAttnPara
 
     // the residual rows are fetched now, under the projection
     half8 xres[NPASS];
-    int my_pix[NPASS];
+    unsigned my_off[NPASS];
     {
         const int li = tid & (LPR - 1), rsub = tid / LPR;
+        const unsigned lane_off = li < PPR ? li * 16u : kNoRow;
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
-            my_pix[ps] = Pix[ps * RPP + rsub][0];
-            const _Float16* src = (my_pix[ps] >= 0 && li < PPR) ? X + (size_t)my_pix[ps] * C + li * 8 : (const _Float16*)kZeroPage;
-            xres[ps] = *(const half8*)src;
+            my_off[ps] = __builtin_elementwise_add_sat((unsigned)Pix[ps * RPP + rsub][0], lane_off);
+            xres[ps] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(X, my_off[ps], 0, 0));
         }
     }
     // ---- proj, transposed: out^T = Wproj Os^T + b (rows = output channels, columns = tokens), so a lane ends with 4 consecutive
@@ -415,25 +433,23 @@ __global__ __launch_bounds__(NTHR, 3) void swin_attn96_kernel(const SwinAttnPara
 
     // ---- row pieces: + residual x, scatter store, LayerNorm statistics for the next op
     {
-        _Float16* __restrict__ Y = (_Float16*)p.y;
         const int li = tid & (LPR - 1), rsub = tid / LPR;
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int r = ps * RPP + rsub;
-            const int pix = my_pix[ps];
-            const bool ok = pix >= 0 && li < PPR;
-            half8 o = {};
-            if (ok) {
-                o = *(const half8*)(Xs + r * LDX + li * 8) + xres[ps];
-                *(half8*)(Y + (size_t)pix * C + li * 8) = o;
-            }
+            const bool ok = my_off[ps] != kNoRow;
+            // (idle lanes read the next row's first pieces - any finite or non-finite bits: their store is dropped)
+            half8 o = *(const half8*)(Xs + r * LDX + li * 8) + xres[ps];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, o), Y, my_off[ps], 0, 0);
             if (p.stats_out) {
+                if (!ok) o = half8{};
+                const size_t pix = my_off[ps] / (C * 2);
                 float s, q;
                 sum_sq8(o, s, q);
                 s = group_sum16(s);
                 q = group_sum16(q);
                 const float mean = s * (1.f / C);
-                if (ok && li == 0) { p.stats_out[2 * (size_t)pix] = mean; p.stats_out[2 * (size_t)pix + 1] = rsqrtf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps_out); }
+                if (ok && li == 0) { p.stats_out[2 * (size_t)pix] = mean; p.stats_out[2 * (size_t)pix + 1] = __builtin_amdgcn_rsqf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps_out); }
             }
         }
     }
@@ -444,10 +460,22 @@ __global__ __launch_bounds__(NTHR, 3) void swin_attn96_kernel(const SwinAttnPara
 hipError_t launch_swin_attn96(const SwinAttnParams& p, hipStream_t s) {
     static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
     if (hipError_t e = ensure_dynamic_lds((const void*)swin_attn96_kernel, SMEM96, lds_ok); e != hipSuccess) return e;
-    const long total_win = (long)p.B * p.nwin;
-    dim3 grid((unsigned)((total_win + G - 1) / G));
-    hipLaunchKernelGGL(swin_attn96_kernel, grid, dim3(NTHR), SMEM96, s, p);
-    return hipGetLastError();
+    // the kernel addresses x / y with 32-bit byte offsets: passes beyond that are cut into runs of whole images (windows never
+    // cross an image, the statistics rows follow the pixels)
+    const size_t img_bytes = (size_t)p.nwin * NTOK * C * 2;
+    if (img_bytes == 0 || img_bytes > kMaxBufBytes) return hipErrorInvalidValue;
+    const int per_run = (int)std::min<size_t>((size_t)p.B, kMaxBufBytes / img_bytes);
+    for (int b0 = 0; b0 < p.B; b0 += per_run) {
+        SwinAttnParams q = p;
+        q.B = std::min(per_run, p.B - b0);
+        q.x = (const char*)p.x + (size_t)b0 * img_bytes;
+        q.y = (char*)p.y + (size_t)b0 * img_bytes;
+        if (p.stats_out) q.stats_out = p.stats_out + (size_t)b0 * p.nwin * NTOK * 2;
+        const long total_win = (long)q.B * q.nwin;
+        hipLaunchKernelGGL(swin_attn96_kernel, dim3((unsigned)((total_win + G - 1) / G)), dim3(NTHR), SMEM96, s, q);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace w2x
