@@ -18,7 +18,7 @@ def test_fused_mlp_kernels_agree_and_are_deterministic(tmp_path):
     csrc = os.path.join(ROOT, "waifu2x-tensorrt_amd", "csrc")
     exe = str(tmp_path / "mlp_ab")
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", csrc, os.path.join(ROOT, "tools", "ab", "mlp_ab.hip"),
-                    os.path.join(ROOT, "tools", "ab", "k_mlp_staged.hip"), os.path.join(csrc, "k_mlp2.hip"), "-o", exe], check=True, timeout=900)
+                    os.path.join(ROOT, "tools", "ab", "k_mlp_staged.hip"), os.path.join(csrc, "k_mlp2.hip"), os.path.join(csrc, "k_mlp96p.hip"), "-o", exe], check=True, timeout=900)
     out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=600).stdout
     cases = re.findall(r"C=(\d+) M=(\d+) stats=(\d): max\|dy\|=([0-9.]+) .*max rel stats diff=([0-9.e+-]+)", out)
     assert len(cases) >= 18, out

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstring>
 #include <filesystem>
 #include <fstream>
 #include <map>
@@ -336,6 +337,16 @@ struct Img2Img::Impl {
         for (const Op& op : plan.ops)   // pixel-shuffle projections served by k_pixgemm.hip
             if (op.kind == OP_GEMM && ((op.g.omode == 2 && (op.g.amode == 0 || (op.g.amode == 2 && op.g.kh == 1 && op.g.kw == 1))) || (op.g.amode == 2 && op.g.kh == 2 && op.g.kw == 2 && op.g.stride == 2) || (op.g.amode == 2 && op.g.kh == 3 && op.g.kw == 3 && op.g.stride == 1 && op.g.omode == 0)) && op.g.K % 32 == 0 && op.g.N % 16 == 0 &&
                 plan.blobs[op.g.w].data.size() == (size_t)op.g.N * op.g.K * 2) frag_major_blob(op.g.w, op.g.N, op.g.K);
+        for (const Op& op : plan.ops)   // 48 -> 96 channel 3x3 convolution (k_conv48.hip): K = 432 padded with zero columns to 14 k-steps of 32
+            if (op.kind == OP_GEMM && op.g.amode == 2 && op.g.kh == 3 && op.g.kw == 3 && op.g.stride == 1 && op.g.omode == 0 && op.g.K == 432 && op.g.N == 96 &&
+                plan.tensors[op.g.a.t].C == 48 && !frag_blobs[op.g.w]) {
+                const auto& d = plan.blobs[op.g.w].data;
+                const int Kw = round_up(op.g.K, 8), Kp = 448;
+                if (d.size() != (size_t)op.g.N * Kw * 2) throw std::runtime_error("plan: weight shape");
+                std::vector<uint16_t> padded((size_t)op.g.N * Kp, 0);
+                for (int n = 0; n < op.g.N; ++n) memcpy(&padded[(size_t)n * Kp], d.data() + (size_t)n * Kw * 2, (size_t)op.g.K * 2);
+                upload_frag(op.g.w, frag_major(padded.data(), op.g.N, Kp));
+            }
         for (const Op& op : plan.ops)
             if (op.kind == OP_MLP && mlp_supported(op.m.C)) { frag_major_blob(op.m.w1, 2 * op.m.C, op.m.C); frag_w2_blob(op.m.w2, op.m.C); }
         for (const Op& op : plan.ops)
@@ -388,9 +399,9 @@ struct Img2Img::Impl {
                     if ((int)i == final_op && out_override) p.out.p = out_override;
                     stamp_begin(0, op.flops);
                     if (op.g.pool_out >= 0) pool_blocks[op.g.pool_out] = conv3_supported(p) ? conv3_tiles(p) : 0;   // partial sums per image written by this launch (0: plan default)
-                    hipAssert(pixgemm_supported(p) ? launch_pixgemm(p, stream) : conv3_supported(p) ? launch_conv3(p, stream) : stem_supported(p) ? launch_stem(p, stream) : launch_gemm(p, stream));
+                    hipAssert(pixgemm_supported(p) ? launch_pixgemm(p, stream) : conv3_supported(p) ? launch_conv3(p, stream) : conv48_supported(p) ? launch_conv48(p, stream) : stem_supported(p) ? launch_stem(p, stream) : launch_gemm(p, stream));
                     stamp_end();
-                    if (check_general && (pixgemm_supported(p) || conv3_supported(p) || stem_supported(p))) {   // diagnostic: the general kernel must agree
+                    if (check_general && (pixgemm_supported(p) || conv3_supported(p) || conv48_supported(p) || stem_supported(p))) {   // diagnostic: the general kernel must agree
                         const TensorDesc& od = plan.tensors[op.g.out.t];
                         const size_t n = (size_t)live * od.H * od.W * od.C;
                         std::vector<uint16_t> a(n), b(n);

@@ -1,0 +1,158 @@
+// Direct 3x3 convolution (stride 1, valid) from 48 to 96 channels for gfx950 - swin_unet's patch convolution, the last launch of
+// that graph that ran on the general implicit-GEMM kernel (k_gemm.hip: every input pixel fetched nine times from L2, 1.64x the
+// algorithmic HBM bytes, 19 % MFMA busy).  Same tiling as k_conv3.hip - a workgroup owns 4 output rows x 64 columns, the
+// 6 x 66 pixel halo tile goes to LDS once and serves all nine taps, wave w computes output row w as four 16-pixel m-tiles x six
+// n-tiles - but 48 channels are not a whole number of 32-wide k-steps, so K = 9 taps x 48 channels = 432 is taken as ONE flat
+// sequence of 14 k-steps (the last half step meets zero weights): lane group g of k-step s covers k = 32s + 8g .. +7, which is 8
+// consecutive channels of ONE tap ((4s+g) / 6) because 48 is a multiple of 8 - its A fragment is still a single 16-byte LDS read,
+// only the (tap, channel) offset differs per lane group.  The whole halo tile (all 48 channels, 44 KB) is staged once; weights
+// stream through LDS two k-steps at a time (fragment-major copy padded to 448 columns, staged by the four waves, double-buffered,
+// one barrier per stage).  The product is computed transposed (rows = output channels), so the epilogue is a float4 bias as the initial
+// accumulator, LeakyReLU / none on 4 consecutive channels of a pixel, 8-byte stores into a per-wave LDS tile, 16-byte row stores.
+#include "kernels.h"
+#include <cstdlib>
+
+namespace w2x {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+#define W2X_PHASE_FENCE() asm volatile("" ::: "memory")
+
+constexpr int CIN = 48, N = 96, NT = N / 16;
+constexpr int TH = 4, TW = 64, HR = TH + 2, HC = TW + 2;      // output tile, halo tile (pixels)
+constexpr int LDP = CIN + 8;                                    // halo pixel stride (halves): 112 B, the 16 pixels of a fragment fall on different banks
+constexpr int KSTEPS = 14, SK = 2, NSTAGE = KSTEPS / SK;        // k-steps of 32 over the padded K = 448; per weight stage
+constexpr int NF = SK * NT, NFW = NF / 4;                       // weight fragments (KiB) per stage / per wave
+constexpr int HALO = HR * HC * LDP * 2, WBUF = NF * 1024;
+constexpr int OT = 16 * (N + 8) * 2;                            // per-wave output m-tile
+constexpr int SMEM48 = HALO + 2 * WBUF;
+constexpr int PPP = CIN / 8;                                    // 16-byte pieces per halo pixel
+static_assert(4 * OT <= HALO && NF % 4 == 0 && KSTEPS % SK == 0, "layout");
+
+__global__ __launch_bounds__(256, 2) void conv48_kernel(const GemmParams p, int Ho, int Wo, int tiles_x, int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    _Float16* Hl = (_Float16*)smem;                                   // [HR][HC][LDP]
+    _Float16* WB = (_Float16*)(smem + HALO);                          // [2][NF][64][8]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    _Float16* Ot = (_Float16*)(smem + wv * OT);                       // [16][N+8], over the halo tile once the last tap is done (the loop ends with a barrier)
+
+    const int tpi = tiles_x * tiles_y;
+    const int b = blockIdx.x / tpi, trem = blockIdx.x - b * tpi;
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const _Float16* __restrict__ Ag = (const _Float16*)p.a.p + ((size_t)(b * p.a.Hs + p.a.y0 + oy0) * p.a.Ws + p.a.x0 + ox0) * CIN;
+    const _Float16* __restrict__ Wf = (const _Float16*)p.wt_frag + lane * 8;        // [NT][KSTEPS][64][8]
+    auto frag_src = [&](int sg, int f) { const int sl = f / NT, nt = f - sl * NT; return Wf + (size_t)(nt * KSTEPS + sg * SK + sl) * 512; };   // fragment f = (local k-step, n-tile) of stage sg
+
+    half8 stg[NFW];
+#pragma unroll
+    for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)frag_src(0, wv * NFW + i);
+
+    // ---- halo tile, all 48 channels (valid convolution: input extent = output extent + 2; pixels beyond it are zeros)
+    const int hrows = min(HR, Ho + 2 - oy0), hcols = min(HC, Wo + 2 - ox0);
+    for (int i = tid; i < HR * HC * PPP; i += 256) {
+        const int pix = i / PPP, c8 = i - pix * PPP, hr = pix / HC, hc = pix - hr * HC;
+        half8 h = {};
+        if (hr < hrows && hc < hcols) h = *(const half8*)(Ag + ((size_t)hr * p.a.Ws + hc) * CIN + c8 * 8);
+        *(half8*)(Hl + pix * LDP + c8 * 8) = h;
+    }
+#pragma unroll
+    for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[i];
+
+    // the product is computed transposed (rows = output channels, columns = 16 pixels), so a lane ends with 4 consecutive channels
+    // of one pixel: the bias is a float4 initial accumulator and the tile reaches LDS in 8-byte stores
+    float4v acc[4][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float4v bv = *(const float4v*)(p.bias + nt * 16 + g * 4);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = bv;
+    }
+    // this lane's piece of the A fragment of every k-step: k = 32s + 8g = (tap q / 6, channels 8 (q % 6) .. +7) with q = 4s + g;
+    // q >= 54 (the padded tail) reads tap 8 again and meets zero weights
+    const _Float16* arow = Hl + (wv * HC + fr) * LDP;
+    int aoff[KSTEPS];
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+        const int q = 4 * s + g, tap = q < 54 ? q / 6 : 8, ch = q < 54 ? q - (q / 6) * 6 : 0;
+        aoff[s] = ((tap / 3) * HC + tap % 3) * LDP + ch * 8;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int sg = 0; sg < NSTAGE; ++sg) {
+        const _Float16* wcur = WB + (size_t)(sg & 1) * (WBUF / 2) + lane * 8;
+        if (sg + 1 < NSTAGE) {
+#pragma unroll
+            for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)frag_src(sg + 1, wv * NFW + i);
+        }
+#pragma unroll
+        for (int sl = 0; sl < SK; ++sl) {
+            const int s = sg * SK + sl;
+            half8 xa[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) xa[mt] = *(const half8*)(arow + mt * 16 * LDP + aoff[s]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const half8 wb = *(const half8*)(wcur + (size_t)(sl * NT + nt) * 512);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, xa[mt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+        if (sg + 1 < NSTAGE) {
+#pragma unroll
+            for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)((sg + 1) & 1) * (WBUF / 2) + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[i];
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: output row oy0 + wv, four m-tiles of 16 pixels through the wave's LDS tile
+    const int oy = oy0 + wv;
+    _Float16* __restrict__ Og = (_Float16*)p.out.p + ((size_t)(b * p.out.Hs + oy) * p.out.Ws + ox0) * p.out.Cs;
+    constexpr int PPO = N / 8, NPO = 16 * PPO / 64;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float4v v = acc[mt][nt];
+            if (p.act == 1) v = __builtin_elementwise_max(v, v * p.alpha);      // LeakyReLU with a slope in [0, 1] (conv48_supported) = max(v, slope v)
+            *(half4*)(Ot + fr * (N + 8) + nt * 16 + g * 4) = (half4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        }
+        W2X_PHASE_FENCE();
+#pragma unroll
+        for (int k = 0; k < NPO; ++k) {
+            const int idx = k * 64 + lane, px = idx / PPO, c = idx - px * PPO;
+            if (oy < Ho && ox0 + mt * 16 + px < Wo)
+                *(half8*)(Og + (size_t)(mt * 16 + px) * p.out.Cs + c * 8) = *(const half8*)(Ot + px * (N + 8) + c * 8);
+        }
+        W2X_PHASE_FENCE();
+    }
+}
+
+}  // namespace
+
+bool conv48_supported(const GemmParams& p) {
+    static const bool off = getenv("W2X_NO_CONV48") != nullptr;   // A/B switch (read once per process)
+    if (off || !p.wt_frag || p.amode != 2 || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.omode != 0 || p.ln || (p.act != 0 && p.act != 1) ||
+        p.has_clip || p.stats_out || p.pool_out || p.res.p || p.res2.p) return false;
+    if (p.act == 1 && !(p.alpha >= 0.f && p.alpha <= 1.f)) return false;
+    if (p.a.Cs != CIN || p.N != N || p.K != 9 * CIN || p.out.Cs != N || p.aW <= 0 || p.Mrows % p.aW) return false;
+    const int Ho = p.Mrows / p.aW, Wo = p.aW;
+    return p.a.y0 + Ho + 2 <= p.a.Hs && p.a.x0 + Wo + 2 <= p.a.Ws && p.out.Hs >= Ho && p.out.Ws >= Wo;
+}
+
+hipError_t launch_conv48(const GemmParams& p, hipStream_t s) {
+    static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
+    if (hipError_t e = ensure_dynamic_lds((const void*)conv48_kernel, SMEM48, lds_ok); e != hipSuccess) return e;
+    const int Ho = p.Mrows / p.aW, Wo = p.aW;
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
+    hipLaunchKernelGGL(conv48_kernel, dim3((unsigned)(p.B * tiles_x * tiles_y)), dim3(256), SMEM48, s, p, Ho, Wo, tiles_x, tiles_y);
+    return hipGetLastError();
+}
+
+}  // namespace w2x

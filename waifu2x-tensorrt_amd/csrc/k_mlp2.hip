@@ -17,6 +17,8 @@
 // TT = 2 for both widths, which leaves C = 96 at 3 waves per SIMD.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace w2x {
 namespace {
 
@@ -303,10 +305,16 @@ hipError_t launch_mlp2_c(const MlpParams& p, hipStream_t s) {
 
 }  // namespace
 
+bool mlp96p_supported(const MlpParams& p);                        // k_mlp96p.hip: C = 96 with both matrices resident in LDS
+hipError_t launch_mlp96p(const MlpParams& p, hipStream_t s);
+
 hipError_t launch_mlp2(const MlpParams& p, hipStream_t s) {
-    // Shared-weight schedule, 32 rows per wave, 4 waves per workgroup for both widths.  Measured alternatives (git history): 6 / 12
-    // waves per workgroup 2.45 / 1.86 ms of MLP time per frame against 1.58; the per-wave register ring (SHARE = false, TT = 4) and
-    // 64 rows per wave with shared weights were slower as well.
+    // C = 96: the resident-weight kernel (k_mlp96p.hip); W2X_MLP96_CHUNKED=1 (read once per process) keeps this file's chunked
+    // schedule for A/B runs.  C = 192 (weights 288 KiB): shared-weight schedule, 32 rows per wave, 4 waves per workgroup.
+    // Measured alternatives (git history): 6 / 12 waves per workgroup 2.45 / 1.86 ms of MLP time per frame against 1.58; the
+    // per-wave register ring (SHARE = false, TT = 4) and 64 rows per wave with shared weights were slower as well.
+    static const bool chunked96 = getenv("W2X_MLP96_CHUNKED") != nullptr;
+    if (p.C == 96 && !chunked96 && mlp96p_supported(p)) return launch_mlp96p(p, s);
     if (p.C == 96) return launch_mlp2_c<96, 2, 4, true>(p, s);
     if (p.C == 192) return launch_mlp2_c<192, 2, 4, true>(p, s);
     return hipErrorInvalidValue;

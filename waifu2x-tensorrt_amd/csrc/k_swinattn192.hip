@@ -53,7 +53,7 @@ __device__ __forceinline__ void swap16(float& a, float& b) { asm volatile("s_nop
 __device__ __forceinline__ void group_sum32_x6(float& a, float& b, float& c, float& d, float& e, float& f) {
     float ta, tb, tc, td, te, tf;
     asm volatile(
-        "s_nop 1\n\t" W2X_DPP6("quad_perm:[1,0,3,2]") W2X_DPP6("quad_perm:[2,3,0,1]") W2X_DPP6("row_half_mirror") W2X_DPP6("row_mirror")
+        "s_nop 2\n\t" W2X_DPP6("quad_perm:[1,0,3,2]") W2X_DPP6("quad_perm:[2,3,0,1]") W2X_DPP6("row_half_mirror") W2X_DPP6("row_mirror")
         "v_mov_b32 %6, %0\n\tv_mov_b32 %7, %1\n\tv_mov_b32 %8, %2\n\tv_mov_b32 %9, %3\n\tv_mov_b32 %10, %4\n\tv_mov_b32 %11, %5\n\t"
         "v_permlane16_swap_b32 %0, %6\n\tv_permlane16_swap_b32 %1, %7\n\tv_permlane16_swap_b32 %2, %8\n\t"
         "v_permlane16_swap_b32 %3, %9\n\tv_permlane16_swap_b32 %4, %10\n\tv_permlane16_swap_b32 %5, %11\n\t"

@@ -84,11 +84,11 @@ __device__ __forceinline__ float group_sum16(float v) {
 #define W2X_DPP6(CTRL) W2X_DPP1("%0", CTRL) W2X_DPP1("%1", CTRL) W2X_DPP1("%2", CTRL) W2X_DPP1("%3", CTRL) W2X_DPP1("%4", CTRL) W2X_DPP1("%5", CTRL)
 #define W2X_DPP4(CTRL) W2X_DPP1("%0", CTRL) W2X_DPP1("%1", CTRL) W2X_DPP1("%2", CTRL) W2X_DPP1("%3", CTRL)
 __device__ __forceinline__ void group_sum16_x4(float& a, float& b, float& c, float& d) {
-    asm volatile("s_nop 1\n\t" W2X_DPP4("quad_perm:[1,0,3,2]") W2X_DPP4("quad_perm:[2,3,0,1]") W2X_DPP4("row_half_mirror") W2X_DPP4("row_mirror")
+    asm volatile("s_nop 2\n\t" W2X_DPP4("quad_perm:[1,0,3,2]") W2X_DPP4("quad_perm:[2,3,0,1]") W2X_DPP4("row_half_mirror") W2X_DPP4("row_mirror")
                  : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 __device__ __forceinline__ void group_sum16_x6(float& a, float& b, float& c, float& d, float& e, float& f) {
-    asm volatile("s_nop 1\n\t" W2X_DPP6("quad_perm:[1,0,3,2]") W2X_DPP6("quad_perm:[2,3,0,1]") W2X_DPP6("row_half_mirror") W2X_DPP6("row_mirror")
+    asm volatile("s_nop 2\n\t" W2X_DPP6("quad_perm:[1,0,3,2]") W2X_DPP6("quad_perm:[2,3,0,1]") W2X_DPP6("row_half_mirror") W2X_DPP6("row_mirror")
                  : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
 }
 // Maximum over the four lanes that hold one query column (lanes fr, fr+16, fr+32, fr+48) for two / three independent values.
