@@ -107,6 +107,22 @@ def test_render_matches_oracle(pkg, onnx_model, model, scale, batch, tile, small
     eng.close()
 
 
+def test_opset13_graph_with_decomposed_layernorm_runs_on_the_fused_kernels(pkg, onnx_model):
+    """The same weights exported at opset 13 (LayerNorm as a ReduceMean / Sub / Pow / ... chain) build, lower onto the same fused
+    kernels and give the same bytes as the opset-17 file."""
+    p13, p17 = onnx_model("swin_unet/art", 4, 2, 64, opset=13), onnx_model("swin_unet/art", 4, 2, 64, opset=17)
+    frame = smooth_frame(100, 140, 9)
+    outs = []
+    for path in (p13, p17):
+        eng = make_engine(pkg, path, 2, 64, 4)
+        outs.append(eng.render(frame))
+        eng.close()
+    assert np.array_equal(outs[0], outs[1])
+    ref = pipeline.render(frame, oracle16(p13), batch=2, tile=64, scaling=4, overlap=(0.0625, 0.0625), net_dtype=np.float16)
+    r = frame_report("render[swin_unet/art s4 B2 T64 full opset13]", outs[0], ref)
+    assert r["psnr_db"] > 50.0 and r["max_lsb"] <= FRAME_MAX_LSB, r
+
+
 def test_tta_bug_compat_mode(pkg, onnx_model):
     """Quirk Q1 (img2img_render.cpp:313-316): optional bug-compatible TTA blends the last de-augmented output."""
     path = onnx_model("swin_unet/art", 2, 4, 64, small=True)
@@ -153,6 +169,33 @@ def test_error_paths(pkg, onnx_model, tmp_path):
     stem = os.path.splitext(os.path.basename(path))[0]
     assert any(n.startswith(stem + "_") and n.endswith(".json") for n in names) and any(n.endswith(".w2x") for n in names)
     eng.close()
+
+
+def test_compatible_but_not_optimized_engine_is_respecialised(pkg, onnx_model):
+    """img2img_load.cpp:100-107: load() takes the first optimized engine, else the first compatible one.  An engine built with a
+    range (min 1 / opt 2 / max 4 tiles of 64..96) serves a render configuration inside the range that is not its opt shape: the plan is
+    specialised again from the same ONNX file (a warning says so) and the frame is the one a dedicated build gives."""
+    path = onnx_model("swin_unet/art", 4, 1, 64, noise=2)
+    frame = smooth_frame(90, 120, 31)
+    eng = pkg.Img2Img()
+    bc = pkg.BuildConfig(0, pkg.Precision.FP16, 1, 2, 4, 3, 3, 3, 64, 64, 96, 64, 64, 96)
+    assert eng.build(path, bc), eng.last_error()
+    assert eng.load(path, pkg.RenderConfig(batchSize=4, height=64, width=64, scaling=4)), eng.last_error()      # inside the range, not opt
+    assert any("compatible with but not optimized" in m for _, m in eng.messages)
+    assert eng.pass_tiles == 4
+    got = eng.render(frame)
+    assert eng.load(path, pkg.RenderConfig(batchSize=8, height=64, width=64, scaling=4)) is False               # outside the range
+    assert "could not satisfy render configuration" in eng.last_error()
+    eng.close()
+    ref = make_engine(pkg, path, 4, 64, 4)          # adds a dedicated (optimized) engine file next to the ranged one
+    assert np.array_equal(ref.render(frame), got)
+    ref.close()
+    eng = pkg.Img2Img()
+    assert eng.load(path, pkg.RenderConfig(batchSize=4, height=64, width=64, scaling=4)), eng.last_error()      # now the optimized one wins
+    assert not any("not optimized" in m for _, m in eng.messages)
+    eng.close()
+    bad = pkg.BuildConfig(0, pkg.Precision.FP16, 4, 2, 1, 3, 3, 3, 64, 64, 64, 64, 64, 64)
+    assert pkg.Img2Img().build(path, bad) is False                                                               # min > opt
 
 
 def test_headline_config_properties(pkg, onnx_model):

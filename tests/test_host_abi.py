@@ -62,6 +62,21 @@ def test_lowering_covers_graph_and_counts_flops(pkg, onnx_model, model, scale, t
     assert f"out=[2,3,{to},{to}]" in d
 
 
+@pytest.mark.parametrize("model,scale,small", [("swin_unet/art", 4, True), ("swin_unet/art", 4, False), ("cunet/art", 2, False)])
+def test_opset13_export_with_decomposed_layernorm_lowers_to_the_same_plan(pkg, onnx_model, model, scale, small):
+    """nvonnxparser takes whatever opset the file was written with (img2img_build.cpp:81-88).  Below opset 17 LayerNorm arrives as
+    ReduceMean / Sub / Pow / ReduceMean / Add / Sqrt / Div / Mul / Add; the lowering must fold that chain exactly like the
+    LayerNormalization node: same fused ops, same FLOP count (names aside), and the oracle agrees between the two files."""
+    p13, p17 = onnx_model(model, scale, 2, 64, small=small, opset=13), onnx_model(model, scale, 2, 64, small=small, opset=17)
+    strip = lambda d: [re.sub(r"\[[^\]]*\]$", "", line) for line in d.splitlines()[2:]]
+    d13, d17 = pkg.describe_plan(p13, 2, 64), pkg.describe_plan(p17, 2, 64)
+    assert strip(d13) == strip(d17)
+    assert re.search(r"flops=(\d+)", d13).group(1) == re.search(r"flops=(\d+)", d17).group(1)
+    if small or model.startswith("cunet"):
+        x = np.random.default_rng(0).random((2, 3, 64, 64), dtype=np.float32)
+        assert np.abs(onnx_exec.Executor(p13).run(x) - onnx_exec.Executor(p17).run(x)).max() < 1e-5
+
+
 def test_lowering_rejects_wrong_shape_and_garbage(pkg, onnx_model, tmp_path):
     import synth_models as sm
     path = sm.export_onnx(sm.make_model("cunet/art", 2), str(tmp_path / "static.onnx"), 2, 64, dynamic=False)

@@ -55,8 +55,38 @@ def run(tag, model, scale, noise, batch, tile, hw, tta=False, oracle_hw=None):
     print(msg, flush=True)
     eng.close()
 
+def graph_delta(tag, model, scale, noise, batch, tile, hw):
+    """hipGraph replay of the network passes against plain launches (W2X_NO_GRAPH, read at load): resident ms per frame and the
+    wall time of render() calls, same engine file, same frame; outputs must be identical."""
+    path = sm.model_path(os.path.join(work, tag), model, scale, noise)
+    if not os.path.exists(path):
+        sm.export_onnx(sm.make_model(model, scale, seed=1234 + noise), path, 1, tile, dynamic=True)
+    f = frame(hw[0], hw[1], 3)
+    res = {}
+    for mode in ("graph", "plain"):
+        if mode == "plain": os.environ["W2X_NO_GRAPH"] = "1"
+        else: os.environ.pop("W2X_NO_GRAPH", None)
+        eng = pkg.Img2Img()
+        assert eng.build(path, pkg.BuildConfig.fixed(batch, tile)), eng.last_error()
+        assert eng.load(path, pkg.RenderConfig(batchSize=batch, height=tile, width=tile, scaling=scale)), eng.last_error()
+        out = eng.render(f); eng.render(f); eng.render(f)          # eager, capture, replay
+        ms = eng.bench_resident(5)
+        t0 = time.perf_counter()
+        for _ in range(5): eng.render(f)
+        wall = (time.perf_counter() - t0) / 5 * 1e3
+        n = pkg.calculate_tiles(hw[1], hw[0], hw[1] * scale, hw[0] * scale, tile, eng.output_tile_size, scale, (0.0625, 0.0625))[0]
+        res[mode] = (ms, wall, out, n, eng.pass_tiles)
+        eng.close()
+    os.environ.pop("W2X_NO_GRAPH", None)
+    g_, p_ = res["graph"], res["plain"]
+    print(f"{tag}: {model} s{scale} B{batch} T{tile} {hw[1]}x{hw[0]}: {g_[3]} tiles in passes of {g_[4]}: hipGraph replay {g_[0]:.2f} ms/frame resident "
+          f"({g_[1]:.2f} ms per render() call) vs plain launches {p_[0]:.2f} ms ({p_[1]:.2f} ms per call); identical output: {np.array_equal(g_[2], p_[2])}", flush=True)
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["2", "4", "5"]
+    which = sys.argv[1:] or ["2", "4", "5", "g"]
+    if "g" in which:
+        graph_delta("graph_t64", "swin_unet/art", 4, 3, 1, 64, (1080, 1920))      # S = 1: one tile per pass, ~40 launches per tile
+        graph_delta("graph_cfg5", "swin_unet/art_scan", 4, 3, 16, 640, (2160, 3840))
     if "2" in which: run("cfg2", "cunet/art", 2, 1, 4, 256, (1080, 1920), oracle_hw=(200, 300))
     if "4" in which: run("cfg4", "swin_unet/photo", 4, 3, 8, 400, (1080, 1920), tta=True, oracle_hw=(100, 380))
     if "5" in which: run("cfg5", "swin_unet/art_scan", 4, 3, 16, 640, (2160, 3840), oracle_hw=(120, 600))

@@ -140,6 +140,31 @@ bool isOptimized(const RenderConfig& r, const BuildConfig& b) {
 
 constexpr const char* kEngineExt = ".w2x";
 
+// Lowering of a model for one input shape, shared by build() (which writes the result to disk) and by load() when the render
+// configuration lies inside an engine's [min, max] range but is not the shape that engine was specialised for.
+// Super-batching: tiles are independent, so one network pass may carry several reference batches (S x batchSize tiles); results
+// are bit-identical, launches per frame drop S-fold and the low-resolution stages fill all 256 CUs.  W2X_SUPERBATCH overrides;
+// the default targets the pixel count of 48 tiles of 256x256 per pass (one 1080p frame at config 3), capped at 64 tiles; small
+// tiles (< 128) keep S = 1.
+Plan lower_for_shape(const std::string& onnxModelPath, int batch, int channels, int height, int width) {
+    int S = 1;
+    if (const char* env = getenv("W2X_SUPERBATCH")) S = std::max(1, atoi(env));
+    else if (height >= 128) {
+        const double want = 48.0 * 256 * 256 / ((double)batch * height * width);
+        S = std::max(1, (int)std::lround(want));
+        while (S > 1 && S * batch > 64) --S;
+    }
+    Plan plan;
+    try {
+        plan = build_plan(onnxModelPath, batch * S, channels, height, width);
+    } catch (const std::exception&) {
+        if (S == 1) throw;
+        plan = build_plan(onnxModelPath, batch, channels, height, width);   // e.g. a graph with a static batch dimension
+    }
+    plan.userB = batch;
+    return plan;
+}
+
 }  // namespace
 
 struct Img2Img::Impl {
@@ -599,28 +624,16 @@ bool Img2Img::build(const std::string& onnxModelPath, const BuildConfig& config)
         W2X_LOG(error, "Failed to set precision: platform does not support TF32");
         return false;
     }
-    // :81-88 parse ; :102-116 one profile - the plan is specialised for the opt shape, channels come from the model
-    // Super-batching: tiles are independent, so one network pass may carry several reference batches (S x batchSize
-    // tiles); results are bit-identical, launches per frame drop S-fold and the low-resolution stages fill all 256 CUs.
-    // W2X_SUPERBATCH overrides; default targets the pixel count of 48 tiles of 256x256 per pass (one 1080p frame at
-    // config 3), capped at 64 tiles; small tiles (< 128) keep S = 1.
-    int S = 1;
-    if (const char* env = getenv("W2X_SUPERBATCH")) S = std::max(1, atoi(env));
-    else if (config.optHeight >= 128) {
-        const double want = 48.0 * 256 * 256 / ((double)config.optBatchSize * config.optHeight * config.optWidth);
-        S = std::max(1, (int)std::lround(want));
-        while (S > 1 && S * config.optBatchSize > 64) --S;
+    // :81-88 parse ; :102-116 one profile: the plan on disk is specialised for the opt shape (channels come from the model);
+    // any other shape inside [min, max] is specialised by load() from the same ONNX file
+    if (config.minBatchSize > config.optBatchSize || config.optBatchSize > config.maxBatchSize || config.minWidth > config.optWidth || config.optWidth > config.maxWidth ||
+        config.minHeight > config.optHeight || config.optHeight > config.maxHeight || config.minChannels > config.optChannels || config.optChannels > config.maxChannels) {
+        W2X_LOG(error, "Failed to build engine: optimization profile is not min <= opt <= max.");
+        return false;
     }
     Plan plan;
     try {
-        try {
-            plan = build_plan(onnxModelPath, config.optBatchSize * S, config.optChannels, config.optHeight, config.optWidth);
-        } catch (const std::exception&) {
-            if (S == 1) throw;
-            S = 1;   // e.g. a graph with a static batch dimension
-            plan = build_plan(onnxModelPath, config.optBatchSize, config.optChannels, config.optHeight, config.optWidth);
-        }
-        plan.userB = config.optBatchSize;
+        plan = lower_for_shape(onnxModelPath, config.optBatchSize, config.optChannels, config.optHeight, config.optWidth);
     } catch (const std::exception& e) {
         W2X_LOG(error, "Failed to parse ONNX model: " + std::string(e.what()) + ".");
         return false;
@@ -659,6 +672,7 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
     }
     // :79-114 getEnginePath
     std::string enginePath;
+    bool optimized = false;
     try {
         if (!fs::exists(modelPath)) throw std::runtime_error("model file does not exist");
         const std::string runningOn = hipGetDeviceName(dev);
@@ -674,8 +688,10 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
             if (!fs::exists(configPath)) continue;
             BuildConfig bc; std::string builtOn;
             deserializeConfig(configPath, bc, builtOn);
-            // the plan is specialised for the opt shape, so only an optimized match can run
-            if (isCompatible(config, bc, builtOn, runningOn) && isOptimized(config, bc)) { enginePath = path.string(); break; }
+            // img2img_load.cpp:100-107: the first optimized engine, else the first compatible one
+            if (!isCompatible(config, bc, builtOn, runningOn)) continue;
+            if (isOptimized(config, bc)) { enginePath = path.string(); optimized = true; break; }
+            if (enginePath.empty()) enginePath = path.string();
         }
         if (enginePath.empty()) throw std::runtime_error("could not satisfy render configuration");
     } catch (const std::exception& e) {
@@ -700,6 +716,19 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
     } catch (const std::exception& e) {
         W2X_LOG(error, "Failed to deserialize engine from buffer: " + std::string(e.what()) + ".");
         return false;
+    }
+    if (!optimized) {
+        // A TensorRT engine runs any shape of its optimization profile (img2img_build.cpp:102-116); a plan is specialised for one
+        // shape, so for a compatible-but-not-optimized engine the same ONNX file is lowered again for the requested shape (the
+        // engine file only vouches for the device, the precision and the range).
+        W2X_LOG(warn, "Engine \"" + enginePath + "\" is compatible with but not optimized for the render configuration; specialising the plan for batch " +
+                          std::to_string(config.batchSize) + ", tile " + std::to_string(config.width) + "x" + std::to_string(config.height) + ".");
+        try {
+            impl->plan = lower_for_shape(modelPath, config.batchSize, config.channels, config.height, config.width);
+        } catch (const std::exception& e) {
+            W2X_LOG(error, "Failed to set input tensor shape: " + std::string(e.what()) + ".");
+            return false;
+        }
     }
     const Plan& plan = impl->plan;
     // :197-203 - the input shape must be the one the plan was specialised for; T' is read from the plan

@@ -4,10 +4,10 @@
 //     uses as MFMA fragments, LayerNorm statistics are the lane's own sums plus two row swaps, and the normalised pieces are
 //     the operand registers of GEMM1 as they stand (LDS program order is the only ordering needed inside a wave, see
 //     W2X_PHASE_FENCE);
-//   * weights (SHARE, the shipped schedule): the four waves of a workgroup stage each 32-hidden-unit chunk once into LDS,
-//     fragment-major (engine.cpp: one contiguous KiB per wave load), double-buffered, one workgroup barrier per chunk - the
-//     per-wave weight stream from L2 was 56 % of the C = 192 kernel's time.  (!SHARE: a per-wave register ring straight from L2,
-//     kept for A/B runs);
+//   * weights: the four waves of a workgroup stage each 32-hidden-unit chunk once into LDS by LDS-DMA (global_load_lds: the
+//     fragment-major copy of engine.cpp makes a fragment one contiguous KiB = one wave instruction, no registers in between),
+//     double-buffered, one workgroup barrier per chunk - per-wave weight streams from L2 were 56 % of the C = 192 kernel's time -
+//     and read them into a ring of six registers, each fragment six fragments ahead of its use;
 //   * GEMM1 is computed transposed (rows = 32 hidden units of the chunk, columns = tokens) so that the GELU'd accumulators
 //     are, as they stand, the B fragments of GEMM2 with a permuted k order (W2 is stored with the same permutation) - no LDS
 //     round trip between the two products; GEMM2 is transposed too (rows = output channels), so a lane ends with 4 consecutive
@@ -76,14 +76,15 @@ __device__ __forceinline__ half8 norm8(const half8 v, float rstd, float nm) {
 // hipcc from forwarding a lane's own store to its later load or moving slab accesses across a phase boundary.
 // History: a first version exchanged per-row LayerNorm statistics through a small float table in the slab
 // (ds_write_b64 by lane = row, ds_read_b64 by the fragment lanes a few instructions later).  That exchange returned stale
-// values on the second wave of a SIMD at full problem size (tools/mlp_ab.hip reproduces it: first workgroup per CU always
+// values on the second wave of a SIMD at full problem size (tools/ab/mlp_ab.hip reproduces it: first workgroup per CU always
 // right, co-resident ones wrong, not cured by s_waitcnt / s_barrier) and was replaced by register swaps.
 #define W2X_PHASE_FENCE() asm volatile("" ::: "memory")
+#define W2X_RING_FENCE() asm volatile("" ::: "memory")   // keeps a ring refill where it is written (the scheduler would sink it to its use)
 
-template <int C, int TT, int NW, bool SHARE>
+template <int C, int TT, int NW>
 struct Mlp2Cfg {
     static constexpr int RW = 16 * TT;           // rows per wave
-    static constexpr int NWV = NW;               // independent waves per workgroup
+    static constexpr int NWV = NW;               // waves per workgroup
     static constexpr int BM = NWV * RW;          // rows per workgroup
     static constexpr int LDX = C + 8;            // slab row stride in halves: 16-byte pieces rotate over the banks
     static constexpr int PPR = C / 8;            // 16-byte pieces per row
@@ -93,27 +94,30 @@ struct Mlp2Cfg {
     static constexpr int NP = RW * PPR / 64;     // flat 16-byte pieces per lane
     static constexpr int SLAB = RW * LDX * 2;    // bytes per wave
     static constexpr int NF = 2 * KS + NT;       // weight fragments (KiB) per hidden chunk
-    static constexpr int WBUF = NF * 1024;       // SHARE: one staged chunk, two buffers
+    static constexpr int WBUF = NF * 1024;       // one staged chunk, two buffers
+    static constexpr int RING = 6;               // weight-fragment registers of a wave
     // KEEP (C = 96): the weight buffers sit behind the slabs (50.6 KB per workgroup, still 3 workgroups per CU), so the raw x rows stay
     // in the slab and serve the residual add - x is read from HBM once.  Otherwise the buffers alias the slabs (x lives in
     // registers by then) and the residual rows are fetched a second time.
-    static constexpr bool KEEP = SHARE && C == 96;
-    static constexpr int SMEM = KEEP ? NWV * SLAB + 2 * WBUF : SHARE ? (NWV * SLAB > 2 * WBUF ? NWV * SLAB : 2 * WBUF) : NWV * SLAB;
-    static_assert(!SHARE || NF % NWV == 0, "fragments per wave");
+    static constexpr bool KEEP = C == 96;
+    static constexpr int SMEM = KEEP ? NWV * SLAB + 2 * WBUF : (NWV * SLAB > 2 * WBUF ? NWV * SLAB : 2 * WBUF);
+    static_assert(NF % NWV == 0 && NF % RING == 0 && 2 * KS >= RING, "fragments per wave / ring slots");
     static_assert(RW * PPR % 64 == 0, "flat piece count");
 };
 
-template <int C, int TT, int NW, bool SHARE>
+template <int C, int TT, int NW>
 // (the second launch bound is hipcc's minimum number of waves per SIMD, not blocks per CU)
-__global__ __launch_bounds__(NW * 64, (SHARE && TT <= 2 && C == 96 ? 3 : (NW >= 8 ? 1 : 8 / NW))) void mlp2_kernel(const MlpParams p) {
-    using K = Mlp2Cfg<C, TT, NW, SHARE>;
-    constexpr int RW = K::RW, LDX = K::LDX, PPR = K::PPR, KS = K::KS, NT = K::NT, NCH = K::NCH, NP = K::NP;
+__global__ __launch_bounds__(NW * 64, (C == 96 ? 3 : 2)) void mlp2_kernel(const MlpParams p) {
+    using K = Mlp2Cfg<C, TT, NW>;
+    constexpr int RW = K::RW, LDX = K::LDX, PPR = K::PPR, KS = K::KS, NT = K::NT, NCH = K::NCH, NP = K::NP, NF = K::NF, RING = K::RING;
+    constexpr int NFW = NF / K::NWV;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, g = lane >> 4;
     _Float16* Xw = (_Float16*)(smem + wv * K::SLAB);          // [RW][LDX]
+    unsigned char* const WBb = smem + (K::KEEP ? K::NWV * K::SLAB : 0);   // two weight buffers of NF fragments [64 lanes][8]
 
     const long row0 = ((long)blockIdx.x * K::NWV + wv) * RW;       // first row of this wave
     const long nrows = p.M - row0 < RW ? p.M - row0 : RW;     // may be <= 0: the wave then only runs dead arithmetic
@@ -122,22 +126,23 @@ __global__ __launch_bounds__(NW * 64, (SHARE && TT <= 2 && C == 96 ? 3 : (NW >= 
     const _Float16* __restrict__ W1 = (const _Float16*)p.w1_frag + lane * 8;   // [NCH*2 row tiles][KS][64][8]
     const _Float16* __restrict__ W2 = (const _Float16*)p.w2_frag + lane * 8;   // [NCH][NT][64][8], k order of the GELU'd accumulators
 
-    // ---- weights.  !SHARE: per-wave register ring, chunk 0 now.  SHARE: the four waves stage each chunk once into LDS
-    //      (two buffers over the slab area; wave w brings fragments w*NFW .. of the next chunk while the current one is consumed)
-    constexpr int NF = K::NF, NFW = NF / K::NWV;
-    half8 w1r[2 * KS], w2r[NT];
-    half8 stg[NFW];
-    _Float16* WB = (_Float16*)(smem + (K::KEEP ? K::NWV * K::SLAB : 0));
+    // ---- weights: the four waves stage each 32-hidden-unit chunk once into LDS (fragment-major: a fragment is one contiguous KiB,
+    //      which is exactly what one LDS-DMA instruction of a wave moves - global_load_lds, 16 bytes per lane, no registers, no
+    //      ds_write), two buffers, wave w brings fragments w*NFW .. of the next chunk while the current one is consumed.
     auto frag_src = [&](int ch, int f) { return f < 2 * KS ? W1 + (size_t)(ch * 2 * KS + f) * 512 : W2 + (size_t)(ch * NT + (f - 2 * KS)) * 512; };
-    if (SHARE) {
+    auto stage = [&](int ch) {
 #pragma unroll
-        for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)frag_src(0, wv * NFW + i);
-    } else {
-#pragma unroll
-        for (int f = 0; f < 2 * KS; ++f) w1r[f] = *(const half8*)(W1 + (size_t)f * 512);
-#pragma unroll
-        for (int f = 0; f < NT; ++f) w2r[f] = *(const half8*)(W2 + (size_t)f * 512);
-    }
+        for (int i = 0; i < NFW; ++i) {
+            const int f = wv * NFW + i;
+            __builtin_amdgcn_global_load_lds((const void*)frag_src(ch, f), (__attribute__((address_space(3))) void*)(WBb + (size_t)(ch & 1) * K::WBUF + (size_t)f * 1024), 16, 0, 0);
+        }
+    };
+    // fragment j of a chunk in the order the products consume them: GEMM1 (k-step j / 2, hidden half j & 1), then GEMM2 (n-tile j - 2 KS)
+    auto lds_frag = [&](int ch, int j) {
+        const int f = j < 2 * KS ? (j & 1) * KS + (j >> 1) : j;
+        return *(const half8*)(WBb + (size_t)(ch & 1) * K::WBUF + (size_t)f * 1024 + lane * 16);
+    };
+    if (K::KEEP) stage(0);                     // separate buffers: under the row loads and the LayerNorm
 
     // ---- x rows: flat coalesced load -> slab
     {
@@ -157,8 +162,8 @@ __global__ __launch_bounds__(NW * 64, (SHARE && TT <= 2 && C == 96 ? 3 : (NW >= 
     }
     W2X_PHASE_FENCE();
     // ---- LayerNorm in fragment layout: lane (fr, g) holds channels ks*32 + 8g .. +7 of row 16tt + fr, so the row sums are the
-    //      lane's own KS pieces plus the three other lane groups (two row swaps).  SHARE: the normalised pieces are the operand
-    //      registers of GEMM1 as they stand; otherwise they go back in place (rows without data hold zeros: 0 * rstd - 0)
+    //      lane's own KS pieces plus the three other lane groups (two row swaps); the normalised pieces are the operand registers
+    //      of GEMM1 as they stand (rows without data hold zeros: 0 * rstd - 0)
     half8 xreg[TT][KS];
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
@@ -169,21 +174,26 @@ __global__ __launch_bounds__(NW * 64, (SHARE && TT <= 2 && C == 96 ? 3 : (NW >= 
         s = rows_sum(s);
         q = rows_sum(q);
         const float mean = s * (1.f / C);
-        const float rstd = rsqrtf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps);
+        const float rstd = __builtin_amdgcn_rsqf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps);   // the argument is >= eps
         const float nm = -mean * rstd;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (SHARE) xreg[tt][ks] = norm8(raw[ks], rstd, nm);
-            else *(half8*)(Xw + (tt * 16 + fr) * LDX + ks * 32 + g * 8) = norm8(raw[ks], rstd, nm);
-        }
+        for (int ks = 0; ks < KS; ++ks) xreg[tt][ks] = norm8(raw[ks], rstd, nm);
     }
     W2X_PHASE_FENCE();
-    if (SHARE) {
-        if (!K::KEEP) __syncthreads();         // every wave holds its rows in registers: the slab area becomes weight buffers
-#pragma unroll
-        for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[i];
-        __syncthreads();
+    if (!K::KEEP) {
+        __syncthreads();                       // every wave holds its rows in registers: the slab area becomes weight buffers
+        stage(0);
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): this wave's share of chunk 0 has landed
+    __syncthreads();
+
+    // Weight fragments reach the MFMAs through a ring of six registers: a fragment is requested from LDS right after the last MFMA
+    // that used its register, six fragments (12 MFMAs) ahead of its use, so no product waits on an LDS round trip.  (Reads placed at
+    // their point of use made the compiler wait for each one.)
+    half8 wr[RING];
+#pragma unroll
+    for (int i = 0; i < RING; ++i) wr[i] = lds_frag(0, i);
+
     // GEMM2 is computed transposed as well (rows = output channels, columns = tokens): a lane ends with 4 consecutive channels of
     // one token (8-byte slab stores) and b2 is the initial accumulator
     float4v acc2[TT][NT];
@@ -196,61 +206,49 @@ __global__ __launch_bounds__(NW * 64, (SHARE && TT <= 2 && C == 96 ? 3 : (NW >= 
 
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {   // fully unrolled: the ring registers are renamed statically
-        // GEMM1 (transposed): acc1[ht][tt] = W1[32ch + 16ht ..][:] * Xn[16tt ..][:]^T   (rows = hidden, columns = tokens)
-        const _Float16* wcur = WB + (size_t)(ch & 1) * (K::WBUF / 2) + lane * 8;      // SHARE: this chunk's fragments in LDS
-        if (SHARE && ch + 1 < NCH) {
-#pragma unroll
-            for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)frag_src(ch + 1, wv * NFW + i);
-        }
+        if (ch + 1 < NCH) stage(ch + 1);       // into the other buffer (last read before the previous barrier); in flight under this chunk
+        // GEMM1 (transposed): acc1[ht][tt] = W1[32ch + 16ht ..][:] * Xn[16tt ..][:]^T   (rows = hidden, columns = tokens), from b1
         float4v acc1[2][TT];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int tt = 0; tt < TT; ++tt) acc1[i][tt] = (float4v){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            half8 xb[TT];
-#pragma unroll
-            for (int tt = 0; tt < TT; ++tt) xb[tt] = SHARE ? xreg[tt][ks] : *(const half8*)(Xw + (tt * 16 + fr) * LDX + ks * 32 + g * 8);
-#pragma unroll
-            for (int ht = 0; ht < 2; ++ht) {
-                const half8 wa = SHARE ? *(const half8*)(wcur + (size_t)(ht * KS + ks) * 512) : w1r[ht * KS + ks];
-#pragma unroll
-                for (int tt = 0; tt < TT; ++tt) acc1[ht][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb[tt], acc1[ht][tt], 0, 0, 0);
-                if (!SHARE && ch + 1 < NCH) w1r[ht * KS + ks] = *(const half8*)(W1 + (size_t)(((ch + 1) * 2 + ht) * KS + ks) * 512);
-            }
-        }
-        // bias + GELU in place; lane holds hidden rows 16ht + 4g + j of token column fr -> B fragment of GEMM2 for the
-        // k order (ht 0: slots 0..3, ht 1: slots 4..7)
-        half8 a2[TT];
         {
             const float4v be = *(const float4v*)(p.b1 + ch * 32 + g * 4);
             const float4v bo = *(const float4v*)(p.b1 + ch * 32 + 16 + g * 4);
 #pragma unroll
-            for (int tt = 0; tt < TT; ++tt) {
-                const float4v e = acc1[0][tt], o = acc1[1][tt];
-                const float2v g0 = gelu_fast2((float2v){e[0], e[1]} + (float2v){be[0], be[1]});
-                const float2v g1 = gelu_fast2((float2v){e[2], e[3]} + (float2v){be[2], be[3]});
-                const float2v g2 = gelu_fast2((float2v){o[0], o[1]} + (float2v){bo[0], bo[1]});
-                const float2v g3 = gelu_fast2((float2v){o[2], o[3]} + (float2v){bo[2], bo[3]});
-                a2[tt] = (half8){(_Float16)g0[0], (_Float16)g0[1], (_Float16)g1[0], (_Float16)g1[1],
-                                 (_Float16)g2[0], (_Float16)g2[1], (_Float16)g3[0], (_Float16)g3[1]};
-            }
+            for (int tt = 0; tt < TT; ++tt) { acc1[0][tt] = be; acc1[1][tt] = bo; }
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * KS; ++j) {
+            const int ks = j >> 1, ht = j & 1;
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) acc1[ht][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[j % RING], xreg[tt][ks], acc1[ht][tt], 0, 0, 0);
+            wr[j % RING] = lds_frag(ch, j + RING);
+            W2X_RING_FENCE();
+        }
+        // GELU in place; lane holds hidden rows 16ht + 4g + j of token column fr -> B fragment of GEMM2 for the
+        // k order (ht 0: slots 0..3, ht 1: slots 4..7)
+        half8 a2[TT];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            const float4v e = acc1[0][tt], o = acc1[1][tt];
+            const float2v g0 = gelu_fast2((float2v){e[0], e[1]});
+            const float2v g1 = gelu_fast2((float2v){e[2], e[3]});
+            const float2v g2 = gelu_fast2((float2v){o[0], o[1]});
+            const float2v g3 = gelu_fast2((float2v){o[2], o[3]});
+            a2[tt] = (half8){(_Float16)g0[0], (_Float16)g0[1], (_Float16)g1[0], (_Float16)g1[1],
+                             (_Float16)g2[0], (_Float16)g2[1], (_Float16)g3[0], (_Float16)g3[1]};
         }
         // GEMM2 (transposed): acc2[tt][nt] += W2[16nt ..][chunk] * H[tokens][chunk]^T
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const half8 wb = SHARE ? *(const half8*)(wcur + (size_t)(2 * KS + nt) * 512) : w2r[nt];
+            const int j = 2 * KS + nt;
 #pragma unroll
-            for (int tt = 0; tt < TT; ++tt) acc2[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, a2[tt], acc2[tt][nt], 0, 0, 0);
-            if (!SHARE && ch + 1 < NCH) w2r[nt] = *(const half8*)(W2 + (size_t)((ch + 1) * NT + nt) * 512);
+            for (int tt = 0; tt < TT; ++tt) acc2[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[j % RING], a2[tt], acc2[tt][nt], 0, 0, 0);
+            if (j + RING < NF) { wr[j % RING] = lds_frag(ch, j + RING); W2X_RING_FENCE(); }
         }
-        if (SHARE) {   // hand the next chunk over: the other buffer was last read one iteration ago, before the previous barrier
-            if (ch + 1 < NCH) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): this wave's share of the next chunk has landed
+        __syncthreads();
+        if (ch + 1 < NCH) {
 #pragma unroll
-                for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)((ch + 1) & 1) * (K::WBUF / 2) + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[i];
-            }
-            __syncthreads();
+            for (int i = 0; i < RING; ++i) wr[i] = lds_frag(ch + 1, i);
         }
     }
 
@@ -289,17 +287,17 @@ __global__ __launch_bounds__(NW * 64, (SHARE && TT <= 2 && C == 96 ? 3 : (NW >= 
         for (int c = 0; c < PPR; ++c) sum_sq8(*(const half8*)(Xw + lane * LDX + c * 8), s, q);
         const float mean = s * (1.f / C);
         p.stats_out[2 * (row0 + lane)] = mean;
-        p.stats_out[2 * (row0 + lane) + 1] = rsqrtf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps_out);
+        p.stats_out[2 * (row0 + lane) + 1] = __builtin_amdgcn_rsqf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps_out);
     }
 }
 
-template <int C, int TT, int NW, bool SHARE>
+template <int C, int TT, int NW>
 hipError_t launch_mlp2_c(const MlpParams& p, hipStream_t s) {
-    using K = Mlp2Cfg<C, TT, NW, SHARE>;
+    using K = Mlp2Cfg<C, TT, NW>;
     static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
-    if (hipError_t e = ensure_dynamic_lds((const void*)mlp2_kernel<C, TT, NW, SHARE>, K::SMEM, lds_ok); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)mlp2_kernel<C, TT, NW>, K::SMEM, lds_ok); e != hipSuccess) return e;
     dim3 grid((unsigned)((p.M + K::BM - 1) / K::BM));
-    hipLaunchKernelGGL((mlp2_kernel<C, TT, NW, SHARE>), grid, dim3(K::NWV * 64), K::SMEM, s, p);
+    hipLaunchKernelGGL((mlp2_kernel<C, TT, NW>), grid, dim3(K::NWV * 64), K::SMEM, s, p);
     return hipGetLastError();
 }
 
@@ -311,12 +309,12 @@ hipError_t launch_mlp96p(const MlpParams& p, hipStream_t s);
 hipError_t launch_mlp2(const MlpParams& p, hipStream_t s) {
     // C = 96: the resident-weight kernel (k_mlp96p.hip); W2X_MLP96_CHUNKED=1 (read once per process) keeps this file's chunked
     // schedule for A/B runs.  C = 192 (weights 288 KiB): shared-weight schedule, 32 rows per wave, 4 waves per workgroup.
-    // Measured alternatives (git history): 6 / 12 waves per workgroup 2.45 / 1.86 ms of MLP time per frame against 1.58; the
-    // per-wave register ring (SHARE = false, TT = 4) and 64 rows per wave with shared weights were slower as well.
+    // Measured alternatives (git history): 6 / 12 waves per workgroup 2.45 / 1.86 ms of MLP time per frame against 1.58; a per-wave
+    // register ring straight from L2 (TT = 4) and 64 rows per wave with shared weights were slower as well.
     static const bool chunked96 = getenv("W2X_MLP96_CHUNKED") != nullptr;
     if (p.C == 96 && !chunked96 && mlp96p_supported(p)) return launch_mlp96p(p, s);
-    if (p.C == 96) return launch_mlp2_c<96, 2, 4, true>(p, s);
-    if (p.C == 192) return launch_mlp2_c<192, 2, 4, true>(p, s);
+    if (p.C == 96) return launch_mlp2_c<96, 2, 4>(p, s);
+    if (p.C == 192) return launch_mlp2_c<192, 2, 4>(p, s);
     return hipErrorInvalidValue;
 }
 

@@ -19,6 +19,8 @@
 // needs no data movement for it: the third tiles of K, V and Q come out of the MFMAs already arranged that way.
 #include "kernels.h"
 
+#include <algorithm>
+
 namespace w2x {
 namespace {
 
@@ -38,11 +40,26 @@ __device__ __forceinline__ void sum_sq8(const half8 v, float& s, float& q) {
         q = __builtin_amdgcn_fdot2(h, h, q, false);
     }
 }
+// (x * rstd + nm) on 8 halves with fp32 arithmetic: v_fma_mixlo / mixhi read the f16 halves directly and write f16
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+typedef int int2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ half8 norm8(const half8 v, float rstd, float nm) {
-    half8 o;
+    uint4v x = __builtin_bit_cast(uint4v, v), o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (_Float16)fmaf((float)v[e], rstd, nm);
-    return o;
+    for (int d = 0; d < 4; ++d) {
+        unsigned r;
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(x[d]), "v"(rstd), "v"(nm));
+        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(x[d]), "v"(rstd), "v"(nm));
+        o[d] = r;
+    }
+    return __builtin_bit_cast(half8, o);
+}
+// Rows are fetched and stored through buffer resources over x / y (k_swinattn96.hip): an offset at or beyond num_records reads zeros
+// and drops stores, so rows that do not exist and the idle lanes of a row need neither a predicate nor masking of the data.
+constexpr unsigned kNoRow = 0xFFFFFFFFu;     // saturating adds keep it there
+constexpr size_t kMaxBufBytes = 0xFFFFFF00u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 // see k_swinattn.hip for why the swaps are inline asm on two registers
 __device__ __forceinline__ void swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b)); }
@@ -87,8 +104,9 @@ constexpr int C = 192, HD = 32, NH = 6, NTOK = 36, G = 2, R = G * NTOK, RT = 5, 
 constexpr int SLAB = 48, RPX = G * SLAB;       // slab rows per window / in the tile
 constexpr int LDX = C + 8;                     // 200 halves: 400-byte rows, 16-byte pieces rotate over the banks
 constexpr int XS = RPX * LDX, OS = RP * LDX;
-constexpr int PIXN = 80;                       // row -> pixel table entries (>= the rows the passes touch)
-constexpr int SMEM192 = (XS + OS) * 2 + PIXN * 4;
+constexpr int NPAD = G * 12;                   // slab rows between the left-over tokens (kept at zero)
+constexpr int SMEM192 = (XS + OS) * 2 + (R + NPAD) * 8;
+constexpr int DUMMY = XS * 2;                  // byte offset of a row nobody reads at that point (first row of Os): target of the stores of idle lanes
 constexpr int LPR = 32, PPR = C / 8, RPP = 256 / LPR, NPASS = R / RPP;   // row passes: 32 lanes per row, 8 rows per pass, 9 passes
 static_assert(R % RPP == 0, "row passes");
 
@@ -113,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* Xs = (_Float16*)smem;              // [RPX][LDX] normalised x slabs; later the output tile [RP][LDX]
     _Float16* Os = Xs + XS;                      // [RP][LDX]  attention output, all heads, token order
-    int* Pix = (int*)(Os + OS);                  // [PIXN] source pixel of each token row (-1: none); valid to the end
+    int2v* Pix = (int2v*)(Os + OS);              // [R] {byte offset of the token row's pixel in x / y (kNoRow: none), byte offset of its slab row}, then [NPAD] {-, pad row}
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -127,7 +145,8 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
     const int wl0 = iw0 - wb0 * p.nwin, wl1 = iw1 - wb1 * p.nwin;
     const int nwx = p.W / 6;
     const int wy0 = wl0 / nwx, wx0 = wl0 - wy0 * nwx, wy1 = wl1 / nwx, wx1 = wl1 - wy1 * nwx;
-    const _Float16* __restrict__ X = (const _Float16*)p.x;
+    const unsigned xbytes = (unsigned)p.B * (unsigned)HW * (C * 2);
+    const __amdgpu_buffer_rsrc_t X = make_rsrc(p.x, xbytes), Y = make_rsrc(p.y, xbytes);
     const _Float16* __restrict__ Wqkv = (const _Float16*)p.wqkv_frag;    // [36 row tiles][6 k-steps][64 lanes][8]
     const _Float16* __restrict__ Wproj = (const _Float16*)p.wproj_frag;  // [12 row tiles][6 k-steps][64 lanes][8]
     const float4v zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -153,13 +172,16 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
     }
     W2X_LOAD_W(0, 0, ahp);
 
-    // ---- source pixel of every token row, worked out once per workgroup (one thread per row) and handed round in LDS
-    {
-        int pix = -1;
-        if (tid < R) {
-            const int w = tid >= NTOK ? 1 : 0;
+    // ---- source pixel and slab row of every token row (and the pad rows), worked out once per workgroup (one thread per row)
+    if (tid < R + NPAD) {
+        int pix = -1, srow;
+        if (tid >= R) {             // the 12 rows between tokens 32..35 of each slab
+            const int k = tid - R, w = k >= 12 ? 1 : 0, kk = k - 12 * w;
+            srow = (w * SLAB + 33 + (kk / 3) * 4 + (kk % 3)) * LDX * 2;
+        } else {
+            const int w = tid >= NTOK ? 1 : 0, t = tid - w * NTOK;
+            srow = (w * SLAB + slab_row(t)) * LDX * 2;
             if (w == 0 ? wok0 : wok1) {
-                const int t = tid - w * NTOK;
                 if (p.ry >= 0) {
                     const int ty = t / 6, tx = t - ty * 6;
                     int y = (w == 0 ? wy0 : wy1) * 6 + ty + p.ry, x = (w == 0 ? wx0 : wx1) * 6 + tx + p.rx;
@@ -168,22 +190,22 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
                 } else pix = (w == 0 ? pixbase0 : pixbase1) + p.table[(w == 0 ? wl0 : wl1) * NTOK + t];
             }
         }
-        if (tid < PIXN) Pix[tid] = pix;
+        Pix[tid] = (int2v){pix < 0 ? (int)kNoRow : pix * (C * 2), srow};
     }
     __syncthreads();
 
     // ---- gather + LayerNorm into the slabs
     {
-        const int li = tid & (LPR - 1);
+        const int li = tid & (LPR - 1), rsub = tid / LPR;
+        const unsigned lane_off = li < PPR ? li * 16u : kNoRow;
         half8 xr[NPASS];
+        int srow[NPASS];
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
-            const int r = ps * RPP + tid / LPR;          // token row 0..71
-            const int pix = Pix[r];
-            // unconditional load from a clamped address (all passes in flight at once), zeroed afterwards
-            half8 h = *(const half8*)(X + (size_t)(pix < 0 ? 0 : pix) * C + (li < PPR ? li : 0) * 8);
-            if (!(pix >= 0 && li < PPR)) h = zero8;
-            xr[ps] = h;
+            const int2v pr = Pix[ps * RPP + rsub];
+            srow[ps] = pr[1];
+            // rows that do not exist and the eight idle lanes of a row read zeros
+            xr[ps] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(X, __builtin_elementwise_add_sat((unsigned)pr[0], lane_off), 0, 0));
         }
         static_assert(NPASS == 9, "the row sums are reduced three passes at a time");
         float sm[NPASS], sq[NPASS];
@@ -195,16 +217,16 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
         }
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
-            const int r = ps * RPP + tid / LPR;
-            const int w = r >= NTOK ? 1 : 0;
             const float mean = sm[ps] * (1.f / C);
-            const float rstd = rsqrtf(fmaxf(sq[ps] * (1.f / C) - mean * mean, 0.f) + p.eps);
-            if (li < PPR) *(half8*)(Xs + (w * SLAB + slab_row(r - w * NTOK)) * LDX + li * 8) = norm8(xr[ps], rstd, -mean * rstd);
+            const float rstd = __builtin_amdgcn_rsqf(fmaxf(sq[ps] * (1.f / C) - mean * mean, 0.f) + p.eps);   // the argument is >= eps
+            // unconditional store: the idle lanes of a row write to the dummy row
+            *(half8*)(smem + (li < PPR ? srow[ps] + li * 16 : DUMMY)) = norm8(xr[ps], rstd, -mean * rstd);
         }
         // the 12 rows between tokens 32..35 of each slab are multiplied like the rest (results ignored): keep them finite
-        for (int i = tid; i < G * 12 * PPR; i += 256) {
-            const int rr = i / PPR, c = i - rr * PPR, w = rr / 12, k = rr - w * 12;
-            *(half8*)(Xs + (w * SLAB + 33 + (k / 3) * 4 + (k % 3)) * LDX + c * 8) = zero8;
+#pragma unroll
+        for (int k = 0; k < (NPAD + RPP - 1) / RPP; ++k) {
+            const int pr = k * RPP + rsub;
+            if (pr < NPAD) *(half8*)(smem + (li < PPR ? Pix[R + pr][1] + li * 16 : DUMMY)) = zero8;
         }
     }
     __syncthreads();
@@ -222,7 +244,10 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
         for (int m = 0; m < 2; ++m) {
             const int cur = (it * 3 + m) & 1;
             W2X_LOAD_W(cur ^ 1, m + 1, h);                                     // next matrix of this head (k, then v)
-            float4v a[2][3] = {{zero4, zero4, zero4}, {zero4, zero4, zero4}};
+            // q: the bias is the initial accumulator, the result is scaled once; k: no bias (q.bk is the same for every key of a query)
+            const float4v b0 = m == 0 ? *(const float4v*)(p.bqkv + h * HD + g * 4) : zero4;
+            const float4v b1 = m == 0 ? *(const float4v*)(p.bqkv + h * HD + 16 + g * 4) : zero4;
+            float4v a[2][3] = {{b0, b0, b0}, {b1, b1, b1}};
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks) {
                 half8 xf[3];
@@ -233,17 +258,12 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
 #pragma unroll
                     for (int tt = 0; tt < 3; ++tt) a[ft][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[cur][ft * 6 + ks], xf[tt], a[ft][tt], 0, 0, 0);
             }
-            float4v b0 = *(const float4v*)(p.bqkv + m * C + h * HD + g * 4);
-            float4v b1 = *(const float4v*)(p.bqkv + m * C + h * HD + 16 + g * 4);
-            if (m == 0) { b0 *= qscale; b1 *= qscale; }
 #pragma unroll
             for (int tt = 0; tt < 3; ++tt) {
                 half8 f;
+                const float4v a0 = m == 0 ? a[0][tt] * qscale : a[0][tt], a1 = m == 0 ? a[1][tt] * qscale : a[1][tt];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (m == 0) { f[j] = (_Float16)fmaf(a[0][tt][j], qscale, b0[j]); f[4 + j] = (_Float16)fmaf(a[1][tt][j], qscale, b1[j]); }
-                    else { f[j] = (_Float16)a[0][tt][j]; f[4 + j] = (_Float16)a[1][tt][j]; }   // no k bias: q.bk is the same for every key of a query
-                }
+                for (int j = 0; j < 4; ++j) { f[j] = (_Float16)a0[j]; f[4 + j] = (_Float16)a1[j]; }
                 if (m == 0) qf[tt] = f; else kf[tt] = f;
             }
         }
@@ -297,10 +317,8 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
 #pragma unroll
         for (int qi = 0; qi < 3; ++qi) {
             s[qi][2][0] += b2[qi];
-            float m = fmaxf(fmaxf(s[qi][0][0], s[qi][0][1]), fmaxf(s[qi][0][2], s[qi][0][3]));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) m = fmaxf(m, s[qi][1][j]);
-            mx[qi] = fmaxf(m, s[qi][2][0]);
+            // plain fmaxf on purpose (the inputs are MFMA results: wait states are only inserted for instructions the compiler sees)
+            mx[qi] = fmaxf(fmaxf(fmaxf(fmaxf(s[qi][0][0], s[qi][0][1]), s[qi][0][2]), fmaxf(fmaxf(s[qi][0][3], s[qi][1][0]), s[qi][1][1])), fmaxf(fmaxf(s[qi][1][2], s[qi][1][3]), s[qi][2][0]));
         }
         rows_max3(mx[0], mx[1], mx[2]);
         half8 pf0[3], pf1[3];
@@ -359,24 +377,25 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
 #undef W2X_LOAD_W
     __syncthreads();      // every wave's head outputs are in Os; nobody reads the slabs any more
 
-    // ---- proj: out = Os * Wproj^T + b -> tile over Xs.  Wave w owns output columns 48w .. 48w+47 for all five row tiles.
+    // ---- proj, transposed: out^T = Wproj Os^T + b (rows = output channels, columns = tokens), so a lane ends with 4 consecutive
+    // channels of one token (bias as the initial accumulator, 8-byte LDS stores).  Wave w owns output channels 48w .. 48w+47 for all
+    // five row tiles; the tile goes over Xs in token order.
     {
-        float bp[3];
+        float4v bp[3];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) bp[t] = p.bproj[(wv * 3 + t) * 16 + fr];
+        for (int t = 0; t < 3; ++t) bp[t] = *(const float4v*)(p.bproj + (wv * 3 + t) * 16 + g * 4);
 #pragma unroll
         for (int mt = 0; mt < RT; ++mt) {
-            float4v acc[3] = {zero4, zero4, zero4};
+            float4v acc[3] = {bp[0], bp[1], bp[2]};
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks) {
                 const half8 of = *(const half8*)(Os + (mt * 16 + fr) * LDX + ks * 32 + g * 8);
 #pragma unroll
-                for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(of, wp[t][ks], acc[t], 0, 0, 0);
+                for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp[t][ks], of, acc[t], 0, 0, 0);
             }
 #pragma unroll
             for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) Xs[(mt * 16 + g * 4 + j) * LDX + (wv * 3 + t) * 16 + fr] = (_Float16)(acc[t][j] + bp[t]);
+                *(half4*)(Xs + (mt * 16 + fr) * LDX + (wv * 3 + t) * 16 + g * 4) = (half4){(_Float16)acc[t][0], (_Float16)acc[t][1], (_Float16)acc[t][2], (_Float16)acc[t][3]};
         }
     }
     __syncthreads();
@@ -384,34 +403,31 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
 
     // ---- row pieces: + residual x, scatter store, LayerNorm statistics for the next op
     {
-        _Float16* __restrict__ Y = (_Float16*)p.y;
-        const int li = tid & (LPR - 1);
+        const int li = tid & (LPR - 1), rsub = tid / LPR;
+        const unsigned lane_off = li < PPR ? li * 16u : kNoRow;
         half8 xres[NPASS];
-        int my_pix[NPASS];
+        unsigned my_off[NPASS];
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
-            my_pix[ps] = Pix[ps * RPP + tid / LPR];
-            half8 h = *(const half8*)(X + (size_t)(my_pix[ps] < 0 ? 0 : my_pix[ps]) * C + (li < PPR ? li : 0) * 8);
-            if (!(my_pix[ps] >= 0 && li < PPR)) h = zero8;
-            xres[ps] = h;
+            my_off[ps] = __builtin_elementwise_add_sat((unsigned)Pix[ps * RPP + rsub][0], lane_off);
+            xres[ps] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(X, my_off[ps], 0, 0));
         }
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
-            const int r = ps * RPP + tid / LPR;
-            const int pix = my_pix[ps];
-            const bool ok = pix >= 0 && li < PPR;
-            half8 o = {};
-            if (ok) {
-                o = *(const half8*)(Xs + r * LDX + li * 8) + xres[ps];
-                *(half8*)(Y + (size_t)pix * C + li * 8) = o;
-            }
+            const int r = ps * RPP + rsub;
+            const bool ok = my_off[ps] != kNoRow;
+            // (idle lanes read the next row's first pieces: their store is dropped)
+            half8 o = *(const half8*)(Xs + r * LDX + li * 8) + xres[ps];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, o), Y, my_off[ps], 0, 0);
             if (p.stats_out) {
+                if (!ok) o = half8{};
+                const size_t pix = my_off[ps] / (C * 2);
                 float s, q;
                 sum_sq8(o, s, q);
                 s = group_sum32(s);
                 q = group_sum32(q);
                 const float mean = s * (1.f / C);
-                if (ok && li == 0) { p.stats_out[2 * (size_t)pix] = mean; p.stats_out[2 * (size_t)pix + 1] = rsqrtf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps_out); }
+                if (ok && li == 0) { p.stats_out[2 * pix] = mean; p.stats_out[2 * pix + 1] = __builtin_amdgcn_rsqf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps_out); }
             }
         }
     }
@@ -424,10 +440,21 @@ hipError_t launch_swin_attn192(const SwinAttnParams& p, hipStream_t s) {
     auto kern = swin_attn192_kernel<false>;   // <true>: per-phase s_memtime stamps into g_sa192_stamps (diagnostic builds only)
     static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
     if (hipError_t e = ensure_dynamic_lds((const void*)kern, SMEM192, lds_ok); e != hipSuccess) return e;
-    const long total_win = (long)p.B * p.nwin;
-    dim3 grid((unsigned)((total_win + G - 1) / G));
-    hipLaunchKernelGGL(kern, grid, dim3(256), SMEM192, s, p);
-    return hipGetLastError();
+    // the kernel addresses x / y with 32-bit byte offsets: passes beyond that are cut into runs of whole images (k_swinattn96.hip)
+    const size_t img_bytes = (size_t)p.nwin * NTOK * C * 2;
+    if (img_bytes == 0 || img_bytes > kMaxBufBytes) return hipErrorInvalidValue;
+    const int per_run = (int)std::min<size_t>((size_t)p.B, kMaxBufBytes / img_bytes);
+    for (int b0 = 0; b0 < p.B; b0 += per_run) {
+        SwinAttnParams q = p;
+        q.B = std::min(per_run, p.B - b0);
+        q.x = (const char*)p.x + (size_t)b0 * img_bytes;
+        q.y = (char*)p.y + (size_t)b0 * img_bytes;
+        if (p.stats_out) q.stats_out = p.stats_out + (size_t)b0 * p.nwin * NTOK * 2;
+        const long total_win = (long)q.B * q.nwin;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((total_win + G - 1) / G)), dim3(256), SMEM192, s, q);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace w2x

@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <list>
 #include <set>
 #include <sstream>
 #include <stdexcept>
@@ -752,6 +753,59 @@ struct Lowerer {
         }
     }
 
+    // ---- LayerNorm as exporters write it below opset 17 (nvonnxparser takes either form, img2img_build.cpp:81-88):
+    //          m = ReduceMean(x, axes=[-1]);  d = Sub(x, m);  v = ReduceMean(Pow(d, 2) | Mul(d, d), axes=[-1]);
+    //          y = Div(d, Sqrt(Add(v, eps)))  [ * gamma ]  [ + beta ]
+    //      -> the same LVal the LayerNormalization node gives (normalisation folded into the consuming product)
+    bool try_lower_decomposed_layernorm(const Node* n) {
+        auto itx = vals.find(n->in[0]);
+        if (itx == vals.end()) return false;
+        const LVal x = itx->second;
+        if (x.kind != LVal::MAP || x.nchw || x.ln) return false;
+        auto last_axis = [&](const Node* r) {
+            std::vector<int64_t> ax = r->aints("axes");
+            if (ax.empty() && r->in.size() > 1 && is_c(r->in[1])) ax = g.cst(r->in[1]).i;          // opset 18: axes as an input
+            return ax.size() == 1 && (ax[0] == -1 || ax[0] == 3) && r->ai("keepdims", 1) == 1;
+        };
+        if (!last_axis(n)) return false;
+        const Node* sub = nullptr;
+        for (auto* u : users(n->out[0])) if (u->op == "Sub" && u->in.size() == 2 && u->in[0] == n->in[0] && u->in[1] == n->out[0]) sub = u;
+        if (!sub || users(n->out[0]).size() != 1) return false;          // the mean feeds the subtraction only (x itself may go on to a residual add)
+        const Node *sq = nullptr, *div = nullptr;
+        for (auto* u : users(sub->out[0])) {
+            const HTensor* c = nullptr; std::string dyn;
+            if (u->op == "Pow" && u->in[0] == sub->out[0] && is_c(u->in[1]) && scalar_near(&g.cst(u->in[1]), 2.0)) sq = u;
+            else if (u->op == "Mul" && u->in[0] == sub->out[0] && u->in[1] == sub->out[0]) sq = u;
+            else if (u->op == "Div" && u->in[0] == sub->out[0]) div = u;
+            (void)c; (void)dyn;
+        }
+        if (!sq || !div || users(sub->out[0]).size() != (sq->op == "Mul" ? 3u : 2u)) return false;
+        const Node* var = only_user(sq->out[0]);
+        if (!var || var->op != "ReduceMean" || !last_axis(var)) return false;
+        const Node* add = only_user(var->out[0]);
+        std::string dyn; const HTensor* ceps = nullptr;
+        if (!add || add->op != "Add" || !split_binary(add, dyn, ceps) || dyn != var->out[0] || ceps->numel() != 1 || !ceps->is_float()) return false;
+        const Node* sqrt = only_user(add->out[0]);
+        if (!sqrt || sqrt->op != "Sqrt" || only_user(sqrt->out[0]) != div || div->in[1] != sqrt->out[0]) return false;
+        LVal y = x; y.ln = true; y.gamma = nullptr; y.beta = nullptr; y.eps = ceps->f[0];
+        std::vector<const Node*> used = {n, sub, sq, var, add, sqrt, div};
+        std::string out = div->out[0];
+        // optional affine part: Mul by gamma [C], Add of beta [C]
+        const Node* mul = only_user(out);
+        const HTensor* cg = nullptr;
+        if (mul && mul->op == "Mul" && split_binary(mul, dyn, cg) && dyn == out && (int)cg->numel() == x.C && cg->is_float()) {
+            y.gamma = cg; used.push_back(mul); out = mul->out[0];
+            const Node* addb = only_user(out);
+            const HTensor* cb = nullptr;
+            if (addb && addb->op == "Add" && split_binary(addb, dyn, cb) && dyn == out && (int)cb->numel() == x.C && cb->is_float()) { y.beta = cb; used.push_back(addb); out = addb->out[0]; }
+        }
+        if (!y.gamma) { ones_c.emplace_back(); HTensor& o = ones_c.back(); o.shape = {x.C}; o.f.assign(x.C, 1.f); y.gamma = &o; }     // no affine part: gamma = 1
+        for (auto* z : used) done.insert(z);
+        vals[out] = y;
+        return true;
+    }
+    std::list<HTensor> ones_c;   // constants synthesised by the lowering (stable addresses)
+
     // ---------------------------------------------------------------------------------------------------------
     Plan run() {
         const Shape& is = shp(g.input);
@@ -766,6 +820,7 @@ struct Lowerer {
             const std::string& op = n->op;
             if (op == "Conv" || op == "ConvTranspose") { lower_conv(n); continue; }
             if (op == "MatMul") { lower_matmul(n); continue; }
+            if (op == "ReduceMean" && try_lower_decomposed_layernorm(n)) continue;
             if (op == "GlobalAveragePool" || op == "ReduceMean") { if (try_lower_se(n)) continue; }
             auto itx = vals.find(n->in[0]);
             if (itx == vals.end()) fail(n, "input \"" + n->in[0] + "\" was not lowered");
