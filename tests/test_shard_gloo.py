@@ -9,6 +9,8 @@ import torch.multiprocessing as mp
 
 import shard
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
@@ -85,3 +87,15 @@ def test_two_ranks_split_one_frame_into_tile_column_strips():
     # config 3: 9x5 tiles; rank 0 owns tile columns 0..3, rank 1 columns 4..8 plus column 3 again for the blend band
     assert plans[0] == (0, 20, 0, 4 * 896) and plans[1] == (15, 30, 4 * 896, 7680)
     assert res[0][3] == 4 * 896 and res[1][3] == 7680 - 4 * 896
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    """bench.py must never print n_gpus != requested: under a launcher whose WORLD_SIZE disagrees with --gpus it stops before
+    touching the GPU; without a launcher and with fewer devices than --gpus the self-spawn path refuses as well."""
+    import subprocess, sys
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing to report n_gpus" in (r.stderr + r.stdout)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "W2X_DEVICE_MAP")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing to report n_gpus" in (r.stderr + r.stdout)

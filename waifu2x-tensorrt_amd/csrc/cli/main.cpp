@@ -10,6 +10,7 @@
 #include <filesystem>
 #include <iostream>
 #include <condition_variable>
+#include <csignal>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -91,6 +92,10 @@ int main(int argc, char** argv) {
 
         // render: one engine per device
         std::vector<std::unique_ptr<Img2Img>> engines;
+        // external tools are probed (fork + exec of a shell) before the first engine brings the HIP runtime up; a dying encoder must
+        // surface as a failed write, not as SIGPIPE
+        const bool have_ffmpeg = on_path("ffmpeg") && on_path("ffprobe");
+        signal(SIGPIPE, SIG_IGN);
         for (int d = 0; d < o.devices; ++d) {
             engines.emplace_back(new Img2Img);
             engines.back()->setMessageCallback(on_message);
@@ -102,7 +107,6 @@ int main(int argc, char** argv) {
         }
         const std::vector<std::string> files = find_inputs(o);
         fileCount = files.size();
-        const bool have_ffmpeg = on_path("ffmpeg") && on_path("ffprobe");
         for (const std::string& file : files) {
             if (cli::is_builtin_still(file)) {
                 frameIndex = 0; frameCount = 1;
@@ -132,7 +136,7 @@ int main(int argc, char** argv) {
                                    " -r " + std::to_string(single ? 1.0 : pr.fps) + " -i - ";
                 if (!single) wcmd += "-c:v " + o.codec + " -pix_fmt " + o.pixFmt + " -crf " + std::to_string(o.crf) + " ";
                 FILE* wr = popen((wcmd + shell_quote(outFile)).c_str(), "w");
-                if (!rd || !wr) throw std::runtime_error("cannot start ffmpeg for " + file);
+                if (!rd || !wr) { if (rd) pclose(rd); if (wr) pclose(wr); throw std::runtime_error("cannot start ffmpeg for " + file); }
                 if (o.devices == 1) {
                     // one device: chunks of frames through renderSequence (upload / compute / download overlapped, buffers
                     // page-locked once).  The ffmpeg pipes run on their own threads over two chunk slots, so decoding chunk
@@ -203,7 +207,9 @@ int main(int argc, char** argv) {
                         oks[d] = engines[d]->render(s2, d2);
                     });
                     for (auto& t : th) t.join();
-                    for (int d = 0; d < got; ++d) { if (!oks[d]) return -1; fwrite(outs[d].data(), 1, outBytes, wr); ++frameIndex; }
+                    bool bad = false;
+                    for (int d = 0; d < got && !bad; ++d) { bad = !oks[d] || fwrite(outs[d].data(), 1, outBytes, wr) != outBytes; ++frameIndex; }
+                    if (bad) { pclose(rd); pclose(wr); return -1; }
                 }
                 pclose(rd); pclose(wr);
             }
