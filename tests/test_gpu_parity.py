@@ -182,7 +182,7 @@ def test_compatible_but_not_optimized_engine_is_respecialised(pkg, onnx_model):
     assert eng.build(path, bc), eng.last_error()
     assert eng.load(path, pkg.RenderConfig(batchSize=4, height=64, width=64, scaling=4)), eng.last_error()      # inside the range, not opt
     assert any("compatible with but not optimized" in m for _, m in eng.messages)
-    assert eng.pass_tiles == 4
+    assert eng.pass_tiles % 4 == 0                                          # whole reference batches per network pass
     got = eng.render(frame)
     assert eng.load(path, pkg.RenderConfig(batchSize=8, height=64, width=64, scaling=4)) is False               # outside the range
     assert "could not satisfy render configuration" in eng.last_error()

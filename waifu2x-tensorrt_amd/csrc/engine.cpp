@@ -144,12 +144,13 @@ constexpr const char* kEngineExt = ".w2x";
 // configuration lies inside an engine's [min, max] range but is not the shape that engine was specialised for.
 // Super-batching: tiles are independent, so one network pass may carry several reference batches (S x batchSize tiles); results
 // are bit-identical, launches per frame drop S-fold and the low-resolution stages fill all 256 CUs.  W2X_SUPERBATCH overrides;
-// the default targets the pixel count of 48 tiles of 256x256 per pass (one 1080p frame at config 3), capped at 64 tiles; small
-// tiles (< 128) keep S = 1.
+// the default targets the pixel count of 48 tiles of 256x256 per pass (one 1080p frame at config 3), capped at 64 tiles.  Small
+// tiles gain the most: at tile 64 / batch 1 a pass of one tile is ~40 launches of a few microseconds of work each (a 1080p frame:
+// 1100 passes, 650 ms, hipGraph replay or not); 64 tiles per pass make it 18 passes.
 Plan lower_for_shape(const std::string& onnxModelPath, int batch, int channels, int height, int width) {
     int S = 1;
     if (const char* env = getenv("W2X_SUPERBATCH")) S = std::max(1, atoi(env));
-    else if (height >= 128) {
+    else {
         const double want = 48.0 * 256 * 256 / ((double)batch * height * width);
         S = std::max(1, (int)std::lround(want));
         while (S > 1 && S * batch > 64) --S;
@@ -937,7 +938,7 @@ bool Img2Img::infer(const float* input, float* output) try {
     }
     hipAssert(hipMemcpyAsync(impl->d_blob_in, input, user_in * sizeof(float), hipMemcpyHostToDevice, stream));
     hipAssert(launch_blob_to_nhwc(impl->d_blob_in, impl->tensors[plan.in_tensor], plan.B, plan.T, stream));
-    impl->run_network(nullptr);                                                        // img2img_infer.cpp:80
+    impl->run_network(nullptr, plan.userB);                                            // img2img_infer.cpp:80 (the slots beyond the caller's batch are not computed)
     hipAssert(launch_nhwc_to_blob(impl->tensors[plan.out_tensor], impl->d_blob_out, plan.B, plan.Tout, stream));
     hipAssert(hipMemcpyAsync(output, impl->d_blob_out, user_out * sizeof(float), hipMemcpyDeviceToHost, stream));
     hipAssert(hipStreamSynchronize(stream));
