@@ -184,17 +184,18 @@ def main():
     full_wall_max = None
     if not strips:
         try:
-            ring = [out] + [np.empty_like(out) for _ in range(2)]
-            for hb in [frame] + ring:
-                eng._L.w2x_pin_host(eng._h, hb.ctypes.data, hb.nbytes)
-            eng.render_sequence([frame] * max(a.warmup, 3), outs=[ring[k % 3] for k in range(max(a.warmup, 3))])
+            pf = eng.alloc_host(frame.shape); pf[...] = frame                    # page-locked frame buffers owned by the engine
+            ring = [eng.alloc_host(out.shape) for _ in range(3)]
+            eng.render_sequence([pf] * max(a.warmup, 3), outs=[ring[k % 3] for k in range(max(a.warmup, 3))])
             sync_all()
             t0 = time.perf_counter()
-            eng.render_sequence([frame] * a.steps, outs=[ring[k % 3] for k in range(a.steps)])
+            eng.render_sequence([pf] * a.steps, outs=[ring[k % 3] for k in range(a.steps)])
             sync_all()
             full_wall_max = shard.max_over_ranks(time.perf_counter() - t0, dist)
-            for hb in [frame] + ring:
-                eng._L.w2x_unpin_host(eng._h, hb.ctypes.data)
+            if not np.array_equal(ring[(a.steps - 1) % 3], out):
+                raise RuntimeError("renderSequence and render disagree")
+            for hb in [pf] + ring:
+                eng.free_host(hb)
         except Exception as e:
             if world > 1:
                 raise
@@ -270,7 +271,7 @@ def main():
                        "full_path_ms_per_frame": None if full_wall_max is None else round(full_wall_max * 1e3 / a.steps, 3),
                        "full_path_frames_per_s": None if full_wall_max is None else round(a.steps * world / full_wall_max, 3),
                        "full_path_mpix_per_s": None if full_wall_max is None else round(a.steps * world / full_wall_max * OUT_MPIX, 2),
-                       "full_path_note": "host frame in -> host frame out for all K frames on every rank (renderSequence, page-locked buffers, H2D/D2H on side streams); max over ranks",
+                       "full_path_note": "host frame in -> host frame out for all K frames on every rank (renderSequence over engine-allocated page-locked buffers, H2D/D2H on side streams); max over ranks",
                        "tiles_per_network_pass": eng.pass_tiles,
                        "algorithmic_tflop_per_frame": round(eng.plan_flops * live / 1e12, 4),
                        "families_ms_per_frame": {k: round(v[0], 3) for k, v in prof.items() if k != "frame_ms"}},

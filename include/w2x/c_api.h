@@ -58,8 +58,12 @@ int w2x_render(w2x_engine* e, const uint8_t* src, int rows, int cols, size_t src
  * it alone composes.  w2x_strip_plan is pure host logic: out[0..3] = first_tile, tile_count, x0, x1 (x in output pixels). */
 int w2x_render_strip(w2x_engine* e, const uint8_t* src, int rows, int cols, size_t src_step, uint8_t* dst, size_t dst_step, int part, int parts);
 /* Frame sequence with the PCIe copies overlapped (no reference counterpart: main.cpp:263-269 renders frame by frame): srcs/dsts are
- * arrays of `count` frame pointers of one size; w2x_pin_host page-locks a caller buffer in place so its copies run by DMA. */
+ * arrays of `count` frame pointers of one size.  The copies run by DMA beside the kernels only for page-locked memory: take the
+ * frame buffers from w2x_alloc_host (engine-owned, w2x_free_host or w2x_destroy releases them).  w2x_pin_host page-locks caller
+ * memory in place and accepts whole pages only (data and bytes multiples of 4096). */
 int w2x_render_sequence(w2x_engine* e, const uint8_t* const* srcs, int rows, int cols, size_t src_step, uint8_t* const* dsts, size_t dst_step, int count);
+void* w2x_alloc_host(w2x_engine* e, size_t bytes);
+void w2x_free_host(w2x_engine* e, void* data);
 int w2x_pin_host(w2x_engine* e, void* data, size_t bytes);
 void w2x_unpin_host(w2x_engine* e, void* data);
 int w2x_strip_plan(int in_w, int in_h, int out_w, int out_h, int tile_in, int tile_out, int scaling, double overlap_x, double overlap_y,

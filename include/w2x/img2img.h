@@ -39,8 +39,14 @@ public:
     // the output columns of strip `part` (w2x_strip_plan); identical bytes to render() there.  render() == renderStrip(.., 0, 1).
     bool renderStrip(const Image& src, Image& dst, int part, int parts);
     // A sequence of equally sized frames (the per-frame loop of main.cpp:263-269) with upload, compute and download overlapped on
-    // three HIP streams; outputs are the bytes render() gives.  For the copies to overlap, page-lock the buffers with pinHost().
+    // three HIP streams; outputs are the bytes render() gives.  The copies only overlap for page-locked host memory: take the frame
+    // buffers from allocHost() (owned by the engine, released by freeHost(), release at destruction at the latest).
     bool renderSequence(const Image* srcs, Image* dsts, int count);
+    void* allocHost(size_t bytes);
+    void freeHost(void* data);
+    // Page-locks caller-owned memory in place.  Only whole pages are accepted (data and bytes multiples of 4096): a registration
+    // covers whole pages, and buffers that share a page with other live data (heap blocks, neighbouring registrations) left stale
+    // registrations behind on this runtime - a later copy from recycled addresses then aborted the process.
     bool pinHost(void* data, size_t bytes);
     void unpinHost(void* data);
     void setMessageCallback(MessageCallback callback);   // img2img.h:21

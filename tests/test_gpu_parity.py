@@ -267,21 +267,33 @@ def test_strips_reassemble_the_frame_bit_exactly(pkg, onnx_model, model, scale, 
     eng.close()
 
 
-@pytest.mark.parametrize("pin,small", [(False, True), (True, True), (True, False)])
-def test_frame_sequence_with_overlapped_copies_matches_render(pkg, onnx_model, pin, small):
+@pytest.mark.parametrize("pinned,small", [(False, True), (True, True), (True, False)])
+def test_frame_sequence_with_overlapped_copies_matches_render(pkg, onnx_model, pinned, small):
     """renderSequence: upload / compute / download of consecutive frames overlap on three streams (two device buffers, events);
-    every frame must come out exactly as from render(), also when output buffers are reused as a ring."""
+    every frame must come out exactly as from render(), also when output buffers are reused as a ring.  pinned: frame buffers
+    from the engine's page-locked allocator (w2x_alloc_host) - the only case in which the copies really run beside the kernels."""
     path = onnx_model("swin_unet/art", 4, 2, 64, small=small)
     eng = make_engine(pkg, path, 2, 64, 4)
     frames = [smooth_frame(90, 130, 40 + k) for k in range(7)]
     want = [eng.render(f) for f in frames]
-    got = eng.render_sequence(frames, pin=pin)
+    if pinned:
+        host = [eng.alloc_host(f.shape) for f in frames]
+        for h, f in zip(host, frames):
+            h[...] = f
+        frames = host
+    got = eng.render_sequence(frames, pinned=pinned)
     assert all(np.array_equal(a, b) for a, b in zip(got, want))
-    ring = [np.empty_like(want[0]) for _ in range(3)]                       # a writer that consumes frames in order
-    eng.render_sequence(frames, outs=[ring[k % 3] for k in range(7)], pin=pin)
+    ring = [eng.alloc_host(want[0].shape) if pinned else np.empty_like(want[0]) for _ in range(3)]   # a writer that consumes frames in order
+    eng.render_sequence(frames, outs=[ring[k % 3] for k in range(7)])
     assert np.array_equal(ring[6 % 3], want[6]) and np.array_equal(ring[5 % 3], want[5]) and np.array_equal(ring[4 % 3], want[4])
     assert np.array_equal(eng.render(frames[2]), want[2])                    # the engine is left in a usable state
     assert eng.last_render_ms > 0
+    if pinned:
+        # in-place page-locking takes whole pages only; a heap block is refused (and the call still works, unpinned)
+        blk = np.zeros(5000, np.uint8)
+        assert eng._L.w2x_pin_host(eng._h, blk.ctypes.data, blk.nbytes) == 0
+        for h in frames + ring:
+            eng.free_host(h)
     eng.close()
 
 
@@ -324,7 +336,7 @@ def test_graph_replay_is_bit_identical_to_plain_launches(pkg, onnx_model, monkey
         assert np.array_equal(eng.render(frame), want), k
         if k == 1:
             assert np.array_equal(eng.render(other), want_other)
-    got = eng.render_sequence([frame, frame, frame, frame, frame], pin=True)
+    got = eng.render_sequence([frame, frame, frame, frame, frame], pinned=True)
     assert all(np.array_equal(g, want) for g in got)
     assert np.array_equal(eng.render(other), want_other) and np.array_equal(eng.render(other), want_other) and np.array_equal(eng.render(other), want_other)
     eng.close()
@@ -353,7 +365,7 @@ def test_engines_on_their_own_host_threads(pkg, onnx_model, monkeypatch):
         try:
             for i in idx:
                 got[i] = e.render(frames[i])
-            got[idx[0]] = e.render_sequence([frames[idx[0]]] * 3, pin=True)[2]
+            got[idx[0]] = e.render_sequence([frames[idx[0]]] * 3, pinned=True)[2]
             whole = np.zeros_like(got[idx[1]])
             for part in range(2):
                 assert e.render_strip(frames[idx[1]], whole, part, 2)

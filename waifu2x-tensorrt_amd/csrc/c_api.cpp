@@ -85,6 +85,8 @@ int w2x_render_sequence(w2x_engine* e, const uint8_t* const* srcs, int rows, int
     }
     return e->engine.renderSequence(s.data(), d.data(), count) ? 1 : 0;
 }
+void* w2x_alloc_host(w2x_engine* e, size_t bytes) { return e ? e->engine.allocHost(bytes) : nullptr; }
+void w2x_free_host(w2x_engine* e, void* data) { if (e) e->engine.freeHost(data); }
 int w2x_pin_host(w2x_engine* e, void* data, size_t bytes) { return e && e->engine.pinHost(data, bytes) ? 1 : 0; }
 void w2x_unpin_host(w2x_engine* e, void* data) { if (e) e->engine.unpinHost(data); }
 

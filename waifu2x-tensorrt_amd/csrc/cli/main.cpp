@@ -142,12 +142,14 @@ int main(int argc, char** argv) {
                     // page-locked once).  The ffmpeg pipes run on their own threads over two chunk slots, so decoding chunk
                     // n+1 and encoding chunk n-1 overlap with rendering chunk n (the reference serialises them, main.cpp:263-269).
                     const int CH = 4, SLOTS = 2;
-                    struct Slot { std::vector<std::vector<uint8_t>> in, out; int frames = 0; int state = 0; };   // 0 free, 1 read, 2 rendered
+                    // frame buffers from the engine's page-locked allocator: their copies run by DMA beside the kernels
+                    struct Slot { std::vector<uint8_t*> in, out; int frames = 0; int state = 0; };   // 0 free, 1 read, 2 rendered
                     std::vector<Slot> slots(SLOTS);
-                    for (Slot& sl : slots) {
-                        sl.in.assign(CH, std::vector<uint8_t>(inBytes)); sl.out.assign(CH, std::vector<uint8_t>(outBytes));
-                        for (int k = 0; k < CH; ++k) { engines[0]->pinHost(sl.in[k].data(), inBytes); engines[0]->pinHost(sl.out[k].data(), outBytes); }
-                    }
+                    for (Slot& sl : slots)
+                        for (int k = 0; k < CH; ++k) {
+                            sl.in.push_back((uint8_t*)engines[0]->allocHost(inBytes)); sl.out.push_back((uint8_t*)engines[0]->allocHost(outBytes));
+                            if (!sl.in.back() || !sl.out.back()) throw std::runtime_error("cannot allocate page-locked frame buffers");
+                        }
                     std::mutex mu; std::condition_variable cv;
                     bool failed = false;
                     std::thread reader([&] {          // slot i: free -> read; a slot with 0 frames marks the end of the stream
@@ -155,7 +157,7 @@ int main(int argc, char** argv) {
                             Slot& sl = slots[i];
                             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return sl.state == 0 || failed; }); if (failed) return; }
                             int got = 0;
-                            for (; got < CH; ++got) if (fread(sl.in[got].data(), 1, inBytes, rd) != inBytes) break;
+                            for (; got < CH; ++got) if (fread(sl.in[got], 1, inBytes, rd) != inBytes) break;
                             { std::lock_guard<std::mutex> lk(mu); sl.frames = got; sl.state = 1; }
                             cv.notify_all();
                             if (got < CH) return;
@@ -166,7 +168,7 @@ int main(int argc, char** argv) {
                             Slot& sl = slots[i];
                             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return sl.state == 2 || failed; }); if (failed) return; }
                             const int n = sl.frames;
-                            for (int k = 0; k < n; ++k) if (fwrite(sl.out[k].data(), 1, outBytes, wr) != outBytes) { std::lock_guard<std::mutex> lk(mu); failed = true; }
+                            for (int k = 0; k < n; ++k) if (fwrite(sl.out[k], 1, outBytes, wr) != outBytes) { std::lock_guard<std::mutex> lk(mu); failed = true; }
                             { std::lock_guard<std::mutex> lk(mu); sl.state = 0; }
                             cv.notify_all();
                             if (n < CH) return;
@@ -178,8 +180,8 @@ int main(int argc, char** argv) {
                         const int got = sl.frames;
                         std::vector<Image> si(got), di(got);
                         for (int k = 0; k < got; ++k) {
-                            si[k] = Image{sl.in[k].data(), pr.height, pr.width, (size_t)pr.width * 3};
-                            di[k] = Image{sl.out[k].data(), pr.height * o.scale, pr.width * o.scale, (size_t)pr.width * o.scale * 3};
+                            si[k] = Image{sl.in[k], pr.height, pr.width, (size_t)pr.width * 3};
+                            di[k] = Image{sl.out[k], pr.height * o.scale, pr.width * o.scale, (size_t)pr.width * o.scale * 3};
                         }
                         const bool ok = got == 0 || engines[0]->renderSequence(si.data(), di.data(), got);
                         { std::lock_guard<std::mutex> lk(mu); if (!ok) failed = true; sl.state = 2; frameIndex += got; }
@@ -188,7 +190,7 @@ int main(int argc, char** argv) {
                         if (!ok || got < CH) break;
                     }
                     reader.join(); writer.join();
-                    for (Slot& sl : slots) for (int k = 0; k < CH; ++k) { engines[0]->unpinHost(sl.in[k].data()); engines[0]->unpinHost(sl.out[k].data()); }
+                    for (Slot& sl : slots) for (int k = 0; k < CH; ++k) { engines[0]->freeHost(sl.in[k]); engines[0]->freeHost(sl.out[k]); }
                     pclose(rd); pclose(wr);
                     if (failed) return -1;
                     ++fileIndex;

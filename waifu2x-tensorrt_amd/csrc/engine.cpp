@@ -209,6 +209,7 @@ struct Img2Img::Impl {
     hipStream_t s_up = nullptr, s_dn = nullptr;
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_dn[2] = {nullptr, nullptr};
     std::vector<void*> pinned;
+    std::vector<void*> host_allocs;     // allocHost(): page-locked buffers handed to the caller
     std::vector<TileSlot> h_slots;
 
     // per-launch HIP-event profiling (profileFrame): events recorded on the compute stream around every launch
@@ -245,7 +246,10 @@ struct Img2Img::Impl {
         graphs.clear(); graph_seen.clear();
     }
 
-    ~Impl() { release(); }
+    ~Impl() {
+        release();
+        for (void* h : host_allocs) if (hipHostFree(h) != hipSuccess) (void)hipGetLastError();
+    }
 
     void release() {
         std::unique_ptr<DeviceGuard> guard;
@@ -259,6 +263,7 @@ struct Img2Img::Impl {
         tensors.clear(); blobs.clear(); gemm.clear(); pool_tensors.clear();
         for (void* h : pinned) if (hipHostUnregister(h) != hipSuccess) (void)hipGetLastError();
         pinned.clear();
+        // (allocHost() buffers belong to the caller's frames and outlive a re-load: they go in the destructor)
         for (hipEvent_t* e : {&ev_up[0], &ev_up[1], &ev_comp[0], &ev_comp[1], &ev_dn[0], &ev_dn[1]}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
         if (s_up) { (void)hipStreamDestroy(s_up); s_up = nullptr; }
         if (s_dn) { (void)hipStreamDestroy(s_dn); s_dn = nullptr; }
@@ -905,9 +910,32 @@ bool Img2Img::renderSequence(const Image* srcs, Image* dsts, int count) try {
     return false;
 }
 
-// Page-lock a caller-owned frame buffer in place so that renderSequence() can copy it by DMA while kernels run.
+// Page-locked frame buffers for renderSequence(): owned by the engine, freed by freeHost() or with the engine.
+void* Img2Img::allocHost(size_t bytes) try {
+    if (!bytes) return nullptr;
+    std::unique_ptr<DeviceGuard> guard;
+    if (impl->device >= 0) guard.reset(new DeviceGuard(impl->device));
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    impl->host_allocs.push_back(p);
+    return p;
+} catch (const std::exception&) {
+    return nullptr;
+}
+void Img2Img::freeHost(void* data) try {
+    auto it = std::find(impl->host_allocs.begin(), impl->host_allocs.end(), data);
+    if (it == impl->host_allocs.end()) return;
+    std::unique_ptr<DeviceGuard> guard;
+    if (impl->device >= 0) guard.reset(new DeviceGuard(impl->device));
+    if (hipHostFree(data) != hipSuccess) (void)hipGetLastError();
+    impl->host_allocs.erase(it);
+} catch (const std::exception&) {
+}
+
+// Page-lock a caller-owned frame buffer in place so that renderSequence() can copy it by DMA while kernels run (whole pages only).
 bool Img2Img::pinHost(void* data, size_t bytes) try {
     if (!data || !bytes) return false;
+    if (((size_t)data | bytes) & 4095) { W2X_LOG(warn, "pinHost: only whole pages can be page-locked in place (use allocHost)."); return false; }
     DeviceGuard guard(impl->device);
     if (hipHostRegister(data, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
     impl->pinned.push_back(data);

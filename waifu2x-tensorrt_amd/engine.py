@@ -105,6 +105,8 @@ def lib():
     L.w2x_render.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t]; L.w2x_render.restype = C.c_int
     L.w2x_render_strip.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_int]; L.w2x_render_strip.restype = C.c_int
     L.w2x_render_sequence.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t, C.c_int]; L.w2x_render_sequence.restype = C.c_int
+    L.w2x_alloc_host.argtypes = [vp, C.c_size_t]; L.w2x_alloc_host.restype = vp
+    L.w2x_free_host.argtypes = [vp, vp]; L.w2x_free_host.restype = None
     L.w2x_pin_host.argtypes = [vp, vp, C.c_size_t]; L.w2x_pin_host.restype = C.c_int
     L.w2x_unpin_host.argtypes = [vp, vp]; L.w2x_unpin_host.restype = None
     L.w2x_strip_plan.argtypes = [C.c_int] * 7 + [C.c_double, C.c_double, C.c_int, C.c_int, vp]; L.w2x_strip_plan.restype = C.c_int
@@ -130,7 +132,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "w2x_create", "w2x_destroy", "w2x_set_message_callback", "w2x_set_progress_callback", "w2x_build", "w2x_load",
     "w2x_render", "w2x_infer", "w2x_output_tile_size", "w2x_plan_flops", "w2x_pass_tiles", "w2x_last_render_ms", "w2x_bench_resident", "w2x_profile_frame", "w2x_op_times",
-    "w2x_render_strip", "w2x_strip_plan", "w2x_render_sequence", "w2x_pin_host", "w2x_unpin_host", "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_write_engine_file", "w2x_validate_engine_file", "w2x_sha256_hex", "w2x_version"]
+    "w2x_render_strip", "w2x_strip_plan", "w2x_render_sequence", "w2x_alloc_host", "w2x_free_host", "w2x_pin_host", "w2x_unpin_host", "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_write_engine_file", "w2x_validate_engine_file", "w2x_sha256_hex", "w2x_version"]
 
 
 class Img2Img:
@@ -224,9 +226,27 @@ class Img2Img:
         return bool(self._L.w2x_render_strip(self._h, src.ctypes.data, src.shape[0], src.shape[1], src.strides[0],
                                              dst.ctypes.data, dst.strides[0], int(part), int(parts)))
 
-    def render_sequence(self, frames, outs=None, pin: bool = False):
+    def alloc_host(self, shape) -> np.ndarray:
+        """A uint8 array over page-locked memory owned by the engine (w2x_alloc_host): frame buffers whose PCIe copies
+        render_sequence() can overlap with the kernels.  Valid until free_host(arr) / close()."""
+        n = int(np.prod(shape))
+        ptr = self._L.w2x_alloc_host(self._h, n)
+        if not ptr:
+            raise W2xError("w2x_alloc_host failed")
+        arr = np.frombuffer((C.c_uint8 * n).from_address(ptr), np.uint8).reshape(shape)
+        self._host_bufs = getattr(self, "_host_bufs", {})
+        self._host_bufs[arr.ctypes.data] = ptr
+        return arr
+
+    def free_host(self, arr: np.ndarray) -> None:
+        ptr = getattr(self, "_host_bufs", {}).pop(arr.ctypes.data, None)
+        if ptr:
+            self._L.w2x_free_host(self._h, ptr)
+
+    def render_sequence(self, frames, outs=None, pinned: bool = False):
         """Equally sized frames with upload / compute / download overlapped (w2x_render_sequence).  outs: list of pre-allocated
-        arrays (may repeat, e.g. a ring of buffers) or None; pin=True page-locks the distinct buffers for the duration of the call."""
+        arrays (may repeat, e.g. a ring of buffers) or None; pinned=True takes the output buffers it allocates from alloc_host()
+        (copies of the results are returned) - pass alloc_host() arrays as frames / outs yourself to avoid that copy."""
         s = getattr(self, "_scaling", 0)
         n = len(frames)
         if n == 0:
@@ -235,25 +255,33 @@ class Img2Img:
         for f in frames:
             if f.dtype != np.uint8 or f.shape != (r, c, 3) or f.strides != (c * 3, 3, 1):
                 raise ValueError("frames must be packed uint8 [rows, cols, 3] arrays of one size")
+        own = []
         if outs is None:
-            outs = [np.empty((r * s, c * s, 3), np.uint8) for _ in range(n)]
+            if pinned:
+                own = [self.alloc_host((r * s, c * s, 3)) for _ in range(min(n, 3))]
+                outs = [own[k % len(own)] for k in range(n)]
+            else:
+                outs = [np.empty((r * s, c * s, 3), np.uint8) for _ in range(n)]
         for o in outs:
             if o.dtype != np.uint8 or o.shape != (r * s, c * s, 3) or o.strides != (c * s * 3, 3, 1):
                 raise ValueError("outs must be packed uint8 arrays of the scaled size")
         import ctypes as C
         sp = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
         dp = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
-        pinned = []
-        if pin:
-            for a in {id(x): x for x in list(frames) + list(outs)}.values():
-                if self._L.w2x_pin_host(self._h, a.ctypes.data, a.nbytes):
-                    pinned.append(a)
-        try:
-            ok = bool(self._L.w2x_render_sequence(self._h, sp, r, c, c * 3, dp, c * s * 3, n))
-        finally:
-            for a in pinned:
-                self._L.w2x_unpin_host(self._h, a.ctypes.data)
-        if not ok:
+        if own:          # a ring of three engine-owned buffers: run the sequence in pieces and copy each result out
+            res = []
+            try:
+                for k0 in range(0, n, len(own)):
+                    m = min(len(own), n - k0)
+                    if not self._L.w2x_render_sequence(self._h, (C.c_void_p * m)(*[f.ctypes.data for f in frames[k0:k0 + m]]), r, c, c * 3,
+                                                       (C.c_void_p * m)(*[o.ctypes.data for o in own[:m]]), c * s * 3, m):
+                        raise W2xError(self.last_error() or "render_sequence failed")
+                    res += [o.copy() for o in own[:m]]
+            finally:
+                for o in own:
+                    self.free_host(o)
+            return res
+        if not self._L.w2x_render_sequence(self._h, sp, r, c, c * 3, dp, c * s * 3, n):
             raise W2xError(self.last_error() or "render_sequence failed")
         return outs
 
