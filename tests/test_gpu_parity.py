@@ -123,6 +123,24 @@ def test_opset13_graph_with_decomposed_layernorm_runs_on_the_fused_kernels(pkg, 
     assert r["psnr_db"] > 50.0 and r["max_lsb"] <= FRAME_MAX_LSB, r
 
 
+def test_unfused_attention_core_on_full_width_graphs(pkg, onnx_model, monkeypatch):
+    """Graphs whose transformer shapes the fused kernels do not cover keep the QKV / proj linears on the general MFMA GEMM and run
+    the attention core on k_attn.hip: attn_mfma_kernel (head sizes 8 / 16 / 32 on v_mfma_f32_16x16x16_f16; the 48-channel test
+    graphs use head size 8 everywhere in this file) or, under W2X_ATTN_VALU, the lane-per-query kernel it replaced.  Here the
+    full-width graph is forced down that path (W2X_NO_FUSE_ATTN at build time): head sizes 16 and 32, shifted windows, all
+    mask classes, against the same oracle and bounds as the fused kernels."""
+    path = onnx_model("swin_unet/art", 4, 1, 64, noise=1)
+    monkeypatch.setenv("W2X_NO_FUSE_ATTN", "1")
+    eng = make_engine(pkg, path, 1, 64, 4)
+    monkeypatch.delenv("W2X_NO_FUSE_ATTN")
+    rng = np.random.default_rng(11)
+    x = rng.random((1, 3, 64, 64), dtype=np.float32).astype(np.float16).astype(np.float32)
+    y = eng.infer(x)
+    r = network_report("network[swin_unet/art s4 B1 T64 full, un-fused attention core]", y, oracle16(path)(x), onnx_exec.Executor(path).run(x))
+    assert r["max_ulp16"] <= NET_MAX_ULP16 and r["mean_abs"] <= NET_MEAN_ABS, r
+    eng.close()
+
+
 def test_tta_bug_compat_mode(pkg, onnx_model):
     """Quirk Q1 (img2img_render.cpp:313-316): optional bug-compatible TTA blends the last de-augmented output."""
     path = onnx_model("swin_unet/art", 2, 4, 64, small=True)
