@@ -205,7 +205,7 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
                 if (t == 0) Cls[w] = p.maskid[wl];
             } else if (t == 0) Cls[w] = 0;
         }
-        Pix[tid] = (int2v){pix < 0 ? (int)kNoRow : pix * (C * 2), srow};
+        Pix[tid] = (int2v){pix < 0 ? (int)kNoRow : (int)((unsigned)pix * (unsigned)(C * 2)), srow};   // offsets are unsigned 32-bit (up to 4 GB per run)
     }
     __syncthreads();
 
