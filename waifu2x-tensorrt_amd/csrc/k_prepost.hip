@@ -68,58 +68,126 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherParams p) {
     }
 }
 
-__global__ __launch_bounds__(256) void compose_kernel(const ComposeParams p) {
-    const int x1 = p.x1 > 0 ? p.x1 : p.outW, sw = x1 - p.x0;
-    const long total = (long)sw * p.outH;
+// One output pixel: the covering tiles in ascending tile index (img2img_render.cpp:329-330), ramp weights L, T, R, B in that order on
+// the clipped rect (:110-120), fp32 sums, then rint(x * 255) saturated (:342), RGB -> BGR (:343).  Returns b | g << 8 | r << 16.
+__device__ __forceinline__ unsigned quantize_bgr(float r, float g, float b) {
+    const unsigned B = (unsigned)min(max(__float2int_rn(b * 255.f), 0), 255), G = (unsigned)min(max(__float2int_rn(g * 255.f), 0), 255),
+                   R = (unsigned)min(max(__float2int_rn(r * 255.f), 0), 255);
+    return B | G << 8 | R << 16;
+}
+__device__ __forceinline__ unsigned compose_pixel(const ComposeParams& p, const half4* tiles, int X, int Y) {
     const int To = p.To, n = To - 1;
     const int steps = p.tta ? 8 : 1;
-    const half4* tiles = (const half4*)p.tiles;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int Y = (int)(i / sw), X = p.x0 + (int)(i - (long)Y * sw);
-        // candidate tile columns/rows: origin = idx*stride, extent To (clipped to the canvas)
-        int i0 = X - To + 1; i0 = i0 <= 0 ? 0 : (i0 + p.stride_x - 1) / p.stride_x;
-        int i1 = min(p.nx - 1, X / p.stride_x);
-        int j0 = Y - To + 1; j0 = j0 <= 0 ? 0 : (j0 + p.stride_y - 1) / p.stride_y;
-        int j1 = min(p.ny - 1, Y / p.stride_y);
-        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
-        for (int ti = i0; ti <= i1; ++ti) {
-            const int ox = ti * p.stride_x, lx = X - ox;
-            const int rw = ox + To > p.outW ? p.outW - ox : To;
-            for (int tj = j0; tj <= j1; ++tj) {
-                const int oy = tj * p.stride_y, ly = Y - oy;
-                const int rh = oy + To > p.outH ? p.outH - oy : To;
-                const long tile = (long)ti * p.ny + tj - p.first_tile;
-                const half4* tp = tiles + tile * steps * (long)To * To;
-                float v0, v1, v2;
-                if (!p.tta) {
-                    half4 h = tp[(long)ly * To + lx];
-                    v0 = (float)h[0]; v1 = (float)h[1]; v2 = (float)h[2];
-                } else {
-                    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-                    half4 h;
+    // candidate tile columns/rows: origin = idx*stride, extent To (clipped to the canvas)
+    int i0 = X - To + 1; i0 = i0 <= 0 ? 0 : (i0 + p.stride_x - 1) / p.stride_x;
+    int i1 = min(p.nx - 1, X / p.stride_x);
+    int j0 = Y - To + 1; j0 = j0 <= 0 ? 0 : (j0 + p.stride_y - 1) / p.stride_y;
+    int j1 = min(p.ny - 1, Y / p.stride_y);
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+    for (int ti = i0; ti <= i1; ++ti) {
+        const int ox = ti * p.stride_x, lx = X - ox;
+        const int rw = ox + To > p.outW ? p.outW - ox : To;
+        for (int tj = j0; tj <= j1; ++tj) {
+            const int oy = tj * p.stride_y, ly = Y - oy;
+            const int rh = oy + To > p.outH ? p.outH - oy : To;
+            const long tile = (long)ti * p.ny + tj - p.first_tile;
+            const half4* tp = tiles + tile * steps * (long)To * To;
+            float v0, v1, v2;
+            if (!p.tta) {
+                half4 h = tp[(long)ly * To + lx];
+                v0 = (float)h[0]; v1 = (float)h[1]; v2 = (float)h[2];
+            } else {
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+                half4 h;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        int sy, sx;
-                        deaug_src(k, n, ly, lx, sy, sx);
-                        h = tp[(long)k * To * To + (long)sy * To + sx];
-                        s0 += (float)h[0]; s1 += (float)h[1]; s2 += (float)h[2];
+                for (int k = 0; k < 8; ++k) {
+                    int sy, sx;
+                    deaug_src(k, n, ly, lx, sy, sx);
+                    h = tp[(long)k * To * To + (long)sy * To + sx];
+                    s0 += (float)h[0]; s1 += (float)h[1]; s2 += (float)h[2];
+                }
+                if (p.tta_bug_compat) { v0 = (float)h[0]; v1 = (float)h[1]; v2 = (float)h[2]; }
+                else { v0 = s0 * 0.125f; v1 = s1 * 0.125f; v2 = s2 * 0.125f; }
+            }
+            if (p.ovx || p.ovy) {
+                if (ox > 0 && lx < p.ovx) { float w = p.ramp_x[lx]; v0 *= w; v1 *= w; v2 *= w; }
+                if (oy > 0 && ly < p.ovy) { float w = p.ramp_y[ly]; v0 *= w; v1 *= w; v2 *= w; }
+                if (ox + rw < p.outW && n - lx < p.ovx) { float w = p.ramp_x[n - lx]; v0 *= w; v1 *= w; v2 *= w; }
+                if (oy + rh < p.outH && n - ly < p.ovy) { float w = p.ramp_y[n - ly]; v0 *= w; v1 *= w; v2 *= w; }
+            }
+            acc0 += v0; acc1 += v1; acc2 += v2;
+        }
+    }
+    return quantize_bgr(acc0, acc1, acc2);
+}
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// A thread owns four consecutive pixels of a row.  Where the four have the same covering tiles, lie inside each of them and no TTA
+// is involved (all but the columns next to a tile edge), a tile contributes its four pixels as two 16-byte loads and the 12
+// output bytes leave as three dwords; the per-pixel arithmetic and its order are those of compose_pixel, so the bytes are the
+// same.  Everything else takes the per-pixel path.  (The output is 100 MB of u8 per 4K frame: single-byte stores and 8-byte loads
+// were the kernel's bound; four pixels per thread on the per-pixel path alone lose the loads' coalescing and measured slower.)
+__global__ __launch_bounds__(256) void compose_kernel(const ComposeParams p) {
+    const int x1 = p.x1 > 0 ? p.x1 : p.outW, sw = x1 - p.x0;
+    const int gw = (sw + 3) >> 2;                                   // pixel groups per row
+    const long total = (long)gw * p.outH;
+    const half4* tiles = (const half4*)p.tiles;
+    const int To = p.To, n = To - 1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int Y = (int)(i / gw), X = p.x0 + 4 * (int)(i - (long)Y * gw);
+        uint8_t* d = p.dst + (size_t)Y * p.dst_step + (size_t)X * 3;
+        const int np = min(4, x1 - X);
+        unsigned px[4] = {0u, 0u, 0u, 0u};
+        // tile columns covering the first and the last pixel of the group
+        int a0 = X - To + 1; a0 = a0 <= 0 ? 0 : (a0 + p.stride_x - 1) / p.stride_x;
+        int b0 = X + 3 - To + 1; b0 = b0 <= 0 ? 0 : (b0 + p.stride_x - 1) / p.stride_x;
+        const int a1 = min(p.nx - 1, X / p.stride_x), b1 = min(p.nx - 1, (X + 3) / p.stride_x);
+        const bool fast = np == 4 && !p.tta && a0 == b0 && a1 == b1 && (((size_t)d) & 3) == 0;
+        if (fast) {
+            int j0 = Y - To + 1; j0 = j0 <= 0 ? 0 : (j0 + p.stride_y - 1) / p.stride_y;
+            const int j1 = min(p.ny - 1, Y / p.stride_y);
+            float acc[4][3] = {};
+            for (int ti = a0; ti <= a1; ++ti) {
+                const int ox = ti * p.stride_x, lx = X - ox;
+                const int rw = ox + To > p.outW ? p.outW - ox : To;
+                for (int tj = j0; tj <= j1; ++tj) {
+                    const int oy = tj * p.stride_y, ly = Y - oy;
+                    const int rh = oy + To > p.outH ? p.outH - oy : To;
+                    const long tile = (long)ti * p.ny + tj - p.first_tile;
+                    const half4* tp = tiles + tile * (long)To * To + (long)ly * To + lx;
+                    half4 h[4];
+                    if ((((size_t)tp) & 15) == 0) { const half8 u0 = *(const half8*)tp, u1 = *(const half8*)(tp + 2);
+                        h[0] = (half4){u0[0], u0[1], u0[2], u0[3]}; h[1] = (half4){u0[4], u0[5], u0[6], u0[7]}; h[2] = (half4){u1[0], u1[1], u1[2], u1[3]}; h[3] = (half4){u1[4], u1[5], u1[6], u1[7]}; }
+                    else { h[0] = tp[0]; h[1] = tp[1]; h[2] = tp[2]; h[3] = tp[3]; }
+                    const bool wl = ox > 0, wt = oy > 0 && ly < p.ovy, wr = ox + rw < p.outW, wb = oy + rh < p.outH && n - ly < p.ovy;
+                    const float fy_t = wt ? p.ramp_y[ly] : 1.f, fy_b = wb ? p.ramp_y[n - ly] : 1.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float v0 = (float)h[k][0], v1 = (float)h[k][1], v2 = (float)h[k][2];
+                        if (p.ovx || p.ovy) {
+                            const int lk = lx + k;
+                            if (wl && lk < p.ovx) { float w = p.ramp_x[lk]; v0 *= w; v1 *= w; v2 *= w; }
+                            if (wt) { v0 *= fy_t; v1 *= fy_t; v2 *= fy_t; }
+                            if (wr && n - lk < p.ovx) { float w = p.ramp_x[n - lk]; v0 *= w; v1 *= w; v2 *= w; }
+                            if (wb) { v0 *= fy_b; v1 *= fy_b; v2 *= fy_b; }
+                        }
+                        acc[k][0] += v0; acc[k][1] += v1; acc[k][2] += v2;
                     }
-                    if (p.tta_bug_compat) { v0 = (float)h[0]; v1 = (float)h[1]; v2 = (float)h[2]; }
-                    else { v0 = s0 * 0.125f; v1 = s1 * 0.125f; v2 = s2 * 0.125f; }
                 }
-                if (p.ovx || p.ovy) {
-                    if (ox > 0 && lx < p.ovx) { float w = p.ramp_x[lx]; v0 *= w; v1 *= w; v2 *= w; }
-                    if (oy > 0 && ly < p.ovy) { float w = p.ramp_y[ly]; v0 *= w; v1 *= w; v2 *= w; }
-                    if (ox + rw < p.outW && n - lx < p.ovx) { float w = p.ramp_x[n - lx]; v0 *= w; v1 *= w; v2 *= w; }
-                    if (oy + rh < p.outH && n - ly < p.ovy) { float w = p.ramp_y[n - ly]; v0 *= w; v1 *= w; v2 *= w; }
-                }
-                acc0 += v0; acc1 += v1; acc2 += v2;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) px[k] = quantize_bgr(acc[k][0], acc[k][1], acc[k][2]);
+            unsigned* dw = (unsigned*)d;
+            dw[0] = px[0] | px[1] << 24;
+            dw[1] = px[1] >> 8 | px[2] << 16;
+            dw[2] = px[2] >> 16 | px[3] << 8;
+        } else {
+            for (int k = 0; k < np; ++k) {
+                const unsigned v = compose_pixel(p, tiles, X + k, Y);
+                d[3 * k] = (uint8_t)v; d[3 * k + 1] = (uint8_t)(v >> 8); d[3 * k + 2] = (uint8_t)(v >> 16);
             }
         }
-        uint8_t* d = p.dst + (size_t)Y * p.dst_step + (size_t)X * 3;
-        d[0] = (uint8_t)min(max(__float2int_rn(acc2 * 255.f), 0), 255);
-        d[1] = (uint8_t)min(max(__float2int_rn(acc1 * 255.f), 0), 255);
-        d[2] = (uint8_t)min(max(__float2int_rn(acc0 * 255.f), 0), 255);
     }
 }
 
@@ -214,7 +282,7 @@ hipError_t launch_gather(const GatherParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_compose(const ComposeParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(compose_kernel, dim3(grid_for((long)((p.x1 > 0 ? p.x1 : p.outW) - p.x0) * p.outH)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(compose_kernel, dim3(grid_for((long)((((p.x1 > 0 ? p.x1 : p.outW) - p.x0) + 3) / 4) * p.outH)), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 hipError_t launch_se(const SeParams& p, hipStream_t s) {
