@@ -1,20 +1,19 @@
+// Round-2 intermediate schedule of the C = 192 fused attention (a wave = (window, 3 heads), two alternating sets of 12 weight registers),
+// kept for tools/ab/attn192_variants.sh (rebuilds k_swinattn192.o from this file and benches both on one box): 2.23 vs 2.14 ms per frame.
 // Fused Swin attention branch, C = 192 / 6 heads of 32 / window 6x6, register-resident variant for gfx950.
 //     y = x + proj( W-MSA( LayerNorm(x) ) )
-// Same math, parameters and bias-table layout as k_swinattn96.hip, and the same unit mapping: a workgroup = 4 waves = 2 windows,
-// wave v takes head v on BOTH windows (a head's weights are read once for two windows, every fragment feeds six MFMAs) and then head
-// 4 + (v >> 1) on window v & 1.  With a head dimension of 32 the accumulator layout of v_mfma_f32_16x16x32_f16 (lane (col, g)
-// holds rows 4g..4g+3) IS an operand layout (lane (row|col, g) holds 8 k-values) once two 16-feature tiles are paired, with the
-// k order permuted the same way on both sides.  So
+// Same math, parameters and bias-table layout as k_swinattn.hip; the schedule follows k_swinattn96.hip (a workgroup =
+// 4 waves = 2 windows, wave (w, hp) owns window w and the heads 2*it + hp) and goes one step further: with a head
+// dimension of 32 the accumulator layout of v_mfma_f32_16x16x32_f16 (lane (col, g) holds rows 4g..4g+3) IS an operand
+// layout (lane (row|col, g) holds 8 k-values) once two 16-feature tiles are paired, with the k order permuted the same
+// way on both sides.  So
 //     q^T, k^T (rows = features) -> B / A operands of S^T = K Q^T      straight from the accumulators,
 //     v (rows = tokens)          -> A operand of O^T = V^T P^T         straight from the accumulators,
 //     S^T after the softmax      -> B operand of O^T                   (as in the other variants),
-// and q, k, v, S, P never touch LDS.  LDS only holds the normalised x slabs (MFMA operand of the q/k/v products, read by
-// all waves) and the head outputs (operand of proj).  Weights come from L2 as fragments through a ring of eight registers, each
-// fragment requested eight fragments ahead of its use across matrix and unit boundaries; x fragments are requested one k-step
-// ahead.  Four workgroup barriers in the whole kernel; the vector work around the products is trimmed as in k_swinattn96.hip
-// (ones-operand MFMA for the softmax denominators, folded k / v biases, q bias as initial accumulator, packed fp32, buffer loads /
-// stores and v_fma_mix in the row phases, transposed proj).  At 234 VGPRs = two workgroups per CU the kernel is latency-bound:
-// ring depths of 6 / 8 / 12 measure the same, a third workgroup does not fit LDS (70 KB each).
+// and q, k, v, S, P never touch LDS.  LDS only holds the normalised x slab (MFMA operand of the q/k/v products, read by
+// both waves of a window) and the head outputs (operand of proj).  Weights come from L2 as fragments, one 32x192 matrix
+// (12 fragments) ahead of its use.  Four workgroup barriers in the whole kernel; the vector work around the products is
+// trimmed as in k_swinattn96.hip (ones-operand MFMA for the softmax denominators, folded k / v biases, packed fp32).
 //
 // Window slab: 48 rows; tokens 0..31 on rows 0..31, tokens 32..35 on rows 32, 36, 40, 44, zero rows between.  That puts
 // key 32+g on row 4g of the third key tile (one per lane group, register j = 0: the softmax touches 9 instead of 12
@@ -157,27 +156,25 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
     unsigned long long tprev = 0;
     if (STAMPS) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); if (lane == 0) atomicAdd(&g_sa192_stamps[7], 1ull); }
 
-    // this wave's three (window, head) units: head hA on both windows, head hC on window wC (k_swinattn96.hip's mapping): a head's
-    // weights are read once for two windows, every fragment feeds 6 MFMAs there instead of 3
-    const int hA = wv, hC = 4 + (wv >> 1), wC = wv & 1;
-    const int amask0 = wok0 ? p.maskid[wl0] : 0, amask1 = wok1 ? p.maskid[wl1] : 0;
+    // this wave's attention unit
+    const int aw = wv >> 1, ahp = wv & 1;
+    const bool aok = aw == 0 ? wok0 : wok1;
+    const int amask = aok ? p.maskid[aw == 0 ? wl0 : wl1] : 0;
+    const int sbase = aw * SLAB, tbase = aw * NTOK;
 
-    // Weight fragments reach the MFMAs through a ring of RING registers.  The six 32 x 192 matrices of a wave (q, k, v of head hA,
-    // then of head hC) are 72 fragments in consumption order (matrix, k-step, feature tile); fragment i+RING is requested from L2
-    // right after the last MFMA that used the register of fragment i - across matrix boundaries and across the softmax phases -
-    // so a load has RING x 6 (or 3) MFMAs and everything between the products to land.  (Before: two alternating sets of 12
-    // registers, 96 VGPRs, which the scheduler partly sank to the consumers anyway.)
-    constexpr int RING = 8, NFRAG = 72;
+    // weight fragments of one 32 x 192 matrix (M = 0 q, 1 k, 2 v) of head H: fragment [ft*6 + ks] = rows ft*16 + fr,
+    // columns ks*32 + 8g .. +7; stored fragment-major, so the twelve loads are twelve consecutive KiB.
+    // Two register sets alternate (the unrolled matrix sequence indexes them statically).
+    half8 wr[2][12];
     const _Float16* wlane = Wqkv + lane * 8;
-    auto wfrag = [&](int q) {                   // q = matrix * 12 + k-step * 2 + feature tile
-        const int mat = q / 12, j = q - mat * 12, M = mat % 3, ks = j >> 1, ft = j & 1;
-        const int H = mat < 3 ? hA : hC;
-        return *(const half8*)(wlane + (size_t)((M * NH + H) * 12 + ft * 6 + ks) * 512);
-    };
-    half8 wr[RING];
-#pragma unroll
-    for (int i = 0; i < RING; ++i) wr[i] = wfrag(i);
-#define W2X_RING_NEXT(Q) do { if ((Q) + RING < NFRAG) { wr[(Q) % RING] = wfrag((Q) + RING); asm volatile("" ::: "memory"); } } while (0)
+#define W2X_LOAD_W(SET, M, H)                                                                                \
+    {                                                                                                        \
+        _Pragma("unroll") for (int f = 0; f < 12; ++f)                                                       \
+            wr[SET][f] = *(const half8*)(wlane + (size_t)(((M) * NH + (H)) * 12 + f) * 512);                 \
+    }
+    W2X_LOAD_W(0, 0, ahp);
+    // (Pinning these loads where they are written with a compiler fence - the scheduler sinks part of them towards their consumers -
+    // measured no faster: 8.65 vs 8.67 ms per frame on one box.)
 
     // ---- source pixel and slab row of every token row (and the pad rows), worked out once per workgroup (one thread per row)
     if (tid < R + NPAD) {
@@ -241,13 +238,42 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
 
     const float qscale = p.scale * 1.44269504088896341f;   // log2(e) folded into q: softmax uses exp2
     const int lane2 = g * 16 + (fr >> 2);                  // bias-table lane of the query this lane holds in query tile 2
-    half8 wp[3][6];                                        // proj fragments of this wave's three n-tiles, fetched under the last unit
-
-    // ---- one (window, head) unit from its q / k / v fragments: S^T = K Q^T on top of the bias, softmax over the keys (lane-local +
-    // two row swaps), O^T = V^T P^T scaled by 1/l and parked in Os (token order).  The denominators come off the matrix pipe (a
-    // ones matrix in place of V^T, see k_swinattn96.hip); the k bias drops out of the softmax, the v bias is added to the
-    // normalised output.
-    auto attend = [&](const int w, const int h, const bool ok, const int amask, const half8 (&qf)[3], const half8 (&kf)[3], const half8 (&vf0)[2], const half8 (&vf1)[2], const bool last) {
+    half8 wp[3][6];                                        // proj fragments of this wave's three n-tiles, fetched at the end of the last head
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int h = 2 * it + ahp;
+        half8 qf[3], kf[3], vf0[2], vf1[2];
+        // ---- q^T and k^T: rows = features (A = weights), columns = slab rows (B = x)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int cur = (it * 3 + m) & 1;
+            W2X_LOAD_W(cur ^ 1, m + 1, h);                                     // next matrix of this head (k, then v)
+            // q: the bias is the initial accumulator, the result is scaled once; k: no bias (q.bk is the same for every key of a query)
+            const float4v b0 = m == 0 ? *(const float4v*)(p.bqkv + h * HD + g * 4) : zero4;
+            const float4v b1 = m == 0 ? *(const float4v*)(p.bqkv + h * HD + 16 + g * 4) : zero4;
+            float4v a[2][3] = {{b0, b0, b0}, {b1, b1, b1}};
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                half8 xf[3];
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt) xf[tt] = *(const half8*)(Xs + (sbase + tt * 16 + fr) * LDX + ks * 32 + g * 8);
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                    for (int tt = 0; tt < 3; ++tt) a[ft][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[cur][ft * 6 + ks], xf[tt], a[ft][tt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt) {
+                half8 f;
+                const float4v a0 = m == 0 ? a[0][tt] * qscale : a[0][tt], a1 = m == 0 ? a[1][tt] * qscale : a[1][tt];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { f[j] = (_Float16)a0[j]; f[4 + j] = (_Float16)a1[j]; }
+                if (m == 0) qf[tt] = f; else kf[tt] = f;
+            }
+        }
+        W2X_STAMP(1)
+        // bias (+ shift mask) of this unit in load order (lower.cpp): per query tile 2 x float4 + 1 float per lane;
+        // fetched under the v products, it is the initial accumulator of S^T
         float4v s[3][3];
         float b2[3];
         {
@@ -261,6 +287,32 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
                 b2[qi] = bias[qi * 576 + 512 + bl];       // key tile 2 holds one key per lane: added after the product
             }
         }
+        // ---- v: rows = slab rows (A = x), columns = features (B = weights)
+        {
+            const int cur = (it * 3 + 2) & 1;
+            if (it < 2) W2X_LOAD_W(cur ^ 1, 0, h + 2)                          // q of the next head
+            float4v a[3][2] = {{zero4, zero4}, {zero4, zero4}, {zero4, zero4}};
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                half8 xf[3];
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt) xf[tt] = *(const half8*)(Xs + (sbase + tt * 16 + fr) * LDX + ks * 32 + g * 8);
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                    for (int tt = 0; tt < 3; ++tt) a[tt][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[tt], wr[cur][ft * 6 + ks], a[tt][ft], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) {
+                half8 f0, f1 = zero8;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { f0[j] = (_Float16)a[0][ft][j]; f0[4 + j] = (_Float16)a[1][ft][j]; }   // the v bias is added to the normalised output
+                f1[0] = (_Float16)a[2][ft][0];                          // slab row 32 + 4g = token 32 + g
+                vf0[ft] = f0; vf1[ft] = f1;
+            }
+        }
+        W2X_STAMP(2)
+        // ---- S^T = K Q^T on top of the bias, softmax over the keys (lane-local + two row swaps)
 #pragma unroll
         for (int qi = 0; qi < 3; ++qi)
 #pragma unroll
@@ -288,12 +340,15 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
             half8 t = zero8; t[0] = (_Float16)__builtin_amdgcn_exp2f(s[qi][2][0] - mx[qi]);
             pf1[qi] = t;
         }
-        if (last) {   // fetch this wave's proj fragments under the last products
+        W2X_STAMP(3)
+        if (it == 2) {   // the weight registers are free now: fetch this wave's proj fragments under the last products
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
                 for (int ks = 0; ks < 6; ++ks) wp[t][ks] = *(const half8*)(Wproj + (size_t)(((wv * 3 + t) * 6 + ks) * 64 + lane) * 8);
         }
+        // ---- O^T = V^T P^T: rows = features, columns = queries; scaled by 1/l and parked in Os (token order).  The
+        // denominators come off the matrix pipe (a ones matrix in place of V^T, see k_swinattn96.hip).
         float inv[3];
         const float4v bv[2] = {*(const float4v*)(p.bqkv + 2 * C + h * HD + g * 4), *(const float4v*)(p.bqkv + 2 * C + h * HD + 16 + g * 4)};
         {
@@ -313,129 +368,17 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
                 float4v o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf0[ft], pf0[qi], zero4, 0, 0, 0);
                 o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf1[ft], pf1[qi], o, 0, 0, 0);
                 const int query = qi < 2 ? qi * 16 + fr : 32 + (fr >> 2);
-                if (ok && (qi < 2 || (fr & 3) == 0)) {
+                if (aok && (qi < 2 || (fr & 3) == 0)) {
                     const float2v i2 = {inv[qi], inv[qi]};
                     const float2v o0 = __builtin_elementwise_fma((float2v){o[0], o[1]}, i2, (float2v){bv[ft][0], bv[ft][1]});
                     const float2v o1 = __builtin_elementwise_fma((float2v){o[2], o[3]}, i2, (float2v){bv[ft][2], bv[ft][3]});
                     const half4 oh = {(_Float16)o0[0], (_Float16)o0[1], (_Float16)o1[0], (_Float16)o1[1]};
-                    *(half4*)(Os + (w * NTOK + query) * LDX + h * HD + ft * 16 + g * 4) = oh;
+                    *(half4*)(Os + (tbase + query) * LDX + h * HD + ft * 16 + g * 4) = oh;
                 }
             }
-    };
-    // accumulators of one window -> operand fragments: q^T / k^T (rows = features): tile tt = [feature tile 0 | feature tile 1];
-    // v (rows = slab rows): vf0 = tokens 0..31, vf1 = slab row 32 + 4g = token 32 + g
-    auto pack_qk = [&](const float4v (&a)[2][3], const bool is_q, half8 (&f)[3]) {
-#pragma unroll
-        for (int tt = 0; tt < 3; ++tt) {
-            const float4v a0 = is_q ? a[0][tt] * qscale : a[0][tt], a1 = is_q ? a[1][tt] * qscale : a[1][tt];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { f[tt][j] = (_Float16)a0[j]; f[tt][4 + j] = (_Float16)a1[j]; }
-        }
-    };
-    auto pack_v = [&](const float4v (&a)[3][2], half8 (&vf0)[2], half8 (&vf1)[2]) {
-#pragma unroll
-        for (int ft = 0; ft < 2; ++ft) {
-            half8 f0, f1 = zero8;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { f0[j] = (_Float16)a[0][ft][j]; f0[4 + j] = (_Float16)a[1][ft][j]; }
-            f1[0] = (_Float16)a[2][ft][0];
-            vf0[ft] = f0; vf1[ft] = f1;
-        }
-    };
-
-    // ---- head hA on both windows: every weight fragment multiplies six token tiles
-#define W2X_LOAD_X2(DST, KS_)                                                                                                   \
-    _Pragma("unroll") for (int w_ = 0; w_ < 2; ++w_) _Pragma("unroll") for (int t_ = 0; t_ < 3; ++t_)                           \
-        DST[w_][t_] = *(const half8*)(Xs + (w_ * SLAB + t_ * 16 + fr) * LDX + (KS_) * 32 + g * 8);
-    {
-        half8 qf[2][3], kf[2][3], vf0[2][2], vf1[2][2];
-        const float4v bq0 = *(const float4v*)(p.bqkv + hA * HD + g * 4), bq1 = *(const float4v*)(p.bqkv + hA * HD + 16 + g * 4);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {      // q^T (bias = initial accumulator) and k^T (no bias): rows = features (A = weights), columns = slab rows (B = x)
-            const float4v b0 = m == 0 ? bq0 : zero4, b1 = m == 0 ? bq1 : zero4;
-            float4v a[2][2][3] = {{{b0, b0, b0}, {b1, b1, b1}}, {{b0, b0, b0}, {b1, b1, b1}}};
-            half8 xf[2][2][3];             // x fragments of k-step ks in xf[ks & 1], requested one k-step ahead
-            W2X_LOAD_X2(xf[0], 0);
-#pragma unroll
-            for (int j = 0; j < 12; ++j) {
-                const int ks = j >> 1, ft = j & 1, q = m * 12 + j;
-                if (ft == 0 && ks + 1 < 6) W2X_LOAD_X2(xf[(ks + 1) & 1], ks + 1);
-#pragma unroll
-                for (int w = 0; w < 2; ++w)
-#pragma unroll
-                    for (int tt = 0; tt < 3; ++tt) a[w][ft][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[q % RING], xf[ks & 1][w][tt], a[w][ft][tt], 0, 0, 0);
-                W2X_RING_NEXT(q);
-            }
-            pack_qk(a[0], m == 0, m == 0 ? qf[0] : kf[0]);
-            pack_qk(a[1], m == 0, m == 0 ? qf[1] : kf[1]);
-        }
-        W2X_STAMP(1)
-        {                                  // v: rows = slab rows (A = x), columns = features (B = weights)
-            float4v a[2][3][2] = {{{zero4, zero4}, {zero4, zero4}, {zero4, zero4}}, {{zero4, zero4}, {zero4, zero4}, {zero4, zero4}}};
-            half8 xf[2][2][3];
-            W2X_LOAD_X2(xf[0], 0);
-#pragma unroll
-            for (int j = 0; j < 12; ++j) {
-                const int ks = j >> 1, ft = j & 1, q = 24 + j;
-                if (ft == 0 && ks + 1 < 6) W2X_LOAD_X2(xf[(ks + 1) & 1], ks + 1);
-#pragma unroll
-                for (int w = 0; w < 2; ++w)
-#pragma unroll
-                    for (int tt = 0; tt < 3; ++tt) a[w][tt][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[ks & 1][w][tt], wr[q % RING], a[w][tt][ft], 0, 0, 0);
-                W2X_RING_NEXT(q);
-            }
-            pack_v(a[0], vf0[0], vf1[0]);
-            pack_v(a[1], vf0[1], vf1[1]);
-        }
-        W2X_STAMP(2)
-        attend(0, hA, wok0, amask0, qf[0], kf[0], vf0[0], vf1[0], false);
-        attend(1, hA, wok1, amask1, qf[1], kf[1], vf0[1], vf1[1], false);
-        W2X_STAMP(3)
-    }
-    // ---- head hC on window wC
-    {
-        half8 qf[3], kf[3], vf0[2], vf1[2];
-        const _Float16* xs = Xs + wC * SLAB * LDX;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const float4v b0 = m == 0 ? *(const float4v*)(p.bqkv + hC * HD + g * 4) : zero4;
-            const float4v b1 = m == 0 ? *(const float4v*)(p.bqkv + hC * HD + 16 + g * 4) : zero4;
-            float4v a[2][3] = {{b0, b0, b0}, {b1, b1, b1}};
-            half8 xf[3];
-#pragma unroll
-            for (int j = 0; j < 12; ++j) {
-                const int ks = j >> 1, ft = j & 1, q = 36 + m * 12 + j;
-                if (ft == 0) {
-#pragma unroll
-                    for (int tt = 0; tt < 3; ++tt) xf[tt] = *(const half8*)(xs + (tt * 16 + fr) * LDX + ks * 32 + g * 8);
-                }
-#pragma unroll
-                for (int tt = 0; tt < 3; ++tt) a[ft][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[q % RING], xf[tt], a[ft][tt], 0, 0, 0);
-                W2X_RING_NEXT(q);
-            }
-            pack_qk(a, m == 0, m == 0 ? qf : kf);
-        }
-        {
-            float4v a[3][2] = {{zero4, zero4}, {zero4, zero4}, {zero4, zero4}};
-            half8 xf[3];
-#pragma unroll
-            for (int j = 0; j < 12; ++j) {
-                const int ks = j >> 1, ft = j & 1, q = 60 + j;
-                if (ft == 0) {
-#pragma unroll
-                    for (int tt = 0; tt < 3; ++tt) xf[tt] = *(const half8*)(xs + (tt * 16 + fr) * LDX + ks * 32 + g * 8);
-                }
-#pragma unroll
-                for (int tt = 0; tt < 3; ++tt) a[tt][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[tt], wr[q % RING], a[tt][ft], 0, 0, 0);
-                W2X_RING_NEXT(q);
-            }
-            pack_v(a, vf0, vf1);
-        }
-        attend(wC, hC, wC == 0 ? wok0 : wok1, wC == 0 ? amask0 : amask1, qf, kf, vf0, vf1, true);
         W2X_STAMP(4)
     }
-#undef W2X_RING_NEXT
-#undef W2X_LOAD_X2
+#undef W2X_LOAD_W
     __syncthreads();      // every wave's head outputs are in Os; nobody reads the slabs any more
 
     // ---- proj, transposed: out^T = Wproj Os^T + b (rows = output channels, columns = tokens), so a lane ends with 4 consecutive
