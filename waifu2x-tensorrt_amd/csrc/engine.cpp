@@ -430,9 +430,9 @@ struct Img2Img::Impl {
                     if ((int)i == final_op && out_override) p.out.p = out_override;
                     stamp_begin(0, op.flops);
                     if (op.g.pool_out >= 0) pool_blocks[op.g.pool_out] = conv3_supported(p) ? conv3_tiles(p) : 0;   // partial sums per image written by this launch (0: plan default)
-                    hipAssert(pixgemm_supported(p) ? launch_pixgemm(p, stream) : conv3_supported(p) ? launch_conv3(p, stream) : conv48_supported(p) ? launch_conv48(p, stream) : stem_supported(p) ? launch_stem(p, stream) : launch_gemm(p, stream));
+                    hipAssert(pixgemm_supported(p) ? launch_pixgemm(p, stream) : conv3_supported(p) ? launch_conv3(p, stream) : conv3h_supported(p) ? launch_conv3h(p, stream) : conv48_supported(p) ? launch_conv48(p, stream) : stem_supported(p) ? launch_stem(p, stream) : launch_gemm(p, stream));
                     stamp_end();
-                    if (check_general && (pixgemm_supported(p) || conv3_supported(p) || conv48_supported(p) || stem_supported(p))) {   // diagnostic: the general kernel must agree
+                    if (check_general && (pixgemm_supported(p) || conv3_supported(p) || conv3h_supported(p) || conv48_supported(p) || stem_supported(p))) {   // diagnostic: the general kernel must agree
                         const TensorDesc& od = plan.tensors[op.g.out.t];
                         const size_t n = (size_t)live * od.H * od.W * od.C;
                         std::vector<uint16_t> a(n), b(n);

@@ -1,0 +1,147 @@
+// Direct 3x3 convolution (stride 1, valid) onto FEW output channels for gfx950 - cunet's two image heads:
+//   * unet2 conv_bottom: 64 -> 3 channels (stored as 4 halves per pixel), cropped skip add from unet1, clip to [0, 1];
+//   * unet1 conv_bottom: the 4x4 stride-2 ConvTranspose 64 -> 3, lowered to a 3x3 convolution onto 4 sub-pixels x 4 stored channels
+//     with a 2x pixel shuffle.
+// gemm_kernel (k_gemm.hip) runs these as an implicit GEMM that fetches every input pixel nine times and pads N to a 64-row tile:
+// 1.30 + 0.39 ms of config 2's 11.5 ms at 0.9 / 1.1 TB/s.  The launches are pure input streams (1.19 GB + 0.35 GB read, 16 MFMA per
+// 16 pixels), so the kernel is k_conv3.hip's halo tile with everything else removed:
+//   * a workgroup owns 4 output rows x 64 columns; its 6 x 66 pixel halo tile with ALL input channels goes to LDS in one batch of
+//     16-byte loads per thread (pixel stride CIN + 8 halves: the 16 pixels of a fragment fall on different banks), one barrier;
+//   * the product is transposed (out^T = W X^T): the weights are the A operand - 9 taps x CIN/32 fragments, loaded once per wave
+//     straight from the [N][K] matrix (rows >= N read as zero) and held in registers for the whole tile - the pixels the B operand,
+//     so a lane ends up with 4 consecutive stored channels of ONE pixel: channels 4g .. 4g+3 of pixel fr.  Rows output: lanes g = 0
+//     hold the pixel (8-byte store); pixel-shuffle output: g is the sub-pixel (dy, dx) = (g >> 1, g & 1), every lane stores 8 bytes;
+//   * epilogue in registers: bias (initial accumulator), LeakyReLU / none, skip add, clip, ONE rounding to fp16 (gemm_kernel rounds
+//     before and after the skip add).
+#include "kernels.h"
+#include <cstdlib>
+
+namespace w2x {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+template <int CIN>
+struct Conv3hCfg {
+    static constexpr int TH = 4, TW = 64, HR = TH + 2, HC = TW + 2;
+    static constexpr int LDP = CIN + 8, KS = CIN / 32, PPP = CIN / 8;
+    static constexpr int NP = HR * HC * PPP, NI = (NP + 255) / 256;    // 16-byte pieces of the halo tile, per thread
+    static constexpr int SMEM = HR * HC * LDP * 2;
+};
+
+template <int CIN, int PIX>
+__global__ __launch_bounds__(256, 2) void conv3h_kernel(const GemmParams p, int Ho, int Wo, int tiles_x, int tiles_y) {
+    using C = Conv3hCfg<CIN>;
+    constexpr int HR = C::HR, HC = C::HC, LDP = C::LDP, KS = C::KS, PPP = C::PPP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    _Float16* Hl = (_Float16*)smem;                                   // [HR][HC][LDP]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+
+    const int tpi = tiles_x * tiles_y;
+    const int b = blockIdx.x / tpi, trem = blockIdx.x - b * tpi;
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    const int oy0 = ty * C::TH, ox0 = tx * C::TW;
+    const _Float16* __restrict__ Ag = (const _Float16*)p.a.p + ((size_t)(b * p.a.Hs + p.a.y0 + oy0) * p.a.Ws + p.a.x0 + ox0) * CIN;
+
+    // halo tile: pixels past the input extent of a ragged tile (input extent = output extent + 2) are zeros
+    const int hrows = min(HR, Ho + 2 - oy0), hcols = min(HC, Wo + 2 - ox0);
+    half8 h[C::NI];
+#pragma unroll
+    for (int i = 0; i < C::NI; ++i) {
+        const int idx = tid + i * 256, pix = idx / PPP, c8 = idx - pix * PPP, hr = pix / HC, hc = pix - hr * HC;
+        h[i] = (half8){};
+        if (idx < C::NP && hr < hrows && hc < hcols) h[i] = *(const half8*)(Ag + ((size_t)hr * p.a.Ws + hc) * CIN + c8 * 8);
+    }
+    // weights [N][Kw], k = tap * CIN + channel: fragment (tap, ks) of lane (fr, g) = W[fr][tap][32 ks + 8g .. + 7]
+    const _Float16* __restrict__ Wt = (const _Float16*)p.wt + (size_t)fr * p.Kw + g * 8;
+    half8 wf[9][KS];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wf[t][ks] = fr < p.N ? *(const half8*)(Wt + t * CIN + ks * 32) : (half8){};
+    float4v bv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[j] = 4 * g + j < p.N ? p.bias[4 * g + j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < C::NI; ++i) {
+        const int idx = tid + i * 256, pix = idx / PPP, c8 = idx - pix * PPP;
+        if (idx < C::NP) *(half8*)(Hl + pix * LDP + c8 * 8) = h[i];
+    }
+    __syncthreads();
+
+    // wave wv: output row oy0 + wv, four groups of 16 pixels
+    float4v acc[4] = {bv, bv, bv, bv};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int ky = t / 3, kx = t - ky * 3;
+        const _Float16* arow = Hl + ((wv + ky) * HC + kx + fr) * LDP + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            half8 xa[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) xa[mt] = *(const half8*)(arow + mt * 16 * LDP + ks * 32);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t][ks], xa[mt], acc[mt], 0, 0, 0);
+        }
+    }
+
+    const int oy = oy0 + wv;
+    if (oy >= Ho) return;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int ox = ox0 + mt * 16 + fr;
+        if (ox >= Wo || (!PIX && g != 0)) continue;
+        const int Y = PIX ? 2 * oy + (g >> 1) : oy, X = PIX ? 2 * ox + (g & 1) : ox;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = acc[mt][j]; if (p.act == 1) v[j] = v[j] > 0.f ? v[j] : v[j] * p.alpha; }
+        if (!PIX && p.res.p) {
+            const half4 r = *(const half4*)((const _Float16*)p.res.p + ((size_t)(b * p.res.Hs + Y + p.res.y0) * p.res.Ws + X + p.res.x0) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+        }
+        if (p.has_clip) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(v[j], p.clip_lo), p.clip_hi);
+        }
+        *(half4*)((_Float16*)p.out.p + ((size_t)(b * p.out.Hs + Y) * p.out.Ws + X) * 4) = (half4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    }
+}
+
+template <int CIN, int PIX>
+hipError_t launch_c3h(const GemmParams& p, int Ho, int Wo, hipStream_t s) {
+    using C = Conv3hCfg<CIN>;
+    static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
+    if (hipError_t e = ensure_dynamic_lds((const void*)conv3h_kernel<CIN, PIX>, C::SMEM, lds_ok); e != hipSuccess) return e;
+    const int tiles_x = (Wo + C::TW - 1) / C::TW, tiles_y = (Ho + C::TH - 1) / C::TH;
+    hipLaunchKernelGGL((conv3h_kernel<CIN, PIX>), dim3((unsigned)(p.B * tiles_x * tiles_y)), dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool conv3h_supported(const GemmParams& p) {
+    static const bool off = getenv("W2X_NO_CONV3H") != nullptr;   // A/B switch
+    if (off || p.amode != 2 || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.ln || (p.act != 0 && p.act != 1) || p.stats_out || p.pool_out || p.res2.p) return false;
+    const int Cin = p.a.Cs;
+    if ((Cin != 64 && Cin != 32) || p.K != 9 * Cin || p.Kw != p.K || p.out.Cs != 4 || p.aW <= 0 || p.Mrows % p.aW || p.B <= 0) return false;
+    const int Ho = p.Mrows / p.aW, Wo = p.aW;
+    if (p.a.y0 < 0 || p.a.x0 < 0 || p.a.y0 + Ho + 2 > p.a.Hs || p.a.x0 + Wo + 2 > p.a.Ws) return false;
+    if (p.omode == 0) {   // rows: (b, m / aW, m % aW) of the output view, skip add from a cropped view of the same extent
+        if (p.N > 4 || p.out.Hs < Ho || p.out.Ws < Wo) return false;
+        return !p.res.p || (p.res.Cs == 4 && p.res.y0 >= 0 && p.res.x0 >= 0 && p.res.y0 + Ho <= p.res.Hs && p.res.x0 + Wo <= p.res.Ws);
+    }
+    return p.omode == 2 && p.r == 2 && p.N == 16 && !p.res.p && p.out.Hs >= 2 * Ho && p.out.Ws >= 2 * Wo;
+}
+
+hipError_t launch_conv3h(const GemmParams& p, hipStream_t s) {
+    const int Ho = p.Mrows / p.aW, Wo = p.aW;
+    if (p.a.Cs == 64) return p.omode == 2 ? launch_c3h<64, 1>(p, Ho, Wo, s) : launch_c3h<64, 0>(p, Ho, Wo, s);
+    return p.omode == 2 ? launch_c3h<32, 1>(p, Ho, Wo, s) : launch_c3h<32, 0>(p, Ho, Wo, s);
+}
+
+}  // namespace w2x

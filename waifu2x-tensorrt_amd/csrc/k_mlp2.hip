@@ -31,6 +31,18 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 // min / max / exp2 have no packed form.  Same operations per element as the scalar form, so the results are identical.
 typedef float float2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2v splat2(float c) { return (float2v){c, c}; }
+#ifdef W2X_GELU_SCALAR   // A/B: the same polynomial on single-value instructions
+__device__ __forceinline__ float gelu_fast1(float x) {
+    const float u = fminf(fabsf(x), 6.5f);
+    float q = fmaf(-2.992485764e-05f, u, 7.398797018e-04f);
+    q = fmaf(q, u, -7.977479093e-03f);
+    q = fmaf(q, u, 5.323820859e-02f);
+    q = fmaf(q, u, 4.589156733e-01f);
+    q = fmaf(q, u, 1.151147085e+00f);
+    return fmaf(-0.5f * u, __builtin_amdgcn_exp2f(-(q * u)), fmaxf(x, 0.f));
+}
+__device__ __forceinline__ float2v gelu_fast2(float2v x) { return (float2v){gelu_fast1(x[0]), gelu_fast1(x[1])}; }
+#else
 __device__ __forceinline__ float2v gelu_fast2(float2v x) {
     const float2v u = {fminf(fabsf(x[0]), 6.5f), fminf(fabsf(x[1]), 6.5f)};
     float2v q = __builtin_elementwise_fma(splat2(-2.992485764e-05f), u, splat2(7.398797018e-04f));
@@ -43,6 +55,7 @@ __device__ __forceinline__ float2v gelu_fast2(float2v x) {
     const float2v m = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
     return __builtin_elementwise_fma(splat2(-0.5f) * u, e, m);
 }
+#endif
 __device__ __forceinline__ void sum_sq8(const half8 v, float& s, float& q) {
     const half2v one = {(_Float16)1.f, (_Float16)1.f};
 #pragma unroll

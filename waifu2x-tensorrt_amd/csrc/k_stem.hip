@@ -6,9 +6,11 @@
 // element by element for the 4-channel input and reaches 1.5 TB/s.  Here a pixel IS an operand register pair:
 //   * K = 9 taps x 4 stored channels = 36, taken as three k-steps of v_mfma_f32_16x16x16_f16: k-step s covers the taps
 //     4s .. 4s+3, so lane (fr, g) of the B operand holds tap 4s+g of pixel fr - one 8-byte load, no shuffling;
-//   * the product is computed transposed (out^T = W X^T: rows = channels, columns = 16 pixels of an output row), so a lane
-//     ends up with 4 consecutive channels of one pixel and stores them as 8 bytes; the weights (A operand, 9 register pairs
-//     for 48 channels) and the bias (initial accumulator) stay in registers for the whole workgroup;
+//   * the product is computed transposed (out^T = W X^T: rows = channels, columns = 16 pixels of an output row), and the rows
+//     of the A operand are a permutation of the channels (row 4g + j of n-tile nt = channel 4 NT g + 4 nt + j), so a lane ends
+//     up with 4 NT CONSECUTIVE channels of one pixel and a wave's store covers 16 whole pixels back to back (16-byte stores for
+//     32 / 64 channels; with 8-byte stores at a 2 N byte stride the launch ran at 2.2 TB/s); the weights (A operand, 9 register
+//     pairs for 48 channels) and the bias (initial accumulator) stay in registers for the whole workgroup;
 //   * a workgroup = one output row of one tile, its four waves take the 16-pixel groups round-robin.  No LDS, no barrier.
 #include "kernels.h"
 #include <cstdlib>
@@ -17,6 +19,7 @@ namespace w2x {
 namespace {
 
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
 template <int NT>
@@ -36,9 +39,9 @@ __global__ __launch_bounds__(256) void stem_kernel(const GemmParams p, int Ho, i
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             const int tap = 4 * s + g;
-            wf[nt][s] = tap < 9 ? *(const half4*)(Wt + (size_t)(nt * 16 + fr) * p.Kw + tap * 4) : zero4h;
+            wf[nt][s] = tap < 9 ? *(const half4*)(Wt + (size_t)(4 * NT * (fr >> 2) + 4 * nt + (fr & 3)) * p.Kw + tap * 4) : zero4h;
         }
-        bias[nt] = *(const float4v*)(p.bias + nt * 16 + g * 4);        // accumulator rows = channels 16 nt + 4g + j
+        bias[nt] = *(const float4v*)(p.bias + 4 * NT * g + 4 * nt);    // accumulator row 4g + j of n-tile nt = channel 4 NT g + 4 nt + j
     }
     // tap 4s+g of this lane as an element offset from the pixel under the kernel's top-left corner
     int toff[3];
@@ -59,19 +62,29 @@ __global__ __launch_bounds__(256) void stem_kernel(const GemmParams p, int Ho, i
             const half4 v = *(const half4*)(Arow + (size_t)pxc * 4 + toff[s]);
             xf[s] = 4 * s + g < 9 ? v : zero4h;
         }
+        half4 h[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             float4v acc = bias[nt];
 #pragma unroll
             for (int s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wf[nt][s], xf[s], acc, 0, 0, 0);
-            half4 h;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float v = acc[j];
                 if (p.act == 1) v = v > 0.f ? v : v * p.alpha;
-                h[j] = (_Float16)v;
+                h[nt][j] = (_Float16)v;
             }
-            if (px < Wo) *(half4*)(Orow + (size_t)px * p.out.Cs + nt * 16 + g * 4) = h;
+        }
+        if (px < Wo) {   // the lane's 4 NT channels are consecutive: the four lanes of a pixel write its N channels back to back
+            _Float16* op_ = Orow + (size_t)px * p.out.Cs + 4 * NT * g;
+            if (NT == 3) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) *(half4*)(op_ + 4 * nt) = h[nt];
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < NT; nt += 2)
+                    *(half8*)(op_ + 4 * nt) = (half8){h[nt][0], h[nt][1], h[nt][2], h[nt][3], h[nt + 1][0], h[nt + 1][1], h[nt + 1][2], h[nt + 1][3]};
+            }
         }
     }
 }

@@ -129,6 +129,8 @@ bool conv3_supported(const GemmParams& p);                      // k_conv3.hip: 
 bool stem_supported(const GemmParams& p);
 hipError_t launch_stem(const GemmParams& p, hipStream_t s);
 hipError_t launch_conv3(const GemmParams& p, hipStream_t s);
+bool conv3h_supported(const GemmParams& p);                     // k_conv3h.hip: direct 3x3 convolution onto 4 stored channels (cunet's image heads)
+hipError_t launch_conv3h(const GemmParams& p, hipStream_t s);
 bool conv48_supported(const GemmParams& p);                     // k_conv48.hip: direct 3x3 convolution 48 -> 96 channels (swin_unet's patch convolution)
 hipError_t launch_conv48(const GemmParams& p, hipStream_t s);
 int conv3_tiles(const GemmParams& p);                           // workgroups (= pooling partials) per image of launch_conv3
