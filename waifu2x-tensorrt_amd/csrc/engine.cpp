@@ -189,6 +189,7 @@ struct Img2Img::Impl {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<void*> tensors, blobs;   // tensors point into one arena
     std::vector<void*> frag_blobs;       // per blob id: fragment-major copy of a weight matrix (or null)
+    std::vector<void*> perm_blobs;       // per blob id: frag_conv3b copy of a 3x3 convolution's weights (or null)
     std::vector<int> pool_blocks;        // per tensor id: pooling partials per image written by the last producer (0: plan default)
     void* arena_base = nullptr; size_t arena_bytes = 0;
     std::vector<GemmParams> gemm;      // per op (kind == OP_GEMM)
@@ -260,6 +261,8 @@ struct Img2Img::Impl {
         for (void* p : blobs) if (p) (void)hipFree(p);
         for (void* p : frag_blobs) if (p) (void)hipFree(p);
         frag_blobs.clear();
+        for (void* p : perm_blobs) if (p) (void)hipFree(p);
+        perm_blobs.clear();
         tensors.clear(); blobs.clear(); gemm.clear(); pool_tensors.clear();
         for (void* h : pinned) if (hipHostUnregister(h) != hipSuccess) (void)hipGetLastError();
         pinned.clear();
@@ -366,8 +369,16 @@ struct Img2Img::Impl {
             upload_frag(blob, frag_w2((const uint16_t*)d.data(), Cc));
         };
         for (const Op& op : plan.ops)   // pixel-shuffle projections served by k_pixgemm.hip
-            if (op.kind == OP_GEMM && ((op.g.omode == 2 && (op.g.amode == 0 || (op.g.amode == 2 && op.g.kh == 1 && op.g.kw == 1))) || (op.g.amode == 2 && op.g.kh == 2 && op.g.kw == 2 && op.g.stride == 2) || (op.g.amode == 2 && op.g.kh == 3 && op.g.kw == 3 && op.g.stride == 1 && op.g.omode == 0)) && op.g.K % 32 == 0 && op.g.N % 16 == 0 &&
+            if (op.kind == OP_GEMM && ((op.g.omode == 2 && (op.g.amode == 0 || (op.g.amode == 2 && op.g.kh == 1 && op.g.kw == 1))) || (op.g.amode == 2 && op.g.kh == 2 && op.g.kw == 2 && op.g.stride == 2)) && op.g.K % 32 == 0 && op.g.N % 16 == 0 &&
                 plan.blobs[op.g.w].data.size() == (size_t)op.g.N * op.g.K * 2) frag_major_blob(op.g.w, op.g.N, op.g.K);
+        perm_blobs.assign(plan.blobs.size(), nullptr);
+        for (const Op& op : plan.ops)   // plain 3x3 convolutions onto 64 / 128 / 256 channels (k_conv3.hip)
+            if (op.kind == OP_GEMM && op.g.amode == 2 && op.g.kh == 3 && op.g.kw == 3 && op.g.stride == 1 && op.g.omode == 0 && op.g.K % 32 == 0 && op.g.N % 64 == 0 &&
+                plan.blobs[op.g.w].data.size() == (size_t)op.g.N * op.g.K * 2 && !perm_blobs[op.g.w]) {
+                const std::vector<uint16_t> f = frag_conv3b((const uint16_t*)plan.blobs[op.g.w].data.data(), op.g.N, op.g.K);
+                hipAssert(hipMalloc(&perm_blobs[op.g.w], f.size() * 2 + 256));
+                hipAssert(hipMemcpy(perm_blobs[op.g.w], f.data(), f.size() * 2, hipMemcpyHostToDevice));
+            }
         for (const Op& op : plan.ops)   // 48 -> 96 channel 3x3 convolution (k_conv48.hip): K = 432 padded with zero columns to 14 k-steps of 32
             if (op.kind == OP_GEMM && op.g.amode == 2 && op.g.kh == 3 && op.g.kw == 3 && op.g.stride == 1 && op.g.omode == 0 && op.g.K == 432 && op.g.N == 96 &&
                 plan.tensors[op.g.a.t].C == 48 && !frag_blobs[op.g.w]) {
@@ -392,7 +403,7 @@ struct Img2Img::Impl {
             p.B = plan.B; p.Mrows = g.Mrows; p.aW = g.aW;
             p.win_table = g.win_table >= 0 ? (const int*)blobs[g.win_table] : nullptr;
             p.K = g.K; p.N = g.N; p.Kw = round_up(g.K, 8);
-            p.wt = blobs[g.w]; p.wt_frag = frag_blobs[g.w]; p.bias = (const float*)blobs[g.bias];
+            p.wt = blobs[g.w]; p.wt_frag = frag_blobs[g.w]; p.wt_perm = perm_blobs[g.w]; p.bias = (const float*)blobs[g.bias];
             p.ln = g.ln; p.csum = g.csum >= 0 ? (const float*)blobs[g.csum] : nullptr;
             p.stats_in = g.stats_in >= 0 ? (const float*)tensors[g.stats_in] : nullptr;
             p.act = g.act; p.alpha = g.alpha; p.has_clip = g.has_clip; p.clip_lo = g.clip_lo; p.clip_hi = g.clip_hi;

@@ -22,6 +22,25 @@ inline std::vector<uint16_t> frag_major(const uint16_t* w, int N, int K) {
     return f;
 }
 
+// 3x3 convolution weights W [N][K] for conv3b_kernel (k_conv3.hip) -> [N/64 blocks][K/32 k-steps][4 n-tiles][64 lanes][8]: the A rows
+// of n-tile nt are a permutation of the block's channels - row r = lane & 15 holds channel 32 (nt >> 1) + 8 (r >> 2) + 4 (nt & 1) + (r & 3)
+// - so the transposed product leaves a lane with two runs of 8 consecutive channels of its pixel, and the four lanes of a pixel
+// write 64 contiguous bytes per store instruction
+inline std::vector<uint16_t> frag_conv3b(const uint16_t* w, int N, int K) {
+    if (N % 64 || K % 32) throw std::runtime_error("frag_conv3b: shape");
+    std::vector<uint16_t> f((size_t)N * K);
+    const int KS = K / 32;
+    for (int nb = 0; nb < N / 64; ++nb)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int nt = 0; nt < 4; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = lane & 15, n = nb * 64 + 32 * (nt >> 1) + 8 * (r >> 2) + 4 * (nt & 1) + (r & 3);
+                        f[((((size_t)nb * KS + ks) * 4 + nt) * 64 + lane) * 8 + e] = w[(size_t)n * K + ks * 32 + (lane >> 4) * 8 + e];
+                    }
+    return f;
+}
+
 // Second MLP matrix W2 [C][2C] -> [2C/32 chunks][C/16 n-tiles][64 lanes][8]: lane (n & 15, g) holds the hidden units of the
 // chunk in the order the GELU'd accumulators of the transposed first product present them (slots 0..3: 4g+j, 4..7: 16+4g+j)
 inline std::vector<uint16_t> frag_w2(const uint16_t* w, int C) {

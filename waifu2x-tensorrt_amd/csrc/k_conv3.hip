@@ -1,14 +1,31 @@
-// Direct 3x3 convolution (stride 1, valid) for gfx950 with the input staged ONCE per output tile:
+// Direct 3x3 convolution (stride 1, valid) for gfx950 - cunet's 3x3 layers onto 64 / 128 / 256 channels:
 //     out[b][y][x][n] = act( sum_{ky,kx,c} in[b][y+ky][x+kx][c] * W[n][(ky*3+kx)*Cin + c] + bias[n] )
-// gemm_kernel (k_gemm.hip) treats the same convolution as an implicit GEMM whose A rows are gathered per K-chunk, i.e. every
-// input pixel is fetched from L2 nine times (once per tap); on cunet that is 10 GB of L2 reads for a 1.2 GB activation and the
-// convolutions sit at ~10 % of the MFMA peak.  Here a workgroup owns an output tile of 4 rows x 64 columns: per chunk of KC input
-// channels the 6 x 66 pixel halo tile goes to LDS once and serves all nine taps (the A fragment of tap (ky,kx) is just a shifted
-// 16-byte read, pixel stride KC+8 halves so the 16 pixels of a fragment fall on different banks); weights stream through LDS per
-// kernel row (three taps; fragment-major copy, staged once per workgroup by its four waves, double-buffered, one barrier per stage).  Wave w computes
-// output row w of the tile: four 16-pixel m-tiles x N/16 n-tiles of accumulators for the whole K loop.
-// Epilogue: bias (initial accumulator), LeakyReLU / none, fp16, through a small per-wave LDS tile into 16-byte row stores.
-// Covers the plain convolutions (rows output, no LayerNorm / residual / clip / statistics / pooling); the rest stays on gemm_kernel.
+// gemm_kernel (k_gemm.hip) treats the same convolution as an implicit GEMM whose A rows are gathered per K-chunk, i.e. every input
+// pixel is fetched from L2 nine times (once per tap).  Here a workgroup owns an output tile of 8 rows x 64 columns of one 64-channel
+// block; per chunk of 32 input channels its 10 x 66 pixel halo tile goes to LDS once and serves all nine taps.
+//   * a wave owns TWO adjacent output rows (2 x 64 pixels x 64 channels = 128 accumulator registers): a halo row's fragments are
+//     read once and feed tap ky of the upper and tap ky - 1 of the lower row - 48 instead of 72 fragment reads per chunk;
+//   * the weights never enter LDS: they are stored per 64-channel block and k-step as four contiguous fragments (fragorder.h
+//     frag_conv3b) and stream from L2 through a ring of three taps (48 registers), each tap fetched one to two steps (32-48 MFMA)
+//     before its first use - weight traffic on the vector-memory path, pixel traffic on the LDS path;
+//   * barriers only around the halo tile of a chunk (288 MFMA per wave between them), two workgroups per CU;
+//   * halo image in LDS: [10 rows][66 pixels][4 pieces of 8 channels], 64 bytes per pixel, no padding, the pieces of a pixel rotated
+//     by 2 * ((x >> 2) & 3) slots.  A ds_read_b128 is served in groups of 16 lanes that pair the k-groups (g = 0 with 1, 2 with 3)
+//     over complementary row sets ({0-3, 12-15} with {4-11}: MI355X_MICROARCH.md, LDS) on 64 banks; of the four pixels of a group
+//     that share x mod 4 two are read for piece g and two for g + 1, and the rotation sends them to four different slots:
+//     conflict-free, where a padded pixel-major tile (pixel stride 80 bytes) pays a second cycle on every group
+//     (SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE).  The stores (8 lanes = 2 whole pixels) are conflict-free too;
+//   * the product is transposed (out^T = W X^T) with the A rows a permutation of the channels (row 4g + j of n-tile nt = channel
+//     32 (nt >> 1) + 8g + 4 (nt & 1) + j of the block): a lane ends up with two runs of 8 consecutive channels of one pixel and a
+//     store instruction writes 64 contiguous bytes per pixel, straight from registers; bias is the initial accumulator, LeakyReLU
+//     max(v, v * alpha); squeeze-excite pooling partials per workgroup in a fixed order.
+// Input, weights and output go through buffer resources (32-bit offsets, rows past a ragged edge read zeros / drop stores).
+// Measured on config 2 (tools/op_times.py): the 3x3 layers 6.2 -> 5.4 ms per frame (550-770 TFLOP/s) against the first schedule
+// (tools/ab/k_conv3_v1.hip: one tap of one chunk per barrier, both operands through LDS).  What is left is not the products:
+// without the halo fetch the layers run 30-35 % faster, without the stores 25 % - fetch, products and stores of a workgroup run one
+// after the other and the two workgroups of a CU stay in phase.  A persistent variant with the halo tiles double-buffered by
+// LDS-DMA (tools/ab/k_conv3c_persistent.hip) overlaps them in program order but came out 2-4 % slower: one 72 KB tile in flight
+// per CU leaves the fetch latency-bound (16k cycles per step with the products removed), and LDS has no room for a third buffer.
 #include "kernels.h"
 #include <cstdlib>
 
@@ -17,189 +34,193 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 
-#define W2X_PHASE_FENCE() asm volatile("" ::: "memory")
-// sum over the four 16-lane rows of a wave (see k_swinattn.hip for why the swaps are inline asm on two registers)
-__device__ __forceinline__ void swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ float rows_sum(float v) { float a = v, b = v; swap16(a, b); v = a + b; a = v; b = v; swap32(a, b); return a + b; }
+constexpr unsigned kNoPix = 0xFFFFFFFFu;     // buffer offset past every resource: reads zeros, drops stores
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);   // raw buffer, 32-bit offsets, bounds-checked
+}
 
-template <int KC, int N, int TS_>
 struct Conv3Cfg {
-    static constexpr int TH = 4, TW = 64, HR = TH + 2, HC = TW + 2;   // output tile, halo tile (pixels)
-    static constexpr int LDP = KC + 8;                                  // halo pixel stride (halves)
-    static constexpr int KS = KC / 32, NT = N / 16;
-    static constexpr int HALO = HR * HC * LDP * 2;                      // bytes
-    static constexpr int TS = TS_;                                      // taps per weight stage (3 = one kernel row; 1 where LDS is short)
-    static constexpr int NF = TS * NT * KS, NFW = NF / 4;               // weight fragments per stage / per wave
-    static constexpr int WBUF = NF * 1024;
-    static constexpr int OT = 16 * (N + 8) * 2;                         // per-wave output m-tile
-    static constexpr int SMEM = HALO + 2 * WBUF;                        // the per-wave output tiles reuse the halo area after the last tap
-    static_assert(4 * OT <= HALO, "output tiles alias the halo tile");
-    static constexpr int PPP = KC / 8;                                  // 16-byte pieces per halo pixel
-    static_assert(NF % 4 == 0, "fragments per wave");
+    static constexpr int TH = 8, TW = 64, HR = TH + 2, HC = TW + 2;
+    static constexpr int ROWB = HC * 64;                               // bytes per halo row (32 channels)
+    static constexpr int SMEM = HR * ROWB;
 };
+// byte offset of piece pc (8 channels) of halo pixel x inside its row
+__device__ __forceinline__ int halo_slot(int x, int pc) { return x * 64 + ((pc + 2 * ((x >> 2) & 3)) & 3) * 16; }
 
-template <int KC, int N, int TS>
-__global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int Ho, int Wo, int tiles_x, int tiles_y, int n0) {
-    using C = Conv3Cfg<KC, N, TS>;
-    constexpr int TH = C::TH, TW = C::TW, HR = C::HR, HC = C::HC, LDP = C::LDP, KS = C::KS, NT = C::NT, NF = C::NF, NFW = C::NFW, PPP = C::PPP;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    _Float16* Hl = (_Float16*)smem;                                   // [HR][HC][LDP]
-    _Float16* WB = (_Float16*)(smem + C::HALO);                       // [2][NF][64][8]
+template <bool POOL>
+__global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int Ho, int Wo, int tiles_x, int tiles_y, int nblk) {
+    using C = Conv3Cfg;
+    constexpr int HR = C::HR, HC = C::HC;
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, g = lane >> 4;
-    _Float16* Ot = (_Float16*)(smem + wv * C::OT);                    // [16][N+8], over the halo tile once the last tap is done (the loop ends with a barrier)
 
+    const int nb = blockIdx.x % nblk, tidx = blockIdx.x / nblk;      // the blocks of a tile run side by side: its halo is fetched from HBM once
     const int tpi = tiles_x * tiles_y;
-    const int b = blockIdx.x / tpi, trem = blockIdx.x - b * tpi;
+    const int b = tidx / tpi, trem = tidx - b * tpi;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int Cin = p.a.Cs, nchunk = Cin / KC, KST = p.K / 32;
-    const _Float16* __restrict__ Ag = (const _Float16*)p.a.p + ((size_t)(b * p.a.Hs + p.a.y0 + oy0) * p.a.Ws + p.a.x0 + ox0) * Cin;
-    const _Float16* __restrict__ Wf = (const _Float16*)p.wt_frag + lane * 8;        // [N_total/16][KST][64][8]
-    const int nt_base = n0 / 16;
-    // weight fragment f = (kx * NT + nt) * KS + ks of stage (chunk kc, kernel row ky): n-tile nt_base + nt, k-step ((ky*3+kx) * Cin + kc * KC) / 32 + ks
-    constexpr int SPC = 9 / TS;                                        // stages per channel chunk
-    auto frag_src = [&](int kc, int sg, int f) {                      // fragment f = (local tap * NT + nt) * KS + ks of stage sg of chunk kc
-        const int tl = f / (NT * KS), r2 = f - tl * (NT * KS), nt = r2 / KS, ks = r2 - nt * KS;
-        return Wf + (size_t)((nt_base + nt) * KST + ((sg * TS + tl) * Cin + kc * KC) / 32 + ks) * 512;
-    };
+    const int oy0 = ty * C::TH, ox0 = tx * C::TW, n0 = nb * 64;
+    const int Cin = p.a.Cs, nchunk = Cin / 32, KST = p.K / 32;
+    const __amdgpu_buffer_rsrc_t A = make_rsrc((const _Float16*)p.a.p + ((size_t)(b * p.a.Hs + p.a.y0 + oy0) * p.a.Ws + p.a.x0 + ox0) * Cin, 0x7FFFFFFFu);
+    const __amdgpu_buffer_rsrc_t W = make_rsrc((const _Float16*)p.wt_perm + (size_t)nb * KST * 2048, (unsigned)KST * 4096u);   // [KST][4][64][8] of this block
+    const unsigned wlane = lane * 16u;
 
-    float4v acc[4][NT];
+    float4v acc[2][4][4];                                             // [row of the pair][16-pixel group][n-tile]
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const float bv = p.bias[n0 + nt * 16 + fr];
+    for (int nt = 0; nt < 4; ++nt) {
+        const float4v bv = *(const float4v*)(p.bias + n0 + 32 * (nt >> 1) + 8 * g + 4 * (nt & 1));
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = (float4v){bv, bv, bv, bv};
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[r][mt][nt] = bv;
     }
-    half8 stg[NFW];
-    const int nstage = nchunk * SPC;
+    half8 w[3][4];                                                    // ring: slot = ky
+    auto wload = [&](int slot, int kc, int ky, int kx) {     // past the last chunk the k-step lies beyond the block: the fetch returns zeros, nobody reads them
+        const unsigned vo = wlane + (unsigned)((ky * 3 + kx) * nchunk + kc) * 4096u;    // k-step (tap * Cin + 32 kc) / 32
 #pragma unroll
-    for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)frag_src(0, 0, wv * NFW + i);
+        for (int nt = 0; nt < 4; ++nt) w[slot][nt] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(W, vo + nt * 1024u, 0, 0));
+        asm volatile("" ::: "memory");                                // keeps the fetch where it is written
+    };
+    auto mm = [&](int r, int slot, const half8 (&xa)[4]) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[r][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[slot][nt], xa[mt], acc[r][mt][nt], 0, 0, 0);
+    };
+    wload(0, 0, 0, 0);
+    wload(1, 0, 1, 0);
 
-    // rows / columns of the halo tile that exist in the input (valid convolution: input extent = output extent + 2)
+    // halo copy: thread (pixel column tid >> 2, 16-byte piece tid & 3) takes its column of every halo row; threads 0..79 also take
+    // the two extra columns (64, 65) of row tid >> 3
     const int hrows = min(HR, Ho + 2 - oy0), hcols = min(HC, Wo + 2 - ox0);
-    int stage = 0;
+    const unsigned rowb = (unsigned)p.a.Ws * (unsigned)Cin * 2u;
+    const int hc0 = tid >> 2, c8 = tid & 3, hr1 = tid >> 3, hc1 = 64 + ((tid >> 2) & 1);
+    const unsigned go0 = hc0 < hcols ? (unsigned)(hc0 * Cin + c8 * 8) * 2u : kNoPix;
+    const unsigned go1 = (tid < 80 && hr1 < hrows && hc1 < hcols) ? (unsigned)hr1 * rowb + (unsigned)(hc1 * Cin + c8 * 8) * 2u : kNoPix;
+    unsigned char* lo0 = smem + halo_slot(hc0, c8);
+    unsigned char* lo1 = smem + hr1 * C::ROWB + halo_slot(hc1, c8);
+    // fragment reads: lane (fr, g) wants piece g of pixel x = kx + 16 mt + fr of a halo row ((x >> 2) & 3 does not depend on mt)
+    const unsigned char* xrow = smem + (2 * wv) * C::ROWB;
+    int xoff[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) xoff[kx] = halo_slot(kx + fr, g);
 #pragma unroll 1
     for (int kc = 0; kc < nchunk; ++kc) {
-        __syncthreads();                                   // previous chunk's taps are done with the halo tile
-        for (int i = tid; i < HR * HC * PPP; i += 256) {
-            const int pix = i / PPP, c8 = i - pix * PPP, hr = pix / HC, hc = pix - hr * HC;
-            half8 h = {};
-            if (hr < hrows && hc < hcols) h = *(const half8*)(Ag + ((size_t)hr * p.a.Ws + hc) * Cin + kc * KC + c8 * 8);
-            *(half8*)(Hl + pix * LDP + c8 * 8) = h;
-        }
-        if (kc == 0) {
+        {
+            uint4v h[HR], h1;
 #pragma unroll
-            for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[i];
+            for (int hr = 0; hr < HR; ++hr)
+                h[hr] = __builtin_amdgcn_raw_buffer_load_b128(A, hr < hrows ? go0 : kNoPix, (unsigned)hr * rowb + (unsigned)kc * 64u, 0);
+            h1 = __builtin_amdgcn_raw_buffer_load_b128(A, go1, (unsigned)kc * 64u, 0);
+            __syncthreads();                                   // the previous chunk's products are done with the halo tile
+#pragma unroll
+            for (int hr = 0; hr < HR; ++hr) *(uint4v*)(lo0 + hr * C::ROWB) = h[hr];
+            if (tid < 80) *(uint4v*)lo1 = h1;
         }
         __syncthreads();
-#pragma unroll 1
-        for (int sg = 0; sg < SPC; ++sg, ++stage) {
-            const _Float16* wcur = WB + (size_t)(stage & 1) * (C::WBUF / 2) + lane * 8;
-            if (stage + 1 < nstage) {
-                const int sg1 = sg == SPC - 1 ? 0 : sg + 1, kc1 = sg == SPC - 1 ? kc + 1 : kc;
 #pragma unroll
-                for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)frag_src(kc1, sg1, wv * NFW + i);
-            }
+        for (int kx = 0; kx < 3; ++kx) {
+            half8 xa[4];
+            auto xload = [&](int hh) {
 #pragma unroll
-            for (int tl = 0; tl < TS; ++tl) {
-                const int t = sg * TS + tl, ky = t / 3, kx = t - ky * 3;
-                const _Float16* arow = Hl + ((wv + ky) * HC + kx + fr) * LDP + g * 8;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    half8 xa[4];
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) xa[mt] = *(const half8*)(arow + mt * 16 * LDP + ks * 32);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const half8 wb = *(const half8*)(wcur + (size_t)((tl * NT + nt) * KS + ks) * 512);
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[mt], wb, acc[mt][nt], 0, 0, 0);
-                    }
-                }
-            }
-            if (stage + 1 < nstage) {
-#pragma unroll
-                for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)((stage + 1) & 1) * (C::WBUF / 2) + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[i];
-            }
-            __syncthreads();
+                for (int mt = 0; mt < 4; ++mt) xa[mt] = *(const half8*)(xrow + xoff[kx] + hh * C::ROWB + mt * 1024);
+            };
+            xload(0);
+            mm(0, 0, xa);
+            xload(1);
+            wload(2, kc, 2, kx);
+            mm(0, 1, xa); mm(1, 0, xa);
+            xload(2);
+            if (kx < 2) wload(0, kc, 0, kx + 1); else wload(0, kc + 1, 0, 0);
+            mm(0, 2, xa); mm(1, 1, xa);
+            xload(3);
+            if (kx < 2) wload(1, kc, 1, kx + 1); else wload(1, kc + 1, 1, 0);
+            mm(1, 2, xa);
         }
     }
 
-    // ---- epilogue: output row oy0 + wv, four m-tiles of 16 pixels through the wave's LDS tile
-    const int oy = oy0 + wv;
-    _Float16* __restrict__ Og = (_Float16*)p.out.p + ((size_t)(b * p.out.Hs + oy) * p.out.Ws + ox0) * p.out.Cs + n0;
-    constexpr int PPO = N / 8, NPO = 16 * PPO / 64 > 0 ? 16 * PPO / 64 : 1;
-    float csum[NT];                       // squeeze-excite pooling: column sums of the stored (fp16-rounded) values of this wave's row
+    // ---- epilogue: LeakyReLU / none, fp16, 2 x 16 bytes per lane and pixel; squeeze-excite partial sums of the stored values
+    const __amdgpu_buffer_rsrc_t O = make_rsrc((_Float16*)p.out.p + (size_t)b * p.out.Hs * p.out.Ws * p.out.Cs, 0x7FFFFFFFu);
+    const float slope = p.act == 1 ? p.alpha : 1.f;                    // LeakyReLU as max(v, v * alpha), 0 <= alpha <= 1 (conv3_supported); 1: none
+    float csum[4][4];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) csum[nt] = 0.f;
+    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+        for (int j = 0; j < 4; ++j) csum[nt][j] = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+    for (int r = 0; r < 2; ++r) {
+        const int oy = oy0 + 2 * wv + r;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int ox = ox0 + mt * 16 + fr;
+            const bool valid = oy < Ho && ox < Wo;
+            _Float16 hv[16];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = acc[r][mt][nt][j];
+                    hv[nt * 4 + j] = (_Float16)fmaxf(v, v * slope);
+                    if (POOL && valid) csum[nt][j] += (float)hv[nt * 4 + j];
+                }
+            const unsigned oo = valid ? ((unsigned)(oy * p.out.Ws + ox) * (unsigned)p.out.Cs + (unsigned)(n0 + 8 * g)) * 2u : kNoPix;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, (half8){hv[0], hv[1], hv[2], hv[3], hv[4], hv[5], hv[6], hv[7]}), O, oo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, (half8){hv[8], hv[9], hv[10], hv[11], hv[12], hv[13], hv[14], hv[15]}), O,
+                                                   __builtin_elementwise_add_sat(oo, 64u), 0, 0);
+        }
+    }
+    if (POOL) {   // per-workgroup partial sums in a fixed order (pixels of a lane, lanes of a row group, waves 0..3); se_kernel adds the tiles of an image
+        __syncthreads();                                        // all waves are done with the halo tile
+        float* ws = (float*)smem;                               // [4][64]
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float v = acc[mt][nt][j];
-                if (p.act == 1) v = v > 0.f ? v : v * p.alpha;
-                const _Float16 h = (_Float16)v;
-                Ot[(g * 4 + j) * (N + 8) + nt * 16 + fr] = h;
-                if (p.pool_out && oy < Ho && ox0 + mt * 16 + g * 4 + j < Wo) csum[nt] += (float)h;
+                float t = csum[nt][j];
+                t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
+                if (fr == 0) ws[wv * 64 + 32 * (nt >> 1) + 8 * g + 4 * (nt & 1) + j] = t;
             }
-        W2X_PHASE_FENCE();
-#pragma unroll
-        for (int k = 0; k < NPO; ++k) {
-            const int idx = k * 64 + lane, px = idx / PPO, c = idx - px * PPO;
-            if (idx < 16 * PPO && oy < Ho && ox0 + mt * 16 + px < Wo)
-                *(half8*)(Og + (size_t)(mt * 16 + px) * p.out.Cs + c * 8) = *(const half8*)(Ot + px * (N + 8) + c * 8);
-        }
-        W2X_PHASE_FENCE();
-    }
-    if (p.pool_out) {   // per-workgroup partial sums in a fixed order (rows of a wave, then waves 0..3): se_kernel adds the tiles of an image
-        float* ws = (float*)WB;                                  // [4][N]; the weight buffers are idle (last tap ended with a barrier)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { const float t = rows_sum(csum[nt]); if (g == 0) ws[wv * N + nt * 16 + fr] = t; }
         __syncthreads();
-        for (int n = tid; n < N; n += 256) p.pool_out[(size_t)blockIdx.x * p.out.Cs + n0 + n] = ws[n] + ws[N + n] + ws[2 * N + n] + ws[3 * N + n];
+        if (tid < 64) p.pool_out[(size_t)tidx * p.out.Cs + n0 + tid] = ws[tid] + ws[64 + tid] + ws[128 + tid] + ws[192 + tid];
     }
-}
-
-template <int KC, int N, int TS>
-hipError_t launch_c3(const GemmParams& p, int Ho, int Wo, int n0, hipStream_t s) {
-    using C = Conv3Cfg<KC, N, TS>;
-    static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
-    if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<KC, N, TS>, C::SMEM, lds_ok); e != hipSuccess) return e;
-    const int tiles_x = (Wo + C::TW - 1) / C::TW, tiles_y = (Ho + C::TH - 1) / C::TH;
-    hipLaunchKernelGGL((conv3_kernel<KC, N, TS>), dim3((unsigned)(p.B * tiles_x * tiles_y)), dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, n0);
-    return hipGetLastError();
 }
 
 }  // namespace
 
-int conv3_tiles(const GemmParams& p) { const int Ho = p.Mrows / p.aW, Wo = p.aW; return ((Wo + 63) / 64) * ((Ho + 3) / 4); }   // workgroups per image
+int conv3_tiles(const GemmParams& p) {   // workgroups (pooling partials) per image and 64-channel block
+    const int Ho = p.Mrows / p.aW, Wo = p.aW;
+    return ((Wo + Conv3Cfg::TW - 1) / Conv3Cfg::TW) * ((Ho + Conv3Cfg::TH - 1) / Conv3Cfg::TH);
+}
 
 bool conv3_supported(const GemmParams& p) {
     static const bool off = getenv("W2X_NO_CONV3") != nullptr;   // A/B switch
-    if (off || !p.wt_frag || p.amode != 2 || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.omode != 0 || p.ln || (p.act != 0 && p.act != 1) ||
+    if (off || !p.wt_perm || p.amode != 2 || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.omode != 0 || p.ln || (p.act != 0 && p.act != 1) ||
         p.has_clip || p.stats_out || p.res.p || p.res2.p) return false;
+    if (p.act == 1 && !(p.alpha >= 0.f && p.alpha <= 1.f)) return false;   // LeakyReLU as max(v, v * alpha)
     const int Cin = p.a.Cs;
     if (p.K != 9 * Cin || p.Kw != p.K || Cin % 32 || p.out.Cs != p.N || p.aW <= 0 || p.Mrows % p.aW) return false;
     const int Ho = p.Mrows / p.aW, Wo = p.aW;
     if (p.a.y0 + Ho + 2 > p.a.Hs || p.a.x0 + Wo + 2 > p.a.Ws || p.out.Hs < Ho || p.out.Ws < Wo) return false;
+    if ((size_t)p.out.Hs * p.out.Ws * p.out.Cs * 2 > 0x7FFFFFFFull || (size_t)(Conv3Cfg::HR + 1) * p.a.Ws * Cin * 2 > 0x7FFFFFFFull) return false;   // 32-bit offsets
     // pooling partials: one per workgroup; the plan sized the buffer for ceil(Mrows / kGemmBM) row tiles per image
     if (p.pool_out && conv3_tiles(p) > (p.Mrows + kGemmBM - 1) / kGemmBM) return false;
     return p.N == 64 || p.N == 128 || p.N == 256;
 }
 
 hipError_t launch_conv3(const GemmParams& p, hipStream_t s) {
-    const int Ho = p.Mrows / p.aW, Wo = p.aW, Cin = p.a.Cs;
-    (void)Cin;   // chunks of 32 input channels for every width: 49 KB (N = 64) / 65 KB (N = 128) of LDS, 3 / 2 workgroups per CU
-    if (p.N == 64) return launch_c3<32, 64, 1>(p, Ho, Wo, 0, s);   // 3 taps per stage (fewer barriers, 2 instead of 3 workgroups per CU) measured 19 % slower
-    hipError_t e = launch_c3<32, 128, 1>(p, Ho, Wo, 0, s);
-    if (e == hipSuccess && p.N == 256) e = launch_c3<32, 128, 1>(p, Ho, Wo, 128, s);
-    return e;
+    using C = Conv3Cfg;
+    const int Ho = p.Mrows / p.aW, Wo = p.aW;
+    static unsigned lds_ok = 0, lds_ok_pool = 0;   // per-device bits: kernels.h ensure_dynamic_lds
+    if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<false>, C::SMEM, lds_ok); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<true>, C::SMEM, lds_ok_pool); e != hipSuccess) return e;
+    const int tiles_x = (Wo + C::TW - 1) / C::TW, tiles_y = (Ho + C::TH - 1) / C::TH, nblk = p.N / 64;
+    const dim3 grid((unsigned)(p.B * tiles_x * tiles_y * nblk));
+    if (p.pool_out) hipLaunchKernelGGL(conv3_kernel<true>, grid, dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, nblk);
+    else hipLaunchKernelGGL(conv3_kernel<false>, grid, dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, nblk);
+    return hipGetLastError();
 }
 
 }  // namespace w2x

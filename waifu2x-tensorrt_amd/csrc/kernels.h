@@ -34,6 +34,7 @@ struct GemmParams {
     int K = 0, N = 0, Kw = 0;       // Kw: row stride of wt (K rounded up to 8, zero padded)
     const void* wt = nullptr;       // fp16 [N][Kw]
     const void* wt_frag = nullptr;  // fragment-major copy (fragorder.h) for k_pixgemm.hip, or null
+    const void* wt_perm = nullptr;  // fragorder.h frag_conv3b copy for k_conv3.hip's conv3b_kernel, or null
     const float* bias = nullptr;    // [N]
     const float* csum = nullptr;    // [N] (ln)
     const float* stats_in = nullptr;  // [pixels of a][2]
