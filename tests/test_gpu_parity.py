@@ -395,3 +395,29 @@ def test_engines_on_their_own_host_threads(pkg, onnx_model, monkeypatch):
     assert not errs, errs
     assert all(np.array_equal(a, b) for a, b in zip(got, want))
     [e.close() for e in engs]
+
+
+@pytest.mark.parametrize("model,scale,tile,kernels", [
+    ("cunet/art", 2, 96, 16),        # stem, 3x3 layers (k_conv3.hip, with and without pooling), both image heads (k_conv3h.hip), 1x1 + pixel shuffle
+    ("cunet/art", 1, 64, 16),
+    ("swin_unet/art", 4, 64, 6),     # stem, 48 -> 96 patch convolution, patch merges, pixel-shuffle projections, image head
+])
+def test_shape_specialised_kernels_agree_with_the_general_kernel(pkg, onnx_model, monkeypatch, model, scale, tile, kernels):
+    """Every launch that a shape-specialised kernel takes (k_stem / k_conv3 / k_conv3h / k_conv48 / k_pixgemm) is repeated on
+    gemm_kernel, the implicit-GEMM kernel that covers all of them (W2X_PIXGEMM_CHECK, engine.cpp): the two outputs may differ by
+    the rounding of one fp16 value (different summation order; k_conv3h rounds once where gemm_kernel rounds before and after the
+    skip add) - 2^-7 at the largest activations of these graphs - and never by more."""
+    path = onnx_model(model, scale, 2, tile, noise=1)
+    monkeypatch.setenv("W2X_PIXGEMM_CHECK", "1")
+    eng = pkg.Img2Img()
+    lines = []
+    eng.setMessageCallback(lambda sev, m: lines.append(m) if "pixgemm check" in m else None)
+    assert eng.build(path, pkg.BuildConfig.fixed(2, tile)), eng.last_error()
+    assert eng.load(path, pkg.RenderConfig(batchSize=2, height=tile, width=tile, scaling=scale)), eng.last_error()
+    monkeypatch.delenv("W2X_PIXGEMM_CHECK")
+    eng.infer(np.random.default_rng(5).random((2, 3, tile, tile), dtype=np.float32))
+    eng.close()
+    import re
+    seen = [(float(m.group(1)), int(m.group(2))) for m in (re.search(r"max\|d\|=([0-9.]+) .*?, (\d+) of \d+ off by", l) for l in lines) if m]
+    assert len(seen) >= kernels, lines
+    assert all(bad == 0 and md <= 2.0 ** -7 for md, bad in seen), lines
