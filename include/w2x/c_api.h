@@ -88,6 +88,8 @@ int w2x_calculate_tiles(int in_w, int in_h, int out_w, int out_h, int tile_in, i
 int w2x_tile_weights(int which, int overlap_x, int overlap_y, int size, float* out);
 /* Lower an ONNX file at [batch,3,tile,tile] and write a textual description of the plan (ops, FLOPs) into buf. */
 int w2x_describe_plan(const char* onnx_path, int batch, int tile, char* buf, size_t cap);
+/* the same for either precision (W2X_PRECISION_FP16 / W2X_PRECISION_TF32: the plan build() would write for that BuildConfig::precision) */
+int w2x_describe_plan_precision(const char* onnx_path, int batch, int tile, int precision, char* buf, size_t cap);
 /* Host-only halves of build() / load() for tools and tests: lower an ONNX file and write the plan (no .json side file, no
  * device); read a plan file back and run the consistency checks load() runs (img2img_load.cpp:149-154 "Failed to deserialize
  * engine"), writing "ok" or the reason into buf. */

@@ -171,9 +171,11 @@ def test_batch_size_invariance_bit_exact(pkg, onnx_model, small):
 def test_error_paths(pkg, onnx_model, tmp_path):
     path = onnx_model("cunet/art", 2, 2, 64)
     eng = pkg.Img2Img()
-    # TF32 is not available on gfx950: build fails like platformHasTf32() == false (img2img_build.cpp:133-135)
-    assert eng.build(path, pkg.BuildConfig.fixed(2, 64, precision=pkg.Precision.TF32)) is False
-    assert "TF32" in eng.last_error()
+    # an engine serves only the precision it was built for (isCompatible, img2img_load.cpp:54-66): a TF32 engine (the fp32 engine
+    # on gfx950) on disk does not satisfy an FP16 render configuration
+    assert eng.build(path, pkg.BuildConfig.fixed(2, 64, precision=pkg.Precision.TF32)), eng.last_error()
+    assert eng.load(path, pkg.RenderConfig(batchSize=2, height=64, width=64, scaling=2)) is False
+    assert "could not satisfy render configuration" in eng.last_error()
     assert eng.build(path, pkg.BuildConfig.fixed(2, 64)), eng.last_error()
     # no engine for this configuration (img2img_load.cpp:111-112)
     assert eng.load(path, pkg.RenderConfig(batchSize=4, height=64, width=64, scaling=2)) is False
@@ -421,3 +423,33 @@ def test_shape_specialised_kernels_agree_with_the_general_kernel(pkg, onnx_model
     seen = [(float(m.group(1)), int(m.group(2))) for m in (re.search(r"max\|d\|=([0-9.]+) .*?, (\d+) of \d+ off by", l) for l in lines) if m]
     assert len(seen) >= kernels, lines
     assert all(bad == 0 and md <= 2.0 ** -7 for md, bad in seen), lines
+
+
+FP32_NET_MAX_ABS = 2e-6   # fp32 engine against the fp32 oracle (outputs in [0, 1]): summation order only; measured <= 6.6e-7 (profiles/r2_final/parity.jsonl)
+
+
+@pytest.mark.parametrize("model,scale,batch,tile", [("cunet/art", 2, 2, 64), ("cunet/art", 1, 1, 64), ("swin_unet/art", 4, 2, 64), ("swin_unet/photo", 2, 1, 88),
+                                                    ("swin_unet/art_scan", 4, 1, 64)])
+def test_fp32_engine_matches_the_fp32_oracle(pkg, onnx_model, model, scale, batch, tile):
+    """Precision::TF32 builds the fp32 engine (k_f32.hip: fp32 maps, fp32 MFMA products, un-fused operator set).  Its output is
+    compared with the fp32 oracle directly - no fp16 rounding on either side, so what remains is summation order: this pins the
+    lowering itself (LayerNorm folding, window tables and masks, pixel shuffles, crops, squeeze-excite) independently of the fp16
+    tolerances above.  Frames must then agree with the oracle pipeline to the byte."""
+    path = onnx_model(model, scale, batch, tile, noise=1)
+    eng = pkg.Img2Img()
+    assert eng.build(path, pkg.BuildConfig.fixed(batch, tile, precision=pkg.Precision.TF32)), eng.last_error()
+    assert eng.load(path, pkg.RenderConfig(precision=pkg.Precision.TF32, batchSize=batch, height=tile, width=tile, scaling=scale, overlap=(0.0625, 0.0625))), eng.last_error()
+    rng = np.random.default_rng(21)
+    x = rng.random((batch, 3, tile, tile), dtype=np.float32)
+    ex = onnx_exec.Executor(path)
+    y, ref = eng.infer(x), ex.run(x)
+    d = np.abs(y.astype(np.float64) - ref.astype(np.float64))
+    from parity_util import _record
+    _record({"test": f"network fp32 [{model} s{scale} B{batch} T{tile}]", "kind": "network_fp32", "max_abs": float(d.max()), "mean_abs": float(d.mean())})
+    assert d.max() <= FP32_NET_MAX_ABS, (d.max(), d.mean())
+    frame = smooth_frame(tile + 37, 2 * tile - 9, 3)
+    out = eng.render(frame)
+    want = pipeline.render(frame, ex.run, batch=batch, tile=tile, scaling=scale, overlap=(0.0625, 0.0625))
+    r = frame_report(f"frame fp32 [{model} s{scale} B{batch} T{tile}]", out, want)
+    assert r["max_lsb"] <= 1 and r["frac_pixels_off_by_1"] < 1e-3, r
+    eng.close()

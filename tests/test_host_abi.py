@@ -173,3 +173,20 @@ def test_infer_validates_the_blob_shape(pkg):
     with pytest.raises(ValueError):
         eng.infer(np.zeros((2, 3, 32, 64), np.float32))
     eng.close()
+
+
+@pytest.mark.parametrize("model,scale", [("cunet/art", 2), ("swin_unet/art", 4)])
+def test_tf32_requests_lower_to_an_fp32_plan_of_unfused_ops(pkg, onnx_model, model, scale):
+    """Precision::TF32 (config.h:7-10) has no matrix instruction on gfx950; such a build gets the fp32 engine: the same graph
+    lowered with fp32 activations, weights and bias tables and none of the fused (fp16) transformer kernels.  The plan must
+    survive the engine-file round trip (describe_plan serialises and validates it)."""
+    path = onnx_model(model, scale, 2, 64, noise=1)
+    d16, d32 = pkg.describe_plan(path, 2, 64), pkg.describe_plan(path, 2, 64, pkg.Precision.TF32)
+    assert "precision=fp16" in d16.splitlines()[0] and "precision=fp32" in d32.splitlines()[0]
+    assert " swinattn " not in d32 and " mlp " not in d32
+    if model.startswith("swin"):
+        assert " swinattn " in d16 and " attn heads=" in d32
+    act = lambda d: int(re.search(r"activation_bytes=(\d+)", d).group(1))
+    flops = lambda d: int(re.search(r"flops=(\d+)", d).group(1))
+    assert flops(d16) == flops(d32)                       # the same algorithmic work
+    assert act(d32) > 1.5 * act(d16) or model.startswith("swin")   # fp32 maps (the un-fused swin plan also keeps qkv / hidden maps)

@@ -1,5 +1,5 @@
 """HIP-event time per plan op for one resident frame of any configuration (bench.py --op-times does this for config 3 only):
-    python tools/op_times.py cunet/art 2 1 4 256 1080 1920 [tta]"""
+    python tools/op_times.py cunet/art 2 1 4 256 1080 1920 [tta] [fp32]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,18 +8,19 @@ import __graft_entry__ as g
 import synth_models as sm
 pkg = g.package()
 model, scale, noise, batch, tile, rows, cols = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
-tta = len(sys.argv) > 8
+tta = "tta" in sys.argv[8:]
+prec = pkg.Precision.TF32 if "fp32" in sys.argv[8:] else pkg.Precision.FP16
 path = sm.model_path("/tmp/w2x_optimes", model, scale, noise)
 if not os.path.exists(path):
     sm.export_onnx(sm.make_model(model, scale, seed=1234 + noise), path, 1, tile, dynamic=True)
 eng = pkg.Img2Img()
-assert eng.build(path, pkg.BuildConfig.fixed(batch, tile)), eng.last_error()
-assert eng.load(path, pkg.RenderConfig(batchSize=batch, height=tile, width=tile, scaling=scale, tta=tta)), eng.last_error()
+assert eng.build(path, pkg.BuildConfig.fixed(batch, tile, precision=prec)), eng.last_error()
+assert eng.load(path, pkg.RenderConfig(precision=prec, batchSize=batch, height=tile, width=tile, scaling=scale, tta=tta)), eng.last_error()
 frame = np.random.default_rng(0).integers(0, 256, (rows, cols, 3), dtype=np.uint8)
 eng.render(frame)
 print(f"{eng.bench_resident(3):.3f} ms per resident frame, {eng.pass_tiles} tile slots per pass")
 prof = eng.profile_frame()
 print({k: round(v[0], 3) for k, v in prof.items() if k != "frame_ms"})
-desc = pkg.describe_plan(path, eng.pass_tiles, tile).splitlines()[2:]
+desc = pkg.describe_plan(path, eng.pass_tiles, tile, prec).splitlines()[2:]
 for line, t in zip(desc, eng.op_times()):
     print(f"{t:8.3f} ms  {line[:170]}")

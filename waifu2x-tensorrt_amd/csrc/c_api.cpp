@@ -126,10 +126,12 @@ int w2x_tile_weights(int which, int overlap_x, int overlap_y, int size, float* o
     return 1;
 }
 
-int w2x_describe_plan(const char* onnx_path, int batch, int tile, char* buf, size_t cap) {
+int w2x_describe_plan(const char* onnx_path, int batch, int tile, char* buf, size_t cap) { return w2x_describe_plan_precision(onnx_path, batch, tile, W2X_PRECISION_FP16, buf, cap); }
+
+int w2x_describe_plan_precision(const char* onnx_path, int batch, int tile, int precision, char* buf, size_t cap) {
     std::string s; int ok = 1;
     try {
-        w2x::Plan plan = w2x::build_plan(onnx_path, batch, 3, tile, tile);
+        w2x::Plan plan = w2x::build_plan(onnx_path, batch, 3, tile, tile, precision != W2X_PRECISION_FP16);
         plan.userB = batch;
         const auto bytes = plan.serialize();                          // what build() writes must be what load() accepts
         s = w2x::Plan::deserialize(bytes.data(), bytes.size()).describe();

@@ -147,7 +147,7 @@ constexpr const char* kEngineExt = ".w2x";
 // the default targets the pixel count of 48 tiles of 256x256 per pass (one 1080p frame at config 3), capped at 64 tiles.  Small
 // tiles gain the most: at tile 64 / batch 1 a pass of one tile is ~40 launches of a few microseconds of work each (a 1080p frame:
 // 1100 passes, 650 ms, hipGraph replay or not); 64 tiles per pass make it 18 passes.
-Plan lower_for_shape(const std::string& onnxModelPath, int batch, int channels, int height, int width) {
+Plan lower_for_shape(const std::string& onnxModelPath, int batch, int channels, int height, int width, bool fp32) {
     int S = 1;
     if (const char* env = getenv("W2X_SUPERBATCH")) S = std::max(1, atoi(env));
     else {
@@ -157,10 +157,10 @@ Plan lower_for_shape(const std::string& onnxModelPath, int batch, int channels, 
     }
     Plan plan;
     try {
-        plan = build_plan(onnxModelPath, batch * S, channels, height, width);
+        plan = build_plan(onnxModelPath, batch * S, channels, height, width, fp32);
     } catch (const std::exception&) {
         if (S == 1) throw;
-        plan = build_plan(onnxModelPath, batch, channels, height, width);   // e.g. a graph with a static batch dimension
+        plan = build_plan(onnxModelPath, batch, channels, height, width, fp32);   // e.g. a graph with a static batch dimension
     }
     plan.userB = batch;
     return plan;
@@ -369,18 +369,18 @@ struct Img2Img::Impl {
             upload_frag(blob, frag_w2((const uint16_t*)d.data(), Cc));
         };
         for (const Op& op : plan.ops)   // pixel-shuffle projections served by k_pixgemm.hip
-            if (op.kind == OP_GEMM && ((op.g.omode == 2 && (op.g.amode == 0 || (op.g.amode == 2 && op.g.kh == 1 && op.g.kw == 1))) || (op.g.amode == 2 && op.g.kh == 2 && op.g.kw == 2 && op.g.stride == 2)) && op.g.K % 32 == 0 && op.g.N % 16 == 0 &&
+            if (plan.elt == 2 && op.kind == OP_GEMM && ((op.g.omode == 2 && (op.g.amode == 0 || (op.g.amode == 2 && op.g.kh == 1 && op.g.kw == 1))) || (op.g.amode == 2 && op.g.kh == 2 && op.g.kw == 2 && op.g.stride == 2)) && op.g.K % 32 == 0 && op.g.N % 16 == 0 &&
                 plan.blobs[op.g.w].data.size() == (size_t)op.g.N * op.g.K * 2) frag_major_blob(op.g.w, op.g.N, op.g.K);
         perm_blobs.assign(plan.blobs.size(), nullptr);
         for (const Op& op : plan.ops)   // plain 3x3 convolutions onto 64 / 128 / 256 channels (k_conv3.hip)
-            if (op.kind == OP_GEMM && op.g.amode == 2 && op.g.kh == 3 && op.g.kw == 3 && op.g.stride == 1 && op.g.omode == 0 && op.g.K % 32 == 0 && op.g.N % 64 == 0 &&
+            if (plan.elt == 2 && op.kind == OP_GEMM && op.g.amode == 2 && op.g.kh == 3 && op.g.kw == 3 && op.g.stride == 1 && op.g.omode == 0 && op.g.K % 32 == 0 && op.g.N % 64 == 0 &&
                 plan.blobs[op.g.w].data.size() == (size_t)op.g.N * op.g.K * 2 && !perm_blobs[op.g.w]) {
                 const std::vector<uint16_t> f = frag_conv3b((const uint16_t*)plan.blobs[op.g.w].data.data(), op.g.N, op.g.K);
                 hipAssert(hipMalloc(&perm_blobs[op.g.w], f.size() * 2 + 256));
                 hipAssert(hipMemcpy(perm_blobs[op.g.w], f.data(), f.size() * 2, hipMemcpyHostToDevice));
             }
         for (const Op& op : plan.ops)   // 48 -> 96 channel 3x3 convolution (k_conv48.hip): K = 432 padded with zero columns to 14 k-steps of 32
-            if (op.kind == OP_GEMM && op.g.amode == 2 && op.g.kh == 3 && op.g.kw == 3 && op.g.stride == 1 && op.g.omode == 0 && op.g.K == 432 && op.g.N == 96 &&
+            if (plan.elt == 2 && op.kind == OP_GEMM && op.g.amode == 2 && op.g.kh == 3 && op.g.kw == 3 && op.g.stride == 1 && op.g.omode == 0 && op.g.K == 432 && op.g.N == 96 &&
                 plan.tensors[op.g.a.t].C == 48 && !frag_blobs[op.g.w]) {
                 const auto& d = plan.blobs[op.g.w].data;
                 const int Kw = round_up(op.g.K, 8), Kp = 448;
@@ -390,9 +390,9 @@ struct Img2Img::Impl {
                 upload_frag(op.g.w, frag_major(padded.data(), op.g.N, Kp));
             }
         for (const Op& op : plan.ops)
-            if (op.kind == OP_MLP && mlp_supported(op.m.C)) { frag_major_blob(op.m.w1, 2 * op.m.C, op.m.C); frag_w2_blob(op.m.w2, op.m.C); }
+            if (plan.elt == 2 && op.kind == OP_MLP && mlp_supported(op.m.C)) { frag_major_blob(op.m.w1, 2 * op.m.C, op.m.C); frag_w2_blob(op.m.w2, op.m.C); }
         for (const Op& op : plan.ops)
-            if (op.kind == OP_SWINATTN) { frag_major_blob(op.sa.wqkv, 3 * op.sa.C, op.sa.C); frag_major_blob(op.sa.wproj, op.sa.C, op.sa.C); }
+            if (plan.elt == 2 && op.kind == OP_SWINATTN) { frag_major_blob(op.sa.wqkv, 3 * op.sa.C, op.sa.C); frag_major_blob(op.sa.wproj, op.sa.C, op.sa.C); }
         gemm.assign(plan.ops.size(), GemmParams{});
         for (size_t i = 0; i < plan.ops.size(); ++i) {
             const Op& op = plan.ops[i];
@@ -440,10 +440,10 @@ struct Img2Img::Impl {
                     p.B = live;
                     if ((int)i == final_op && out_override) p.out.p = out_override;
                     stamp_begin(0, op.flops);
-                    if (op.g.pool_out >= 0) pool_blocks[op.g.pool_out] = conv3_supported(p) ? conv3_tiles(p) : 0;   // partial sums per image written by this launch (0: plan default)
-                    hipAssert(pixgemm_supported(p) ? launch_pixgemm(p, stream) : conv3_supported(p) ? launch_conv3(p, stream) : conv3h_supported(p) ? launch_conv3h(p, stream) : conv48_supported(p) ? launch_conv48(p, stream) : stem_supported(p) ? launch_stem(p, stream) : launch_gemm(p, stream));
+                    if (op.g.pool_out >= 0) pool_blocks[op.g.pool_out] = plan.elt == 2 && conv3_supported(p) ? conv3_tiles(p) : 0;   // partial sums per image written by this launch (0: plan default)
+                    hipAssert(plan.elt == 4 ? launch_gemm_f32(p, stream) : pixgemm_supported(p) ? launch_pixgemm(p, stream) : conv3_supported(p) ? launch_conv3(p, stream) : conv3h_supported(p) ? launch_conv3h(p, stream) : conv48_supported(p) ? launch_conv48(p, stream) : stem_supported(p) ? launch_stem(p, stream) : launch_gemm(p, stream));
                     stamp_end();
-                    if (check_general && (pixgemm_supported(p) || conv3_supported(p) || conv3h_supported(p) || conv48_supported(p) || stem_supported(p))) {   // diagnostic: the general kernel must agree
+                    if (check_general && plan.elt == 2 && (pixgemm_supported(p) || conv3_supported(p) || conv3h_supported(p) || conv48_supported(p) || stem_supported(p))) {   // diagnostic: the general kernel must agree
                         const TensorDesc& od = plan.tensors[op.g.out.t];
                         const size_t n = (size_t)live * od.H * od.W * od.C;
                         std::vector<uint16_t> a(n), b(n);
@@ -481,7 +481,7 @@ struct Img2Img::Impl {
                     p.qkv = tensors[a.qkv]; p.out = tensors[a.out]; p.B = live; p.nwin = a.nwin; p.heads = a.heads; p.hd = a.hd;
                     p.ntok = a.ws * a.ws; p.scale = a.scale; p.bias = blobs[a.bias]; p.maskid = (const int*)blobs[a.maskid];
                     stamp_begin(1, op.flops);
-                    hipAssert(launch_attn(p, stream));
+                    hipAssert(plan.elt == 4 ? launch_attn_f32(p, stream) : launch_attn(p, stream));
                     stamp_end();
                     break;
                 }
@@ -528,7 +528,7 @@ struct Img2Img::Impl {
                 case OP_SCALE_ADD: {
                     const TensorDesc& d = plan.tensors[op.se.pool];
                     stamp_begin(2, 0);
-                    hipAssert(launch_scale(tensors[op.se.pool], (const float*)tensors[op.se.scale], live, d.H * d.W, d.C, stream));
+                    hipAssert(launch_scale(tensors[op.se.pool], (const float*)tensors[op.se.scale], live, d.H * d.W, d.C, plan.elt == 4, stream));
                     stamp_end();
                     break;
                 }
@@ -554,7 +554,7 @@ struct Img2Img::Impl {
         const int userB = plan.userB, S = B / userB;
         const int batchCount = (int)std::lround(std::ceil((double)(sp.tile_count * steps) / userB));   // img2img_render.cpp:249
         const int passCount = (batchCount + S - 1) / S;
-        const size_t slot_bytes = (size_t)To * To * 4 * sizeof(uint16_t);
+        const size_t slot_bytes = (size_t)To * To * 4 * plan.elt;
         if (poison) {
             hipAssert(hipMemsetAsync(arena_base, 0x7E, arena_bytes, stream));
             hipAssert(hipMemsetAsync(d_slab, 0x7E, slab_cap, stream));
@@ -567,7 +567,7 @@ struct Img2Img::Impl {
             auto run_pass = [&] {
                 GatherParams gp;
                 gp.frame = d_frame; gp.rows = rows; gp.cols = cols; gp.step = (size_t)cols * 3;
-                gp.out = tensors[plan.in_tensor]; gp.slots = d_slots + (size_t)bi * B; gp.B = B; gp.T = T;
+                gp.out = tensors[plan.in_tensor]; gp.slots = d_slots + (size_t)bi * B; gp.B = B; gp.T = T; gp.fp32 = plan.elt == 4;
                 stamp_begin(3, 0);
                 hipAssert(launch_gather(gp, stream));
                 stamp_end();
@@ -606,7 +606,7 @@ struct Img2Img::Impl {
             }
         }
         ComposeParams cp;
-        cp.tiles = d_slab; cp.dst = d_out; cp.dst_step = (size_t)cols * cfg.scaling * 3;
+        cp.tiles = d_slab; cp.fp32 = plan.elt == 4; cp.dst = d_out; cp.dst_step = (size_t)cols * cfg.scaling * 3;
         cp.outW = cols * cfg.scaling; cp.outH = rows * cfg.scaling; cp.To = To;
         cp.nx = grid.nx; cp.ny = grid.ny; cp.stride_x = To - grid.outOvX; cp.stride_y = To - grid.outOvY;
         const bool overlapping = cfg.overlapX != 0 || cfg.overlapY != 0;                      // :244
@@ -636,11 +636,10 @@ bool Img2Img::build(const std::string& onnxModelPath, const BuildConfig& config)
         W2X_LOG(error, "Failed to set hip device to device id " + std::to_string(config.deviceId) + ": " + std::string(e.what()) + ".");
         return false;
     }
-    // :123-135 - precision support check
-    if (config.precision == Precision::TF32) {
-        W2X_LOG(error, "Failed to set precision: platform does not support TF32");
-        return false;
-    }
+    // :123-135 - precision: FP16 = the fused fp16 kernels; gfx950 has no TF32 matrix instruction, a TF32 request gets the fp32
+    // engine (fp32 storage, v_mfma_f32_16x16x4_f32 products, fp32 accumulation - a superset of TF32's precision; k_f32.hip)
+    const bool fp32 = config.precision == Precision::TF32;
+    if (fp32) W2X_LOG(info, "Precision TF32: this platform has no TF32 matrix instructions, the engine computes in fp32.");
     // :81-88 parse ; :102-116 one profile: the plan on disk is specialised for the opt shape (channels come from the model);
     // any other shape inside [min, max] is specialised by load() from the same ONNX file
     if (config.minBatchSize > config.optBatchSize || config.optBatchSize > config.maxBatchSize || config.minWidth > config.optWidth || config.optWidth > config.maxWidth ||
@@ -650,7 +649,7 @@ bool Img2Img::build(const std::string& onnxModelPath, const BuildConfig& config)
     }
     Plan plan;
     try {
-        plan = lower_for_shape(onnxModelPath, config.optBatchSize, config.optChannels, config.optHeight, config.optWidth);
+        plan = lower_for_shape(onnxModelPath, config.optBatchSize, config.optChannels, config.optHeight, config.optWidth, fp32);
     } catch (const std::exception& e) {
         W2X_LOG(error, "Failed to parse ONNX model: " + std::string(e.what()) + ".");
         return false;
@@ -741,13 +740,17 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
         W2X_LOG(warn, "Engine \"" + enginePath + "\" is compatible with but not optimized for the render configuration; specialising the plan for batch " +
                           std::to_string(config.batchSize) + ", tile " + std::to_string(config.width) + "x" + std::to_string(config.height) + ".");
         try {
-            impl->plan = lower_for_shape(modelPath, config.batchSize, config.channels, config.height, config.width);
+            impl->plan = lower_for_shape(modelPath, config.batchSize, config.channels, config.height, config.width, config.precision == Precision::TF32);
         } catch (const std::exception& e) {
             W2X_LOG(error, "Failed to set input tensor shape: " + std::string(e.what()) + ".");
             return false;
         }
     }
     const Plan& plan = impl->plan;
+    if ((plan.elt == 4) != (config.precision == Precision::TF32)) {   // the JSON sidecar and the engine file disagree
+        W2X_LOG(error, "Failed to deserialize engine from buffer: precision of the plan differs from the engine's configuration.");
+        return false;
+    }
     // :197-203 - the input shape must be the one the plan was specialised for; T' is read from the plan
     if (plan.userB != config.batchSize || plan.B % std::max(plan.userB, 1) || plan.Cin != config.channels || plan.T != config.height || plan.T != config.width) {
         W2X_LOG(error, "Failed to set input tensor shape.");
@@ -826,7 +829,7 @@ bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, cons
     }
     impl->ensure(impl->d_slots, impl->slots_cap, (size_t)stepCount * sizeof(TileSlot));
     hipAssert(hipMemcpyAsync(impl->d_slots, impl->h_slots.data(), (size_t)stepCount * sizeof(TileSlot), hipMemcpyHostToDevice, stream));
-    impl->ensure(impl->d_slab, impl->slab_cap, (size_t)stepCount * plan.Tout * plan.Tout * 4 * sizeof(uint16_t));
+    impl->ensure(impl->d_slab, impl->slab_cap, (size_t)stepCount * plan.Tout * plan.Tout * 4 * plan.elt);
 
     hipAssert(hipEventRecord(impl->ev0, stream));
     impl->run_frame(rows, cols, grid, true, sp);
@@ -883,7 +886,7 @@ bool Img2Img::renderSequence(const Image* srcs, Image* dsts, int count) try {
     }
     impl->ensure(impl->d_slots, impl->slots_cap, (size_t)stepCount * sizeof(TileSlot));
     hipAssert(hipMemcpyAsync(impl->d_slots, impl->h_slots.data(), (size_t)stepCount * sizeof(TileSlot), hipMemcpyHostToDevice, stream));
-    impl->ensure(impl->d_slab, impl->slab_cap, (size_t)stepCount * plan.Tout * plan.Tout * 4 * sizeof(uint16_t));
+    impl->ensure(impl->d_slab, impl->slab_cap, (size_t)stepCount * plan.Tout * plan.Tout * 4 * plan.elt);
     hipAssert(hipStreamSynchronize(stream));
 
     uint8_t* const frames[2] = {impl->d_frame, impl->d_frame2};
@@ -976,9 +979,9 @@ bool Img2Img::infer(const float* input, float* output) try {
         hipAssert(hipMemsetAsync(impl->d_blob_in, 0, in_elems * sizeof(float), stream));   // slots beyond the caller's batch stay zero
     }
     hipAssert(hipMemcpyAsync(impl->d_blob_in, input, user_in * sizeof(float), hipMemcpyHostToDevice, stream));
-    hipAssert(launch_blob_to_nhwc(impl->d_blob_in, impl->tensors[plan.in_tensor], plan.B, plan.T, stream));
+    hipAssert(launch_blob_to_nhwc(impl->d_blob_in, impl->tensors[plan.in_tensor], plan.B, plan.T, plan.elt == 4, stream));
     impl->run_network(nullptr, plan.userB);                                            // img2img_infer.cpp:80 (the slots beyond the caller's batch are not computed)
-    hipAssert(launch_nhwc_to_blob(impl->tensors[plan.out_tensor], impl->d_blob_out, plan.B, plan.Tout, stream));
+    hipAssert(launch_nhwc_to_blob(impl->tensors[plan.out_tensor], impl->d_blob_out, plan.B, plan.Tout, plan.elt == 4, stream));
     hipAssert(hipMemcpyAsync(output, impl->d_blob_out, user_out * sizeof(float), hipMemcpyDeviceToHost, stream));
     hipAssert(hipStreamSynchronize(stream));
     return true;

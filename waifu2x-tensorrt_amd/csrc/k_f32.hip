@@ -1,0 +1,368 @@
+// The engine's second precision for gfx950: every Conv / ConvTranspose / MatMul and the window attention core in fp32.
+// The reference offers fp16 and TF32 engines (/root/reference/src/tensorrt/config.h:7-10, img2img_build.cpp:123-135); gfx950 has
+// no TF32 / xf32 matrix instruction, so a TF32 request runs here: fp32 storage, fp32 products on v_mfma_f32_16x16x4_f32, fp32
+// accumulation - a superset of TF32's precision.  An fp32 plan (plan.h Plan::elt == 4, lower.cpp) keeps the un-fused operator
+// set (no fused transformer kernels, no shape-specialised convolutions), so two kernels cover it:
+//   gemm32_kernel : gemm_kernel (k_gemm.hip) restated for fp32 - same implicit-GEMM A operand (rows / window gather / kh x kw
+//                   taps), same epilogue (folded LayerNorm, bias, activations, two residual adds, clip, rows / window / pixel-shuffle
+//                   stores, LayerNorm statistics and squeeze-excite partial sums of the stored rows), same 128-row workgroup tile
+//                   (kGemmBM), LDS-staged operands with register prefetch of the next k-chunk.
+//   attn32_kernel : one wave per (window, head), lane = query row, everything in that lane's registers (k_attn.hip attn_kernel
+//                   with fp32 rows).
+// This path exists for precision, not speed (about 10x the fp16 frame time); tests compare it with the fp32 oracle directly.
+#include "kernels.h"
+#include <cmath>
+
+namespace w2x {
+namespace {
+
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float act_fn(float v, int act, float alpha) {
+    switch (act) {
+        case 1: return v > 0.f ? v : v * alpha;
+        case 2: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+        case 3: return v > 0.f ? v : 0.f;
+        case 4: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm32_kernel(const GemmParams p) {
+    constexpr int KB = 16;                      // k-chunk: four v_mfma_f32_16x16x4_f32 steps
+    constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
+    constexpr int LDA = KB + 1, LDC = BN + 4;   // floats
+    constexpr int A_PIECES = BM * KB / 4, B_PIECES = BN * KB / 4;   // pieces of 4 floats
+    constexpr int NA = (A_PIECES + 255) / 256, NB = (B_PIECES + 255) / 256;
+    static_assert(WAVES_M * WAVES_N == 4 && BM == kGemmBM, "4 waves, kGemmBM rows");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* As = (float*)smem;
+    float* Bs = As + BM * LDA;
+    float* Cs = (float*)smem;                   // aliases As / Bs after the main loop
+    constexpr int AB_BYTES = (BM + BN) * LDA * 4, C_BYTES = BM * LDC * 4;
+    constexpr int MAIN_BYTES = AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES;
+    int* s_aoff = (int*)(smem + MAIN_BYTES);
+    int* s_ob = s_aoff + BM;
+    int* s_oy = s_ob + BM;
+    int* s_ox = s_oy + BM;
+    float* s_mean = (float*)(s_ox + BM);
+    float* s_rstd = s_mean + BM;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / WAVES_N, wn = wv % WAVES_N;
+    const int tpi = (p.Mrows + BM - 1) / BM;    // row tiles never straddle batch items
+    const int tile_b = blockIdx.x / tpi;
+    const int ml0 = (blockIdx.x - tile_b * tpi) * BM;
+    const int n0 = blockIdx.y * BN;
+    const float* __restrict__ Ag = (const float*)p.a.p;
+    const float* __restrict__ Wg = (const float*)p.wt;
+
+    for (int i = tid; i < BM; i += 256) {
+        const int ml = ml0 + i;
+        int aoff = -1, ob = 0, oy = 0, ox = 0;
+        float mean = 0.f, rstd = 1.f;
+        if (ml < p.Mrows) {
+            const int b = tile_b;
+            int y, x;
+            if (p.amode == 1) { const int pix = p.win_table[ml]; y = pix / p.aW; x = pix - y * p.aW; }
+            else { y = ml / p.aW; x = ml - y * p.aW; }
+            const int pixoff = (b * p.a.Hs + y * p.stride + p.a.y0) * p.a.Ws + x * p.stride + p.a.x0;
+            aoff = pixoff * p.a.Cs;
+            if (p.ln) { mean = p.stats_in[2 * pixoff]; rstd = p.stats_in[2 * pixoff + 1]; }
+            ob = b;
+            if (p.omode == 1) { const int pix = p.win_table[ml]; oy = pix / p.out.Ws; ox = pix - oy * p.out.Ws; }
+            else { oy = ml / p.aW; ox = ml - oy * p.aW; }
+        }
+        s_aoff[i] = aoff; s_ob[i] = ob; s_oy[i] = oy; s_ox[i] = ox; s_mean[i] = mean; s_rstd[i] = rstd;
+    }
+    __syncthreads();
+
+    float4v ra[NA], rb[NB];
+    const int Cin = p.a.Cs, kwCin = p.kw * Cin;
+    auto load_regs = [&](int kc) {
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+            const int idx = tid + t * 256;
+            float4v v = {0.f, 0.f, 0.f, 0.f};
+            if (A_PIECES % 256 == 0 || idx < A_PIECES) {
+                const int row = idx / (KB / 4), kp = idx - row * (KB / 4), k = kc + kp * 4, aoff = s_aoff[row];
+                if (aoff >= 0 && k < p.K) {
+                    int off;
+                    if (p.amode == 2) { const int ky = k / kwCin, rem = k - ky * kwCin; off = aoff + ky * p.a.Ws * Cin + rem; }
+                    else off = aoff + k;
+                    v = *(const float4v*)(Ag + off);
+                }
+            }
+            ra[t] = v;
+        }
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            const int idx = tid + t * 256;
+            float4v v = {0.f, 0.f, 0.f, 0.f};
+            if (B_PIECES % 256 == 0 || idx < B_PIECES) {
+                const int row = idx / (KB / 4), kp = idx - row * (KB / 4), k = kc + kp * 4, n = n0 + row;
+                if (n < p.N && k < p.Kw) v = *(const float4v*)(Wg + (size_t)n * p.Kw + k);
+            }
+            rb[t] = v;
+        }
+    };
+    auto store_lds = [&]() {
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+            const int idx = tid + t * 256;
+            if (A_PIECES % 256 == 0 || idx < A_PIECES) {
+                const int row = idx / (KB / 4), kp = idx - row * (KB / 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) As[row * LDA + kp * 4 + e] = ra[t][e];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            const int idx = tid + t * 256;
+            if (B_PIECES % 256 == 0 || idx < B_PIECES) {
+                const int row = idx / (KB / 4), kp = idx - row * (KB / 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Bs[row * LDA + kp * 4 + e] = rb[t][e];
+            }
+        }
+    };
+
+    float4v acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = (p.K + KB - 1) / KB;
+    const int frow = lane & 15, fk = lane >> 4;
+    load_regs(0);
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();
+        store_lds();
+        __syncthreads();
+        if (c + 1 < nchunks) load_regs((c + 1) * KB);
+#pragma unroll
+        for (int ks = 0; ks < KB / 4; ++ks) {
+            float af[WM];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) af[i] = As[((wm * WM + i) * 16 + frow) * LDA + ks * 4 + fk];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const float bf = Bs[((wn * WN + j) * 16 + frow) * LDA + ks * 4 + fk];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue phase 1: accumulators -> (LayerNorm algebra, bias, activation) -> fp32 tile in LDS
+    {
+        const int ccol = lane & 15, crow = (lane >> 4) * 4;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = (wn * WN + j) * 16 + ccol, n = n0 + col;
+            float bias = 0.f, cs = 0.f;
+            if (n < p.N) { bias = p.bias ? p.bias[n] : 0.f; if (p.ln) cs = p.csum[n]; }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = (wm * WM + i) * 16 + crow + e;
+                    float v = acc[i][j][e];
+                    if (p.ln) v = s_rstd[row] * (v - s_mean[row] * cs);
+                    v += bias;
+                    Cs[row * LDC + col] = act_fn(v, p.act, p.alpha);
+                }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue phase 2: pieces of 4 floats: residual adds, clip, store, LayerNorm statistics, SE pooling
+    {
+        float* __restrict__ Og = (float*)p.out.p;
+        const int Cso = p.out.Cs;
+        const bool pix = p.omode == 2;
+        const int ppc = (pix ? Cso : BN) / 4;                  // pieces per (row, sub-pixel) in this tile
+        const int subs = pix ? BN / Cso : 1;
+        int gs = 1; while (gs < ppc) gs <<= 1;
+        const int groups = 256 / gs;
+        const int items = BM * subs;
+        const int jp = tid & (gs - 1);
+        for (int q0 = 0; q0 < items; q0 += groups) {
+            int q = q0 + tid / gs;
+            if (q >= items) q = items - 1;   // clamp (duplicates are masked by `valid` below)
+            const int i = q / subs, s = q - i * subs;
+            bool valid = (q0 + tid / gs) < items && jp < ppc && s_aoff[i] >= 0;
+            const int ccol = pix ? s * Cso + jp * 4 : jp * 4;     // column inside the LDS tile
+            const int ch = pix ? jp * 4 : n0 + jp * 4;            // channel inside the output pixel
+            const int sg = pix ? n0 / Cso + s : 0;
+            if (pix ? sg >= p.r * p.r : ch >= p.N) valid = false;
+            const int dy = pix ? sg / p.r : 0, dx = pix ? sg - dy * p.r : 0;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            int b = 0, Y = 0, X = 0;
+            if (valid) {
+                b = s_ob[i]; Y = s_oy[i] * p.r + dy; X = s_ox[i] * p.r + dx;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = Cs[i * LDC + ccol + e];
+                if (p.res.p) {
+                    const float4v r = *(const float4v*)((const float*)p.res.p + (size_t)((b * p.res.Hs + Y + p.res.y0) * p.res.Ws + X + p.res.x0) * p.res.Cs + ch);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += r[e];
+                }
+                if (p.res2.p) {
+                    const float4v r = *(const float4v*)((const float*)p.res2.p + (size_t)((b * p.res2.Hs + Y + p.res2.y0) * p.res2.Ws + X + p.res2.x0) * p.res2.Cs + ch);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += r[e];
+                }
+                if (p.has_clip) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], p.clip_lo), p.clip_hi);
+                }
+                *(float4v*)(Og + (size_t)((b * p.out.Hs + Y) * p.out.Ws + X) * Cso + ch) = (float4v){v[0], v[1], v[2], v[3]};
+                if (p.pool_out) *(float4v*)(Cs + i * LDC + ccol) = (float4v){v[0], v[1], v[2], v[3]};   // final values for the column sums below
+            }
+            if (p.stats_out) {   // uniform branch; all lanes take part in the shuffles
+                float sum = v[0] + v[1] + v[2] + v[3];
+                for (int msk = gs >> 1; msk > 0; msk >>= 1) sum += __shfl_xor(sum, msk);
+                const float mean = sum / (float)p.Cout;
+                float sq = 0.f;
+                if (valid) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; sq += d * d; }
+                }
+                for (int msk = gs >> 1; msk > 0; msk >>= 1) sq += __shfl_xor(sq, msk);
+                if (valid && jp == 0) {
+                    const size_t pixi = (size_t)(b * p.out.Hs + Y) * p.out.Ws + X;
+                    p.stats_out[2 * pixi] = mean;
+                    p.stats_out[2 * pixi + 1] = rsqrtf(sq / (float)p.Cout + p.ln_eps);
+                }
+            }
+        }
+        if (p.pool_out) {   // per-workgroup column sums in row order; se_kernel adds the partials of a batch item in tile order
+            __syncthreads();
+            for (int c = tid; c < BN; c += 256) {
+                float sum = 0.f;
+                for (int i = 0; i < BM; ++i) if (s_aoff[i] >= 0) sum += Cs[i * LDC + c];
+                if (n0 + c < p.N) p.pool_out[(size_t)blockIdx.x * Cso + n0 + c] = sum;
+            }
+        }
+    }
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+hipError_t launch_cfg32(const GemmParams& p, hipStream_t s) {
+    constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16, LDA = 17, LDC = BN + 4;
+    constexpr int AB = (BM + BN) * LDA * 4, CB = BM * LDC * 4;
+    constexpr int SMEM = (AB > CB ? AB : CB) + BM * 6 * 4;
+    auto kern = gemm32_kernel<WAVES_M, WAVES_N, WM, WN>;
+    static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
+    if (hipError_t e = ensure_dynamic_lds((const void*)kern, SMEM, lds_ok); e != hipSuccess) return e;
+    const dim3 grid(p.B * ((p.Mrows + BM - 1) / BM), (p.N + BN - 1) / BN);
+    hipLaunchKernelGGL(kern, grid, dim3(256), SMEM, s, p);
+    return hipGetLastError();
+}
+
+// ---- window attention core, fp32 rows ------------------------------------------------------------------------------------------
+template <int HD, int NTOK>
+__global__ __launch_bounds__(256) void attn32_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) float sK[4][NTOK][HD];
+    __shared__ __attribute__((aligned(16))) float sV[4][NTOK][HD];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int C = p.heads * HD;
+    const long total = (long)p.B * p.nwin * p.heads;
+    long unit = (long)blockIdx.x * 4 + wv;
+    const bool active_wave = unit < total;
+    if (!active_wave) unit = total - 1;   // keep the wave alive for the barrier; results are not stored
+    const int h = (int)(unit % p.heads);
+    const long win = unit / p.heads;           // global window index (b * nwin + w)
+    const int w = (int)(win % p.nwin);
+    const bool act = lane < NTOK;
+    const float* base = (const float*)p.qkv + (win * NTOK + (act ? lane : 0)) * (long)(3 * C) + h * HD;
+
+    float q[HD];
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+        const float4v qv = *(const float4v*)(base + d), kv = *(const float4v*)(base + C + d), vv = *(const float4v*)(base + 2 * C + d);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[d + e] = qv[e] * p.scale;
+        if (act) { *(float4v*)&sK[wv][lane][d] = kv; *(float4v*)&sV[wv][lane][d] = vv; }
+    }
+    __syncthreads();
+
+    const float* bias = (const float*)p.bias + (((long)p.maskid[w] * p.heads + h) * NTOK + (act ? lane : 0)) * NTOK;
+    float s[NTOK];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NTOK; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) {
+            const float4v kv = *(const float4v*)&sK[wv][j][d];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a += q[d + e] * kv[e];
+        }
+        a += bias[j];
+        s[j] = a;
+        mx = fmaxf(mx, a);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NTOK; ++j) { s[j] = expf(s[j] - mx); sum += s[j]; }
+    const float inv = 1.f / sum;
+    float o[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NTOK; ++j) {
+        const float pj = s[j];
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) {
+            const float4v vv = *(const float4v*)&sV[wv][j][d];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[d + e] += pj * vv[e];
+        }
+    }
+    if (act && active_wave) {
+        float* op_ = (float*)p.out + (win * NTOK + lane) * (long)C + h * HD;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) *(float4v*)(op_ + d) = (float4v){o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv};
+    }
+}
+
+}  // namespace
+
+// Tile selection as in launch_gemm (k_gemm.hip): the tile width follows N; pixel-shuffle outputs take whole output pixels.
+hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s) {
+    if (p.a.Cs % 4 || p.out.Cs % 4 || p.Kw % 4 || p.K % 4) return hipErrorInvalidValue;   // pieces of four floats
+    int bn;
+    if (p.omode == 2) bn = (p.out.Cs <= 192 && 192 % p.out.Cs == 0 && p.N >= 192) ? 192 : p.out.Cs;
+    else bn = p.N % 192 == 0 ? 192 : p.N % 96 == 0 ? 96 : p.N % 128 == 0 ? 128 : p.N % 64 == 0 ? 64 : p.N % 48 == 0 ? 48 : p.N % 32 == 0 ? 32 : p.N <= 16 ? 16 : 0;
+    if (p.omode == 2 && bn < 16) bn = 16;                           // 4 sub-pixels x 4 stored channels and the like: whole tile
+    if (p.stats_out && p.omode != 2 && bn < p.N) return hipErrorInvalidValue;
+    if (p.omode == 2 && (bn % p.out.Cs)) return hipErrorInvalidValue;
+    switch (bn) {
+        case 192: return launch_cfg32<2, 2, 4, 6>(p, s);
+        case 128: return launch_cfg32<2, 2, 4, 4>(p, s);
+        case 96: return launch_cfg32<4, 1, 2, 6>(p, s);
+        case 64: return launch_cfg32<4, 1, 2, 4>(p, s);
+        case 48: return launch_cfg32<4, 1, 2, 3>(p, s);
+        case 32: return launch_cfg32<4, 1, 2, 2>(p, s);
+        case 16: return launch_cfg32<4, 1, 2, 1>(p, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_attn_f32(const AttnParams& p, hipStream_t s) {
+    const long total = (long)p.B * p.nwin * p.heads;
+    const dim3 grid((unsigned)((total + 3) / 4));
+#define W2X_ATTN32_CASE(HD_, NTOK_)                                                                                     \
+    if (p.ntok == NTOK_ && p.hd == HD_) { hipLaunchKernelGGL((attn32_kernel<HD_, NTOK_>), grid, dim3(256), 0, s, p); return hipGetLastError(); }
+    W2X_ATTN32_CASE(16, 36) W2X_ATTN32_CASE(32, 36) W2X_ATTN32_CASE(8, 36) W2X_ATTN32_CASE(16, 64) W2X_ATTN32_CASE(32, 64)
+#undef W2X_ATTN32_CASE
+    return hipErrorInvalidValue;
+}
+
+}  // namespace w2x

@@ -16,6 +16,11 @@ namespace {
 
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+// a tile pixel is four stored channels (r, g, b, 0) in the plan's precision: half4 (fp16 engines) or float4v (fp32 engines)
+template <typename P> __device__ __forceinline__ P make_px(float r, float g, float b);
+template <> __device__ __forceinline__ half4 make_px<half4>(float r, float g, float b) { return (half4){(_Float16)r, (_Float16)g, (_Float16)b, (_Float16)0.f}; }
+template <> __device__ __forceinline__ float4v make_px<float4v>(float r, float g, float b) { return (float4v){r, g, b, 0.f}; }
 
 // source coordinate inside the un-augmented tile for pixel (y,x) of the augmented tile (applyAugmentation)
 __device__ __forceinline__ void aug_src(int k, int n, int y, int x, int& sy, int& sx) {
@@ -44,6 +49,7 @@ __device__ __forceinline__ void deaug_src(int k, int n, int y, int x, int& sy, i
     }
 }
 
+template <typename P>
 __global__ __launch_bounds__(256) void gather_kernel(const GatherParams p) {
     const int T = p.T;
     const long total = (long)p.B * T * T;
@@ -53,18 +59,16 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherParams p) {
         int rem = (int)(i - (long)b * T * T);
         int y = rem / T, x = rem - y * T;
         TileSlot sl = p.slots[b];
-        half4 v = (half4){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        P v = make_px<P>(0.f, 0.f, 0.f);
         if (sl.valid) {
             int sy, sx;
             aug_src(sl.aug, T - 1, y, x, sy, sx);
             int fy = min(max(sl.y + sy, 0), p.rows - 1);
             int fx = min(max(sl.x + sx, 0), p.cols - 1);
             const uint8_t* px = p.frame + (size_t)fy * p.step + (size_t)fx * 3;
-            v[0] = (_Float16)((float)px[2] * inv255);
-            v[1] = (_Float16)((float)px[1] * inv255);
-            v[2] = (_Float16)((float)px[0] * inv255);
+            v = make_px<P>((float)px[2] * inv255, (float)px[1] * inv255, (float)px[0] * inv255);
         }
-        *((half4*)p.out + i) = v;
+        *((P*)p.out + i) = v;
     }
 }
 
@@ -75,7 +79,8 @@ __device__ __forceinline__ unsigned quantize_bgr(float r, float g, float b) {
                    R = (unsigned)min(max(__float2int_rn(r * 255.f), 0), 255);
     return B | G << 8 | R << 16;
 }
-__device__ __forceinline__ unsigned compose_pixel(const ComposeParams& p, const half4* tiles, int X, int Y) {
+template <typename P>
+__device__ __forceinline__ unsigned compose_pixel(const ComposeParams& p, const P* tiles, int X, int Y) {
     const int To = p.To, n = To - 1;
     const int steps = p.tta ? 8 : 1;
     // candidate tile columns/rows: origin = idx*stride, extent To (clipped to the canvas)
@@ -91,14 +96,14 @@ __device__ __forceinline__ unsigned compose_pixel(const ComposeParams& p, const 
             const int oy = tj * p.stride_y, ly = Y - oy;
             const int rh = oy + To > p.outH ? p.outH - oy : To;
             const long tile = (long)ti * p.ny + tj - p.first_tile;
-            const half4* tp = tiles + tile * steps * (long)To * To;
+            const P* tp = tiles + tile * steps * (long)To * To;
             float v0, v1, v2;
             if (!p.tta) {
-                half4 h = tp[(long)ly * To + lx];
+                const P h = tp[(long)ly * To + lx];
                 v0 = (float)h[0]; v1 = (float)h[1]; v2 = (float)h[2];
             } else {
                 float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-                half4 h;
+                P h;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     int sy, sx;
@@ -128,11 +133,13 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // output bytes leave as three dwords; the per-pixel arithmetic and its order are those of compose_pixel, so the bytes are the
 // same.  Everything else takes the per-pixel path.  (The output is 100 MB of u8 per 4K frame: single-byte stores and 8-byte loads
 // were the kernel's bound; four pixels per thread on the per-pixel path alone lose the loads' coalescing and measured slower.)
+template <typename P>
 __global__ __launch_bounds__(256) void compose_kernel(const ComposeParams p) {
+    constexpr bool kHalf = sizeof(P) == 8;                          // the four-pixel fast path reads fp16 tiles
     const int x1 = p.x1 > 0 ? p.x1 : p.outW, sw = x1 - p.x0;
     const int gw = (sw + 3) >> 2;                                   // pixel groups per row
     const long total = (long)gw * p.outH;
-    const half4* tiles = (const half4*)p.tiles;
+    const P* tiles = (const P*)p.tiles;
     const int To = p.To, n = To - 1;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int Y = (int)(i / gw), X = p.x0 + 4 * (int)(i - (long)Y * gw);
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(256) void compose_kernel(const ComposeParams p) {
         int a0 = X - To + 1; a0 = a0 <= 0 ? 0 : (a0 + p.stride_x - 1) / p.stride_x;
         int b0 = X + 3 - To + 1; b0 = b0 <= 0 ? 0 : (b0 + p.stride_x - 1) / p.stride_x;
         const int a1 = min(p.nx - 1, X / p.stride_x), b1 = min(p.nx - 1, (X + 3) / p.stride_x);
-        const bool fast = np == 4 && !p.tta && a0 == b0 && a1 == b1 && (((size_t)d) & 3) == 0;
+        const bool fast = kHalf && np == 4 && !p.tta && a0 == b0 && a1 == b1 && (((size_t)d) & 3) == 0;
         if (fast) {
             int j0 = Y - To + 1; j0 = j0 <= 0 ? 0 : (j0 + p.stride_y - 1) / p.stride_y;
             const int j1 = min(p.ny - 1, Y / p.stride_y);
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(256) void compose_kernel(const ComposeParams p) {
                     const int oy = tj * p.stride_y, ly = Y - oy;
                     const int rh = oy + To > p.outH ? p.outH - oy : To;
                     const long tile = (long)ti * p.ny + tj - p.first_tile;
-                    const half4* tp = tiles + tile * (long)To * To + (long)ly * To + lx;
+                    const half4* tp = (const half4*)p.tiles + tile * (long)To * To + (long)ly * To + lx;
                     half4 h[4];
                     if ((((size_t)tp) & 15) == 0) { const half8 u0 = *(const half8*)tp, u1 = *(const half8*)(tp + 2);
                         h[0] = (half4){u0[0], u0[1], u0[2], u0[3]}; h[1] = (half4){u0[4], u0[5], u0[6], u0[7]}; h[2] = (half4){u1[0], u1[1], u1[2], u1[3]}; h[3] = (half4){u1[4], u1[5], u1[6], u1[7]}; }
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(256) void compose_kernel(const ComposeParams p) {
             dw[2] = px[2] >> 16 | px[3] << 8;
         } else {
             for (int k = 0; k < np; ++k) {
-                const unsigned v = compose_pixel(p, tiles, X + k, Y);
+                const unsigned v = compose_pixel<P>(p, tiles, X + k, Y);
                 d[3 * k] = (uint8_t)v; d[3 * k + 1] = (uint8_t)(v >> 8); d[3 * k + 2] = (uint8_t)(v >> 16);
             }
         }
@@ -250,24 +257,38 @@ __global__ __launch_bounds__(256) void scale_kernel(_Float16* x, const float* sc
     }
 }
 
-__global__ __launch_bounds__(256) void blob_to_nhwc_kernel(const float* nchw, _Float16* out, int B, int T) {
+__global__ __launch_bounds__(256) void scale32_kernel(float* x, const float* scale, int B, long HW, int Cs) {
+    const int pc = Cs / 4;
+    const long total = (long)B * HW * pc;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cp = (int)(i % pc);
+        const int b = (int)(i / pc / HW);
+        float4v v = *((float4v*)x + i);
+        const float* sc = scale + b * Cs + cp * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= sc[e];
+        *((float4v*)x + i) = v;
+    }
+}
+
+template <typename P>
+__global__ __launch_bounds__(256) void blob_to_nhwc_kernel(const float* nchw, P* out, int B, int T) {
     const long total = (long)B * T * T;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int b = (int)(i / ((long)T * T));
         long rem = i - (long)b * T * T;
         const float* s = nchw + (long)b * 3 * T * T + rem;
-        half4 v;
-        v[0] = (_Float16)s[0]; v[1] = (_Float16)s[(long)T * T]; v[2] = (_Float16)s[2L * T * T]; v[3] = (_Float16)0.f;
-        *((half4*)out + i) = v;
+        out[i] = make_px<P>(s[0], s[(long)T * T], s[2L * T * T]);
     }
 }
 
-__global__ __launch_bounds__(256) void nhwc_to_blob_kernel(const _Float16* in, float* nchw, int B, int T) {
+template <typename P>
+__global__ __launch_bounds__(256) void nhwc_to_blob_kernel(const P* in, float* nchw, int B, int T) {
     const long total = (long)B * T * T;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int b = (int)(i / ((long)T * T));
         long rem = i - (long)b * T * T;
-        half4 v = *((const half4*)in + i);
+        const P v = in[i];
         float* d = nchw + (long)b * 3 * T * T + rem;
         d[0] = (float)v[0]; d[(long)T * T] = (float)v[1]; d[2L * T * T] = (float)v[2];
     }
@@ -278,11 +299,15 @@ inline unsigned grid_for(long total) { long g = (total + 255) / 256; return (uns
 }  // namespace
 
 hipError_t launch_gather(const GatherParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(gather_kernel, dim3(grid_for((long)p.B * p.T * p.T)), dim3(256), 0, s, p);
+    const dim3 grid(grid_for((long)p.B * p.T * p.T));
+    if (p.fp32) hipLaunchKernelGGL(gather_kernel<float4v>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(gather_kernel<half4>, grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 hipError_t launch_compose(const ComposeParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(compose_kernel, dim3(grid_for((long)((((p.x1 > 0 ? p.x1 : p.outW) - p.x0) + 3) / 4) * p.outH)), dim3(256), 0, s, p);
+    const dim3 grid(grid_for((long)((((p.x1 > 0 ? p.x1 : p.outW) - p.x0) + 3) / 4) * p.outH));
+    if (p.fp32) hipLaunchKernelGGL(compose_kernel<float4v>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(compose_kernel<half4>, grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 hipError_t launch_se(const SeParams& p, hipStream_t s) {
@@ -290,16 +315,21 @@ hipError_t launch_se(const SeParams& p, hipStream_t s) {
     hipLaunchKernelGGL(se_kernel, dim3(p.B), dim3(threads), (p.C + p.Cmid + slices * p.C) * sizeof(float), s, p);
     return hipGetLastError();
 }
-hipError_t launch_scale(void* x, const float* scale, int B, int HW, int Cs, hipStream_t s) {
-    hipLaunchKernelGGL(scale_kernel, dim3(grid_for((long)B * HW * (Cs / 8))), dim3(256), 0, s, (_Float16*)x, scale, B, (long)HW, Cs);
+hipError_t launch_scale(void* x, const float* scale, int B, int HW, int Cs, bool fp32, hipStream_t s) {
+    if (fp32) hipLaunchKernelGGL(scale32_kernel, dim3(grid_for((long)B * HW * (Cs / 4))), dim3(256), 0, s, (float*)x, scale, B, (long)HW, Cs);
+    else hipLaunchKernelGGL(scale_kernel, dim3(grid_for((long)B * HW * (Cs / 8))), dim3(256), 0, s, (_Float16*)x, scale, B, (long)HW, Cs);
     return hipGetLastError();
 }
-hipError_t launch_blob_to_nhwc(const float* nchw, void* out, int B, int T, hipStream_t s) {
-    hipLaunchKernelGGL(blob_to_nhwc_kernel, dim3(grid_for((long)B * T * T)), dim3(256), 0, s, nchw, (_Float16*)out, B, T);
+hipError_t launch_blob_to_nhwc(const float* nchw, void* out, int B, int T, bool fp32, hipStream_t s) {
+    const dim3 grid(grid_for((long)B * T * T));
+    if (fp32) hipLaunchKernelGGL(blob_to_nhwc_kernel<float4v>, grid, dim3(256), 0, s, nchw, (float4v*)out, B, T);
+    else hipLaunchKernelGGL(blob_to_nhwc_kernel<half4>, grid, dim3(256), 0, s, nchw, (half4*)out, B, T);
     return hipGetLastError();
 }
-hipError_t launch_nhwc_to_blob(const void* in, float* nchw, int B, int T, hipStream_t s) {
-    hipLaunchKernelGGL(nhwc_to_blob_kernel, dim3(grid_for((long)B * T * T)), dim3(256), 0, s, (const _Float16*)in, nchw, B, T);
+hipError_t launch_nhwc_to_blob(const void* in, float* nchw, int B, int T, bool fp32, hipStream_t s) {
+    const dim3 grid(grid_for((long)B * T * T));
+    if (fp32) hipLaunchKernelGGL(nhwc_to_blob_kernel<float4v>, grid, dim3(256), 0, s, (const float4v*)in, nchw, B, T);
+    else hipLaunchKernelGGL(nhwc_to_blob_kernel<half4>, grid, dim3(256), 0, s, (const half4*)in, nchw, B, T);
     return hipGetLastError();
 }
 

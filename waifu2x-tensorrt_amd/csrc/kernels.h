@@ -100,13 +100,15 @@ struct TileSlot { int x, y, aug, valid; };   // input rect origin (may be negati
 
 struct GatherParams {
     const uint8_t* frame = nullptr; int rows = 0, cols = 0; size_t step = 0;  // u8 BGR interleaved
-    void* out = nullptr;            // fp16 [B][T][T][4]
+    void* out = nullptr;            // fp16 (fp32 engines: fp32) [B][T][T][4]
+    int fp32 = 0;
     const TileSlot* slots = nullptr;
     int B = 0, T = 0;
 };
 
 struct ComposeParams {
-    const void* tiles = nullptr;    // fp16 [slots][To][To][4], slot = tile*steps + aug
+    const void* tiles = nullptr;    // fp16 (fp32 engines: fp32) [slots][To][To][4], slot = tile*steps + aug
+    int fp32 = 0;
     uint8_t* dst = nullptr; size_t dst_step = 0;    // u8 BGR
     int outW = 0, outH = 0;
     int To = 0;
@@ -136,16 +138,19 @@ bool conv48_supported(const GemmParams& p);                     // k_conv48.hip:
 hipError_t launch_conv48(const GemmParams& p, hipStream_t s);
 int conv3_tiles(const GemmParams& p);                           // workgroups (= pooling partials) per image of launch_conv3
 hipError_t launch_attn(const AttnParams& p, hipStream_t s);
+// k_f32.hip: the fp32 engine's kernels (Plan::elt == 4): general GEMM / convolution and the window attention core on fp32 rows
+hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s);
+hipError_t launch_attn_f32(const AttnParams& p, hipStream_t s);
 hipError_t launch_mlp(const MlpParams& p, hipStream_t s);
 hipError_t launch_swin_attn(const SwinAttnParams& p, hipStream_t s);
 bool swin_attn_supported(int C, int heads, int hd, int ws);
 bool mlp_supported(int C);
 hipError_t launch_se(const SeParams& p, hipStream_t s);
-hipError_t launch_scale(void* x, const float* scale, int B, int HW, int Cs, hipStream_t s);
+hipError_t launch_scale(void* x, const float* scale, int B, int HW, int Cs, bool fp32, hipStream_t s);
 hipError_t launch_gather(const GatherParams& p, hipStream_t s);
 hipError_t launch_compose(const ComposeParams& p, hipStream_t s);
 // debug/test helpers used by w2x_infer (mirrors blobFromImages / imagesFromBlob, img2img_infer.cpp:5-39)
-hipError_t launch_blob_to_nhwc(const float* nchw, void* out_nhwc4, int B, int T, hipStream_t s);
-hipError_t launch_nhwc_to_blob(const void* in_nhwc4, float* nchw, int B, int T, hipStream_t s);
+hipError_t launch_blob_to_nhwc(const float* nchw, void* out_nhwc4, int B, int T, bool fp32, hipStream_t s);
+hipError_t launch_nhwc_to_blob(const void* in_nhwc4, float* nchw, int B, int T, bool fp32, hipStream_t s);
 
 }  // namespace w2x

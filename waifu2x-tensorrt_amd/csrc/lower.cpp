@@ -77,8 +77,8 @@ struct Lowerer {
     static std::vector<int64_t> perm_of(const Node* n) { return n->aints("perm"); }
 
     // ---- plan helpers
-    int new_tensor(int B, int H, int W, int C, int elt = 2) {
-        TensorDesc t; t.B = B; t.H = H; t.W = W; t.C = C; t.elt = elt;
+    int new_tensor(int B, int H, int W, int C, int elt = 0) {   // elt 0: an activation map in the plan's precision
+        TensorDesc t; t.B = B; t.H = H; t.W = W; t.C = C; t.elt = elt ? elt : plan.elt;
         plan.tensors.push_back(t);
         return (int)plan.tensors.size() - 1;
     }
@@ -96,6 +96,7 @@ struct Lowerer {
     }
     int blob_f32(const std::vector<float>& v) { std::vector<uint8_t> b(v.size() * 4); memcpy(b.data(), v.data(), b.size()); return add_blob(std::move(b)); }
     int blob_i32(const std::vector<int32_t>& v) { std::vector<uint8_t> b(v.size() * 4); memcpy(b.data(), v.data(), b.size()); return add_blob(std::move(b)); }
+    int blob_w(const std::vector<float>& v) { return plan.elt == 4 ? blob_f32(v) : blob_f16(v); }   // weights / bias tables in the plan's precision
     int blob_f16(const std::vector<float>& v) {
         std::vector<uint8_t> b(v.size() * 2);
         for (size_t k = 0; k < v.size(); ++k) { uint16_t h = f32_to_f16(v[k]); memcpy(&b[2 * k], &h, 2); }
@@ -353,11 +354,11 @@ struct Lowerer {
         }
         if (o.ln) {
             // csum over the fp16-rounded weights so that mean*csum cancels exactly what the MFMA accumulates
-            for (int n = 0; n < Np; ++n) { double s = 0; for (int k = 0; k < K; ++k) s += f16_to_f32(f32_to_f16(wt[(size_t)n * Kw + k])); cs[n] = (float)s; }
+            for (int n = 0; n < Np; ++n) { double s = 0; for (int k = 0; k < K; ++k) s += plan.elt == 4 ? wt[(size_t)n * Kw + k] : f16_to_f32(f32_to_f16(wt[(size_t)n * Kw + k])); cs[n] = (float)s; }
             o.csum = blob_f32(cs);
         }
         o.N = Np;
-        o.w = blob_f16(wt);
+        o.w = blob_w(wt);
         o.bias = blob_f32(bs);
         Op op; op.kind = OP_GEMM; op.g = o; op.flops = p.flops; op.name = p.name;
         plan.ops.push_back(op);
@@ -576,7 +577,7 @@ struct Lowerer {
         std::vector<float> bm((size_t)a.nmask * heads * Ntok * Ntok);
         for (int m = 0; m < a.nmask; ++m) for (int h = 0; h < heads; ++h) for (int e = 0; e < Ntok * Ntok; ++e)
             bm[((size_t)m * heads + h) * Ntok * Ntok + e] = bias[(size_t)h * Ntok * Ntok + e] + masks[m][e];
-        a.bias = blob_f16(bm);
+        a.bias = blob_w(bm);
         a.maskid = blob_i32(maskid);
         op.flops = 2.0 * 2.0 * (double)plan.B * nwin * heads * Ntok * Ntok * hd;
         plan.ops.push_back(op);
@@ -894,7 +895,7 @@ struct Lowerer {
         const TensorDesc& td = plan.tensors[y.v.t];
         if (y.v.y0 || y.v.x0 || y.v.H != td.H || y.v.W != td.W) throw std::runtime_error("graph output is a cropped view");
         plan.out_tensor = y.v.t; plan.Tout = (int)os[2]; plan.Cout = 3;
-        if (!getenv("W2X_NO_FUSE")) { if (!getenv("W2X_NO_FUSE_ATTN")) fuse_attn(); fuse_mlp(); }
+        if (!getenv("W2X_NO_FUSE") && plan.elt == 2) { if (!getenv("W2X_NO_FUSE_ATTN")) fuse_attn(); fuse_mlp(); }   // the fused kernels are fp16 kernels
         for (auto& op : plan.ops) plan.flops += op.flops;
         bool has_attn = false; for (auto& op : plan.ops) has_attn |= op.kind == OP_ATTN;
         plan.model_kind = has_attn ? "swin_unet" : "cunet";
@@ -904,15 +905,16 @@ struct Lowerer {
 
 }  // namespace
 
-Plan lower_graph(const FoldedGraph& g) {
+Plan lower_graph(const FoldedGraph& g, bool fp32) {
     Lowerer l(g);
+    l.plan.elt = fp32 ? 4 : 2;
     return l.run();
 }
 
-Plan build_plan(const std::string& onnx_path, int batch, int channels, int height, int width) {
+Plan build_plan(const std::string& onnx_path, int batch, int channels, int height, int width, bool fp32) {
     Model m = load_onnx(onnx_path);
     FoldedGraph g = fold_graph(m, {batch, channels, height, width});
-    return lower_graph(g);
+    return lower_graph(g, fp32);
 }
 
 }  // namespace w2x

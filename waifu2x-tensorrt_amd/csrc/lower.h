@@ -7,9 +7,10 @@
 
 namespace w2x {
 
-Plan lower_graph(const FoldedGraph& g);
+// fp32: activations, weights and bias tables in fp32 and none of the fused (fp16) transformer kernels - the engine's second precision
+Plan lower_graph(const FoldedGraph& g, bool fp32 = false);
 
 // Convenience: load + fold + lower.  input is [B,3,T,T].
-Plan build_plan(const std::string& onnx_path, int batch, int channels, int height, int width);
+Plan build_plan(const std::string& onnx_path, int batch, int channels, int height, int width, bool fp32 = false);
 
 }  // namespace w2x

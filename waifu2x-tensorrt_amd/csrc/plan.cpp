@@ -15,7 +15,7 @@ static_assert(std::is_trivially_copyable<SeOp>::value, "SeOp must be POD for ser
 std::string Plan::describe() const {
     std::ostringstream o;
     o << "plan " << model_kind << " in=[" << B << "," << Cin << "," << T << "," << T << "] out=[" << B << "," << Cout << "," << Tout << "," << Tout
-      << "] ops=" << ops.size() << " tensors=" << tensors.size() << " blobs=" << blobs.size() << " flops=" << (long long)flops << "\n";
+      << "] ops=" << ops.size() << " tensors=" << tensors.size() << " blobs=" << blobs.size() << " flops=" << (long long)flops << " precision=" << (elt == 4 ? "fp32" : "fp16") << "\n";
     int64_t act = 0; for (auto& t : tensors) act += t.bytes();
     int64_t wb = 0; for (auto& b : blobs) wb += (int64_t)b.data.size();
     o << "activation_bytes=" << act << " constant_bytes=" << wb << "\n";
@@ -63,14 +63,14 @@ struct Reader {
     std::vector<uint8_t> bytes() { uint64_t n = pod<uint64_t>(); if ((uint64_t)(e - p) < n) throw std::runtime_error("engine file truncated"); std::vector<uint8_t> v(p, p + n); p += n; return v; }
 };
 constexpr uint64_t kMagic = 0x3158325755464957ull;  // "WIFUW2X1"
-constexpr uint32_t kVersion = 8;
+constexpr uint32_t kVersion = 9;
 }  // namespace
 
 std::vector<uint8_t> Plan::serialize() const {
     Writer w;
     w.pod(kMagic); w.pod(kVersion);
     w.pod<uint32_t>(sizeof(GemmOp)); w.pod<uint32_t>(sizeof(AttnOp)); w.pod<uint32_t>(sizeof(SeOp) + sizeof(MlpOp) + sizeof(SwinAttnOp));
-    w.pod(B); w.pod(userB); w.pod(Cin); w.pod(T); w.pod(Tout); w.pod(Cout); w.pod(in_tensor); w.pod(out_tensor); w.pod(flops);
+    w.pod(B); w.pod(userB); w.pod(Cin); w.pod(T); w.pod(Tout); w.pod(Cout); w.pod(elt); w.pod(in_tensor); w.pod(out_tensor); w.pod(flops);
     w.str(model_kind);
     w.pod<uint64_t>(tensors.size()); for (auto& t : tensors) w.pod(t);
     w.pod<uint64_t>(blobs.size()); for (auto& b : blobs) w.bytes(b.data);
@@ -85,7 +85,7 @@ Plan Plan::deserialize(const uint8_t* p, size_t n) {
     if (r.pod<uint32_t>() != kVersion) throw std::runtime_error("engine file version mismatch");
     if (r.pod<uint32_t>() != sizeof(GemmOp) || r.pod<uint32_t>() != sizeof(AttnOp) || r.pod<uint32_t>() != sizeof(SeOp) + sizeof(MlpOp) + sizeof(SwinAttnOp)) throw std::runtime_error("engine file layout mismatch");
     Plan pl;
-    pl.B = r.pod<int>(); pl.userB = r.pod<int>(); pl.Cin = r.pod<int>(); pl.T = r.pod<int>(); pl.Tout = r.pod<int>(); pl.Cout = r.pod<int>();
+    pl.B = r.pod<int>(); pl.userB = r.pod<int>(); pl.Cin = r.pod<int>(); pl.T = r.pod<int>(); pl.Tout = r.pod<int>(); pl.Cout = r.pod<int>(); pl.elt = r.pod<int>();
     pl.in_tensor = r.pod<int>(); pl.out_tensor = r.pod<int>(); pl.flops = r.pod<double>();
     pl.model_kind = r.str();
     uint64_t nt = r.pod<uint64_t>(); pl.tensors.resize(nt); for (auto& t : pl.tensors) t = r.pod<TensorDesc>();
@@ -103,10 +103,12 @@ void Plan::validate() const {
     auto fail = [](const std::string& what) { throw std::runtime_error("engine file inconsistent: " + what); };
     const int nt = (int)tensors.size(), nb = (int)blobs.size();
     if (B <= 0 || userB <= 0 || B % userB || T <= 0 || Tout <= 0 || Cin != 3 || Cout != 3) fail("header");
+    if (elt != 2 && elt != 4) fail("precision");
     if (in_tensor < 0 || in_tensor >= nt || out_tensor < 0 || out_tensor >= nt) fail("input / output tensor id");
     for (const TensorDesc& t : tensors) if (t.B <= 0 || t.H <= 0 || t.W <= 0 || t.C <= 0 || (t.elt != 2 && t.elt != 4) || t.bytes() > ((int64_t)1 << 40)) fail("tensor shape");
     if (tensors[in_tensor].H != T || tensors[in_tensor].W != T || tensors[in_tensor].C != 4 || tensors[in_tensor].B != B) fail("input tensor shape");
     if (tensors[out_tensor].H != Tout || tensors[out_tensor].W != Tout || tensors[out_tensor].C != 4) fail("output tensor shape");
+    if (tensors[in_tensor].elt != elt || tensors[out_tensor].elt != elt) fail("input / output tensor precision");
     auto ten = [&](int id, bool optional) { if (id < (optional ? -1 : 0) || id >= nt) fail("tensor id"); };
     auto blob = [&](int id, bool optional, size_t bytes) {
         if (id < (optional ? -1 : 0) || id >= nb) fail("blob id");
@@ -135,7 +137,8 @@ void Plan::validate() const {
                     if (g.a.y0 < 0 || g.a.x0 < 0 || (int64_t)g.a.y0 + (int64_t)(oH - 1) * g.stride + g.kh > d.H || (int64_t)g.a.x0 + (int64_t)(g.aW - 1) * g.stride + g.kw > d.W) fail("gemm input window outside its tensor");
                     if (g.amode == A_WIN && g.Mrows != d.H * d.W) fail("window gather geometry");
                 }
-                blob(g.w, false, (size_t)g.N * ((g.K + 7) / 8 * 8) * 2);
+                blob(g.w, false, (size_t)g.N * ((g.K + 7) / 8 * 8) * elt);
+                if (tensors[g.a.t].elt != elt || tensors[g.out.t].elt != elt || (g.res.t >= 0 && tensors[g.res.t].elt != elt) || (g.res2.t >= 0 && tensors[g.res2.t].elt != elt)) fail("gemm operand precision");
                 blob(g.bias, false, (size_t)g.N * 4);
                 blob(g.csum, !g.ln, (size_t)g.N * 4);
                 if (g.amode == A_WIN || g.omode == O_WIN) blob(g.win_table, false, (size_t)g.Mrows * 4); else blob(g.win_table, true, 0);
@@ -147,7 +150,8 @@ void Plan::validate() const {
                 ten(a.qkv, false); ten(a.out, false);
                 if (a.heads <= 0 || a.hd <= 0 || a.ws <= 0 || a.nwin <= 0 || a.nmask <= 0) fail("attention shape");
                 const size_t n = (size_t)a.ws * a.ws;
-                blob(a.bias, false, (size_t)a.nmask * a.heads * n * n * 2);
+                blob(a.bias, false, (size_t)a.nmask * a.heads * n * n * elt);
+                if (tensors[a.qkv].elt != elt || tensors[a.out].elt != elt) fail("attention operand precision");
                 blob(a.maskid, false, (size_t)a.nwin * 4);
                 for (int i = 0; i < a.nwin; ++i) { int m; memcpy(&m, blobs[a.maskid].data.data() + 4 * (size_t)i, 4); if (m < 0 || m >= a.nmask) fail("attention mask id"); }
                 break;
@@ -165,6 +169,7 @@ void Plan::validate() const {
                 const MlpOp& m = op.m;
                 ten(m.x, false); ten(m.y, false); ten(m.stats_out, true);
                 if (m.C <= 0 || tensors[m.x].C != m.C || tensors[m.y].C != m.C) fail("MLP width");
+                if (elt != 2) fail("fused MLP in an fp32 plan");
                 blob(m.w1, false, (size_t)2 * m.C * m.C * 2); blob(m.b1, false, (size_t)2 * m.C * 4);
                 blob(m.w2, false, (size_t)2 * m.C * m.C * 2); blob(m.b2, false, (size_t)m.C * 4);
                 break;
@@ -175,6 +180,7 @@ void Plan::validate() const {
                 if (a.C <= 0 || a.heads <= 0 || a.hd <= 0 || a.heads * a.hd != a.C || a.ws <= 0 || a.nwin <= 0 || a.H <= 0 || a.W <= 0) fail("window attention shape");
                 if (tensors[a.x].C != a.C || tensors[a.y].C != a.C || a.H * a.W != a.nwin * a.ws * a.ws || tensors[a.x].H * tensors[a.x].W != a.H * a.W) fail("window attention geometry");
                 if (a.ry >= a.H || a.rx >= a.W) fail("window attention shift");
+                if (elt != 2) fail("fused window attention in an fp32 plan");
                 blob(a.table, false, (size_t)a.H * a.W * 4);
                 blob(a.wqkv, false, (size_t)3 * a.C * a.C * 2); blob(a.bqkv, false, (size_t)3 * a.C * 4);
                 blob(a.wproj, false, (size_t)a.C * a.C * 2); blob(a.bproj, false, (size_t)a.C * 4);

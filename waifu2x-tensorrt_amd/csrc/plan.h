@@ -120,6 +120,7 @@ struct Plan {
     int B = 0, Cin = 3, T = 0;     // network input [B,3,T,T]; B = tiles per network pass (userB x super-batch factor)
     int userB = 0;                 // RenderConfig::batchSize the plan was built for (B is a multiple of it)
     int Tout = 0, Cout = 3;        // network output [B,3,Tout,Tout]
+    int elt = 2;                   // bytes per activation / weight element: 2 = fp16 (Precision::FP16), 4 = fp32 (Precision::TF32 requests)
     int in_tensor = -1, out_tensor = -1;
     std::vector<TensorDesc> tensors;
     std::vector<Blob> blobs;

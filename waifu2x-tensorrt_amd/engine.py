@@ -121,6 +121,7 @@ def lib():
     L.w2x_calculate_tiles.argtypes = [C.c_int] * 7 + [C.c_double, C.c_double, vp, vp, C.c_int]; L.w2x_calculate_tiles.restype = C.c_int
     L.w2x_tile_weights.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp]; L.w2x_tile_weights.restype = C.c_int
     L.w2x_describe_plan.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]; L.w2x_describe_plan.restype = C.c_int
+    L.w2x_describe_plan_precision.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]; L.w2x_describe_plan_precision.restype = C.c_int
     L.w2x_write_engine_file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p]; L.w2x_write_engine_file.restype = C.c_int
     L.w2x_validate_engine_file.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]; L.w2x_validate_engine_file.restype = C.c_int
     L.w2x_sha256_hex.argtypes = [vp, C.c_size_t, C.c_char_p]
@@ -132,7 +133,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "w2x_create", "w2x_destroy", "w2x_set_message_callback", "w2x_set_progress_callback", "w2x_build", "w2x_load",
     "w2x_render", "w2x_infer", "w2x_output_tile_size", "w2x_plan_flops", "w2x_pass_tiles", "w2x_last_render_ms", "w2x_bench_resident", "w2x_profile_frame", "w2x_op_times",
-    "w2x_render_strip", "w2x_strip_plan", "w2x_render_sequence", "w2x_alloc_host", "w2x_free_host", "w2x_pin_host", "w2x_unpin_host", "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_write_engine_file", "w2x_validate_engine_file", "w2x_sha256_hex", "w2x_version"]
+    "w2x_render_strip", "w2x_strip_plan", "w2x_render_sequence", "w2x_alloc_host", "w2x_free_host", "w2x_pin_host", "w2x_unpin_host", "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_describe_plan_precision", "w2x_write_engine_file", "w2x_validate_engine_file", "w2x_sha256_hex", "w2x_version"]
 
 
 class Img2Img:
@@ -362,10 +363,10 @@ def tile_weights(which, ovx, ovy, size):
     return out
 
 
-def describe_plan(onnx_path, batch, tile) -> str:
+def describe_plan(onnx_path, batch, tile, precision=None) -> str:
     L = lib()
     buf = C.create_string_buffer(1 << 20)
-    ok = L.w2x_describe_plan(os.fsencode(onnx_path), batch, tile, buf, len(buf))
+    ok = L.w2x_describe_plan_precision(os.fsencode(onnx_path), batch, tile, int(Precision.FP16 if precision is None else precision), buf, len(buf))
     s = buf.value.decode(errors="replace")
     if not ok:
         raise W2xError(s)
