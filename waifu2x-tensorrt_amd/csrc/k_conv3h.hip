@@ -3,14 +3,17 @@
 //   * unet1 conv_bottom: the 4x4 stride-2 ConvTranspose 64 -> 3, lowered to a 3x3 convolution onto 4 sub-pixels x 4 stored channels
 //     with a 2x pixel shuffle.
 // gemm_kernel (k_gemm.hip) runs these as an implicit GEMM that fetches every input pixel nine times and pads N to a 64-row tile:
-// 1.30 + 0.39 ms of config 2's 11.5 ms at 0.9 / 1.1 TB/s.  The launches are pure input streams (1.19 GB + 0.35 GB read, 16 MFMA per
+// 1.30 + 0.39 ms of config 2's 11.5 ms at 0.9 / 1.1 TB/s (now 0.57 + 0.22).  The launches are pure input streams (1.19 GB + 0.35 GB read, 16 MFMA per
 // 16 pixels), so the kernel is k_conv3.hip's halo tile with everything else removed:
-//   * a workgroup owns 4 output rows x 64 columns; its 6 x 66 pixel halo tile with ALL input channels goes to LDS in one batch of
-//     16-byte loads per thread (pixel stride CIN + 8 halves: the 16 pixels of a fragment fall on different banks), one barrier;
-//   * the product is transposed (out^T = W X^T): the weights are the A operand - 9 taps x CIN/32 fragments, loaded once per wave
-//     straight from the [N][K] matrix (rows >= N read as zero) and held in registers for the whole tile - the pixels the B operand,
-//     so a lane ends up with 4 consecutive stored channels of ONE pixel: channels 4g .. 4g+3 of pixel fr.  Rows output: lanes g = 0
-//     hold the pixel (8-byte store); pixel-shuffle output: g is the sub-pixel (dy, dx) = (g >> 1, g & 1), every lane stores 8 bytes;
+//   * a workgroup owns 4 output rows x 64 columns; per 32-channel chunk its 6 x 66 pixel halo tile goes to LDS in one batch of
+//     16-byte loads per thread (25 KB, unpadded, pieces rotated so that fragment reads and the stores are free of bank conflicts:
+//     halo_slot), four workgroups per CU - the launch is fetch -> products -> store in every workgroup, so it lives off workgroups
+//     that are out of phase (a single 57 KB tile with all 64 channels at two workgroups per CU ran the 9.3 M-pixel head in 0.69 ms,
+//     this runs it in 0.57: 2.1 TB/s of input, 3.2 TB/s into the CUs with the 1.55x halo overlap of 4-row tiles);
+//   * the product is transposed (out^T = W X^T): the weights are the A operand - 9 taps per chunk, loaded per wave straight from
+//     the [N][K] matrix (rows >= N read as zero) into registers - the pixels the B operand, so a lane ends up with 4 consecutive
+//     stored channels of ONE pixel: channels 4g .. 4g+3 of pixel fr.  Rows output: lanes g = 0 hold the pixel (8-byte store);
+//     pixel-shuffle output: g is the sub-pixel (dy, dx) = (g >> 1, g & 1), every lane stores 8 bytes;
 //   * epilogue in registers: bias (initial accumulator), LeakyReLU / none, skip add, clip, ONE rounding to fp16 (gemm_kernel rounds
 //     before and after the skip add).
 #include "kernels.h"
@@ -23,20 +26,22 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
-template <int CIN>
 struct Conv3hCfg {
     static constexpr int TH = 4, TW = 64, HR = TH + 2, HC = TW + 2;
-    static constexpr int LDP = CIN + 8, KS = CIN / 32, PPP = CIN / 8;
-    static constexpr int NP = HR * HC * PPP, NI = (NP + 255) / 256;    // 16-byte pieces of the halo tile, per thread
-    static constexpr int SMEM = HR * HC * LDP * 2;
+    static constexpr int ROWB = HC * 64;                               // bytes per halo row (one chunk of 32 channels)
+    static constexpr int NP = HR * HC * 4, NI = (NP + 255) / 256;      // 16-byte pieces of a chunk's halo tile, per thread
+    static constexpr int SMEM = HR * ROWB;
 };
+// byte offset of piece pc (8 channels) of halo pixel x inside its row: 64 bytes per pixel, the pieces rotated by 2 * ((x >> 2) & 3)
+// slots - ds_read_b128 serves 16-lane groups that pair k-groups over complementary row sets, the rotation keeps them conflict-free
+// (k_conv3.hip has the derivation)
+__device__ __forceinline__ int halo_slot(int x, int pc) { return x * 64 + ((pc + 2 * ((x >> 2) & 3)) & 3) * 16; }
 
-template <int CIN, int PIX>
-__global__ __launch_bounds__(256, 2) void conv3h_kernel(const GemmParams p, int Ho, int Wo, int tiles_x, int tiles_y) {
-    using C = Conv3hCfg<CIN>;
-    constexpr int HR = C::HR, HC = C::HC, LDP = C::LDP, KS = C::KS, PPP = C::PPP;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    _Float16* Hl = (_Float16*)smem;                                   // [HR][HC][LDP]
+template <int PIX>
+__global__ __launch_bounds__(256, 4) void conv3h_kernel(const GemmParams p, int Ho, int Wo, int tiles_x, int tiles_y) {
+    using C = Conv3hCfg;
+    constexpr int HR = C::HR, HC = C::HC;
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, g = lane >> 4;
@@ -45,47 +50,48 @@ __global__ __launch_bounds__(256, 2) void conv3h_kernel(const GemmParams p, int 
     const int b = blockIdx.x / tpi, trem = blockIdx.x - b * tpi;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
     const int oy0 = ty * C::TH, ox0 = tx * C::TW;
-    const _Float16* __restrict__ Ag = (const _Float16*)p.a.p + ((size_t)(b * p.a.Hs + p.a.y0 + oy0) * p.a.Ws + p.a.x0 + ox0) * CIN;
+    const int Cin = p.a.Cs, nchunk = Cin / 32;
+    const _Float16* __restrict__ Ag = (const _Float16*)p.a.p + ((size_t)(b * p.a.Hs + p.a.y0 + oy0) * p.a.Ws + p.a.x0 + ox0) * Cin;
 
-    // halo tile: pixels past the input extent of a ragged tile (input extent = output extent + 2) are zeros
+    // halo tile of a 32-channel chunk: pixels past the input extent of a ragged tile (input extent = output extent + 2) are zeros
     const int hrows = min(HR, Ho + 2 - oy0), hcols = min(HC, Wo + 2 - ox0);
-    half8 h[C::NI];
-#pragma unroll
-    for (int i = 0; i < C::NI; ++i) {
-        const int idx = tid + i * 256, pix = idx / PPP, c8 = idx - pix * PPP, hr = pix / HC, hc = pix - hr * HC;
-        h[i] = (half8){};
-        if (idx < C::NP && hr < hrows && hc < hcols) h[i] = *(const half8*)(Ag + ((size_t)hr * p.a.Ws + hc) * CIN + c8 * 8);
-    }
-    // weights [N][Kw], k = tap * CIN + channel: fragment (tap, ks) of lane (fr, g) = W[fr][tap][32 ks + 8g .. + 7]
-    const _Float16* __restrict__ Wt = (const _Float16*)p.wt + (size_t)fr * p.Kw + g * 8;
-    half8 wf[9][KS];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) wf[t][ks] = fr < p.N ? *(const half8*)(Wt + t * CIN + ks * 32) : (half8){};
+    const _Float16* __restrict__ Wt = (const _Float16*)p.wt + (size_t)fr * p.Kw + g * 8;   // [N][Kw], k = tap * Cin + channel
     float4v bv;
 #pragma unroll
     for (int j = 0; j < 4; ++j) bv[j] = 4 * g + j < p.N ? p.bias[4 * g + j] : 0.f;
+    float4v acc[4] = {bv, bv, bv, bv};                                 // wave wv: output row oy0 + wv, four groups of 16 pixels
+    int xoff[3];
 #pragma unroll
-    for (int i = 0; i < C::NI; ++i) {
-        const int idx = tid + i * 256, pix = idx / PPP, c8 = idx - pix * PPP;
-        if (idx < C::NP) *(half8*)(Hl + pix * LDP + c8 * 8) = h[i];
-    }
-    __syncthreads();
-
-    // wave wv: output row oy0 + wv, four groups of 16 pixels
-    float4v acc[4] = {bv, bv, bv, bv};
+    for (int kx = 0; kx < 3; ++kx) xoff[kx] = halo_slot(kx + fr, g);
+    const unsigned char* xrow = smem + wv * C::ROWB;
+#pragma unroll 1
+    for (int kc = 0; kc < nchunk; ++kc) {
+        half8 h[C::NI];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int ky = t / 3, kx = t - ky * 3;
-        const _Float16* arow = Hl + ((wv + ky) * HC + kx + fr) * LDP + g * 8;
+        for (int i = 0; i < C::NI; ++i) {
+            const int idx = tid + i * 256, pix = idx >> 2, c8 = idx & 3, hr = pix / HC, hc = pix - hr * HC;
+            h[i] = (half8){};
+            if (idx < C::NP && hr < hrows && hc < hcols) h[i] = *(const half8*)(Ag + ((size_t)hr * p.a.Ws + hc) * Cin + kc * 32 + c8 * 8);
+        }
+        // weights of this chunk: fragment (tap) of lane (fr, g) = W[fr][tap][32 kc + 8g .. + 7], rows >= N read as zero
+        half8 wf[9];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        for (int t = 0; t < 9; ++t) wf[t] = fr < p.N ? *(const half8*)(Wt + t * Cin + kc * 32) : (half8){};
+        __syncthreads();                                   // the previous chunk's products are done with the halo tile
+#pragma unroll
+        for (int i = 0; i < C::NI; ++i) {
+            const int idx = tid + i * 256, pix = idx >> 2, c8 = idx & 3, hr = pix / HC, hc = pix - hr * HC;
+            if (idx < C::NP) *(half8*)(smem + hr * C::ROWB + halo_slot(hc, c8)) = h[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t - ky * 3;
             half8 xa[4];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) xa[mt] = *(const half8*)(arow + mt * 16 * LDP + ks * 32);
+            for (int mt = 0; mt < 4; ++mt) xa[mt] = *(const half8*)(xrow + ky * C::ROWB + xoff[kx] + mt * 1024);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t][ks], xa[mt], acc[mt], 0, 0, 0);
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t], xa[mt], acc[mt], 0, 0, 0);
         }
     }
 
@@ -112,13 +118,13 @@ __global__ __launch_bounds__(256, 2) void conv3h_kernel(const GemmParams p, int 
     }
 }
 
-template <int CIN, int PIX>
+template <int PIX>
 hipError_t launch_c3h(const GemmParams& p, int Ho, int Wo, hipStream_t s) {
-    using C = Conv3hCfg<CIN>;
+    using C = Conv3hCfg;
     static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
-    if (hipError_t e = ensure_dynamic_lds((const void*)conv3h_kernel<CIN, PIX>, C::SMEM, lds_ok); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)conv3h_kernel<PIX>, C::SMEM, lds_ok); e != hipSuccess) return e;
     const int tiles_x = (Wo + C::TW - 1) / C::TW, tiles_y = (Ho + C::TH - 1) / C::TH;
-    hipLaunchKernelGGL((conv3h_kernel<CIN, PIX>), dim3((unsigned)(p.B * tiles_x * tiles_y)), dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y);
+    hipLaunchKernelGGL((conv3h_kernel<PIX>), dim3((unsigned)(p.B * tiles_x * tiles_y)), dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y);
     return hipGetLastError();
 }
 
@@ -128,7 +134,7 @@ bool conv3h_supported(const GemmParams& p) {
     static const bool off = getenv("W2X_NO_CONV3H") != nullptr;   // A/B switch
     if (off || p.amode != 2 || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.ln || (p.act != 0 && p.act != 1) || p.stats_out || p.pool_out || p.res2.p) return false;
     const int Cin = p.a.Cs;
-    if ((Cin != 64 && Cin != 32) || p.K != 9 * Cin || p.Kw != p.K || p.out.Cs != 4 || p.aW <= 0 || p.Mrows % p.aW || p.B <= 0) return false;
+    if (Cin % 32 || Cin > 256 || p.K != 9 * Cin || p.Kw != p.K || p.out.Cs != 4 || p.aW <= 0 || p.Mrows % p.aW || p.B <= 0) return false;
     const int Ho = p.Mrows / p.aW, Wo = p.aW;
     if (p.a.y0 < 0 || p.a.x0 < 0 || p.a.y0 + Ho + 2 > p.a.Hs || p.a.x0 + Wo + 2 > p.a.Ws) return false;
     if (p.omode == 0) {   // rows: (b, m / aW, m % aW) of the output view, skip add from a cropped view of the same extent
@@ -140,8 +146,7 @@ bool conv3h_supported(const GemmParams& p) {
 
 hipError_t launch_conv3h(const GemmParams& p, hipStream_t s) {
     const int Ho = p.Mrows / p.aW, Wo = p.aW;
-    if (p.a.Cs == 64) return p.omode == 2 ? launch_c3h<64, 1>(p, Ho, Wo, s) : launch_c3h<64, 0>(p, Ho, Wo, s);
-    return p.omode == 2 ? launch_c3h<32, 1>(p, Ho, Wo, s) : launch_c3h<32, 0>(p, Ho, Wo, s);
+    return p.omode == 2 ? launch_c3h<1>(p, Ho, Wo, s) : launch_c3h<0>(p, Ho, Wo, s);
 }
 
 }  // namespace w2x
