@@ -116,6 +116,40 @@ def test_cli_build_and_render_match_the_library(pkg, tmp_path):
     assert np.array_equal(got, ref[..., ::-1])
 
 
+@pytest.mark.gpu
+def test_cli_two_devices_render_a_still_as_strips_and_a_tf32_engine(pkg, tmp_path):
+    """`--devices 2` on a still: one engine per device, each renders its tile-column strip straight into the shared output image
+    (SURVEY 8e); the bytes are those of the single-device frame.  The box has one GPU, so W2X_DEVICE_MAP=0,0 puts both logical
+    devices on it (engine.cpp physical_device).  The same command line with --precision tf32 builds and renders on the fp32 engine."""
+    Image = pytest.importorskip("PIL.Image")
+    import synth_models as sm
+    models = tmp_path / "models"
+    path = sm.model_path(str(tmp_path), "cunet/art", 2, 1)
+    sm.export_onnx(sm.make_model("cunet/art", 2, seed=6), path, 2, 64, dynamic=True)
+    rgb = np.random.default_rng(2).integers(0, 256, (150, 210, 3), dtype=np.uint8)
+    Image.fromarray(rgb).save(tmp_path / "in.png")
+    common = ["--models", str(models), "--model", "cunet/art", "--scale", "2", "--noise", "1", "--batchSize", "2", "--tileSize", "64"]
+    env = dict(os.environ, W2X_DEVICE_MAP="0,0")
+    def cli(*a):
+        return subprocess.run([W2X, *common, *a], capture_output=True, text=True, timeout=180, env=env)
+    r = cli("build")
+    assert r.returncode == 0, r.stderr
+    outs = {}
+    for name, extra in (("one", []), ("two", ["--devices", "2"])):
+        out = tmp_path / name; out.mkdir()
+        r = cli("render", "-i", str(tmp_path / "in.png"), "-o", str(out), *extra)
+        assert r.returncode == 0, r.stderr
+        outs[name] = np.array(Image.open(out / "in(cunet_art)(noise1)(scale2).png"))
+    assert outs["one"].shape == (300, 420, 3) and np.array_equal(outs["one"], outs["two"])
+    r = cli("--precision", "tf32", "build")
+    assert r.returncode == 0, r.stderr
+    out = tmp_path / "tf32"; out.mkdir()
+    r = cli("--precision", "tf32", "render", "-i", str(tmp_path / "in.png"), "-o", str(out))
+    assert r.returncode == 0, r.stderr
+    got32 = np.array(Image.open(out / "in(cunet_art)(noise1)(scale2).png")).astype(np.int32)
+    assert np.abs(got32 - outs["one"].astype(np.int32)).max() <= 2       # fp16 against fp32 engine: a couple of LSBs at most
+
+
 FAKE_FFPROBE = """#!/usr/bin/env python3
 # stand-in for ffprobe on a raw bgr24 clip: prints width,height,r_frame_rate,nb_read_packets like `-of csv=p=0`
 import os, sys
