@@ -453,3 +453,21 @@ def test_fp32_engine_matches_the_fp32_oracle(pkg, onnx_model, model, scale, batc
     r = frame_report(f"frame fp32 [{model} s{scale} B{batch} T{tile}]", out, want)
     assert r["max_lsb"] <= 1 and r["frac_pixels_off_by_1"] < 1e-3, r
     eng.close()
+
+
+def test_folded_squeeze_excite_gates_equal_the_in_place_pass(pkg, onnx_model, monkeypatch):
+    """cunet's squeeze-excite gates are folded into their consumers (the 1x1 / 2x2 (transposed) convolutions scale their operand
+    on load, the skip add scales its residual: lower.cpp pending_gate) with the rounding of the separate in-place pass they
+    replace (W2X_NO_SE_FOLD=1 keeps that pass): the network outputs and the frames are bit-identical."""
+    path = onnx_model("cunet/art", 2, 2, 96, noise=1)
+    x = np.random.default_rng(9).random((2, 3, 96, 96), dtype=np.float32)
+    frame = smooth_frame(150, 170, 4)
+    outs = []
+    for nofold in (True, False):
+        if nofold: monkeypatch.setenv("W2X_NO_SE_FOLD", "1")
+        else: monkeypatch.delenv("W2X_NO_SE_FOLD")
+        assert (" scale t" in pkg.describe_plan(path, 2, 96)) == nofold
+        eng = make_engine(pkg, path, 2, 96, 2)
+        outs.append((eng.infer(x), eng.render(frame)))
+        eng.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])

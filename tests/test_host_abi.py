@@ -190,3 +190,15 @@ def test_tf32_requests_lower_to_an_fp32_plan_of_unfused_ops(pkg, onnx_model, mod
     flops = lambda d: int(re.search(r"flops=(\d+)", d).group(1))
     assert flops(d16) == flops(d32)                       # the same algorithmic work
     assert act(d32) > 1.5 * act(d16) or model.startswith("swin")   # fp32 maps (the un-fused swin plan also keeps qkv / hidden maps)
+
+
+def test_cunet_gates_are_folded_into_their_consumers(pkg, onnx_model, monkeypatch):
+    """No in-place scaling pass is left in a cunet plan: each squeeze-excite gate rides on the operand load of the (transposed)
+    convolution that consumes the map and on the skip add that reads it; W2X_NO_SE_FOLD=1 and fp32 plans keep the pass."""
+    path = onnx_model("cunet/art", 2, 2, 64, noise=1)
+    d = pkg.describe_plan(path, 2, 64)
+    assert " scale t" not in d and d.count(" a*gate") == 4 and d.count(" res*gate") == 1
+    assert pkg.describe_plan(path, 2, 64, pkg.Precision.TF32).count(" scale t") == 4
+    monkeypatch.setenv("W2X_NO_SE_FOLD", "1")
+    d = pkg.describe_plan(path, 2, 64)
+    assert d.count(" scale t") == 4 and "gate" not in d

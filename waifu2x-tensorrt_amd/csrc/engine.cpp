@@ -298,7 +298,7 @@ struct Img2Img::Impl {
             for (int i = 0; i < nops; ++i) {
                 const Op& op = plan.ops[i];
                 switch (op.kind) {
-                    case OP_GEMM: touch(op.g.a.t, i); touch(op.g.res.t, i); touch(op.g.res2.t, i); touch(op.g.stats_in, i);
+                    case OP_GEMM: touch(op.g.a.t, i); touch(op.g.res.t, i); touch(op.g.res2.t, i); touch(op.g.stats_in, i); touch(op.g.se_scale, i); touch(op.g.res_scale, i);
                                   touch(op.g.out.t, i); touch(op.g.stats_out, i); touch(op.g.pool_out, i); break;
                     case OP_ATTN: touch(op.at.qkv, i); touch(op.at.out, i); break;
                     case OP_SE: touch(op.se.pool, i); touch(op.se.scale, i); break;
@@ -411,6 +411,9 @@ struct Img2Img::Impl {
             p.omode = g.omode; p.r = g.r; p.Cout = g.Cout;
             p.stats_out = g.stats_out >= 0 ? (float*)tensors[g.stats_out] : nullptr; p.ln_eps = g.ln_eps;
             p.pool_out = g.pool_out >= 0 ? (float*)tensors[g.pool_out] : nullptr;
+            p.a_scale = g.se_scale >= 0 ? (const float*)tensors[g.se_scale] : nullptr;
+            p.res_scale = g.res_scale >= 0 ? (const float*)tensors[g.res_scale] : nullptr;
+            if ((p.a_scale || p.res_scale) && plan.elt != 2) throw std::runtime_error("plan: folded gates in an fp32 plan");
             if (g.pool_out >= 0) pool_tensors.push_back(g.pool_out);
             if (g.out.t == plan.out_tensor) final_op = (int)i;
             // shape checks the kernels rely on (a wrong shape would fault on the device)

@@ -197,7 +197,7 @@ int conv3_tiles(const GemmParams& p) {   // workgroups (pooling partials) per im
 
 bool conv3_supported(const GemmParams& p) {
     static const bool off = getenv("W2X_NO_CONV3") != nullptr;   // A/B switch
-    if (off || !p.wt_perm || p.amode != 2 || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.omode != 0 || p.ln || (p.act != 0 && p.act != 1) ||
+    if (off || p.a_scale || p.res_scale || !p.wt_perm || p.amode != 2 || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.omode != 0 || p.ln || (p.act != 0 && p.act != 1) ||
         p.has_clip || p.stats_out || p.res.p || p.res2.p) return false;
     if (p.act == 1 && !(p.alpha >= 0.f && p.alpha <= 1.f)) return false;   // LeakyReLU as max(v, v * alpha)
     const int Cin = p.a.Cs;

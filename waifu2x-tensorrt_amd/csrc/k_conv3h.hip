@@ -132,7 +132,7 @@ hipError_t launch_c3h(const GemmParams& p, int Ho, int Wo, hipStream_t s) {
 
 bool conv3h_supported(const GemmParams& p) {
     static const bool off = getenv("W2X_NO_CONV3H") != nullptr;   // A/B switch
-    if (off || p.amode != 2 || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.ln || (p.act != 0 && p.act != 1) || p.stats_out || p.pool_out || p.res2.p) return false;
+    if (off || p.a_scale || p.res_scale || p.amode != 2 || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.ln || (p.act != 0 && p.act != 1) || p.stats_out || p.pool_out || p.res2.p) return false;
     const int Cin = p.a.Cs;
     if (Cin % 32 || Cin > 256 || p.K != 9 * Cin || p.Kw != p.K || p.out.Cs != 4 || p.aW <= 0 || p.Mrows % p.aW || p.B <= 0) return false;
     const int Ho = p.Mrows / p.aW, Wo = p.aW;

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void conv48_kernel(const GemmParams p, int 
 
 bool conv48_supported(const GemmParams& p) {
     static const bool off = getenv("W2X_NO_CONV48") != nullptr;   // A/B switch (read once per process)
-    if (off || !p.wt_frag || p.amode != 2 || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.omode != 0 || p.ln || (p.act != 0 && p.act != 1) ||
+    if (off || p.a_scale || !p.wt_frag || p.amode != 2 || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.omode != 0 || p.ln || (p.act != 0 && p.act != 1) ||
         p.has_clip || p.stats_out || p.pool_out || p.res.p || p.res2.p) return false;
     if (p.act == 1 && !(p.alpha >= 0.f && p.alpha <= 1.f)) return false;
     if (p.a.Cs != CIN || p.N != N || p.K != 9 * CIN || p.out.Cs != N || p.aW <= 0 || p.Mrows % p.aW) return false;

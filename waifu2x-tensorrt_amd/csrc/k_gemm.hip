@@ -109,8 +109,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
                     int off;
                     if (p.amode == 2) { int ky = k / kwCin; int rem = k - ky * kwCin; off = aoff + ky * p.a.Ws * Cin + rem; }
                     else off = aoff + k;
-                    if (AP == 8) v = *(const uint4*)(Ag + off);
-                    else { uint2 u = *(const uint2*)(Ag + off); v.x = u.x; v.y = u.y; }
+                    if (AP == 8) {
+                        v = *(const uint4*)(Ag + off);
+                        if (p.a_scale) {   // squeeze-excite gate of the input map: fp16(x * s), the rounding of the in-place pass
+                            const float* sc = p.a_scale + tile_b * Cin + (p.amode == 2 ? (k % kwCin) % Cin : k);
+                            half8 h = __builtin_bit_cast(half8, v);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) h[e] = (_Float16)((float)h[e] * sc[e]);
+                            v = __builtin_bit_cast(uint4, h);
+                        }
+                    } else { uint2 u = *(const uint2*)(Ag + off); v.x = u.x; v.y = u.y; }
                 }
             }
             ra[t] = v;
@@ -233,6 +241,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
                 if (p.res.p) {
                     const _Float16* rp = (const _Float16*)p.res.p + (size_t)((b * p.res.Hs + Y + p.res.y0) * p.res.Ws + X + p.res.x0) * p.res.Cs + ch;
                     if (OP == 8) { half8 r = *(const half8*)rp;
+                        if (p.res_scale) {
+                            const float* rs = p.res_scale + b * p.res.Cs + ch;
+#pragma unroll
+                            for (int e = 0; e < OP; ++e) r[e] = (_Float16)((float)r[e] * rs[e]);
+                        }
 #pragma unroll
                         for (int e = 0; e < OP; ++e) v[e] += (float)r[e]; }
                     else { half4 r = *(const half4*)rp;
@@ -313,6 +326,7 @@ hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
 // Tile selection.  BN follows N (all widths in these networks are multiples of 16 after padding); KB = 96 when it
 // divides K (Swin C = 96/192, 3x3 convs over 32/64/128/256 channels), else 64.
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
+    if ((p.a_scale && (p.a.Cs == 4 || p.a.Cs % 8)) || (p.res_scale && (p.out.Cs == 4 || !p.res.p))) return hipErrorInvalidValue;   // gates ride on 8-half pieces
     const bool op4 = p.out.Cs == 4;
     if (p.a.Cs == 4) {                       // first convolution: 4 stored input channels, K = 36
         if (p.N <= 32) return launch_cfg<64, 4, 1, 2, 2, 4, 8>(p, s);

@@ -74,6 +74,17 @@ __global__ __launch_bounds__(256, 2) void pixgemm_kernel(const GemmParams p) {
             if (idx < npieces) h = *(const half8*)(X + (size_t)idx * 8);
             xr[k] = h;
         }
+        if (p.a_scale) {   // squeeze-excite gate of the input map: fp16(x * s), the rounding of the in-place pass
+#pragma unroll
+            for (int k = 0; k < C::NPI; ++k) {
+                const int idx = k * 64 + lane, rr = idx / C::PPI, c = idx - rr * C::PPI;
+                const float* sc = p.a_scale + (size_t)((row0 + rr) / p.Mrows) * K + c * 8;
+                if (idx < npieces) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xr[k][e] = (_Float16)((float)xr[k][e] * sc[e]);
+                }
+            }
+        }
 #pragma unroll
         for (int k = 0; k < C::NPI; ++k) {
             const int idx = k * 64 + lane, rr = idx / C::PPI, c = idx - rr * C::PPI;
@@ -142,7 +153,15 @@ __global__ __launch_bounds__(256, 2) void pixgemm_kernel(const GemmParams p) {
                 const int idx = k * 64 + lane, rr = idx / C::PPO, c = idx - rr * C::PPO;
                 if (rr < nrows) {
                     half8 o = *(const half8*)(Ot + rr * LDO + c * 8);
-                    if (Rg) o += *(const half8*)(Rg + (size_t)Rb[2 * rr + 1] + rshift + c * 8);   // fp16 + fp16 rounded once == fp32 add rounded to fp16
+                    if (Rg) {
+                        half8 rv = *(const half8*)(Rg + (size_t)Rb[2 * rr + 1] + rshift + c * 8);
+                        if (p.res_scale) {   // gated skip connection
+                            const float* rs = p.res_scale + (size_t)((row0 + rr) / p.Mrows) * p.res.Cs + c * 8;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) rv[e] = (_Float16)((float)rv[e] * rs[e]);
+                        }
+                        o += rv;                                   // fp16 + fp16 rounded once == fp32 add rounded to fp16
+                    }
                     *(half8*)(Og + (size_t)Rb[2 * rr] + oshift + c * 8) = o;
                 }
             }
@@ -382,14 +401,14 @@ bool pixgemm_supported(const GemmParams& p) {
     static const bool off = getenv("W2X_NO_PIXGEMM") != nullptr;   // A/B switch
     if (!off && p.wt_frag && p.amode == 2 && p.kh == 2 && p.kw == 2 && p.stride == 2 && p.omode == 0 && !p.ln && p.act == 0 && !p.has_clip &&
         !p.stats_out && !p.pool_out && !p.res.p && !p.res2.p && p.N == 192 && p.out.Cs == 192 && p.Kw == p.K &&
-        (p.a.Cs == 96 || p.a.Cs == 192) && p.K == 4 * p.a.Cs && (long)p.out.Hs * p.out.Ws == p.Mrows && p.out.Ws == p.aW) return true;   // patch merge
+        !p.a_scale && (p.a.Cs == 96 || p.a.Cs == 192) && p.K == 4 * p.a.Cs && (long)p.out.Hs * p.out.Ws == p.Mrows && p.out.Ws == p.aW) return true;   // patch merge
     // rows = a Linear, or a 1x1 convolution: cunet's 2x2 stride-2 ConvTranspose is lowered to 1x1 + pixel shuffle with LeakyReLU and a
     // cropped skip add (K = 64 / 128)
     const bool rows = p.amode == 0 || (p.amode == 2 && p.kh == 1 && p.kw == 1);
     if (off || !p.wt_frag || p.omode != 2 || !rows || p.ln || (p.act != 0 && p.act != 1) || p.stats_out || p.pool_out || p.res2.p) return false;
     if (p.stride != 1 || p.a.y0 || p.a.x0 || p.a.Ws != p.aW || (long)p.a.Hs * p.a.Ws != p.Mrows || p.a.Cs != p.K || p.Kw != p.K) return false;
     if (p.N != p.r * p.r * p.out.Cs) return false;
-    if (p.K == 96 && p.out.Cs == 4 && p.r == 4 && p.N == 64 && !p.res.p && p.act == 0 && p.amode == 0) return true;   // image head
+    if (p.K == 96 && p.out.Cs == 4 && p.r == 4 && p.N == 64 && !p.res.p && p.act == 0 && p.amode == 0 && !p.a_scale) return true;   // image head
     if (p.has_clip || p.Cout != p.out.Cs || (p.res.p && p.res.Cs != p.out.Cs)) return false;
     if ((p.K == 64 && p.out.Cs == 64) || (p.K == 128 && p.out.Cs == 128)) return true;
     return (p.K == 192 && (p.out.Cs == 96 || p.out.Cs == 192));

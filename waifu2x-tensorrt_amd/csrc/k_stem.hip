@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const GemmParams p, int Ho, i
 
 bool stem_supported(const GemmParams& p) {
     static const bool off = getenv("W2X_NO_STEM") != nullptr;   // A/B switch
-    if (off || p.amode != 2 || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.omode != 0 || p.ln || (p.act != 0 && p.act != 1) || p.has_clip ||
+    if (off || p.a_scale || p.res_scale || p.amode != 2 || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.omode != 0 || p.ln || (p.act != 0 && p.act != 1) || p.has_clip ||
         p.stats_out || p.pool_out || p.res.p || p.res2.p) return false;
     if (p.a.Cs != 4 || p.K != 36 || p.Kw < 36 || p.Kw % 4 || (p.N != 32 && p.N != 48 && p.N != 64) || p.out.Cs != p.N || p.aW <= 0 || p.Mrows % p.aW) return false;
     const int Ho = p.Mrows / p.aW, Wo = p.aW;

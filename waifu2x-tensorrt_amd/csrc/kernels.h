@@ -41,6 +41,8 @@ struct GemmParams {
     int ln = 0;
     int act = 0; float alpha = 0.f;
     int has_clip = 0; float clip_lo = 0.f, clip_hi = 0.f;
+    const float* a_scale = nullptr;   // fp32 [B][a.Cs]: squeeze-excite gate of the input map, applied to A on load (rounded to fp16 like the in-place pass)
+    const float* res_scale = nullptr; // fp32 [B][res.Cs]: the same for the first residual
     TView res, res2;                // p == nullptr: none
     TView out;
     int omode = 0, r = 1, Cout = 0;

@@ -43,6 +43,7 @@ struct Lowerer {
     std::set<const Node*> done;
     std::map<int, int> tensor_producer;  // tensor -> op index that wrote it (for stats_out / pool_out requests)
     std::map<std::string, int> blob_cache;
+    std::map<int, int> pending_gate;     // map tensor -> fp32 [B][C] squeeze-excite gate not yet applied to it (folded into its consumers)
 
     explicit Lowerer(const FoldedGraph& g_) : g(g_) {}
 
@@ -306,6 +307,9 @@ struct Lowerer {
             if (it == vals.end() || !same_geometry(it->second, p, H, W, C)) return;
             View& slot = p.op.res.t < 0 ? p.op.res : p.op.res2;
             if (slot.t >= 0) return;
+            if (auto pg = pending_gate.find(it->second.v.t); pg != pending_gate.end()) {   // gated skip connection
+                if (&slot == &p.op.res) p.op.res_scale = pg->second; else apply_gate(it->second.v.t);
+            }
             slot = it->second.v;
             done.insert(u); p.cur = u->out[0];
         }
@@ -429,6 +433,9 @@ struct Lowerer {
             if (p.outH * 2 != os[2] || p.outW * 2 != os[3]) fail(n, "transposed convolution output size mismatch");
         }
         o.Mrows = p.outH * p.outW; o.aW = p.outW;
+        if (auto pg = pending_gate.find(x.v.t); pg != pending_gate.end()) {   // gated input: 1x1 / 2x2 kernels scale it on load
+            if (o.kh <= 2) o.se_scale = pg->second; else apply_gate(x.v.t);
+        }
         p.bias.assign(o.N, 0.f);
         if (n->in.size() > 2 && !n->in[2].empty()) {
             const HTensor& b = g.cst(n->in[2]);
@@ -455,6 +462,7 @@ struct Lowerer {
         GemmOp& o = p.op;
         const TensorDesc& td = plan.tensors[x.v.t];
         if (td.C != K) fail(n, "MatMul input has padded channels");
+        apply_gate(x.v.t);
         o.a = x.v; o.K = K; o.N = N;
         p.w.assign((size_t)N * K, 0.f);
         p.bias.assign(N, 0.f);
@@ -587,6 +595,17 @@ struct Lowerer {
     }
 
     // ---- cunet squeeze-excite: mean(H,W) -> 1x1 conv -> relu -> 1x1 conv -> sigmoid -> x * s
+    std::map<int, std::string> gate_names;
+    // in-place scaling pass for a map whose gate is still pending
+    void apply_gate(int t) {
+        auto it = pending_gate.find(t);
+        if (it == pending_gate.end()) return;
+        Op sc; sc.kind = OP_SCALE_ADD; sc.name = gate_names[t];
+        sc.se.scale = it->second; sc.se.pool = t; sc.se.C = plan.tensors[t].C;
+        plan.ops.push_back(sc);
+        pending_gate.erase(it);
+    }
+
     bool try_lower_se(const Node* n) {
         if (!(n->op == "GlobalAveragePool" || n->op == "ReduceMean")) return false;
         const LVal& x = vals.at(n->in[0]);
@@ -633,10 +652,12 @@ struct Lowerer {
         s.b1 = blob_f32(b1); s.b2 = blob_f32(b2);
         op.flops = 2.0 * plan.B * (2.0 * C * Cm);
         plan.ops.push_back(op);
-        // in-place scaling pass
-        Op sc; sc.kind = OP_SCALE_ADD; sc.name = mul->name.empty() ? "se_scale" : mul->name;
-        sc.se.scale = s.scale; sc.se.pool = x.v.t; sc.se.C = td.C;
-        plan.ops.push_back(sc);
+        // The gate multiplies the whole map.  Its consumers in these graphs are 1x1 / 2x2 (transposed) convolutions and skip adds,
+        // which take the multiplier on their operand load (same fp16 rounding as a separate pass); anything else gets the
+        // in-place pass first (apply_gate).  Saves a read + write of the map per squeeze-excite block.
+        gate_names[x.v.t] = mul->name.empty() ? "se_scale" : mul->name;
+        pending_gate[x.v.t] = s.scale;
+        if (plan.elt != 2 || getenv("W2X_NO_SE_FOLD")) apply_gate(x.v.t);
         for (auto* z : {n, c1, r, c2, sg, mul}) done.insert(z);
         vals[mul->out[0]] = x;
         return true;
@@ -827,6 +848,8 @@ struct Lowerer {
             if (itx == vals.end()) fail(n, "input \"" + n->in[0] + "\" was not lowered");
             const LVal x = itx->second;
             if (op == "Pad") { lower_pad(n, x); continue; }
+            if (op != "Slice")   // crops are views; every other consumer of a gated map gets the in-place pass first
+                for (const std::string& in : n->in) { auto iv = vals.find(in); if (iv != vals.end() && iv->second.kind == LVal::MAP) apply_gate(iv->second.v.t); }
             if (op == "Slice" && x.kind == LVal::MAP && x.nchw && !x.ln && true) {
                 // crop expressed as Slice on H/W
                 std::vector<int64_t> starts = g.cst(n->in[1]).i, ends = g.cst(n->in[2]).i;

@@ -30,6 +30,8 @@ std::string Plan::describe() const {
             if (g.amode == A_CONV) o << g.kh << "x" << g.kw << "s" << g.stride;
             o << " M=" << (int64_t)B * g.Mrows << " K=" << g.K << " N=" << g.N << " ln=" << g.ln << " act=" << g.act << " o=" << om;
             if (g.omode == O_PIXSHUF) o << g.r;
+            if (g.se_scale >= 0) o << " a*gate";
+            if (g.res_scale >= 0) o << " res*gate";
             o << " res=" << (g.res.t >= 0) + (g.res2.t >= 0) << " clip=" << g.has_clip << " stats=" << (g.stats_out >= 0) << " pool=" << (g.pool_out >= 0)
               << " t" << g.a.t << "->t" << g.out.t;
         } else if (op.kind == OP_ATTN) {
@@ -63,7 +65,7 @@ struct Reader {
     std::vector<uint8_t> bytes() { uint64_t n = pod<uint64_t>(); if ((uint64_t)(e - p) < n) throw std::runtime_error("engine file truncated"); std::vector<uint8_t> v(p, p + n); p += n; return v; }
 };
 constexpr uint64_t kMagic = 0x3158325755464957ull;  // "WIFUW2X1"
-constexpr uint32_t kVersion = 9;
+constexpr uint32_t kVersion = 10;
 }  // namespace
 
 std::vector<uint8_t> Plan::serialize() const {
@@ -126,7 +128,10 @@ void Plan::validate() const {
                 const GemmOp& g = op.g;
                 view(g.res, true); view(g.res2, true); view(g.out, false);
                 ten(g.a.t, false);
-                ten(g.stats_in, true); ten(g.stats_out, true); ten(g.pool_out, true); ten(g.se_scale, true);
+                ten(g.stats_in, true); ten(g.stats_out, true); ten(g.pool_out, true); ten(g.se_scale, true); ten(g.res_scale, true);
+                if (g.res_scale >= 0 && g.res.t < 0) fail("residual gate without a residual");
+                if (g.se_scale >= 0 && (tensors[g.se_scale].elt != 4 || (int64_t)tensors[g.se_scale].B * tensors[g.se_scale].H * tensors[g.se_scale].W * tensors[g.se_scale].C < (int64_t)B * tensors[g.a.t].C)) fail("input gate shape");
+                if (g.res_scale >= 0 && (tensors[g.res_scale].elt != 4 || (int64_t)tensors[g.res_scale].B * tensors[g.res_scale].H * tensors[g.res_scale].W * tensors[g.res_scale].C < (int64_t)B * tensors[g.res.t].C)) fail("residual gate shape");
                 if (g.K <= 0 || g.N <= 0 || g.Mrows <= 0 || g.kh <= 0 || g.kw <= 0 || g.stride <= 0 || g.r <= 0 || g.aW <= 0) fail("gemm shape");
                 if (g.amode < A_ROWS || g.amode > A_CONV || g.omode < O_ROWS || g.omode > O_PIXSHUF) fail("gemm mode");
                 if (g.K != g.kh * g.kw * tensors[g.a.t].C) fail("gemm K");

@@ -55,7 +55,8 @@ struct GemmOp {
     float clip_lo = 0.f, clip_hi = 0.f;
     View res;               // optional residual (t = -1: none), same logical geometry as out
     View res2;              // optional second residual (cunet skip adds)
-    int se_scale = -1;      // optional tensor fp32 [B][C]: per-(batch,channel) multiplier applied to A on load (cunet SE)
+    int se_scale = -1;      // optional tensor fp32 [B][C]: per-(batch,channel) multiplier applied to A on load (cunet squeeze-excite gate folded into its consumer)
+    int res_scale = -1;     // the same for the first residual operand
     int omode = O_ROWS;
     View out;
     int r = 1;              // O_PIXSHUF: upscale factor; N = r*r*Cout', columns ordered (dy,dx,c)
