@@ -447,7 +447,7 @@ def test_fp32_engine_matches_the_fp32_oracle(pkg, onnx_model, model, scale, batc
     from parity_util import _record
     _record({"test": f"network fp32 [{model} s{scale} B{batch} T{tile}]", "kind": "network_fp32", "max_abs": float(d.max()), "mean_abs": float(d.mean())})
     assert d.max() <= FP32_NET_MAX_ABS, (d.max(), d.mean())
-    frame = smooth_frame(tile + 37, 2 * tile - 9, 3)
+    frame = smooth_frame(tile + 37, 2 * tile - 9, 3) if scale > 1 else smooth_frame(70, 75, 3)   # (x1: 8-pixel output tiles, keep the grid small)
     out = eng.render(frame)
     want = pipeline.render(frame, ex.run, batch=batch, tile=tile, scaling=scale, overlap=(0.0625, 0.0625))
     r = frame_report(f"frame fp32 [{model} s{scale} B{batch} T{tile}]", out, want)
