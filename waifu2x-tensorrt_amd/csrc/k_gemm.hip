@@ -113,10 +113,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
                         v = *(const uint4*)(Ag + off);
                         if (p.a_scale) {   // squeeze-excite gate of the input map: fp16(x * s), the rounding of the in-place pass
                             const float* sc = p.a_scale + tile_b * Cin + (p.amode == 2 ? (k % kwCin) % Cin : k);
-                            half8 h = __builtin_bit_cast(half8, v);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) h[e] = (_Float16)((float)h[e] * sc[e]);
-                            v = __builtin_bit_cast(uint4, h);
+                            v = __builtin_bit_cast(uint4, gate::gate8(__builtin_bit_cast(half8, v), sc));
                         }
                     } else { uint2 u = *(const uint2*)(Ag + off); v.x = u.x; v.y = u.y; }
                 }
@@ -243,8 +240,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
                     if (OP == 8) { half8 r = *(const half8*)rp;
                         if (p.res_scale) {
                             const float* rs = p.res_scale + b * p.res.Cs + ch;
-#pragma unroll
-                            for (int e = 0; e < OP; ++e) r[e] = (_Float16)((float)r[e] * rs[e]);
+                            r = gate::gate8(r, rs);
                         }
 #pragma unroll
                         for (int e = 0; e < OP; ++e) v[e] += (float)r[e]; }

@@ -79,10 +79,7 @@ __global__ __launch_bounds__(256, 2) void pixgemm_kernel(const GemmParams p) {
             for (int k = 0; k < C::NPI; ++k) {
                 const int idx = k * 64 + lane, rr = idx / C::PPI, c = idx - rr * C::PPI;
                 const float* sc = p.a_scale + (size_t)((row0 + rr) / p.Mrows) * K + c * 8;
-                if (idx < npieces) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) xr[k][e] = (_Float16)((float)xr[k][e] * sc[e]);
-                }
+                if (idx < npieces) xr[k] = gate::gate8(xr[k], sc);
             }
         }
 #pragma unroll
@@ -156,9 +153,7 @@ __global__ __launch_bounds__(256, 2) void pixgemm_kernel(const GemmParams p) {
                     if (Rg) {
                         half8 rv = *(const half8*)(Rg + (size_t)Rb[2 * rr + 1] + rshift + c * 8);
                         if (p.res_scale) {   // gated skip connection
-                            const float* rs = p.res_scale + (size_t)((row0 + rr) / p.Mrows) * p.res.Cs + c * 8;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) rv[e] = (_Float16)((float)rv[e] * rs[e]);
+                            rv = gate::gate8(rv, p.res_scale + (size_t)((row0 + rr) / p.Mrows) * p.res.Cs + c * 8);
                         }
                         o += rv;                                   // fp16 + fp16 rounded once == fp32 add rounded to fp16
                     }
@@ -266,43 +261,56 @@ __global__ __launch_bounds__(256, 2) void toimage_kernel(const GemmParams p) {
     }
 }
 
-// Patch merge: Conv 2x2 stride 2 (Cin -> 192).  Output pixel (y, x) reads the input pixels (2y+ky, 2x+kx): for each ky one
-// contiguous run of 2*Cin halves, so K = 4*Cin is walked in sub-chunks of 192 contiguous channels.  A wave owns 32 output
-// pixels and all 192 output columns (accumulators stay in registers over the whole K), rows of a sub-chunk pass through the
+// Conv 2x2 stride 2: the Swin patch merge (Cin 96 / 192 -> 192) and cunet's down convolutions (64 -> 64, 128 -> 128, LeakyReLU, the
+// input optionally gated by its squeeze-excite block).  Output pixel (y, x) reads the input pixels (2y+ky, 2x+kx): for each ky one
+// contiguous run of 2*Cin halves, so K = 4*Cin is walked in sub-chunks of SUB contiguous channels.  A wave owns 32 output
+// pixels and all N output columns (accumulators stay in registers over the whole K), rows of a sub-chunk pass through the
 // wave's LDS slab into A fragments, weights stream through LDS in stages of two n-tiles shared by the four waves.
-template <int CIN>
+template <int CIN, int N, int SUB>
+struct MergeCfg {
+    static constexpr int K = 4 * CIN, NT = N / 16, KST = K / 32, NQ = K / SUB, QPK = 2 * CIN / SUB, KSS = SUB / 32;   // sub-chunks total / per ky, k-steps per sub-chunk
+    static constexpr int TT = 2, RW = 32, G = 2, NF = G * KSS, NFW = NF / 4, LDS_ROW = (SUB > N ? SUB : N) + 8, PPC = SUB / 8, NPI = RW * PPC / 64;
+    static constexpr int PPO = N / 8, NPO = RW * PPO / 64;
+    static constexpr int WBUF = NF * 1024, SLAB = RW * LDS_ROW * 2 + RW * 8, SMEM = 2 * WBUF + 4 * SLAB;
+    static_assert(NF % 4 == 0 && NT % G == 0 && (2 * CIN) % SUB == 0 && RW * PPC % 64 == 0 && RW * PPO % 64 == 0, "tiling");
+};
+
+template <int CIN, int N, int SUB>
 __global__ __launch_bounds__(256, 2) void merge_kernel(const GemmParams p) {
-    constexpr int K = 4 * CIN, N = 192, NT = N / 16, KST = K / 32, NQ = K / 192, QPK = 2 * CIN / 192;   // sub-chunks total / per ky
-    constexpr int TT = 2, RW = 32, G = 2, NF = G * 6, NFW = NF / 4, LDS_ROW = 200, PPC = 24, NPI = RW * PPC / 64;
-    constexpr int WBUF = NF * 1024, SLAB = RW * LDS_ROW * 2 + RW * 4;
+    using C = MergeCfg<CIN, N, SUB>;
+    constexpr int NT = C::NT, KST = C::KST, NQ = C::NQ, QPK = C::QPK, KSS = C::KSS;
+    constexpr int TT = C::TT, RW = C::RW, G = C::G, NFW = C::NFW, LDS_ROW = C::LDS_ROW, PPC = C::PPC, NPI = C::NPI;
+    constexpr int WBUF = C::WBUF, SLAB = C::SLAB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, g = lane >> 4;
     _Float16* WB = (_Float16*)smem;
-    _Float16* Sl = (_Float16*)(smem + 2 * WBUF + wv * SLAB);              // [RW][200]: input sub-chunk, later the output tile
+    _Float16* Sl = (_Float16*)(smem + 2 * WBUF + wv * SLAB);              // [RW][LDS_ROW]: input sub-chunk, later the output tile
     int* Tb = (int*)(smem + 2 * WBUF + wv * SLAB + RW * LDS_ROW * 2);      // [RW] element offset of input pixel (2y, 2x), -1: no row
+    int* Gb = Tb + RW;                                                     // [RW] offset of the row's image in the gate table (b * CIN)
     const long M = (long)p.B * p.Mrows;
     const long row0 = ((long)blockIdx.x * 4 + wv) * RW;
     const long nrows = M - row0 < RW ? M - row0 : RW;
     const _Float16* __restrict__ Xg = (const _Float16*)p.a.p;
     const _Float16* __restrict__ Wf = (const _Float16*)p.wt_frag + lane * 8;   // [NT][KST][64][8]
-    auto frag_src = [&](int stage, int f) {   // stage = q * (NT / G) + s; fragment f = t * 6 + ks  ->  n-tile s*G + t, k-step q*6 + ks
-        const int q = stage / (NT / G), s2 = stage - q * (NT / G), t = f / 6, ks = f - t * 6;
-        return Wf + (size_t)((s2 * G + t) * KST + q * 6 + ks) * 512;
+    auto frag_src = [&](int stage, int f) {   // stage = q * (NT / G) + s; fragment f = t * KSS + ks  ->  n-tile s*G + t, k-step q*KSS + ks
+        const int q = stage / (NT / G), s2 = stage - q * (NT / G), t = f / KSS, ks = f - t * KSS;
+        return Wf + (size_t)((s2 * G + t) * KST + q * KSS + ks) * 512;
     };
     half8 stg[NFW];
 #pragma unroll
     for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)frag_src(0, wv * NFW + i);
     if (lane < RW) {
         const long gr = row0 + lane;
-        int off = -1;
+        int off = -1, gb = 0;
         if (gr < M) {
             const int b = (int)(gr / p.Mrows), ml = (int)(gr - (long)b * p.Mrows);
             const int oy = ml / p.aW, ox = ml - oy * p.aW;
             off = ((b * p.a.Hs + oy * 2 + p.a.y0) * p.a.Ws + ox * 2 + p.a.x0) * CIN;
+            gb = b * CIN;
         }
-        Tb[lane] = off;
+        Tb[lane] = off; Gb[lane] = gb;
     }
 #pragma unroll
     for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[i];
@@ -319,8 +327,8 @@ __global__ __launch_bounds__(256, 2) void merge_kernel(const GemmParams p) {
     int stage = 0;
 #pragma unroll 1
     for (int q = 0; q < NQ; ++q) {
-        // rows of this sub-chunk: 192 contiguous halves per output pixel
-        const int ky = q / QPK, inner = (q - ky * QPK) * 192;
+        // rows of this sub-chunk: SUB contiguous halves per output pixel
+        const int ky = q / QPK, inner = (q - ky * QPK) * SUB;
         const int shift = ky * p.a.Ws * CIN + inner;
         {
             half8 xr[NPI];
@@ -329,7 +337,10 @@ __global__ __launch_bounds__(256, 2) void merge_kernel(const GemmParams p) {
                 const int idx = k * 64 + lane, rr = idx / PPC, c = idx - rr * PPC;
                 const int off = Tb[rr];
                 half8 h = {};
-                if (off >= 0) h = *(const half8*)(Xg + (size_t)off + shift + c * 8);
+                if (off >= 0) {
+                    h = *(const half8*)(Xg + (size_t)off + shift + c * 8);
+                    if (p.a_scale) h = gate::gate8(h, p.a_scale + Gb[rr] + (inner + c * 8) % CIN);   // squeeze-excite gate of the input map
+                }
                 xr[k] = h;
             }
 #pragma unroll
@@ -339,11 +350,11 @@ __global__ __launch_bounds__(256, 2) void merge_kernel(const GemmParams p) {
             }
         }
         W2X_PHASE_FENCE();
-        half8 xa[TT][6];
+        half8 xa[TT][KSS];
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-            for (int ks = 0; ks < 6; ++ks) xa[tt][ks] = *(const half8*)(Sl + (tt * 16 + fr) * LDS_ROW + ks * 32 + g * 8);
+            for (int ks = 0; ks < KSS; ++ks) xa[tt][ks] = *(const half8*)(Sl + (tt * 16 + fr) * LDS_ROW + ks * 32 + g * 8);
         W2X_PHASE_FENCE();
 #pragma unroll
         for (int s2 = 0; s2 < NT / G; ++s2, ++stage) {
@@ -355,8 +366,8 @@ __global__ __launch_bounds__(256, 2) void merge_kernel(const GemmParams p) {
 #pragma unroll
             for (int t = 0; t < G; ++t)
 #pragma unroll
-                for (int ks = 0; ks < 6; ++ks) {
-                    const half8 wb = *(const half8*)(wcur + (size_t)(t * 6 + ks) * 512);
+                for (int ks = 0; ks < KSS; ++ks) {
+                    const half8 wb = *(const half8*)(wcur + (size_t)(t * KSS + ks) * 512);
 #pragma unroll
                     for (int tt = 0; tt < TT; ++tt) acc[tt][s2 * G + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[tt][ks], wb, acc[tt][s2 * G + t], 0, 0, 0);
                 }
@@ -373,24 +384,28 @@ __global__ __launch_bounds__(256, 2) void merge_kernel(const GemmParams p) {
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) Sl[(tt * 16 + g * 4 + j) * LDS_ROW + t * 16 + fr] = (_Float16)acc[tt][t][j];
+            for (int j = 0; j < 4; ++j) {
+                float v = acc[tt][t][j];
+                if (p.act == 1) v = v > 0.f ? v : v * p.alpha;
+                Sl[(tt * 16 + g * 4 + j) * LDS_ROW + t * 16 + fr] = (_Float16)v;
+            }
     W2X_PHASE_FENCE();
     _Float16* __restrict__ Og = (_Float16*)p.out.p + row0 * N;
-    const int npieces = nrows > 0 ? (int)nrows * PPC : 0;
+    const int npieces = nrows > 0 ? (int)nrows * C::PPO : 0;
 #pragma unroll
-    for (int k = 0; k < NPI; ++k) {
-        const int idx = k * 64 + lane, rr = idx / PPC, c = idx - rr * PPC;
+    for (int k = 0; k < C::NPO; ++k) {
+        const int idx = k * 64 + lane, rr = idx / C::PPO, c = idx - rr * C::PPO;
         if (idx < npieces) *(half8*)(Og + (size_t)idx * 8) = *(const half8*)(Sl + rr * LDS_ROW + c * 8);
     }
 }
 
-template <int CIN>
+template <int CIN, int N, int SUB>
 hipError_t launch_merge(const GemmParams& p, hipStream_t s) {
-    constexpr int SM = 2 * 12 * 1024 + 4 * (32 * 200 * 2 + 32 * 4);
+    constexpr int SM = MergeCfg<CIN, N, SUB>::SMEM;
     static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
-    if (hipError_t e = ensure_dynamic_lds((const void*)merge_kernel<CIN>, SM, lds_ok); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)merge_kernel<CIN, N, SUB>, SM, lds_ok); e != hipSuccess) return e;
     const long M = (long)p.B * p.Mrows;
-    hipLaunchKernelGGL(merge_kernel<CIN>, dim3((unsigned)((M + 127) / 128)), dim3(256), SM, s, p);
+    hipLaunchKernelGGL((merge_kernel<CIN, N, SUB>), dim3((unsigned)((M + 127) / 128)), dim3(256), SM, s, p);
     return hipGetLastError();
 }
 
@@ -399,9 +414,9 @@ hipError_t launch_merge(const GemmParams& p, hipStream_t s) {
 // true if this launch can take the streaming kernel (everything else stays on gemm_kernel)
 bool pixgemm_supported(const GemmParams& p) {
     static const bool off = getenv("W2X_NO_PIXGEMM") != nullptr;   // A/B switch
-    if (!off && p.wt_frag && p.amode == 2 && p.kh == 2 && p.kw == 2 && p.stride == 2 && p.omode == 0 && !p.ln && p.act == 0 && !p.has_clip &&
-        !p.stats_out && !p.pool_out && !p.res.p && !p.res2.p && p.N == 192 && p.out.Cs == 192 && p.Kw == p.K &&
-        !p.a_scale && (p.a.Cs == 96 || p.a.Cs == 192) && p.K == 4 * p.a.Cs && (long)p.out.Hs * p.out.Ws == p.Mrows && p.out.Ws == p.aW) return true;   // patch merge
+    if (!off && p.wt_frag && p.amode == 2 && p.kh == 2 && p.kw == 2 && p.stride == 2 && p.omode == 0 && !p.ln && (p.act == 0 || p.act == 1) && !p.has_clip &&
+        !p.stats_out && !p.pool_out && !p.res.p && !p.res2.p && p.out.Cs == p.N && p.Kw == p.K && p.K == 4 * p.a.Cs && (long)p.out.Hs * p.out.Ws == p.Mrows && p.out.Ws == p.aW &&
+        (((p.a.Cs == 96 || p.a.Cs == 192) && p.N == 192) || (p.a.Cs == 64 && p.N == 64) || (p.a.Cs == 128 && p.N == 128))) return true;   // patch merge / cunet down convolution
     // rows = a Linear, or a 1x1 convolution: cunet's 2x2 stride-2 ConvTranspose is lowered to 1x1 + pixel shuffle with LeakyReLU and a
     // cropped skip add (K = 64 / 128)
     const bool rows = p.amode == 0 || (p.amode == 2 && p.kh == 1 && p.kw == 1);
@@ -415,7 +430,7 @@ bool pixgemm_supported(const GemmParams& p) {
 }
 
 hipError_t launch_pixgemm(const GemmParams& p, hipStream_t s) {
-    if (p.amode == 2 && p.kh == 2) return p.a.Cs == 96 ? launch_merge<96>(p, s) : launch_merge<192>(p, s);
+    if (p.amode == 2 && p.kh == 2) return p.a.Cs == 96 ? launch_merge<96, 192, 192>(p, s) : p.a.Cs == 192 ? launch_merge<192, 192, 192>(p, s) : p.a.Cs == 64 ? launch_merge<64, 64, 128>(p, s) : launch_merge<128, 128, 128>(p, s);
     if (p.out.Cs == 4) {
         constexpr int SM = 4 * 64 * 104 * 2;
         const long M = (long)p.B * p.Mrows;

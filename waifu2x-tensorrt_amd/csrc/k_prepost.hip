@@ -249,11 +249,7 @@ __global__ __launch_bounds__(256) void scale_kernel(_Float16* x, const float* sc
         int cp = (int)(i % pc);
         long pix = i / pc;
         int b = (int)(pix / HW);
-        half8 v = *((half8*)x + i);
-        const float* sc = scale + b * Cs + cp * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (_Float16)((float)v[e] * sc[e]);
-        *((half8*)x + i) = v;
+        *((half8*)x + i) = gate::gate8(*((half8*)x + i), scale + b * Cs + cp * 8);   // the arithmetic of the folded gates (kernels.h)
     }
 }
 

@@ -155,4 +155,29 @@ hipError_t launch_compose(const ComposeParams& p, hipStream_t s);
 hipError_t launch_blob_to_nhwc(const float* nchw, void* out_nhwc4, int B, int T, bool fp32, hipStream_t s);
 hipError_t launch_nhwc_to_blob(const void* in_nhwc4, float* nchw, int B, int T, bool fp32, hipStream_t s);
 
+#ifdef __HIPCC__
+namespace gate {
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+// x * s on 8 halves, s fp32 per channel (cunet's squeeze-excite gates: the in-place pass scale_kernel and the gated operand loads of
+// k_gemm / k_pixgemm all go through this, so folding a gate never changes a bit): v_fma_mixlo / mixhi read the f16 halves directly,
+// multiply by the fp32 gate and write f16 - one instruction per element
+typedef unsigned gate_u4 __attribute__((ext_vector_type(4)));
+typedef float gate_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ half8 gate8(const half8 v, const float* sc) {
+    const gate_f4 s0 = *(const gate_f4*)sc, s1 = *(const gate_f4*)(sc + 4);
+    const float s[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+    gate_u4 x = __builtin_bit_cast(gate_u4, v), o;
+    const float zero = 0.f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        unsigned r;
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(x[d]), "v"(s[2 * d]), "v"(zero));
+        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(x[d]), "v"(s[2 * d + 1]), "v"(zero));
+        o[d] = r;
+    }
+    return __builtin_bit_cast(half8, o);
+}
+}  // namespace gate
+#endif
+
 }  // namespace w2x
