@@ -5,19 +5,20 @@ level of Abramowitz-Stegun 7.1.26 - with one transcendental (exp2) instead of tw
 import numpy as np
 from scipy.special import erfc, erf
 
-UMAX, DEG = 6.5, 6
+import sys
+UMAX, DEG = 6.5, int(sys.argv[1]) if len(sys.argv) > 1 else 4   # number of coefficients of q: 6 -> 3.1e-7, 5 -> 7.1e-7, 4 -> 8.7e-6 (shipped)
 u = np.linspace(0, UMAX, 20001)
 E = erfc(u / np.sqrt(2))
 q = -np.log2(E)
 w = 0.5 * u * E * np.log(2) + 1e-9
 V = np.vander(u / UMAX, DEG + 1, increasing=True)[:, 1:]
 ww = w.copy()
-for _ in range(60):
+for _ in range(200):
     c, *_ = np.linalg.lstsq(V * ww[:, None], q * ww, rcond=None)
     err = np.abs((V @ c - q) * w)
     ww = ww * (1 + 2 * err / err.max()); ww /= ww.max() / w.max()
 coef = c / (UMAX ** np.arange(1, DEG + 1))
-print("coefficients c1..c6 of q(u) = u*(c1 + c2 u + ... + c6 u^5):")
+print(f"coefficients c1..c{DEG} of q(u) = u*(c1 + c2 u + ...):")
 print(", ".join(f"{v:.9e}f" for v in coef))
 
 x = np.linspace(-9, 9, 600001).astype(np.float32)
