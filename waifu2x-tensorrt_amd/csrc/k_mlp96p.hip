@@ -57,10 +57,10 @@ __device__ __forceinline__ float2v gelu_fast2(float2v x) {
     q = __builtin_elementwise_fma(q, u, splat2(4.589156733e-01f));
     q = __builtin_elementwise_fma(q, u, splat2(1.151147085e+00f));
 #endif
-    const float2v t = q * u;
+    const float2v t = __builtin_elementwise_fma(q, u, splat2(1.f));              // the factor 1/2 rides in the exponent: 0.5 * 2^-qu = 2^-(qu + 1)
     const float2v e = {__builtin_amdgcn_exp2f(-t[0]), __builtin_amdgcn_exp2f(-t[1])};
     const float2v m = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
-    return __builtin_elementwise_fma(splat2(-0.5f) * u, e, m);
+    return __builtin_elementwise_fma(-u, e, m);
 }
 #endif
 __device__ __forceinline__ void sum_sq8(const half8 v, float& s, float& q) {
