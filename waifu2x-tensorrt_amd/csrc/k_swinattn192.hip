@@ -168,11 +168,14 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
     // so a load has RING x 6 (or 3) MFMAs and everything between the products to land.  (Before: two alternating sets of 12
     // registers, 96 VGPRs, which the scheduler partly sank to the consumers anyway.)
     constexpr int RING = 8, NFRAG = 72;
-    const _Float16* wlane = Wqkv + lane * 8;
+    // (through buffer resources: the lane part of a fragment address is lane * 16 for every fragment, the rest is scalar arithmetic -
+    // as global loads each fragment cost a 64-bit vector add)
+    const __amdgpu_buffer_rsrc_t WQ = make_rsrc(Wqkv, 3u * C * C * 2u), WP = make_rsrc(Wproj, (unsigned)C * C * 2u);
+    const unsigned wl16 = lane * 16u;
     auto wfrag = [&](int q) {                   // q = matrix * 12 + k-step * 2 + feature tile
         const int mat = q / 12, j = q - mat * 12, M = mat % 3, ks = j >> 1, ft = j & 1;
         const int H = mat < 3 ? hA : hC;
-        return *(const half8*)(wlane + (size_t)((M * NH + H) * 12 + ft * 6 + ks) * 512);
+        return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(WQ, wl16, (unsigned)((M * NH + H) * 12 + ft * 6 + ks) * 1024u, 0));
     };
     half8 wr[RING];
 #pragma unroll
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
-                for (int ks = 0; ks < 6; ++ks) wp[t][ks] = *(const half8*)(Wproj + (size_t)(((wv * 3 + t) * 6 + ks) * 64 + lane) * 8);
+                for (int ks = 0; ks < 6; ++ks) wp[t][ks] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(WP, wl16, (unsigned)((wv * 3 + t) * 6 + ks) * 1024u, 0));
         }
         float inv[3];
         const float4v bv[2] = {*(const float4v*)(p.bqkv + 2 * C + h * HD + g * 4), *(const float4v*)(p.bqkv + 2 * C + h * HD + 16 + g * 4)};
