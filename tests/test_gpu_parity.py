@@ -453,6 +453,17 @@ def test_fp32_engine_matches_the_fp32_oracle(pkg, onnx_model, model, scale, batc
     r = frame_report(f"frame fp32 [{model} s{scale} B{batch} T{tile}]", out, want)
     assert r["max_lsb"] <= 1 and r["frac_pixels_off_by_1"] < 1e-3, r
     eng.close()
+    if model == "cunet/art" and scale == 2:   # the fp32 tile path with TTA, as two strips
+        eng = pkg.Img2Img()
+        assert eng.load(path, pkg.RenderConfig(precision=pkg.Precision.TF32, batchSize=batch, height=tile, width=tile, scaling=scale, overlap=(0.0625, 0.0625), tta=True)), eng.last_error()
+        small = smooth_frame(70, 130, 5)
+        want = pipeline.render(small, ex.run, batch=batch, tile=tile, scaling=scale, overlap=(0.0625, 0.0625), tta=True)
+        out = np.zeros_like(want)
+        for part in range(2):
+            assert eng.render_strip(small, out, part, 2), eng.last_error()
+        r = frame_report(f"frame fp32 tta strips [{model} s{scale} B{batch} T{tile}]", out, want)
+        assert r["max_lsb"] <= 1 and r["frac_pixels_off_by_1"] < 1e-3, r
+        eng.close()
 
 
 def test_folded_squeeze_excite_gates_equal_the_in_place_pass(pkg, onnx_model, monkeypatch):
