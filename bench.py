@@ -125,6 +125,12 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: refusing to report n_gpus != requested")
 
+    # Rank 0's stdout carries exactly one line, the JSON record: native libraries print there too (gloo announces its peers on
+    # std::cout), so file descriptor 1 points at stderr until that line is written.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import __graft_entry__ as g
     import synth_models as sm
@@ -279,7 +285,8 @@ def main():
         }
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(a.work, threads=min(os.cpu_count() or 1, 32))
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=json_out, flush=True)
+    json_out.close()
     eng.close()
     if dist is not None:
         dist.destroy_process_group()
