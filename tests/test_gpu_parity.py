@@ -482,3 +482,22 @@ def test_folded_squeeze_excite_gates_equal_the_in_place_pass(pkg, onnx_model, mo
         outs.append((eng.infer(x), eng.render(frame)))
         eng.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("model,scale,tile,tta", [("cunet/art", 2, 64, False), ("swin_unet/art", 4, 64, True)])
+def test_two_tile_groups_on_two_streams_are_bit_identical_to_one(pkg, onnx_model, monkeypatch, model, scale, tile, tta):
+    """A pass is cut into two tile groups that run side by side on two streams, each in its own half of the activation arena
+    (engine.cpp run_frame); W2X_NO_SPLIT=1 keeps the pass in one piece.  Tiles never exchange data: same bytes, also through the
+    captured graphs (three renders per engine) and for an odd number of live tiles."""
+    path = onnx_model(model, scale, 2, tile, noise=1)
+    frame = smooth_frame(150, 170, 8)
+    outs = []
+    for nosplit in (True, False):
+        if nosplit: monkeypatch.setenv("W2X_NO_SPLIT", "1")
+        else: monkeypatch.delenv("W2X_NO_SPLIT")
+        eng = make_engine(pkg, path, 2, tile, scale, tta=tta)
+        rs = [eng.render(frame) for _ in range(3)]
+        assert np.array_equal(rs[0], rs[1]) and np.array_equal(rs[0], rs[2])
+        outs.append(rs[0])
+        eng.close()
+    assert np.array_equal(outs[0], outs[1])

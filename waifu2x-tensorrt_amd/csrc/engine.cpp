@@ -187,6 +187,9 @@ struct Img2Img::Impl {
     RenderConfig cfg;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t stream2 = nullptr;       // second tile group of a pass (run_frame)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool split_pass = true;              // W2X_NO_SPLIT: every pass in one piece on one stream
     std::vector<void*> tensors, blobs;   // tensors point into one arena
     std::vector<void*> frag_blobs;       // per blob id: fragment-major copy of a weight matrix (or null)
     std::vector<void*> perm_blobs;       // per blob id: frag_conv3b copy of a 3x3 convolution's weights (or null)
@@ -276,6 +279,9 @@ struct Img2Img::Impl {
         frame_cap = out_cap = slab_cap = slots_cap = 0;
         if (ev0) { (void)hipEventDestroy(ev0); ev0 = nullptr; }
         if (ev1) { (void)hipEventDestroy(ev1); ev1 = nullptr; }
+        if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
+        if (ev_join) { (void)hipEventDestroy(ev_join); ev_join = nullptr; }
+        if (stream2) { (void)hipStreamDestroy(stream2); stream2 = nullptr; }
         if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
         loaded = false;
     }
@@ -337,8 +343,8 @@ struct Img2Img::Impl {
                 for (int t = 0; t < nt; ++t) if (placed[t] == 1 && last[t] == step) { release(off[t], (size_t)plan.tensors[t].bytes()); placed[t] = 2; }
             }
             for (int t = 0; t < nt; ++t) if (!placed[t]) { off[t] = alloc((size_t)plan.tensors[t].bytes()); placed[t] = 1; }   // unused tensors
-            hipAssert(hipMalloc(&arena_base, arena + 256));
-            hipAssert(hipMemsetAsync(arena_base, 0, arena + 256, stream));
+            hipAssert(hipMalloc(&arena_base, arena + 1024));   // slack: vector reads past a table's last row; two half-arenas rounded up to 256 bytes
+            hipAssert(hipMemsetAsync(arena_base, 0, arena + 1024, stream));
             arena_bytes = arena;
             pool_blocks.assign(nt, 0);
         tensors.assign(nt, nullptr);
@@ -432,8 +438,21 @@ struct Img2Img::Impl {
     // one pass of the network over the tiles currently in plan.in_tensor; the last op writes to `out_override`
     // `live` = tiles of this pass that carry image data; the zero-pad slots the reference appends to fill its last batch
     // (img2img_render.cpp:281) are never read back (:298-299), so they are not computed at all.
-    void run_network(void* out_override, int live = -1) {
-        if (live < 0 || live > plan.B) live = plan.B;
+    // `grp` / `s`: the pass may be cut into two tile groups that run side by side on two streams (run_frame).  Tensors with disjoint
+    // lifetimes share arena memory, which only holds while the ops run one after the other - so each group gets its own HALF of the
+    // arena, laid out like the whole one at half the size (a tensor of B tiles at offset o becomes B/2 tiles at o/2): group grp of
+    // up to B/2 tiles runs the plan on arena_base + grp * arena_half.  out_override is the slab address of the group's first tile.
+    size_t arena_half() const { return ((arena_bytes / 2) + 255) / 256 * 256; }
+    uint8_t* group_ptr(const void* full, int grp) const {
+        return full ? (uint8_t*)arena_base + (size_t)grp * arena_half() + (size_t)((const uint8_t*)full - (const uint8_t*)arena_base) / 2 : nullptr;
+    }
+    void run_network(void* out_override, int live = -1, int grp = -1, hipStream_t s = nullptr) {
+        if (!s) s = stream;
+        const int cap = grp < 0 ? plan.B : plan.B / 2;
+        if (live < 0 || live > cap) live = cap;
+        auto tp = [&](int t) -> uint8_t* { return t < 0 ? nullptr : grp < 0 ? (uint8_t*)tensors[t] : group_ptr(tensors[t], grp); };
+        auto shift = [&](const void* ptr, int) -> void* { return group_ptr(ptr, grp); };
+        const int b0 = grp < 0 ? 0 : 1;   // (non-zero: re-address the prepared parameters)
         for (size_t i = 0; i < plan.ops.size(); ++i) {
             const Op& op = plan.ops[i];
             cur_op = (int)i;
@@ -441,10 +460,16 @@ struct Img2Img::Impl {
                 case OP_GEMM: {
                     GemmParams p = gemm[i];
                     p.B = live;
+                    if (b0) {
+                        const GemmOp& g = op.g;
+                        p.a.p = shift(p.a.p, g.a.t); p.res.p = shift(p.res.p, g.res.t); p.res2.p = shift(p.res2.p, g.res2.t); p.out.p = shift(p.out.p, g.out.t);
+                        p.stats_in = (const float*)shift(p.stats_in, g.stats_in); p.stats_out = (float*)shift(p.stats_out, g.stats_out); p.pool_out = (float*)shift(p.pool_out, g.pool_out);
+                        p.a_scale = (const float*)shift(p.a_scale, g.se_scale); p.res_scale = (const float*)shift(p.res_scale, g.res_scale);
+                    }
                     if ((int)i == final_op && out_override) p.out.p = out_override;
                     stamp_begin(0, op.flops);
                     if (op.g.pool_out >= 0) pool_blocks[op.g.pool_out] = plan.elt == 2 && conv3_supported(p) ? conv3_tiles(p) : 0;   // partial sums per image written by this launch (0: plan default)
-                    hipAssert(plan.elt == 4 ? launch_gemm_f32(p, stream) : pixgemm_supported(p) ? launch_pixgemm(p, stream) : conv3_supported(p) ? launch_conv3(p, stream) : conv3h_supported(p) ? launch_conv3h(p, stream) : conv48_supported(p) ? launch_conv48(p, stream) : stem_supported(p) ? launch_stem(p, stream) : launch_gemm(p, stream));
+                    hipAssert(plan.elt == 4 ? launch_gemm_f32(p, s) : pixgemm_supported(p) ? launch_pixgemm(p, s) : conv3_supported(p) ? launch_conv3(p, s) : conv3h_supported(p) ? launch_conv3h(p, s) : conv48_supported(p) ? launch_conv48(p, s) : stem_supported(p) ? launch_stem(p, s) : launch_gemm(p, s));
                     stamp_end();
                     if (check_general && plan.elt == 2 && (pixgemm_supported(p) || conv3_supported(p) || conv3h_supported(p) || conv48_supported(p) || stem_supported(p))) {   // diagnostic: the general kernel must agree
                         const TensorDesc& od = plan.tensors[op.g.out.t];
@@ -481,10 +506,10 @@ struct Img2Img::Impl {
                 case OP_ATTN: {
                     const AttnOp& a = op.at;
                     AttnParams p;
-                    p.qkv = tensors[a.qkv]; p.out = tensors[a.out]; p.B = live; p.nwin = a.nwin; p.heads = a.heads; p.hd = a.hd;
+                    p.qkv = tp(a.qkv); p.out = tp(a.out); p.B = live; p.nwin = a.nwin; p.heads = a.heads; p.hd = a.hd;
                     p.ntok = a.ws * a.ws; p.scale = a.scale; p.bias = blobs[a.bias]; p.maskid = (const int*)blobs[a.maskid];
                     stamp_begin(1, op.flops);
-                    hipAssert(plan.elt == 4 ? launch_attn_f32(p, stream) : launch_attn(p, stream));
+                    hipAssert(plan.elt == 4 ? launch_attn_f32(p, s) : launch_attn(p, s));
                     stamp_end();
                     break;
                 }
@@ -492,14 +517,14 @@ struct Img2Img::Impl {
                     const SwinAttnOp& a = op.sa;
                     const TensorDesc& d = plan.tensors[a.x];
                     SwinAttnParams p;
-                    p.x = tensors[a.x]; p.y = tensors[a.y]; p.table = (const int*)blobs[a.table]; p.H = a.H; p.W = a.W; p.ry = a.ry; p.rx = a.rx; p.B = live; p.nwin = a.nwin; p.C = a.C; p.hd = a.hd;
+                    p.x = tp(a.x); p.y = tp(a.y); p.table = (const int*)blobs[a.table]; p.H = a.H; p.W = a.W; p.ry = a.ry; p.rx = a.rx; p.B = live; p.nwin = a.nwin; p.C = a.C; p.hd = a.hd;
                     p.wqkv = blobs[a.wqkv]; p.bqkv = (const float*)blobs[a.bqkv]; p.scale = a.scale; p.bias32 = (const float*)blobs[a.bias]; p.maskid = (const int*)blobs[a.maskid];
                     p.wproj = blobs[a.wproj]; p.bproj = (const float*)blobs[a.bproj]; p.eps = a.eps;
                     p.wqkv_frag = frag_blobs[a.wqkv]; p.wproj_frag = frag_blobs[a.wproj];
-                    p.stats_out = a.stats_out >= 0 ? (float*)tensors[a.stats_out] : nullptr; p.eps_out = a.eps_out;
+                    p.stats_out = (float*)tp(a.stats_out); p.eps_out = a.eps_out;
                     if (d.C != a.C || plan.tensors[a.y].C != a.C || d.H * d.W != a.nwin * a.ws * a.ws) throw std::runtime_error("plan: attention geometry mismatch");
                     stamp_begin(1, op.flops);
-                    hipAssert(launch_swin_attn(p, stream));
+                    hipAssert(launch_swin_attn(p, s));
                     stamp_end();
                     break;
                 }
@@ -507,31 +532,31 @@ struct Img2Img::Impl {
                     const MlpOp& m = op.m;
                     const TensorDesc& d = plan.tensors[m.x];
                     MlpParams p;
-                    p.x = tensors[m.x]; p.y = tensors[m.y]; p.M = (long)live * d.H * d.W; p.C = m.C;
+                    p.x = tp(m.x); p.y = tp(m.y); p.M = (long)live * d.H * d.W; p.C = m.C;
                     p.w1 = blobs[m.w1]; p.b1 = (const float*)blobs[m.b1]; p.w2 = blobs[m.w2]; p.b2 = (const float*)blobs[m.b2];
                     p.w1_frag = frag_blobs[m.w1]; p.w2_frag = frag_blobs[m.w2];
-                    p.eps = m.eps; p.stats_out = m.stats_out >= 0 ? (float*)tensors[m.stats_out] : nullptr; p.eps_out = m.eps_out;
+                    p.eps = m.eps; p.stats_out = (float*)tp(m.stats_out); p.eps_out = m.eps_out;
                     if (d.C != m.C || plan.tensors[m.y].C != m.C) throw std::runtime_error("plan: MLP width mismatch");
                     stamp_begin(5, op.flops);
-                    hipAssert(launch_mlp(p, stream));
+                    hipAssert(launch_mlp(p, s));
                     stamp_end();
                     break;
                 }
                 case OP_SE: {
-                    const SeOp& s = op.se;
+                    const SeOp& se = op.se;
                     SeParams p;
-                    p.pool = (const float*)tensors[s.pool]; p.scale = (float*)tensors[s.scale]; p.B = live; p.C = s.C;
-                    p.Cs = plan.tensors[s.pool].C; p.Cmid = s.Cmid; p.inv_count = s.inv_count; p.nblocks = pool_blocks[s.pool] > 0 ? pool_blocks[s.pool] : s.nblocks; p.Mrows = s.Mrows;
-                    p.w1 = (const float*)blobs[s.w1]; p.b1 = (const float*)blobs[s.b1]; p.w2 = (const float*)blobs[s.w2]; p.b2 = (const float*)blobs[s.b2];
+                    p.pool = (const float*)tp(se.pool); p.scale = (float*)tp(se.scale); p.B = live; p.C = se.C;
+                    p.Cs = plan.tensors[se.pool].C; p.Cmid = se.Cmid; p.inv_count = se.inv_count; p.nblocks = pool_blocks[se.pool] > 0 ? pool_blocks[se.pool] : se.nblocks; p.Mrows = se.Mrows;
+                    p.w1 = (const float*)blobs[se.w1]; p.b1 = (const float*)blobs[se.b1]; p.w2 = (const float*)blobs[se.w2]; p.b2 = (const float*)blobs[se.b2];
                     stamp_begin(2, 0);
-                    hipAssert(launch_se(p, stream));
+                    hipAssert(launch_se(p, s));
                     stamp_end();
                     break;
                 }
                 case OP_SCALE_ADD: {
                     const TensorDesc& d = plan.tensors[op.se.pool];
                     stamp_begin(2, 0);
-                    hipAssert(launch_scale(tensors[op.se.pool], (const float*)tensors[op.se.scale], live, d.H * d.W, d.C, plan.elt == 4, stream));
+                    hipAssert(launch_scale(tp(op.se.pool), (const float*)tp(op.se.scale), live, d.H * d.W, d.C, plan.elt == 4, s));
                     stamp_end();
                     break;
                 }
@@ -571,10 +596,33 @@ struct Img2Img::Impl {
                 GatherParams gp;
                 gp.frame = d_frame; gp.rows = rows; gp.cols = cols; gp.step = (size_t)cols * 3;
                 gp.out = tensors[plan.in_tensor]; gp.slots = d_slots + (size_t)bi * B; gp.B = B; gp.T = T; gp.fp32 = plan.elt == 4;
-                stamp_begin(3, 0);
-                hipAssert(launch_gather(gp, stream));
-                stamp_end();
-                run_network(slab_out, live);
+                const int nA = (live + 1) / 2;
+                const bool split = split_pass && !profiling && !check_general && !poison && live >= 8 && B % 2 == 0 && nA <= B / 2 && 2 * arena_half() <= arena_bytes + 512;
+                if (!split) {
+                    stamp_begin(3, 0);
+                    hipAssert(launch_gather(gp, stream));
+                    stamp_end();
+                    run_network(slab_out, live);
+                    return;
+                }
+                if (!stream2) {
+                    hipAssert(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+                    hipAssert(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+                    hipAssert(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+                }
+                for (int grp = 0; grp < 2; ++grp) {      // each group's tiles at the start of its half of the arena
+                    gp.out = group_ptr(tensors[plan.in_tensor], grp); gp.slots = d_slots + (size_t)bi * B + (size_t)grp * nA; gp.B = grp ? live - nA : nA;
+                    hipAssert(launch_gather(gp, stream));
+                }
+                // Two tile groups side by side: tiles never exchange data, so the second half of the pass runs the same launches on
+                // a second stream in its own half of the arena.  Each kernel then has half the workgroups, but a kernel's ramp and
+                // tail (and the gaps between launches) fill with the other group's work.  Bit-identical by construction.
+                hipAssert(hipEventRecord(ev_fork, stream));
+                hipAssert(hipStreamWaitEvent(stream2, ev_fork, 0));
+                run_network(slab_out, nA, 0, stream);
+                run_network((uint8_t*)slab_out + (size_t)nA * slot_bytes, live - nA, 1, stream2);
+                hipAssert(hipEventRecord(ev_join, stream2));
+                hipAssert(hipStreamWaitEvent(stream, ev_join, 0));
             };
             if (!graphable) run_pass();
             else {
@@ -762,6 +810,7 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
     hipAssert(hipStreamCreateWithFlags(&impl->stream, hipStreamNonBlocking));   // :206
     hipAssert(hipEventCreate(&impl->ev0));
     hipAssert(hipEventCreate(&impl->ev1));
+    impl->split_pass = getenv("W2X_NO_SPLIT") == nullptr;   // (the second stream is created by the first pass that splits)
     try {
         impl->upload_plan();                                                      // :225-248
     } catch (const std::exception& e) {
