@@ -187,9 +187,9 @@ struct Img2Img::Impl {
     RenderConfig cfg;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipStream_t stream2 = nullptr;       // second tile group of a pass (run_frame)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool split_pass = true;              // W2X_NO_SPLIT: every pass in one piece on one stream
+    hipStream_t gstream[3] = {nullptr, nullptr, nullptr};   // further tile groups of a pass (run_frame)
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    int groups = 2;                      // W2X_GROUPS (1..4; W2X_NO_SPLIT = 1): tile groups a pass is cut into
     std::vector<void*> tensors, blobs;   // tensors point into one arena
     std::vector<void*> frag_blobs;       // per blob id: fragment-major copy of a weight matrix (or null)
     std::vector<void*> perm_blobs;       // per blob id: frag_conv3b copy of a 3x3 convolution's weights (or null)
@@ -280,8 +280,8 @@ struct Img2Img::Impl {
         if (ev0) { (void)hipEventDestroy(ev0); ev0 = nullptr; }
         if (ev1) { (void)hipEventDestroy(ev1); ev1 = nullptr; }
         if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
-        if (ev_join) { (void)hipEventDestroy(ev_join); ev_join = nullptr; }
-        if (stream2) { (void)hipStreamDestroy(stream2); stream2 = nullptr; }
+        for (hipEvent_t& e : ev_join) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        for (hipStream_t& st : gstream) if (st) { (void)hipStreamDestroy(st); st = nullptr; }
         if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
         loaded = false;
     }
@@ -320,7 +320,7 @@ struct Img2Img::Impl {
             std::vector<Block> free_list;
             std::vector<size_t> off(nt, 0);
             size_t arena = 0;
-            auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+            auto align = [](size_t v) { return (v + 3071) / 3072 * 3072; };   // 256 bytes x 12: offsets stay 256-byte aligned when the arena is cut into 2, 3 or 4 group parts (run_network)
             auto alloc = [&](size_t bytes) -> size_t {
                 bytes = align(bytes);
                 int best = -1;
@@ -343,7 +343,7 @@ struct Img2Img::Impl {
                 for (int t = 0; t < nt; ++t) if (placed[t] == 1 && last[t] == step) { release(off[t], (size_t)plan.tensors[t].bytes()); placed[t] = 2; }
             }
             for (int t = 0; t < nt; ++t) if (!placed[t]) { off[t] = alloc((size_t)plan.tensors[t].bytes()); placed[t] = 1; }   // unused tensors
-            hipAssert(hipMalloc(&arena_base, arena + 1024));   // slack: vector reads past a table's last row; two half-arenas rounded up to 256 bytes
+            hipAssert(hipMalloc(&arena_base, arena + 1024));   // slack: vector reads past a table's last row; the group parts rounded up to 256 bytes
             hipAssert(hipMemsetAsync(arena_base, 0, arena + 1024, stream));
             arena_bytes = arena;
             pool_blocks.assign(nt, 0);
@@ -438,17 +438,19 @@ struct Img2Img::Impl {
     // one pass of the network over the tiles currently in plan.in_tensor; the last op writes to `out_override`
     // `live` = tiles of this pass that carry image data; the zero-pad slots the reference appends to fill its last batch
     // (img2img_render.cpp:281) are never read back (:298-299), so they are not computed at all.
-    // `grp` / `s`: the pass may be cut into two tile groups that run side by side on two streams (run_frame).  Tensors with disjoint
-    // lifetimes share arena memory, which only holds while the ops run one after the other - so each group gets its own HALF of the
-    // arena, laid out like the whole one at half the size (a tensor of B tiles at offset o becomes B/2 tiles at o/2): group grp of
-    // up to B/2 tiles runs the plan on arena_base + grp * arena_half.  out_override is the slab address of the group's first tile.
-    size_t arena_half() const { return ((arena_bytes / 2) + 255) / 256 * 256; }
+    // `grp` / `s`: the pass may be cut into NG tile groups that run side by side on NG streams (run_frame).  Tensors with disjoint
+    // lifetimes share arena memory, which only holds while the ops run one after the other - so each group gets its own PART of the
+    // arena, laid out like the whole one at 1/NG of the size (a tensor of B tiles at offset o becomes B/NG tiles at o/NG; offsets are
+    // multiples of 3072 bytes): group grp of up to B/NG tiles runs the plan on arena_base + grp * arena_part.  out_override is the
+    // slab address of the group's first tile.
+    int ng_now = 1;                      // NG of the pass being issued
+    size_t arena_part() const { return ((arena_bytes / ng_now) + 255) / 256 * 256; }
     uint8_t* group_ptr(const void* full, int grp) const {
-        return full ? (uint8_t*)arena_base + (size_t)grp * arena_half() + (size_t)((const uint8_t*)full - (const uint8_t*)arena_base) / 2 : nullptr;
+        return full ? (uint8_t*)arena_base + (size_t)grp * arena_part() + (size_t)((const uint8_t*)full - (const uint8_t*)arena_base) / ng_now : nullptr;
     }
     void run_network(void* out_override, int live = -1, int grp = -1, hipStream_t s = nullptr) {
         if (!s) s = stream;
-        const int cap = grp < 0 ? plan.B : plan.B / 2;
+        const int cap = grp < 0 ? plan.B : plan.B / ng_now;
         if (live < 0 || live > cap) live = cap;
         auto tp = [&](int t) -> uint8_t* { return t < 0 ? nullptr : grp < 0 ? (uint8_t*)tensors[t] : group_ptr(tensors[t], grp); };
         auto shift = [&](const void* ptr, int) -> void* { return group_ptr(ptr, grp); };
@@ -596,33 +598,40 @@ struct Img2Img::Impl {
                 GatherParams gp;
                 gp.frame = d_frame; gp.rows = rows; gp.cols = cols; gp.step = (size_t)cols * 3;
                 gp.out = tensors[plan.in_tensor]; gp.slots = d_slots + (size_t)bi * B; gp.B = B; gp.T = T; gp.fp32 = plan.elt == 4;
-                const int nA = (live + 1) / 2;
-                const bool split = split_pass && !profiling && !check_general && !poison && live >= 8 && B % 2 == 0 && nA <= B / 2 && 2 * arena_half() <= arena_bytes + 512;
+                const int NG = groups;
+                ng_now = NG;
+                const bool split = NG > 1 && !profiling && !check_general && !poison && live >= 4 * NG && B % NG == 0 && (size_t)NG * arena_part() <= arena_bytes + 1024;
                 if (!split) {
+                    ng_now = 1;
                     stamp_begin(3, 0);
                     hipAssert(launch_gather(gp, stream));
                     stamp_end();
                     run_network(slab_out, live);
                     return;
                 }
-                if (!stream2) {
-                    hipAssert(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
-                    hipAssert(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-                    hipAssert(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+                if (!ev_fork) hipAssert(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+                for (int k = 0; k + 1 < NG; ++k) if (!gstream[k]) {
+                    hipAssert(hipStreamCreateWithFlags(&gstream[k], hipStreamNonBlocking));
+                    hipAssert(hipEventCreateWithFlags(&ev_join[k], hipEventDisableTiming));
                 }
-                for (int grp = 0; grp < 2; ++grp) {      // each group's tiles at the start of its half of the arena
-                    gp.out = group_ptr(tensors[plan.in_tensor], grp); gp.slots = d_slots + (size_t)bi * B + (size_t)grp * nA; gp.B = grp ? live - nA : nA;
+                // NG tile groups side by side: tiles never exchange data, so the groups run the same launches on their own streams in
+                // their own parts of the arena.  Each kernel then has 1/NG of the workgroups, but a kernel's ramp and tail (and the
+                // gaps between launches) fill with the other groups' work.  Bit-identical by construction.
+                int first[5] = {0, 0, 0, 0, 0};
+                for (int grp = 0; grp < NG; ++grp) first[grp + 1] = first[grp] + live / NG + (grp < live % NG ? 1 : 0);
+                for (int grp = 0; grp < NG; ++grp) {      // each group's tiles at the start of its part of the arena
+                    gp.out = group_ptr(tensors[plan.in_tensor], grp); gp.slots = d_slots + (size_t)bi * B + (size_t)first[grp]; gp.B = first[grp + 1] - first[grp];
                     hipAssert(launch_gather(gp, stream));
                 }
-                // Two tile groups side by side: tiles never exchange data, so the second half of the pass runs the same launches on
-                // a second stream in its own half of the arena.  Each kernel then has half the workgroups, but a kernel's ramp and
-                // tail (and the gaps between launches) fill with the other group's work.  Bit-identical by construction.
                 hipAssert(hipEventRecord(ev_fork, stream));
-                hipAssert(hipStreamWaitEvent(stream2, ev_fork, 0));
-                run_network(slab_out, nA, 0, stream);
-                run_network((uint8_t*)slab_out + (size_t)nA * slot_bytes, live - nA, 1, stream2);
-                hipAssert(hipEventRecord(ev_join, stream2));
-                hipAssert(hipStreamWaitEvent(stream, ev_join, 0));
+                for (int grp = 1; grp < NG; ++grp) hipAssert(hipStreamWaitEvent(gstream[grp - 1], ev_fork, 0));
+                for (int grp = 0; grp < NG; ++grp)
+                    run_network((uint8_t*)slab_out + (size_t)first[grp] * slot_bytes, first[grp + 1] - first[grp], grp, grp ? gstream[grp - 1] : stream);
+                for (int grp = 1; grp < NG; ++grp) {
+                    hipAssert(hipEventRecord(ev_join[grp - 1], gstream[grp - 1]));
+                    hipAssert(hipStreamWaitEvent(stream, ev_join[grp - 1], 0));
+                }
+                ng_now = 1;
             };
             if (!graphable) run_pass();
             else {
@@ -810,7 +819,7 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
     hipAssert(hipStreamCreateWithFlags(&impl->stream, hipStreamNonBlocking));   // :206
     hipAssert(hipEventCreate(&impl->ev0));
     hipAssert(hipEventCreate(&impl->ev1));
-    impl->split_pass = getenv("W2X_NO_SPLIT") == nullptr;   // (the second stream is created by the first pass that splits)
+    impl->groups = getenv("W2X_NO_SPLIT") ? 1 : getenv("W2X_GROUPS") ? std::min(4, std::max(1, atoi(getenv("W2X_GROUPS")))) : 2;   // (the extra streams are created by the first pass that splits)
     try {
         impl->upload_plan();                                                      // :225-248
     } catch (const std::exception& e) {
