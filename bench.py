@@ -252,6 +252,7 @@ def main():
                 "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tflops / MFMA_F16_PEAK_TFLOPS), 5), "traffic": None,
                 "kernel": symbols.get(dom, "gemm_kernel / pixgemm kernels" if dom[0] == "gemm" else dom[0]),
                 "launches_per_frame": dom_n, "avg_launch_us": round(dom_ms * 1e3 / dom_n, 2),
+                "launch_note": "HIP events around each launch with every pass in one piece on one stream (the engine's profiling pass, = W2X_NO_SPLIT=1: a launch covers all live tiles); the timed region of `value` runs each pass as two tile groups on two streams",
                 "algorithmic_gflop_per_launch": round(dom_flop / dom_n / 1e9, 3),
                 "algorithmic_mbyte_per_launch": round(dom_bytes / dom_n / 1e6, 3),
                 "other_roof": {"unit": "TFLOP/s" if hbm_bound else "GB/s", "achieved": round(tflops if hbm_bound else gbs, 2),
