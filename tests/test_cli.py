@@ -86,6 +86,28 @@ def test_builtin_png_and_ppm_codecs_round_trip(tmp_path):
         im.save(tmp_path / f"{name}.png")
         assert run("convert", "-i", str(tmp_path / f"{name}.png"), "-o", str(tmp_path / f"{name}_o.png")).returncode == 0, name
         assert np.array_equal(np.array(Image.open(tmp_path / f"{name}_o.png")), np.array(Image.open(tmp_path / f"{name}.png").convert("RGB"))), name
+    # 16-bit samples (gray, RGB, RGB + alpha; rows filtered with Sub so the two-byte pixel stride is exercised): the decoder keeps
+    # the high byte, as cv::imread(IMREAD_COLOR) does for the reference (libpng strip_16)
+    import struct, zlib
+    def png16(path, arr16):                  # arr16: [h, w, ch] uint16, ch in {1, 3, 4}
+        h, w, ch = arr16.shape
+        ctype = {1: 0, 3: 2, 4: 6}[ch]
+        be = arr16.astype(">u2").tobytes()
+        stride, bpp = w * ch * 2, ch * 2
+        raw = bytearray()
+        for y in range(h):
+            line = np.frombuffer(be[y * stride:(y + 1) * stride], np.uint8).astype(np.int32)
+            left = np.concatenate([np.zeros(bpp, np.int32), line[:-bpp]])
+            raw += b"\x01" + ((line - left) & 255).astype(np.uint8).tobytes()
+        def chunk(t, body): return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body))
+        open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, ctype, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b""))
+    for ch in (1, 3, 4):
+        a16 = rng.integers(0, 65536, (19, 23, ch), dtype=np.uint16)
+        png16(tmp_path / f"deep{ch}.png", a16)
+        assert run("convert", "-i", str(tmp_path / f"deep{ch}.png"), "-o", str(tmp_path / f"deep{ch}_o.png")).returncode == 0, ch
+        want = (a16 >> 8).astype(np.uint8)
+        want = np.repeat(want, 3, axis=2) if ch == 1 else want[..., :3]
+        assert np.array_equal(np.array(Image.open(tmp_path / f"deep{ch}_o.png")), want), ch
     r = run("convert", "-i", str(tmp_path / "missing.png"), "-o", str(tmp_path / "x.png"))
     assert r.returncode != 0 and "cannot open" in r.stderr
 

@@ -47,10 +47,13 @@ Bitmap read_png(const std::vector<uint8_t>& d, const std::string& path) {
     }
     if (w <= 0 || h <= 0) throw std::runtime_error(path + ": PNG without IHDR");
     const bool packed = depth < 8 && (ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4);   // sub-byte gray / palette
-    if ((depth != 8 && !packed) || interlace) throw std::runtime_error(path + ": only 1..8-bit non-interlaced PNG is built in (use ffmpeg for the rest)");
+    // 16-bit samples keep their high byte, what cv::imread(IMREAD_COLOR) hands the reference (libpng strip_16); alpha is dropped
+    const bool wide = depth == 16 && ctype != 3;
+    if ((depth != 8 && !packed && !wide) || interlace) throw std::runtime_error(path + ": only non-interlaced PNG is built in (use ffmpeg for the rest)");
     const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!ch) throw std::runtime_error(path + ": unsupported PNG colour type");
-    const size_t stride = packed ? ((size_t)w * depth + 7) / 8 : (size_t)w * ch;
+    const int bps = wide ? 2 : 1, bpp = ch * bps;                    // bytes per sample / per pixel (the filters' left neighbour)
+    const size_t stride = packed ? ((size_t)w * depth + 7) / 8 : (size_t)w * bpp;
     std::vector<uint8_t> raw((stride + 1) * h);
     uLongf rawlen = raw.size();
     if (uncompress(raw.data(), &rawlen, idat.data(), idat.size()) != Z_OK || rawlen != raw.size()) throw std::runtime_error(path + ": PNG data does not inflate");
@@ -60,7 +63,7 @@ Bitmap read_png(const std::vector<uint8_t>& d, const std::string& path) {
         const uint8_t* line = &raw[(stride + 1) * y];
         const int ft = line[0];
         for (size_t i = 0; i < stride; ++i) {
-            const int a = i >= (size_t)ch ? cur[i - ch] : 0, up = prev[i], c = i >= (size_t)ch ? prev[i - ch] : 0, x = line[1 + i];
+            const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, up = prev[i], c = i >= (size_t)bpp ? prev[i - bpp] : 0, x = line[1 + i];
             int v;
             switch (ft) { case 0: v = x; break; case 1: v = x + a; break; case 2: v = x + up; break; case 3: v = x + ((a + up) >> 1); break; case 4: v = x + paeth(a, up, c); break;
                           default: throw std::runtime_error(path + ": bad PNG filter"); }
@@ -72,9 +75,9 @@ Bitmap read_png(const std::vector<uint8_t>& d, const std::string& path) {
             uint8_t sample = 0;
             if (packed) { const int per = 8 / depth, sh = (per - 1 - x % per) * depth; sample = (cur[x / per] >> sh) & ((1 << depth) - 1); }
             if (ctype == 0 && packed) r = g = bl = (uint8_t)(sample * 255 / ((1 << depth) - 1));
-            else if (ctype == 0 || ctype == 4) r = g = bl = cur[(size_t)x * ch];
+            else if (ctype == 0 || ctype == 4) r = g = bl = cur[(size_t)x * bpp];
             else if (ctype == 3) { const size_t k = (size_t)(packed ? sample : cur[x]) * 3; if (k + 3 > plte.size()) throw std::runtime_error(path + ": palette index out of range"); r = plte[k]; g = plte[k + 1]; bl = plte[k + 2]; }
-            else { r = cur[(size_t)x * ch]; g = cur[(size_t)x * ch + 1]; bl = cur[(size_t)x * ch + 2]; }
+            else { r = cur[(size_t)x * bpp]; g = cur[(size_t)x * bpp + bps]; bl = cur[(size_t)x * bpp + 2 * bps]; }
             o[3 * x] = bl; o[3 * x + 1] = g; o[3 * x + 2] = r;
         }
         prev.swap(cur);
