@@ -108,6 +108,22 @@ def test_builtin_png_and_ppm_codecs_round_trip(tmp_path):
         want = (a16 >> 8).astype(np.uint8)
         want = np.repeat(want, 3, axis=2) if ch == 1 else want[..., :3]
         assert np.array_equal(np.array(Image.open(tmp_path / f"deep{ch}_o.png")), want), ch
+    # Adam7-interlaced files (PIL cannot write them: built here from the seven sub-images, filter None)
+    def png_adam7(path, arr8):               # arr8: [h, w, 3] uint8
+        h, w, _ = arr8.shape
+        raw = bytearray()
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = arr8[y0::dy, x0::dx]
+            if sub.size:
+                for row in sub: raw += b"\x00" + row.tobytes()
+        def chunk(t, body): return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body))
+        open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b""))
+    for shape in ((37, 53, 3), (3, 2, 3), (9, 1, 3)):
+        ai = rng.integers(0, 256, shape, dtype=np.uint8)
+        png_adam7(tmp_path / "ilace.png", ai)
+        assert np.array_equal(np.array(Image.open(tmp_path / "ilace.png")), ai)          # the file is what PIL reads as the same image
+        assert run("convert", "-i", str(tmp_path / "ilace.png"), "-o", str(tmp_path / "ilace_o.png")).returncode == 0, shape
+        assert np.array_equal(np.array(Image.open(tmp_path / "ilace_o.png")), ai), shape
     r = run("convert", "-i", str(tmp_path / "missing.png"), "-o", str(tmp_path / "x.png"))
     assert r.returncode != 0 and "cannot open" in r.stderr
 

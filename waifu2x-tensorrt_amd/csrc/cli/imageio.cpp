@@ -47,40 +47,59 @@ Bitmap read_png(const std::vector<uint8_t>& d, const std::string& path) {
     }
     if (w <= 0 || h <= 0) throw std::runtime_error(path + ": PNG without IHDR");
     const bool packed = depth < 8 && (ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4);   // sub-byte gray / palette
-    // 16-bit samples keep their high byte, what cv::imread(IMREAD_COLOR) hands the reference (libpng strip_16); alpha is dropped
+    // 16-bit samples keep their high byte, what cv::imread(IMREAD_COLOR) hands the reference (libpng strip_16); alpha is dropped;
+    // Adam7-interlaced files are seven sub-images, each filtered on its own
     const bool wide = depth == 16 && ctype != 3;
-    if ((depth != 8 && !packed && !wide) || interlace) throw std::runtime_error(path + ": only non-interlaced PNG is built in (use ffmpeg for the rest)");
+    if ((depth != 8 && !packed && !wide) || interlace > 1) throw std::runtime_error(path + ": unsupported PNG bit depth / interlace method");
     const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!ch) throw std::runtime_error(path + ": unsupported PNG colour type");
     const int bps = wide ? 2 : 1, bpp = ch * bps;                    // bytes per sample / per pixel (the filters' left neighbour)
-    const size_t stride = packed ? ((size_t)w * depth + 7) / 8 : (size_t)w * bpp;
-    std::vector<uint8_t> raw((stride + 1) * h);
+    struct Pass { int x0, y0, dx, dy; };
+    static const Pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    static const Pass whole = {0, 0, 1, 1};
+    const int npass = interlace ? 7 : 1;
+    auto pass_dims = [&](const Pass& ps, int& pw, int& ph, size_t& stride) {
+        pw = (w - ps.x0 + ps.dx - 1) / ps.dx; ph = (h - ps.y0 + ps.dy - 1) / ps.dy;
+        if (pw < 0) pw = 0;
+        if (ph < 0) ph = 0;
+        stride = packed ? ((size_t)pw * depth + 7) / 8 : (size_t)pw * bpp;
+    };
+    size_t total = 0;
+    for (int k = 0; k < npass; ++k) { int pw, ph; size_t st; pass_dims(interlace ? adam7[k] : whole, pw, ph, st); if (pw && ph) total += (st + 1) * ph; }
+    std::vector<uint8_t> raw(total);
     uLongf rawlen = raw.size();
     if (uncompress(raw.data(), &rawlen, idat.data(), idat.size()) != Z_OK || rawlen != raw.size()) throw std::runtime_error(path + ": PNG data does not inflate");
-    std::vector<uint8_t> prev(stride, 0), cur(stride);
     Bitmap b; b.rows = h; b.cols = w; b.bgr.resize((size_t)w * h * 3);
-    for (int y = 0; y < h; ++y) {
-        const uint8_t* line = &raw[(stride + 1) * y];
-        const int ft = line[0];
-        for (size_t i = 0; i < stride; ++i) {
-            const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, up = prev[i], c = i >= (size_t)bpp ? prev[i - bpp] : 0, x = line[1 + i];
-            int v;
-            switch (ft) { case 0: v = x; break; case 1: v = x + a; break; case 2: v = x + up; break; case 3: v = x + ((a + up) >> 1); break; case 4: v = x + paeth(a, up, c); break;
-                          default: throw std::runtime_error(path + ": bad PNG filter"); }
-            cur[i] = (uint8_t)v;
+    size_t at = 0;
+    for (int k = 0; k < npass; ++k) {
+        const Pass& ps = interlace ? adam7[k] : whole;
+        int pw, ph; size_t stride;
+        pass_dims(ps, pw, ph, stride);
+        if (!pw || !ph) continue;
+        std::vector<uint8_t> prev(stride, 0), cur(stride);
+        for (int y = 0; y < ph; ++y) {
+            const uint8_t* line = &raw[at]; at += stride + 1;
+            const int ft = line[0];
+            for (size_t i = 0; i < stride; ++i) {
+                const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, up = prev[i], c = i >= (size_t)bpp ? prev[i - bpp] : 0, x = line[1 + i];
+                int v;
+                switch (ft) { case 0: v = x; break; case 1: v = x + a; break; case 2: v = x + up; break; case 3: v = x + ((a + up) >> 1); break; case 4: v = x + paeth(a, up, c); break;
+                              default: throw std::runtime_error(path + ": bad PNG filter"); }
+                cur[i] = (uint8_t)v;
+            }
+            for (int x = 0; x < pw; ++x) {
+                uint8_t r, g, bl;
+                uint8_t sample = 0;
+                if (packed) { const int per = 8 / depth, sh = (per - 1 - x % per) * depth; sample = (cur[x / per] >> sh) & ((1 << depth) - 1); }
+                if (ctype == 0 && packed) r = g = bl = (uint8_t)(sample * 255 / ((1 << depth) - 1));
+                else if (ctype == 0 || ctype == 4) r = g = bl = cur[(size_t)x * bpp];
+                else if (ctype == 3) { const size_t kk = (size_t)(packed ? sample : cur[x]) * 3; if (kk + 3 > plte.size()) throw std::runtime_error(path + ": palette index out of range"); r = plte[kk]; g = plte[kk + 1]; bl = plte[kk + 2]; }
+                else { r = cur[(size_t)x * bpp]; g = cur[(size_t)x * bpp + bps]; bl = cur[(size_t)x * bpp + 2 * bps]; }
+                uint8_t* o = &b.bgr[((size_t)(ps.y0 + y * ps.dy) * w + ps.x0 + x * ps.dx) * 3];
+                o[0] = bl; o[1] = g; o[2] = r;
+            }
+            prev.swap(cur);
         }
-        uint8_t* o = &b.bgr[(size_t)y * w * 3];
-        for (int x = 0; x < w; ++x) {
-            uint8_t r, g, bl;
-            uint8_t sample = 0;
-            if (packed) { const int per = 8 / depth, sh = (per - 1 - x % per) * depth; sample = (cur[x / per] >> sh) & ((1 << depth) - 1); }
-            if (ctype == 0 && packed) r = g = bl = (uint8_t)(sample * 255 / ((1 << depth) - 1));
-            else if (ctype == 0 || ctype == 4) r = g = bl = cur[(size_t)x * bpp];
-            else if (ctype == 3) { const size_t k = (size_t)(packed ? sample : cur[x]) * 3; if (k + 3 > plte.size()) throw std::runtime_error(path + ": palette index out of range"); r = plte[k]; g = plte[k + 1]; bl = plte[k + 2]; }
-            else { r = cur[(size_t)x * bpp]; g = cur[(size_t)x * bpp + bps]; bl = cur[(size_t)x * bpp + 2 * bps]; }
-            o[3 * x] = bl; o[3 * x + 1] = g; o[3 * x + 2] = r;
-        }
-        prev.swap(cur);
     }
     return b;
 }
