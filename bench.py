@@ -281,6 +281,7 @@ def main():
                        "full_path_mpix_per_s": None if full_wall_max is None else round(a.steps * world / full_wall_max * OUT_MPIX, 2),
                        "full_path_note": "host frame in -> host frame out for all K frames on every rank (renderSequence over engine-allocated page-locked buffers, H2D/D2H on side streams); max over ranks",
                        "tiles_per_network_pass": eng.pass_tiles,
+                       "tile_groups_per_pass": 1 if os.environ.get("W2X_NO_SPLIT") else int(os.environ.get("W2X_GROUPS", "2")),
                        "algorithmic_tflop_per_frame": round(eng.plan_flops * live / 1e12, 4),
                        "families_ms_per_frame": {k: round(v[0], 3) for k, v in prof.items() if k != "frame_ms"}},
             "roofline": roof,
