@@ -1,5 +1,5 @@
 """Generates the end-to-end golden vectors in this directory with the oracle (fp32 network, fp16 engine boundary):
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [case ...]
 Inputs are seeded; the graphs are the synthetic-weight exports of tools/synth_models.py (seed 1234+noise).
 The reference itself cannot produce vectors here (TensorRT/OpenCV-CUDA absent, no ONNX weights: SURVEY.md 8c)."""
 import os
@@ -18,6 +18,9 @@ CASES = [
     ("cunet_s2", "cunet/art", 2, 0, False, 1, 64, (64, 80), 0.0625, False),
     ("swin_s4", "swin_unet/art", 4, 3, True, 2, 64, (50, 70), 0.0625, False),
     ("swin_s2_tta", "swin_unet/art", 2, 1, True, 4, 40, (30, 44), 0.125, True),
+    # full-width graphs (96 / 192 channels): the fused attention / MLP / projection kernels of the benchmark
+    ("swin_full_s4", "swin_unet/art", 4, 3, False, 2, 64, (50, 70), 0.0625, False),
+    ("swin_full_s2_tta", "swin_unet/photo", 2, 1, False, 4, 64, (40, 60), 0.125, True),
 ]
 
 
@@ -33,6 +36,8 @@ def main():
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:
         for name, model, scale, noise, small, batch, tile, shape, ov, tta in CASES:
+            if len(sys.argv) > 1 and name not in sys.argv[1:]:
+                continue
             path = sm.model_path(os.path.join(tmp, name), model, scale, noise)
             sm.export_onnx(sm.make_model(model, scale, seed=1234 + noise, small=small), path, batch, tile)
             frame = frame_for(name, shape)

@@ -46,7 +46,10 @@ def test_hip_engine_matches_golden(f, onnx_model, pkg):
     assert eng.load(path, pkg.RenderConfig(batchSize=c["batch"], height=c["tile"], width=c["tile"], scaling=c["scale"],
                                            overlap=(c["ov"], c["ov"]), tta=c["tta"])), eng.last_error()
     out = eng.render(c["frame"])
-    d = np.abs(out.astype(int) - c["expected"].astype(int))
-    # tolerance: north_star asks PSNR > 50 dB against the reference-semantics output; fp16 network => <= 2 LSB per pixel
-    assert psnr(out, c["expected"]) > 50.0 and d.max() <= 2, (psnr(out, c["expected"]), d.max())
+    from parity_util import frame_report
+    r = frame_report(f"golden {os.path.basename(f)} (expected = oracle pipeline around the fp32 network)", out, c["expected"])
+    # The expected frames come from the FP32 network (only the engine boundary is rounded to fp16), so this is the fp16 engine's
+    # distance from fp32 arithmetic, not from a model of itself.  north_star: PSNR > 50 dB.  Full-width graphs (the fused kernels of
+    # the benchmark) and cunet: <= 1 LSB; the 48-channel graphs (un-fused path, one more fp16 rounding per operator): <= 2 LSB.
+    assert r["psnr_db"] > 50.0 and r["max_lsb"] <= (2 if c["small"] else 1), r
     eng.close()

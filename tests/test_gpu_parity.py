@@ -3,11 +3,12 @@
 Tolerances, stated here and asserted below (units: tests/parity_util.py; every comparison is printed and recorded):
   * network output [B,3,T',T'] against the oracle in fp16-boundary mode (an fp16 engine modelled layer by layer):
     max |d| <= NET_MAX_ULP16 fp16 ULPs of the output range (2^-11), mean |d| <= NET_MEAN_ABS; against the fp32 oracle the
-    same run is recorded (it adds the fp16 model's own distance from fp32, ~2 ULP).  Measured in round 2: see
-    profiles/r2_*/parity.jsonl; the bounds sit one ULP above the largest figure measured.
+    same run is asserted too (NET_MAX_ULP16_VS_FP32), so the bound does not rest on a model of the engine alone.  Measured: see
+    profiles/r*_*/parity.jsonl; each bound sits 0.5-1 ULP above the largest figure measured for its path.
   * frames (u8) against the oracle pipeline with the fp16-boundary network: <= FRAME_MAX_LSB, PSNR > 50 dB;
-  * everything that is integer / byte work (tile order, padding, TTA index maps, blend masks, u8 rounding) is bit-exact:
-    batch-size, super-batch, strip, sequence, graph-replay and poison tests compare with == on bytes."""
+  * everything that is integer / byte work (tile order, padding, TTA index maps, blend masks, u8 rounding) is bit-exact
+    AGAINST THE ORACLE in tests/test_gpu_pipeline_bytes.py (the oracle pipeline around the engine's own network == render());
+    the batch-size, super-batch, strip, sequence, graph-replay and poison tests here compare engine renders with == on bytes."""
 import os
 import threading
 
@@ -16,11 +17,13 @@ import pytest
 
 import synth_models as sm
 from oracle import onnx_exec, pipeline
-from parity_util import ULP16, frame_report, network_report, psnr
+from parity_util import BLOCK_MEAN_TOL, ULP16, check_config_fixture, frame_report, network_report, psnr, smooth_frame  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
-NET_MAX_ULP16 = 3.0      # fp16 ULPs of [0.5, 1) = 2^-11 each; measured 2.0 on every graph (profiles/r2_final/parity.jsonl), north_star asks 1 against TensorRT itself
+NET_MAX_ULP16 = 3.0      # fp16 ULPs of [0.5, 1) = 2^-11 each, fused kernels (full-width graphs, cunet); measured 1.0-2.25 (profiles/r2_final/parity.jsonl), north_star asks 1 against TensorRT itself
+NET_MAX_ULP16_UNFUSED = 3.5   # the un-fused operator path (48-channel graphs, W2X_NO_FUSE_ATTN): one more fp16 rounding per operator; measured 2.5-3.0
+NET_MAX_ULP16_VS_FP32 = 3.3   # the same outputs against the FP32 oracle (no model of the engine's rounding points in between); measured 1.0-2.31
 NET_MEAN_ABS = 2.2e-4    # measured <= 1.7e-4
 FRAME_MAX_LSB = 1        # u8; measured 1 on every case
 
@@ -34,13 +37,6 @@ def make_engine(pkg, path, batch, tile, scale, **kw):
     assert eng.build(path, pkg.BuildConfig.fixed(batch, tile)), eng.last_error()
     assert eng.load(path, pkg.RenderConfig(batchSize=batch, height=tile, width=tile, scaling=scale, **kw)), eng.last_error()
     return eng
-
-
-def smooth_frame(rows, cols, seed):
-    rng = np.random.default_rng(seed)
-    yy, xx = np.mgrid[0:rows, 0:cols]
-    img = 120 + 70 * np.sin(xx / 11.0 + seed) * np.cos(yy / 9.0) + 30 * np.sin((xx + yy) / 23.0)
-    return np.clip(img[..., None] + rng.integers(-6, 7, (rows, cols, 3)), 0, 255).astype(np.uint8)
 
 
 @pytest.mark.parametrize("model,scale,batch,tile,small", [
@@ -60,7 +56,9 @@ def test_network_matches_oracle(pkg, onnx_model, model, scale, batch, tile, smal
     ref16 = oracle16(path)(x)
     assert not np.isnan(y).any()
     r = network_report(f"network[{model} s{scale} B{batch} T{tile} {'small' if small else 'full'}]", y, ref16, ref32)
-    assert r["max_ulp16"] <= NET_MAX_ULP16 and r["mean_abs"] <= NET_MEAN_ABS, r
+    assert r["max_ulp16"] <= (NET_MAX_ULP16_UNFUSED if small else NET_MAX_ULP16) and r["mean_abs"] <= NET_MEAN_ABS, r
+    # and against fp32 arithmetic itself: a loss of accuracy that the fp16-boundary oracle happens to share would still fail here
+    assert r["max_ulp16_vs_fp32_oracle"] <= NET_MAX_ULP16_VS_FP32 and r["mean_abs_vs_fp32_oracle"] <= NET_MEAN_ABS, r
     # batch items are independent: same tile in slot 0 and slot B-1 gives the same bytes
     if batch > 1:
         x2 = np.repeat(x[:1], batch, axis=0)
@@ -137,7 +135,7 @@ def test_unfused_attention_core_on_full_width_graphs(pkg, onnx_model, monkeypatc
     x = rng.random((1, 3, 64, 64), dtype=np.float32).astype(np.float16).astype(np.float32)
     y = eng.infer(x)
     r = network_report("network[swin_unet/art s4 B1 T64 full, un-fused attention core]", y, oracle16(path)(x), onnx_exec.Executor(path).run(x))
-    assert r["max_ulp16"] <= NET_MAX_ULP16 and r["mean_abs"] <= NET_MEAN_ABS, r
+    assert r["max_ulp16"] <= NET_MAX_ULP16_UNFUSED and r["mean_abs"] <= NET_MEAN_ABS and r["max_ulp16_vs_fp32_oracle"] <= NET_MAX_ULP16_VS_FP32, r
     eng.close()
 
 
@@ -242,9 +240,13 @@ def test_headline_config_properties(pkg, onnx_model):
     # small frame (2x2 tiles at T=256) against the oracle
     small = smooth_frame(300, 420, 13)
     o3 = eng.render(small)
-    ref = pipeline.render(small, oracle16(path), batch=4, tile=256, scaling=4, overlap=(0.0625, 0.0625), net_dtype=np.float16)
-    r = frame_report("config3[swin_unet/art s4 B4 T256 300x420]", o3, ref)
-    assert r["psnr_db"] > 50.0 and r["max_lsb"] <= FRAME_MAX_LSB, r
+    if os.environ.get("W2X_LIVE_ORACLE"):
+        ref = pipeline.render(small, oracle16(path), batch=4, tile=256, scaling=4, overlap=(0.0625, 0.0625), net_dtype=np.float16)
+        r = frame_report("config3[swin_unet/art s4 B4 T256 300x420]", o3, ref)
+        assert r["psnr_db"] > 50.0 and r["max_lsb"] <= FRAME_MAX_LSB, r
+    else:           # the oracle's frame as a committed fixture (tests/golden/make_config_fixtures.py)
+        r = check_config_fixture("3", o3)
+        assert r["psnr_db"] > 50.0 and r["max_lsb"] <= FRAME_MAX_LSB and r["max_block_mean_diff"] <= BLOCK_MEAN_TOL, r
     eng.close()
 
 

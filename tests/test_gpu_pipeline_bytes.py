@@ -1,0 +1,130 @@
+"""The byte / index half of the path against the ORACLE, bit for bit, on the GPU.
+
+Every other frame comparison with the oracle lets the network's fp16 tolerance in (<= 1 LSB).  Here the oracle pipeline
+(oracle/pipeline.py: calculateTiles, padRoi, the 8 dihedral augmentations and their inverses, the batch fill with zero-pad slots,
+the TTA sum and its 1/8, the L,T,R,B ramp products on the clipped rect, the canvas add in tile order, rint(x*255) with saturation,
+RGB<->BGR; img2img_render.cpp:7-352, img2img_load.cpp:29-52, img2img_infer.cpp:5-39) is run on the CPU with the ENGINE's own
+network as its `net` (Img2Img.infer through the C ABI = the reference's private infer(), img2img_infer.cpp:41-93), so that both
+sides see identical network outputs and everything around the network must agree to the byte:
+
+        pipeline.render(frame, net=eng.infer, ...)  ==  eng.render(frame)
+
+This is the tier's bar for integer / byte work.  Network outputs of a tile do not depend on its batch slot or on the tiles it shares
+a pass with (asserted bit-exactly in test_gpu_parity.py), which is what lets infer() stand in for the passes render() runs."""
+import numpy as np
+import pytest
+
+from oracle import onnx_exec, pipeline
+from parity_util import frame_report
+from test_gpu_parity import make_engine, smooth_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def noisy_frame(rows, cols, seed):
+    """i.i.d. uniform bytes: saturation / clip paths and every rounding tie the smooth frames do not reach."""
+    return np.random.default_rng(seed).integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+
+
+def oracle_with_engine_net(eng, frame, *, batch, tile, scale, ov, tta=False, bug=False, fp16=True):
+    return pipeline.render(frame, eng.infer, batch=batch, tile=tile, scaling=scale, overlap=(ov, ov), tta=tta, tta_bug_compat=bug,
+                           net_dtype=np.float16 if fp16 else None, tile_out=eng.output_tile_size)
+
+
+def assert_same_bytes(tag, out, ref):
+    if not np.array_equal(out, ref):
+        d = np.abs(out.astype(np.int32) - ref.astype(np.int32))
+        nz = np.argwhere(d.any(-1))
+        raise AssertionError(f"{tag}: {len(nz)} pixels differ (max {int(d.max())} LSB), rows [{nz[:, 0].min()}, {nz[:, 0].max()}] "
+                             f"cols [{nz[:, 1].min()}, {nz[:, 1].max()}], first {nz[:5].tolist()}")
+
+
+@pytest.mark.parametrize("ov", [0.125, 0.0625, 0.03125, 0.0])
+@pytest.mark.parametrize("tta,bug", [(False, False), (True, False), (True, True)])
+def test_tile_pipeline_is_byte_exact_against_the_oracle(pkg, onnx_model, ov, tta, bug):
+    """Full-width swin_unet graph (the fused kernels of the benchmark) at T=64, batch 3: every blend setting of the CLI
+    (main.cpp:110-121), TTA off / on / bug-compatible (Q1, img2img_render.cpp:313-316), a ragged frame whose tile count is not a
+    multiple of the batch (partial last batch, zero-pad slots) and whose last row / column of tiles is clipped."""
+    path = onnx_model("swin_unet/art", 4, 3, 64)
+    eng = make_engine(pkg, path, 3, 64, 4, overlap=(ov, ov), tta=tta, ttaBugCompat=bug)
+    for k, frame in enumerate((smooth_frame(101, 139, 3), noisy_frame(75, 50, 4))):
+        out = eng.render(frame)
+        ref = oracle_with_engine_net(eng, frame, batch=3, tile=64, scale=4, ov=ov, tta=tta, bug=bug)
+        assert_same_bytes(f"ov{ov} tta{int(tta)} bug{int(bug)} frame{k}", out, ref)
+    eng.close()
+
+
+@pytest.mark.parametrize("model,scale,batch,tile,tta,shape", [
+    ("cunet/art", 2, 4, 64, False, (100, 77)), ("cunet/art", 1, 2, 96, True, (70, 50)), ("swin_unet/photo", 2, 2, 88, True, (80, 75)),
+    ("swin_unet/art_scan", 1, 1, 64, False, (60, 64)), ("swin_unet/art", 4, 2, 64, False, (48, 48))])
+def test_other_graph_families_and_scales_byte_exact(pkg, onnx_model, model, scale, batch, tile, tta, shape):
+    """x1 / x2 / x4 output geometry (T' = 56..192), the cunet border (18) and the swin border (8), single-tile frames."""
+    path = onnx_model(model, scale, batch, tile)
+    eng = make_engine(pkg, path, batch, tile, scale, overlap=(0.0625, 0.0625), tta=tta)
+    frame = noisy_frame(*shape, 9)
+    assert_same_bytes(f"{model} s{scale}", eng.render(frame), oracle_with_engine_net(eng, frame, batch=batch, tile=tile, scale=scale, ov=0.0625, tta=tta))
+    eng.close()
+
+
+@pytest.mark.parametrize("tta", [False, True])
+def test_strips_are_byte_exact_against_the_oracle(pkg, onnx_model, tta):
+    """the frame rendered as 2 and 3 tile-column strips (w2x_render_strip), reassembled, against the oracle's whole frame."""
+    path = onnx_model("swin_unet/art", 4, 2, 64)
+    eng = make_engine(pkg, path, 2, 64, 4, tta=tta)
+    frame = smooth_frame(100, 300, 31)
+    ref = oracle_with_engine_net(eng, frame, batch=2, tile=64, scale=4, ov=0.0625, tta=tta)
+    for parts in (2, 3):
+        out = np.full_like(ref, 77)
+        for part in range(parts):
+            assert eng.render_strip(frame, out, part, parts), eng.last_error()
+        assert_same_bytes(f"{parts} strips tta{int(tta)}", out, ref)
+    eng.close()
+
+
+def test_config3_engine_byte_exact_at_300x420(pkg, onnx_model):
+    """BASELINE configs[2] (swin_unet/art s4 n3 B4 T256, blend 1/16): the benchmark's engine on a 2 x 2-tile frame (one full batch of
+    four 256 x 256 tiles, T' = 960, 64-pixel ramps) and on a 3 x 2-tile one (a partial second batch)."""
+    path = onnx_model("swin_unet/art", 4, 4, 256)
+    eng = make_engine(pkg, path, 4, 256, 4)
+    for shape, seed in (((300, 420), 13), ((260, 500), 14)):
+        frame = smooth_frame(*shape, seed)
+        assert_same_bytes(f"config 3 {shape}", eng.render(frame), oracle_with_engine_net(eng, frame, batch=4, tile=256, scale=4, ov=0.0625))
+    eng.close()
+
+
+@pytest.mark.parametrize("model,scale,tta", [("swin_unet/art", 4, True), ("cunet/art", 2, False)])
+def test_fp32_engine_tile_pipeline_byte_exact(pkg, onnx_model, model, scale, tta):
+    """The same identity on the fp32 engine (Precision::TF32 requests): fp32 tiles cross the engine boundary unrounded, as in the
+    reference (IO tensors are f32, img2img_load.cpp:230)."""
+    path = onnx_model(model, scale, 2, 64, noise=1)
+    eng = pkg.Img2Img()
+    assert eng.build(path, pkg.BuildConfig.fixed(2, 64, precision=pkg.Precision.TF32)), eng.last_error()
+    assert eng.load(path, pkg.RenderConfig(precision=pkg.Precision.TF32, batchSize=2, height=64, width=64, scaling=scale, overlap=(0.0625, 0.0625), tta=tta)), eng.last_error()
+    frame = noisy_frame(90, 110, 2)
+    assert_same_bytes(f"fp32 {model}", eng.render(frame), oracle_with_engine_net(eng, frame, batch=2, tile=64, scale=scale, ov=0.0625, tta=tta, fp16=False))
+    eng.close()
+
+
+def test_config1_as_written_fp32_b1_t64_256x256(pkg, onnx_model):
+    """BASELINE configs[0] exactly as stated: cunet/art scale2 noise0, batch 1, tile 64, fp32, one 256 x 256 image = 11 x 11 = 121
+    tiles in 121 batches of one (KAT row 1 of SURVEY 8c: T' = 56, sIn 28, border 18, overlaps 4 / 8).  The fp32 engine against the
+    fp32 oracle end to end (no fp16 anywhere: <= 1 LSB, ties of rint only), the same frame byte for byte against the oracle pipeline
+    fed with the engine's network, and the step schedule of img2img_render.cpp:246-250 through the progress callback."""
+    path = onnx_model("cunet/art", 2, 1, 64, noise=0)
+    eng = pkg.Img2Img()
+    assert eng.build(path, pkg.BuildConfig.fixed(1, 64, precision=pkg.Precision.TF32)), eng.last_error()
+    assert eng.load(path, pkg.RenderConfig(precision=pkg.Precision.TF32, batchSize=1, height=64, width=64, scaling=2, overlap=(0.0625, 0.0625))), eng.last_error()
+    assert eng.output_tile_size == 56
+    n, rin, rout = pkg.calculate_tiles(256, 256, 512, 512, 64, 56, 2, (0.0625, 0.0625))
+    assert n == 121 and tuple(rin[0]) == (-18, -18, 64, 64) and tuple(rin[-1]) == (222, 222, 64, 64) and tuple(rout[-1]) == (480, 480, 32, 32)
+    frame = smooth_frame(256, 256, 1)
+    prog = []
+    eng.setProgressCallback(lambda c, t, s: prog.append((c, t)))
+    out = eng.render(frame)
+    assert [c for c, _ in prog] == list(range(1, 122)) and all(t == 121 for _, t in prog)
+    eng.setProgressCallback(None)
+    assert_same_bytes("configs[0] pipeline", out, oracle_with_engine_net(eng, frame, batch=1, tile=64, scale=2, ov=0.0625, fp16=False))
+    ref = pipeline.render(frame, onnx_exec.Executor(path).run, batch=1, tile=64, scaling=2, overlap=(0.0625, 0.0625), tile_out=56)
+    r = frame_report("configs[0] cunet/art s2 n0 B1 T64 fp32 256x256 (121 tiles) vs the fp32 oracle", out, ref)
+    assert r["max_lsb"] <= 1 and r["frac_pixels_off_by_1"] < 1e-3, r
+    eng.close()
