@@ -6,13 +6,16 @@
 
 namespace w2x {
 
-// Arithmetic of the network.  gfx950 has no TF32 / xf32 matrix instructions: TF32 is accepted by the command line for
-// compatibility and refused by build() / load() with a message (the reference's own error convention).
+// Arithmetic of the network.  gfx950 has no TF32 / xf32 matrix instructions: a Precision::TF32 request builds and loads the
+// FP32 engine instead (fp32 maps and weights, v_mfma_f32_16x16x4_f32 products - a superset of TF32's precision; build() says
+// so in an info message).  An engine file serves only the precision it was built for (img2img_load.cpp:54-66).
 enum class Precision { TF32, FP16 };
 
 // What build() specialises a plan for.  The reference hands TensorRT a min / opt / max optimisation profile per
-// dimension (img2img_build.cpp:102-116) and its command line always sets the three equal (main.cpp:276-291); this engine
-// requires them equal (static shapes) and keys the plan cache on all of them, like the reference's JSON side file.
+// dimension (img2img_build.cpp:102-116); its command line always sets the three equal (main.cpp:276-291).  build() checks
+// min <= opt <= max, writes the plan for the opt shape and keys the plan cache on all of them, like the reference's JSON side
+// file; load() takes the first optimized engine, else the first compatible one (img2img_load.cpp:100-107) and re-specialises
+// the plan from the same ONNX file for a shape inside the range that is not the opt shape.
 struct BuildConfig {
     int deviceId = 0;                                             // HIP device ordinal
     Precision precision = Precision::FP16;

@@ -78,5 +78,5 @@ def check_config_fixture(name, out):
     B = 32
     mine = out[:hb * B, :wb * B].reshape(hb, B, wb, B, 3).astype(np.float64).mean(axis=(1, 3))
     rec["max_block_mean_diff"] = float(np.abs(mine - bm).max())
-    print("PARITY " + json.dumps({"test": f"config fixture {name} block means", "max_block_mean_diff": rec["max_block_mean_diff"]}), flush=True)
+    _record({"test": f"config fixture {name}: 32x32 block means of the whole frame", "kind": "block_means", "max_block_mean_diff": rec["max_block_mean_diff"]})
     return rec

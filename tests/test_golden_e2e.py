@@ -50,6 +50,7 @@ def test_hip_engine_matches_golden(f, onnx_model, pkg):
     r = frame_report(f"golden {os.path.basename(f)} (expected = oracle pipeline around the fp32 network)", out, c["expected"])
     # The expected frames come from the FP32 network (only the engine boundary is rounded to fp16), so this is the fp16 engine's
     # distance from fp32 arithmetic, not from a model of itself.  north_star: PSNR > 50 dB.  Full-width graphs (the fused kernels of
-    # the benchmark) and cunet: <= 1 LSB; the 48-channel graphs (un-fused path, one more fp16 rounding per operator): <= 2 LSB.
-    assert r["psnr_db"] > 50.0 and r["max_lsb"] <= (2 if c["small"] else 1), r
+    # the benchmark), cunet and the 48-channel graphs (un-fused path) alike: <= 1 LSB, measured on 1.7-3.9 % of the pixels
+    # (profiles/r3_*/parity.jsonl).
+    assert r["psnr_db"] > 50.0 and r["max_lsb"] <= 1, r
     eng.close()

@@ -31,8 +31,9 @@ def test_fused_mlp_kernels_agree_and_are_deterministic(tmp_path):
 
 @pytest.mark.gpu
 def test_fused_attention96_schedules_agree_with_each_other_and_with_fp32(tmp_path):
-    """tools/ab/attn_ab.hip: the round-1 schedule of the C = 96 fused attention (2 windows per workgroup, a wave = 3 heads) against the
-    shipped one (4 windows per workgroup, a wave = a head, left-over queries of the four windows in one tile) on random token maps,
+    """tools/ab/attn_ab.hip: the round-1 schedule of the C = 96 fused attention (2 windows per workgroup, a wave = a window's 3 heads)
+    against the shipped one (2 windows per workgroup, three (window, head) units per wave of which two share a head, the left-over
+    queries of a wave's units in one tile) on random token maps,
     shifted and unshifted windows, several mask classes, window counts that do not fill the last workgroup - and both against a
     plain fp32 host evaluation of y = x + proj(W-MSA(LN(x)))."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

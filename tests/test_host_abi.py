@@ -160,6 +160,31 @@ def test_engine_file_is_validated_on_read(pkg, onnx_model, tmp_path, model, scal
         ok, why = pkg.validate_engine_file(bad)
         refused += (not ok)
     assert refused >= 50
+    # sizes the kernels index with.  Every tensor an op touches (describe_plan: refs=...) must keep the plan's B tile slots
+    # (per-image strides, tile-group addressing of the arena) and may not shrink in H, W, C or element size behind the ops' backs:
+    # the squeeze-excite pool / gate tensors, the attention qkv / out rows, the LayerNorm statistics side tensors, the gated maps.
+    import re
+    import struct
+    desc = pkg.describe_plan(path, 2, tile)
+    refs = sorted({int(t) for m in re.finditer(r"refs=([t0-9,]+)", desc) for t in re.findall(r"t(\d+)", m.group(1))})
+    assert len(refs) >= 20
+    off = 68                                                       # magic, version, 3 struct sizes, 9 header ints, flops (plan.cpp serialize)
+    off += 8 + struct.unpack_from("<Q", good, off)[0]              # model kind
+    nt = struct.unpack_from("<Q", good, off)[0]; off += 8
+    assert max(refs) < nt
+    edits = 0
+    for k in refs:
+        for f, name in enumerate("BHWCe"):
+            v = struct.unpack_from("<i", good, off + 20 * k + 4 * f)[0]
+            for nv in ([v + 1, v // 2] if f == 0 else [6 - v] if f == 4 else [v // 2]):
+                if nv == v or nv <= 0:
+                    continue
+                b = bytearray(good); struct.pack_into("<i", b, off + 20 * k + 4 * f, nv)
+                open(bad, "wb").write(bytes(b))
+                ok, why = pkg.validate_engine_file(bad)
+                assert not ok and why, (k, name, v, nv)
+                edits += 1
+    assert edits >= 100
 
 
 def test_infer_validates_the_blob_shape(pkg):

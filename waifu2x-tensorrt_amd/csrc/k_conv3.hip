@@ -21,10 +21,10 @@
 //     max(v, v * alpha); squeeze-excite pooling partials per workgroup in a fixed order.
 // Input, weights and output go through buffer resources (32-bit offsets, rows past a ragged edge read zeros / drop stores).
 // Measured on config 2 (tools/op_times.py): the 3x3 layers 6.2 -> 5.4 ms per frame (550-770 TFLOP/s) against the first schedule
-// (tools/ab/k_conv3_v1.hip: one tap of one chunk per barrier, both operands through LDS).  What is left is not the products:
+// (round-2 git history, tools/ab/k_conv3_v1.hip: one tap of one chunk per barrier, both operands through LDS).  What is left is not the products:
 // without the halo fetch the layers run 30-35 % faster, without the stores 25 % - fetch, products and stores of a workgroup run one
 // after the other and the two workgroups of a CU stay in phase.  A persistent variant with the halo tiles double-buffered by
-// LDS-DMA (tools/ab/k_conv3c_persistent.hip) overlaps them in program order but came out 2-4 % slower: one 72 KB tile in flight
+// LDS-DMA (round-2 git history, tools/ab/k_conv3c_persistent.hip) overlaps them in program order but came out 2-4 % slower: one 72 KB tile in flight
 // per CU leaves the fetch latency-bound (16k cycles per step with the products removed), and LDS has no room for a third buffer.
 #include "kernels.h"
 #include <cstdlib>

@@ -3,7 +3,7 @@
 //  .V, head merge, proj MatMul+Add, window reverse + reverse roll, residual Add of the ONNX graph: one launch.)
 //
 // A workgroup = 4 waves = 2 windows (72 token rows), three workgroups per CU (one wave of each per SIMD: workgroups whose wave
-// count is not a multiple of four load the SIMDs unevenly - tools/ab/k_swinattn96_g4.hip measured that).  The 12 (window, head)
+// count is not a multiple of four load the SIMDs unevenly - a 6-wave variant measured that in round 2: git history, tools/ab/k_swinattn96_g4.hip).  The 12 (window, head)
 // units of a workgroup go 3 to a wave so that two of them share a head:
 //     wave v:  unit 0 = (window 0, head v),  unit 1 = (window 1, head v),  unit 2 = (window v & 1, head 4 + (v >> 1)).
 // The q/k/v weight fragments of a head are read once per wave from the fragment-major copy (one contiguous KiB per load) and

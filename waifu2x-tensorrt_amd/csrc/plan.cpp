@@ -46,6 +46,20 @@ std::string Plan::describe() const {
         } else if (op.kind == OP_MLP) {
             o << "mlp C=" << op.m.C << " M=" << (int64_t)tensors[op.m.x].B * tensors[op.m.x].H * tensors[op.m.x].W << " stats=" << (op.m.stats_out >= 0) << " t" << op.m.x << "->t" << op.m.y;
         }
+        {   // every tensor the op touches (the set the engine's lifetime analysis uses), for tools and tests
+            std::vector<int> refs;
+            switch (op.kind) {
+                case OP_GEMM: refs = {op.g.a.t, op.g.res.t, op.g.res2.t, op.g.stats_in, op.g.se_scale, op.g.res_scale, op.g.out.t, op.g.stats_out, op.g.pool_out}; break;
+                case OP_ATTN: refs = {op.at.qkv, op.at.out}; break;
+                case OP_SE: case OP_SCALE_ADD: refs = {op.se.pool, op.se.scale}; break;
+                case OP_MLP: refs = {op.m.x, op.m.y, op.m.stats_out}; break;
+                case OP_SWINATTN: refs = {op.sa.x, op.sa.y, op.sa.stats_out}; break;
+                default: break;
+            }
+            o << " refs=";
+            bool first = true;
+            for (int t : refs) if (t >= 0) { o << (first ? "" : ",") << "t" << t; first = false; }
+        }
         o << " flops=" << (long long)op.flops << " [" << op.name << "]\n";
     }
     return o.str();
@@ -107,7 +121,16 @@ void Plan::validate() const {
     if (B <= 0 || userB <= 0 || B % userB || T <= 0 || Tout <= 0 || Cin != 3 || Cout != 3) fail("header");
     if (elt != 2 && elt != 4) fail("precision");
     if (in_tensor < 0 || in_tensor >= nt || out_tensor < 0 || out_tensor >= nt) fail("input / output tensor id");
-    for (const TensorDesc& t : tensors) if (t.B <= 0 || t.H <= 0 || t.W <= 0 || t.C <= 0 || (t.elt != 2 && t.elt != 4) || t.bytes() > ((int64_t)1 << 40)) fail("tensor shape");
+    // every tensor carries the plan's B tile slots: the per-image strides of the kernels and the tile-group addressing of the arena
+    // (a tensor of B tiles at offset o becomes B / NG tiles at o / NG, engine.cpp group_ptr) rest on it
+    for (const TensorDesc& t : tensors) if (t.B != B || t.H <= 0 || t.W <= 0 || t.C <= 0 || (t.elt != 2 && t.elt != 4) || t.bytes() > ((int64_t)1 << 40)) fail("tensor shape");
+    auto floats_per_tile = [&](int id) { const TensorDesc& d = tensors[id]; return (int64_t)d.H * d.W * d.C; };
+    // a [pixels][2] fp32 side tensor with the LayerNorm statistics of the rows of map `of`
+    auto stats_of = [&](int id, int of) {
+        if (id < 0) return;
+        const TensorDesc& d = tensors[id], &m = tensors[of];
+        if (d.elt != 4 || (int64_t)d.H * d.W * d.C < (int64_t)m.H * m.W * 2) fail("statistics tensor shape");
+    };
     if (tensors[in_tensor].H != T || tensors[in_tensor].W != T || tensors[in_tensor].C != 4 || tensors[in_tensor].B != B) fail("input tensor shape");
     if (tensors[out_tensor].H != Tout || tensors[out_tensor].W != Tout || tensors[out_tensor].C != 4) fail("output tensor shape");
     if (tensors[in_tensor].elt != elt || tensors[out_tensor].elt != elt) fail("input / output tensor precision");
@@ -135,6 +158,7 @@ void Plan::validate() const {
                 if (g.K <= 0 || g.N <= 0 || g.Mrows <= 0 || g.kh <= 0 || g.kw <= 0 || g.stride <= 0 || g.r <= 0 || g.aW <= 0) fail("gemm shape");
                 if (g.amode < A_ROWS || g.amode > A_CONV || g.omode < O_ROWS || g.omode > O_PIXSHUF) fail("gemm mode");
                 if (g.K != g.kh * g.kw * tensors[g.a.t].C) fail("gemm K");
+                if (g.Cout <= 0 || tensors[g.out.t].C < g.Cout || (g.res.t >= 0 && tensors[g.res.t].C < g.Cout) || (g.res2.t >= 0 && tensors[g.res2.t].C < g.Cout)) fail("gemm output channels");
                 {   // the A side reads pixel (y0 + oy*stride + ky, x0 + ox*stride + kx) for the Mrows = oH x aW output positions
                     // (a crop folded into a convolution moves y0 / x0 without touching the view's H / W, so those are not used)
                     const TensorDesc& d = tensors[g.a.t];
@@ -148,6 +172,8 @@ void Plan::validate() const {
                 blob(g.csum, !g.ln, (size_t)g.N * 4);
                 if (g.amode == A_WIN || g.omode == O_WIN) blob(g.win_table, false, (size_t)g.Mrows * 4); else blob(g.win_table, true, 0);
                 if (g.ln && g.stats_in < 0) fail("LayerNorm without statistics");
+                stats_of(g.stats_in, g.a.t); stats_of(g.stats_out, g.out.t);
+                if (g.pool_out >= 0 && (tensors[g.pool_out].elt != 4 || floats_per_tile(g.pool_out) < (int64_t)((g.Mrows + 127) / 128) * tensors[g.out.t].C)) fail("pooled sums tensor shape");
                 break;
             }
             case OP_ATTN: {
@@ -157,6 +183,10 @@ void Plan::validate() const {
                 const size_t n = (size_t)a.ws * a.ws;
                 blob(a.bias, false, (size_t)a.nmask * a.heads * n * n * elt);
                 if (tensors[a.qkv].elt != elt || tensors[a.out].elt != elt) fail("attention operand precision");
+                {   // rows in window order: [nwin * ws^2][3 * heads * hd] -> [nwin * ws^2][heads * hd]
+                    const TensorDesc& q = tensors[a.qkv], &o = tensors[a.out];
+                    if (q.C != 3 * a.heads * a.hd || o.C != a.heads * a.hd || (int64_t)q.H * q.W != (int64_t)a.nwin * n || (int64_t)o.H * o.W != (int64_t)a.nwin * n) fail("attention tensor shape");
+                }
                 blob(a.maskid, false, (size_t)a.nwin * 4);
                 for (int i = 0; i < a.nwin; ++i) { int m; memcpy(&m, blobs[a.maskid].data.data() + 4 * (size_t)i, 4); if (m < 0 || m >= a.nmask) fail("attention mask id"); }
                 break;
@@ -164,16 +194,26 @@ void Plan::validate() const {
             case OP_SE: {
                 const SeOp& e = op.se;
                 ten(e.pool, false); ten(e.scale, false);
-                if (e.C <= 0 || e.Cmid <= 0 || e.nblocks <= 0) fail("squeeze-excite shape");
+                if (e.C <= 0 || e.Cmid <= 0 || e.nblocks <= 0 || e.Mrows <= 0) fail("squeeze-excite shape");
+                // pool: [B][nblocks][Cs] partial sums written by the producing convolution, scale: [B][Cs] gates
+                if (tensors[e.pool].elt != 4 || tensors[e.scale].elt != 4 || tensors[e.pool].C < e.C || tensors[e.scale].C != tensors[e.pool].C ||
+                    floats_per_tile(e.pool) < (int64_t)e.nblocks * tensors[e.pool].C || e.nblocks < (e.Mrows + 127) / 128) fail("squeeze-excite tensor shape");
                 blob(e.w1, false, (size_t)e.C * e.Cmid * 4); blob(e.b1, false, (size_t)e.Cmid * 4);
                 blob(e.w2, false, (size_t)e.C * e.Cmid * 4); blob(e.b2, false, (size_t)e.C * 4);
                 break;
             }
-            case OP_SCALE_ADD: ten(op.se.pool, false); ten(op.se.scale, false); break;
+            case OP_SCALE_ADD: {   // in-place gate: map (se.pool) *= gate (se.scale, fp32 [B][C]); rows move as 16-byte pieces
+                ten(op.se.pool, false); ten(op.se.scale, false);
+                const TensorDesc& m = tensors[op.se.pool], &gt = tensors[op.se.scale];
+                if (m.elt != elt || gt.elt != 4 || m.C % (elt == 2 ? 8 : 4) || floats_per_tile(op.se.scale) < m.C) fail("gate pass shape");
+                break;
+            }
             case OP_MLP: {
                 const MlpOp& m = op.m;
                 ten(m.x, false); ten(m.y, false); ten(m.stats_out, true);
                 if (m.C <= 0 || tensors[m.x].C != m.C || tensors[m.y].C != m.C) fail("MLP width");
+                if (tensors[m.x].H != tensors[m.y].H || tensors[m.x].W != tensors[m.y].W || tensors[m.x].elt != 2 || tensors[m.y].elt != 2) fail("MLP tensor shape");
+                stats_of(m.stats_out, m.y);
                 if (elt != 2) fail("fused MLP in an fp32 plan");
                 blob(m.w1, false, (size_t)2 * m.C * m.C * 2); blob(m.b1, false, (size_t)2 * m.C * 4);
                 blob(m.w2, false, (size_t)2 * m.C * m.C * 2); blob(m.b2, false, (size_t)m.C * 4);
@@ -185,6 +225,8 @@ void Plan::validate() const {
                 if (a.C <= 0 || a.heads <= 0 || a.hd <= 0 || a.heads * a.hd != a.C || a.ws <= 0 || a.nwin <= 0 || a.H <= 0 || a.W <= 0) fail("window attention shape");
                 if (tensors[a.x].C != a.C || tensors[a.y].C != a.C || a.H * a.W != a.nwin * a.ws * a.ws || tensors[a.x].H * tensors[a.x].W != a.H * a.W) fail("window attention geometry");
                 if (a.ry >= a.H || a.rx >= a.W) fail("window attention shift");
+                if (tensors[a.y].H * tensors[a.y].W != a.H * a.W || tensors[a.x].elt != 2 || tensors[a.y].elt != 2) fail("window attention tensor shape");
+                stats_of(a.stats_out, a.y);
                 if (elt != 2) fail("fused window attention in an fp32 plan");
                 blob(a.table, false, (size_t)a.H * a.W * 4);
                 blob(a.wqkv, false, (size_t)3 * a.C * a.C * 2); blob(a.bqkv, false, (size_t)3 * a.C * 4);
