@@ -88,8 +88,8 @@ def spawn_ranks(a) -> int:
     JSON line through.  Children rendezvous over gloo on 127.0.0.1."""
     import socket
     import subprocess
-    import torch
-    have = torch.cuda.device_count()                 # counting devices does not initialise the GPU
+    import shard
+    have = len(shard.gpu_nodes())                    # KFD topology in sysfs: this parent makes no HIP / torch.cuda call at all
     if have < a.gpus and not os.environ.get("W2X_DEVICE_MAP"):
         raise SystemExit(f"--gpus {a.gpus} but this node shows {have} GPU(s); refusing to report n_gpus != requested")
     with socket.socket() as s:
@@ -131,6 +131,11 @@ def main():
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
+    import shard
+    # one rank per GPU: run on the CPUs of that GPU's NUMA node (page-locked frame buffers are allocated after this and land there)
+    dmap = os.environ.get("W2X_DEVICE_MAP")
+    phys = int(dmap.split(",")[local_rank]) if dmap and local_rank < len(dmap.split(",")) else local_rank
+    pinned = shard.pin_to_gpu_numa(phys) if world > 1 or os.environ.get("W2X_PIN_NUMA") else set()
     import torch
     import __graft_entry__ as g
     import synth_models as sm
@@ -157,7 +162,6 @@ def main():
         for _, m in eng.messages[-2:]:
             print("[w2x] " + m, file=sys.stderr)
 
-    import shard
     strips = a.mode == "strips"
     my_frames = [0] if strips else shard.frames_for_rank(a.steps * world, rank, world)   # frame f -> rank f mod N; each rank renders K frames
     frame = synthetic_frame(my_frames[0])
@@ -274,7 +278,7 @@ def main():
                                    f"({frame_tiles} tiles, 12 batches); synthetic-weight graph of that architecture, frame resident in HBM",
                        "frames_per_s": round(fps, 3), "device_ms_per_frame": round(ms, 3), "frames_per_rank": a.steps,
                        "parallelism": (f"one frame in {world} tile-column strips (renderStrip), no collectives" if strips else f"frame-sharded x{world}, no collectives") + "; timing barrier over gloo",
-                       "mode": a.mode,
+                       "mode": a.mode, "rank0_cpus": len(pinned) or None,
                        "render_call_ms_pageable": round(pcie_ms_one, 2),
                        "full_path_ms_per_frame": None if full_wall_max is None else round(full_wall_max * 1e3 / a.steps, 3),
                        "full_path_frames_per_s": None if full_wall_max is None else round(a.steps * world / full_wall_max, 3),

@@ -99,3 +99,37 @@ def test_bench_refuses_a_rank_count_that_differs_from_gpus():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "W2X_DEVICE_MAP")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "refusing to report n_gpus" in (r.stderr + r.stdout)
+
+
+def _fake_sysfs(root, gpus):
+    """A KFD topology tree as the driver lays it out: CPU nodes (simd_count 0) first, then GPUs with a DRM render node each."""
+    nodes = os.path.join(root, "class", "kfd", "kfd", "topology", "nodes")
+    os.makedirs(os.path.join(nodes, "0")); os.makedirs(os.path.join(nodes, "1"))
+    for n in (0, 1):
+        open(os.path.join(nodes, str(n), "properties"), "w").write("cpu_cores_count 64\nsimd_count 0\ndrm_render_minor 0\n")
+    for k, (numa, cpus) in enumerate(gpus):
+        d = os.path.join(nodes, str(2 + k)); os.makedirs(d)
+        open(os.path.join(d, "properties"), "w").write(f"cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor {128 + k}\nlocation_id {k}\n")
+        dev = os.path.join(root, "class", "drm", f"renderD{128 + k}", "device"); os.makedirs(dev)
+        open(os.path.join(dev, "numa_node"), "w").write(f"{numa}\n")
+        open(os.path.join(dev, "local_cpulist"), "w").write(cpus + "\n")
+
+
+def test_gpu_count_and_numa_pinning_come_from_sysfs_without_touching_the_gpu(tmp_path):
+    """bench.py's launcher parent counts GPUs from the KFD topology (no HIP / torch.cuda call before the ranks are spawned) and
+    every rank runs on the CPUs local to its GPU: eight GPUs on two NUMA nodes, as on an MI355X node."""
+    root = str(tmp_path)
+    _fake_sysfs(root, [(0, "0-47,96-143")] * 4 + [(1, "48-95,144-191")] * 4)
+    nodes = shard.gpu_nodes(root)
+    assert len(nodes) == 8 and [n["node"] for n in nodes] == list(range(2, 10))
+    assert [n["numa_node"] for n in nodes] == [0] * 4 + [1] * 4
+    assert shard.parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    allowed = os.sched_getaffinity(0)
+    want = shard.parse_cpulist(nodes[5]["cpulist"]) & allowed
+    assert shard.pin_to_gpu_numa(5, root, apply=False) == want        # intersected with the cpuset this process may use
+    assert shard.pin_to_gpu_numa(8, root, apply=False) == set()       # no such GPU: nothing changes
+    assert shard.gpu_nodes(str(tmp_path / "nothing")) == []           # no KFD (this container): zero GPUs, no exception
+    # really applying it keeps the process runnable (restore afterwards)
+    _fake_sysfs(str(tmp_path / "b"), [(0, ",".join(str(c) for c in sorted(allowed)))])
+    assert shard.pin_to_gpu_numa(0, str(tmp_path / "b")) == allowed
+    os.sched_setaffinity(0, allowed)

@@ -28,20 +28,6 @@
 
 #include <algorithm>
 
-// Build switches (tools/ab/attn96_variants.sh times them against each other):
-//   W2X_A96_PV32  O^T = V^T P^T and the softmax denominators over the 32 keys of the two full key tiles as ONE v_mfma_f32_16x16x32_f16
-//                 (the accumulator tiles of S^T and v pair up into its operands with the k order permuted identically on both sides) +
-//                 one 16x16x16 for the left-over keys, instead of three 16x16x16 - which cost the matrix pipe as much as a 16x16x32
-//                 each (tools/issue_model.hip): 16 matrix instructions less per wave.
-//   W2X_A96_BUF   weight fragments, bias tables and the rel-pos bias through buffer loads (lane offset in a VGPR once, everything else
-//                 in the scalar offset) instead of flat loads with 64-bit per-lane addresses.
-#ifndef W2X_A96_PV32
-#define W2X_A96_PV32 0     // measured (tools/ab/attn96_variants.sh, profiles/r3_*/attn96_variants.txt): at 128 registers the wider operands spill
-#endif                     // (4-7 registers to scratch) and the launch is 2-5 % SLOWER; kept as a switch for a build with registers to spare
-#ifndef W2X_A96_BUF
-#define W2X_A96_BUF 1
-#endif
-
 namespace w2x {
 namespace {
 
@@ -151,43 +137,14 @@ static_assert(NPASS == 5, "the row sums are reduced as 3 + 2 passes");
 
 __device__ __forceinline__ int slab_row(int t) { return t < 32 ? t : 32 + 4 * (t - 32); }
 
-// P = exp2(S - max) of one query column as fp16 B-operand fragments (keys on the k axis): p01 = key tiles 0 and 1 (k slot j < 4: key
-// 4g + j, j >= 4: key 16 + 4g + j - 4 - the order concat(v tile 0, v tile 1) has too), p2 = the left-over keys
-__device__ __forceinline__ void probs(const float4v s0, const float4v s1, float s2, float mx, half8& p01, half4& p2) {
+// P = exp2(S - max) of one query column as fp16 B-operand fragments (keys on the k axis)
+__device__ __forceinline__ void probs(const float4v s0, const float4v s1, float s2, float mx, half4& p0, half4& p1, half4& p2) {
     const float2v m2 = {mx, mx};
     const float2v a0 = (float2v){s0[0], s0[1]} - m2, a1 = (float2v){s0[2], s0[3]} - m2;
     const float2v c0 = (float2v){s1[0], s1[1]} - m2, c1 = (float2v){s1[2], s1[3]} - m2;
-    p01 = (half8){(_Float16)__builtin_amdgcn_exp2f(a0[0]), (_Float16)__builtin_amdgcn_exp2f(a0[1]), (_Float16)__builtin_amdgcn_exp2f(a1[0]), (_Float16)__builtin_amdgcn_exp2f(a1[1]),
-                  (_Float16)__builtin_amdgcn_exp2f(c0[0]), (_Float16)__builtin_amdgcn_exp2f(c0[1]), (_Float16)__builtin_amdgcn_exp2f(c1[0]), (_Float16)__builtin_amdgcn_exp2f(c1[1])};
+    p0 = (half4){(_Float16)__builtin_amdgcn_exp2f(a0[0]), (_Float16)__builtin_amdgcn_exp2f(a0[1]), (_Float16)__builtin_amdgcn_exp2f(a1[0]), (_Float16)__builtin_amdgcn_exp2f(a1[1])};
+    p1 = (half4){(_Float16)__builtin_amdgcn_exp2f(c0[0]), (_Float16)__builtin_amdgcn_exp2f(c0[1]), (_Float16)__builtin_amdgcn_exp2f(c1[0]), (_Float16)__builtin_amdgcn_exp2f(c1[1])};
     p2 = (half4){(_Float16)__builtin_amdgcn_exp2f(s2 - mx), (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};   // slab row 32 + 4g = token 32 + g
-}
-__device__ __forceinline__ half4 lo4(const half8 v) { return (half4){v[0], v[1], v[2], v[3]}; }
-__device__ __forceinline__ half4 hi4(const half8 v) { return (half4){v[4], v[5], v[6], v[7]}; }
-// product over the 36 keys: operands (a01 | a2) x (p01 | p2)
-__device__ __forceinline__ float4v keys_product(const half8 a01, const half4 a2, const half8 p01, const half4 p2) {
-    const float4v zero4 = {0.f, 0.f, 0.f, 0.f};
-#if W2X_A96_PV32
-    float4v o = __builtin_amdgcn_mfma_f32_16x16x32_f16(a01, p01, zero4, 0, 0, 0);
-#else
-    float4v o = __builtin_amdgcn_mfma_f32_16x16x16f16(lo4(a01), lo4(p01), zero4, 0, 0, 0);
-    o = __builtin_amdgcn_mfma_f32_16x16x16f16(hi4(a01), hi4(p01), o, 0, 0, 0);
-#endif
-    return __builtin_amdgcn_mfma_f32_16x16x16f16(a2, p2, o, 0, 0, 0);
-}
-// column sums of P (the softmax denominators) off the matrix pipe: a ones matrix in place of V^T.  W2X_A96_PV32 == 2 spends four
-// registers on a ones operand for the 16x16x32 form, otherwise three 16x16x16 products share a two-register one
-__device__ __forceinline__ float4v keys_sum(const half8 p01, const half4 p2) {
-    const float4v zero4 = {0.f, 0.f, 0.f, 0.f};
-#if W2X_A96_PV32 == 2
-    const half8 ones8 = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
-    float4v l = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, p01, zero4, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_16x16x16f16(lo4(ones8), p2, l, 0, 0, 0);
-#else
-    const half4 ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
-    float4v l = __builtin_amdgcn_mfma_f32_16x16x16f16(ones, lo4(p01), zero4, 0, 0, 0);
-    l = __builtin_amdgcn_mfma_f32_16x16x16f16(ones, hi4(p01), l, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_16x16x16f16(ones, p2, l, 0, 0, 0);
-#endif
 }
 
 __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnParams p) {
@@ -216,23 +173,12 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
     // weight fragments of a head (q, k, v rows h*16 + fr; 3 k-steps): lane holds [row][ks*32 + 8g .. +7]; stored
     // fragment-major, so each load is one contiguous KiB
     half8 wq[3], wk[3], wv_[3];
-#if W2X_A96_BUF
-    // every table goes through a buffer resource: the lane part of the address is one VGPR for all loads, the rest is scalar
-    const __amdgpu_buffer_rsrc_t WQ = make_rsrc(Wqkv, 3u * C * C * 2u), WP = make_rsrc(Wproj, (unsigned)C * C * 2u);
-    const __amdgpu_buffer_rsrc_t BQ = make_rsrc(p.bqkv, 3u * C * 4u), BP = make_rsrc(p.bproj, (unsigned)C * 4u), RB = make_rsrc(p.bias32, 0x7FFFFFF0u);
-    const unsigned l16 = lane * 16u, l4 = lane * 4u, g16 = (lane >> 4) * 16u;
-#define W2X_WFRAG(SEL, H, KS) __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(WQ, l16, (unsigned)(((SEL) * NH + (H)) * 3 + (KS)) * 1024u, 0))
-#define W2X_BQKV(OFF) __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(BQ, g16, (unsigned)(OFF) * 4u, 0))
-#else
     const _Float16* wlane = Wqkv + lane * 8;
-#define W2X_WFRAG(SEL, H, KS) (*(const half8*)(wlane + (size_t)(((SEL) * NH + (H)) * 3 + (KS)) * 512))
-#define W2X_BQKV(OFF) (*(const float4v*)(p.bqkv + (OFF) + g * 4))
-#endif
 #define W2X_LOAD_W(H)                                                                           \
     _Pragma("unroll") for (int ks = 0; ks < 3; ++ks) {                                          \
-        wq[ks] = W2X_WFRAG(0, H, ks);                                                           \
-        wk[ks] = W2X_WFRAG(1, H, ks);                                                           \
-        wv_[ks] = W2X_WFRAG(2, H, ks);                                                          \
+        wq[ks] = *(const half8*)(wlane + (size_t)((0 * NH + (H)) * 3 + ks) * 512);              \
+        wk[ks] = *(const half8*)(wlane + (size_t)((1 * NH + (H)) * 3 + ks) * 512);              \
+        wv_[ks] = *(const half8*)(wlane + (size_t)((2 * NH + (H)) * 3 + ks) * 512);             \
     }
     W2X_LOAD_W(hA)
 
@@ -301,6 +247,7 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
 
     const float qscale = p.scale * 1.44269504088896341f;   // log2(e) folded into q: softmax uses exp2
     const float2v qs2 = {qscale, qscale};
+    const half4 ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
     const half4 zeroh4 = {};
     const int xoff = fr * LDX + g * 8;                     // this lane's piece of a 16-row operand fragment
     // left-over query tile: column fr = query 32 + ql of unit ul (ul = 3: unused column, computed like unit 0's and never stored)
@@ -313,7 +260,7 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
     float4v sl[3];          // their scores S_left^T [3 key tiles], accumulated over the units on top of the bias
     float b2l;
     {
-        float4v a = W2X_BQKV(hA * HD);   // q bias = initial accumulator
+        float4v a = *(const float4v*)(p.bqkv + hA * HD + g * 4);   // q bias = initial accumulator
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[ks], *(const half8*)(xq + ks * 32), a, 0, 0, 0);
         const float2v a0 = (float2v){a[0], a[1]} * qs2, a1 = (float2v){a[2], a[3]} * qs2;
@@ -326,8 +273,8 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
         sl[2] = zero4;
         b2l = lb[512 + bl];
     }
-    half8 vk01[NU]; half4 vk2[NU];   // v fragments of every unit (key tiles 0 | 1, left-over keys), also for the left-over queries' O^T at the end
-    half8 pl01; half4 pl2;           // left-over queries' probabilities
+    half4 vkeep[NU][3];     // v fragments of every unit, for the left-over queries' O^T at the end
+    half4 pl[3];            // left-over queries' probabilities
 
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -336,8 +283,8 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
         // biases of this head: q (initial accumulator of q^T, rows = features 4g..4g+3); the k bias adds the same q.bk to every
         // key of a query and drops out of the softmax; the v bias commutes with the weighted mean (sum p (v + bv) / sum p =
         // sum p v / sum p + bv) and is added to the normalised output instead.
-        const float4v bq = W2X_BQKV(h * HD);
-        const float4v bv = W2X_BQKV(2 * C + h * HD);
+        const float4v bq = *(const float4v*)(p.bqkv + h * HD + g * 4);
+        const float4v bv = *(const float4v*)(p.bqkv + 2 * C + h * HD + g * 4);
         if (u == 2) {   // unit 2's left-over queries: q with the second head's weights, merged into its columns
             float4v a = bq;
 #pragma unroll
@@ -349,19 +296,9 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
         // bias (+ shift mask) of this (window class, head) in load order: per query tile 2 x float4 + 1 float per lane;
         // it is the initial accumulator of S^T
         const int cls = __builtin_amdgcn_readfirstlane(Cls[w]);
+        const float* bias = p.bias32 + ((size_t)cls * NH + h) * (3 * 576);
         float4v s[2][3];
         float b2[2];
-#if W2X_A96_BUF
-        const unsigned boff = (unsigned)(cls * NH + h) * (3u * 576u * 4u);
-#pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
-            s[qi][0] = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(RB, l16, boff + (unsigned)(qi * 576) * 4u, 0));
-            s[qi][1] = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(RB, l16, boff + (unsigned)(qi * 576 + 256) * 4u, 0));
-            s[qi][2] = zero4;
-            b2[qi] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(RB, l4, boff + (unsigned)(qi * 576 + 512) * 4u, 0));   // key tile 2 holds one key per lane: added after the product
-        }
-#else
-        const float* bias = p.bias32 + ((size_t)cls * NH + h) * (3 * 576);
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
             s[qi][0] = *(const float4v*)(bias + qi * 576 + lane * 4);
@@ -369,7 +306,6 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
             s[qi][2] = zero4;
             b2[qi] = bias[qi * 576 + 512 + lane];         // key tile 2 holds one key per lane: added after the product
         }
-#endif
         // ---- q^T, k^T (rows = features: A = weights, B = x) and v (rows = slab rows: A = x, B = weights)
         float4v aq[2] = {bq, bq}, ak[3] = {zero4, zero4, zero4}, av[3] = {zero4, zero4, zero4};
 #pragma unroll
@@ -393,9 +329,7 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
 #pragma unroll
         for (int tt = 0; tt < 3; ++tt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) kf[tt][j] = (_Float16)ak[tt][j];
-        vk01[u] = (half8){(_Float16)av[0][0], (_Float16)av[0][1], (_Float16)av[0][2], (_Float16)av[0][3], (_Float16)av[1][0], (_Float16)av[1][1], (_Float16)av[1][2], (_Float16)av[1][3]};
-        vk2[u] = (half4){(_Float16)av[2][0], (_Float16)av[2][1], (_Float16)av[2][2], (_Float16)av[2][3]};
+            for (int j = 0; j < 4; ++j) { kf[tt][j] = (_Float16)ak[tt][j]; vkeep[u][tt][j] = (_Float16)av[tt][j]; }
         // ---- S^T = K Q^T on top of the bias (k = the 16 features); the left-over queries see this unit's keys through the
         // columns of q that belong to it
         const half4 qz = ul == u ? qleft : zeroh4;
@@ -408,23 +342,27 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
         // ---- softmax over the keys (column = query): lane-local maximum of 9, then the 4 lanes of the column
         const float t0 = s[0][2][0] + b2[0], t1 = s[1][2][0] + b2[1];
         float mx0 = max9(s[0][0], s[0][1], t0), mx1 = max9(s[1][0], s[1][1], t1);
-        half8 pf01[2]; half4 pf2[2];
+        half4 pf[2][3];
         if (u < NU - 1) cols_max2(mx0, mx1);
         else {
             const float tl = sl[2][0] + b2l;
             float mxl = max9(sl[0], sl[1], tl);
             cols_max3(mx0, mx1, mxl);
-            probs(sl[0], sl[1], tl, mxl, pl01, pl2);
+            probs(sl[0], sl[1], tl, mxl, pl[0], pl[1], pl[2]);
         }
-        probs(s[0][0], s[0][1], t0, mx0, pf01[0], pf2[0]);
-        probs(s[1][0], s[1][1], t1, mx1, pf01[1], pf2[1]);
-        // ---- O^T = V^T P^T: rows = features, columns = queries; parked in Os (token order).
+        probs(s[0][0], s[0][1], t0, mx0, pf[0][0], pf[0][1], pf[0][2]);
+        probs(s[1][0], s[1][1], t1, mx1, pf[1][0], pf[1][1], pf[1][2]);
+        // ---- O^T = V^T P^T: rows = features, columns = queries (k = 16 keys per product); parked in Os (token order).
         // The softmax denominators come off the matrix pipe too: a ones matrix in place of V^T leaves the sum of the
         // (fp16) probabilities of query fr in every row of its column - the lane that scales the column already holds it.
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
-            const float4v o = keys_product(vk01[u], vk2[u], pf01[qi], pf2[qi]);
-            const float4v l = keys_sum(pf01[qi], pf2[qi]);
+            float4v o = __builtin_amdgcn_mfma_f32_16x16x16f16(vkeep[u][0], pf[qi][0], zero4, 0, 0, 0);
+            float4v l = __builtin_amdgcn_mfma_f32_16x16x16f16(ones, pf[qi][0], zero4, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x16f16(vkeep[u][1], pf[qi][1], o, 0, 0, 0);
+            l = __builtin_amdgcn_mfma_f32_16x16x16f16(ones, pf[qi][1], l, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x16f16(vkeep[u][2], pf[qi][2], o, 0, 0, 0);
+            l = __builtin_amdgcn_mfma_f32_16x16x16f16(ones, pf[qi][2], l, 0, 0, 0);
             const float inv = __builtin_amdgcn_rcpf(l[0]);
             const float2v i2 = {inv, inv};
             const float2v o0 = __builtin_elementwise_fma((float2v){o[0], o[1]}, i2, (float2v){bv[0], bv[1]});
@@ -433,18 +371,20 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
         }
     }
 #undef W2X_LOAD_W
-#undef W2X_WFRAG
-#undef W2X_BQKV
     // ---- left-over queries: O^T against every unit's V, each column keeps the product with its own unit
     {
-        const float4v l = keys_sum(pl01, pl2);
+        float4v l = __builtin_amdgcn_mfma_f32_16x16x16f16(ones, pl[0], zero4, 0, 0, 0);
+        l = __builtin_amdgcn_mfma_f32_16x16x16f16(ones, pl[1], l, 0, 0, 0);
+        l = __builtin_amdgcn_mfma_f32_16x16x16f16(ones, pl[2], l, 0, 0, 0);
         float4v o = zero4;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            const float4v ou = keys_product(vk01[u], vk2[u], pl01, pl2);
+            float4v ou = __builtin_amdgcn_mfma_f32_16x16x16f16(vkeep[u][0], pl[0], zero4, 0, 0, 0);
+            ou = __builtin_amdgcn_mfma_f32_16x16x16f16(vkeep[u][1], pl[1], ou, 0, 0, 0);
+            ou = __builtin_amdgcn_mfma_f32_16x16x16f16(vkeep[u][2], pl[2], ou, 0, 0, 0);
             o = ul == u ? ou : o;
         }
-        const float4v bv = *(const float4v*)(p.bqkv + 2 * C + hl_ * HD + g * 4);   // (hl_ differs per lane)
+        const float4v bv = *(const float4v*)(p.bqkv + 2 * C + hl_ * HD + g * 4);
         const float inv = __builtin_amdgcn_rcpf(l[0]);
         const float2v i2 = {inv, inv};
         const float2v o0 = __builtin_elementwise_fma((float2v){o[0], o[1]}, i2, (float2v){bv[0], bv[1]});
@@ -476,13 +416,8 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
 #pragma unroll
-#if W2X_A96_BUF
-            for (int ks = 0; ks < 3; ++ks) wf[t][ks] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(WP, l16, (unsigned)((n3 + t) * 3 + ks) * 1024u, 0));
-            acc[t] = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(BP, g16, (unsigned)(n3 + t) * 64u, 0));
-#else
             for (int ks = 0; ks < 3; ++ks) wf[t][ks] = *(const half8*)(Wproj + (size_t)(((n3 + t) * 3 + ks) * 64 + lane) * 8);
             acc[t] = *(const float4v*)(p.bproj + (n3 + t) * 16 + g * 4);
-#endif
         }
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {

@@ -24,3 +24,74 @@ def max_over_ranks(value: float, dist=None, device=None) -> float:
 def barrier(dist=None):
     if dist is not None and dist.is_initialized():
         dist.barrier()
+
+
+# ---- node topology without touching the GPU (the launcher parent of bench.py must stay GPU-free: it spawns the ranks)
+def gpu_nodes(sysfs: str = "/sys") -> list[dict]:
+    """GPUs of this node from the KFD topology (/sys/class/kfd/kfd/topology/nodes/*/properties: a node with simd_count > 0 is a
+    GPU), in node order = HIP ordinal order when no *_VISIBLE_DEVICES filter is set.  Each entry: {"node", "render_minor",
+    "numa_node", "cpulist"}; the last two come from the device's DRM render node (its PCIe root's NUMA node and local CPUs)."""
+    import os
+    root = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
+    out = []
+    try:
+        ids = sorted((int(n) for n in os.listdir(root) if n.isdigit()))
+    except OSError:
+        return out
+    for n in ids:
+        props = {}
+        try:
+            for line in open(os.path.join(root, str(n), "properties")):
+                k, _, v = line.strip().partition(" ")
+                props[k] = v.strip()
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0") or 0) <= 0:
+            continue
+        minor = int(props.get("drm_render_minor", "-1") or -1)
+        numa, cpus = -1, ""
+        dev = os.path.join(sysfs, "class", "drm", f"renderD{minor}", "device")
+        try:
+            numa = int(open(os.path.join(dev, "numa_node")).read().strip())
+            cpus = open(os.path.join(dev, "local_cpulist")).read().strip()
+        except (OSError, ValueError):
+            pass
+        out.append({"node": n, "render_minor": minor, "numa_node": numa, "cpulist": cpus})
+    return out
+
+
+def parse_cpulist(text: str) -> set[int]:
+    """'0-3,8,10-11' -> {0,1,2,3,8,10,11} (the kernel's cpulist format)."""
+    cpus: set[int] = set()
+    for part in text.replace("\n", "").split(","):
+        part = part.strip()
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def pin_to_gpu_numa(device: int, sysfs: str = "/sys", apply: bool = True) -> set[int]:
+    """Restrict this process to the CPUs local to GPU `device` (its PCIe root's NUMA node), intersected with what the process may
+    use already (cgroup cpusets).  Page-locked frame buffers allocated afterwards then sit on the GPU's own NUMA node: with one
+    rank per GPU every rank moves 100 MB per 4K frame over PCIe.  Returns the CPU set applied (empty: nothing known, nothing
+    changed)."""
+    import os
+    nodes = gpu_nodes(sysfs)
+    if not (0 <= device < len(nodes)) or not nodes[device]["cpulist"]:
+        return set()
+    want = parse_cpulist(nodes[device]["cpulist"])
+    try:
+        allowed = os.sched_getaffinity(0)
+    except (AttributeError, OSError):
+        return set()
+    cpus = want & allowed
+    if not cpus:
+        return set()
+    if apply:
+        try:
+            os.sched_setaffinity(0, cpus)
+        except OSError:
+            return set()
+    return cpus

@@ -589,7 +589,8 @@ struct Img2Img::Impl {
             hipAssert(hipMemsetAsync(arena_base, 0x7E, arena_bytes, stream));
             hipAssert(hipMemsetAsync(d_slab, 0x7E, slab_cap, stream));
         }
-        const bool graphable = use_graphs && !profiling && !poison && !check_general;
+        // (W2X_POISON fills the whole arena before the frame and so runs the default path: tile groups in their arena parts, replayed graphs)
+        const bool graphable = use_graphs && !profiling && !check_general;
         for (int bi = 0; bi < passCount; ++bi) {
             const auto t0 = std::chrono::steady_clock::now();
             const int live = std::max(0, std::min(B, sp.tile_count * steps - bi * B));
@@ -599,8 +600,9 @@ struct Img2Img::Impl {
                 gp.frame = d_frame; gp.rows = rows; gp.cols = cols; gp.step = (size_t)cols * 3;
                 gp.out = tensors[plan.in_tensor]; gp.slots = d_slots + (size_t)bi * B; gp.B = B; gp.T = T; gp.fp32 = plan.elt == 4;
                 const int NG = groups;
+                struct NgReset { int& r; ~NgReset() { r = 1; } } ng_reset{ng_now};   // also when a launch throws mid-pass
                 ng_now = NG;
-                const bool split = NG > 1 && !profiling && !check_general && !poison && live >= 4 * NG && B % NG == 0 && (size_t)NG * arena_part() <= arena_bytes + 1024;
+                const bool split = NG > 1 && !profiling && !check_general && live >= 4 * NG && B % NG == 0 && (size_t)NG * arena_part() <= arena_bytes + 1024;
                 if (!split) {
                     ng_now = 1;
                     stamp_begin(3, 0);
@@ -638,20 +640,28 @@ struct Img2Img::Impl {
                 const GraphKey key{d_frame, d_slots + (size_t)bi * B, slab_out, arena_base, rows, cols, live};
                 auto it = graphs.find(key);
                 if (it != graphs.end()) { hipAssert(hipGraphLaunch(it->second, stream)); ++graph_replays; }
+                else if (graph_seen.size() >= 4096 && !graph_seen.count(key)) { graph_seen.clear(); run_pass(); ++eager_passes; }   // sizes that keep changing: bounded bookkeeping
                 else if (graph_seen[key]++ == 0) { run_pass(); ++eager_passes; }
                 else {
                     if (graphs.size() >= 1024) drop_graphs();      // frames of ever-changing sizes: start over rather than grow without bound
+                    // Capture -> instantiate -> launch.  Nothing runs while a stream captures, so whatever fails on the way (begin,
+                    // a capture invalidated by a runtime call inside a launcher, end, instantiate) the pass is still to be done:
+                    // graphs are switched off for good (otherwise every later frame would retry and fail again) and it runs on plain launches.
                     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
-                    hipAssert(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-                    try { run_pass(); } catch (...) { (void)hipStreamEndCapture(stream, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
-                    hipAssert(hipStreamEndCapture(stream, &graph));
-                    const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-                    (void)hipGraphDestroy(graph);
-                    if (ie != hipSuccess) {                        // nothing has run yet: fall back to plain launches for good
+                    hipError_t ge = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal);
+                    std::string why = ge == hipSuccess ? "" : std::string("begin capture: ") + hipGetErrorString(ge);
+                    if (ge == hipSuccess) {
+                        try { run_pass(); } catch (const std::exception& e) { why = std::string("capture: ") + e.what(); }
+                        ge = hipStreamEndCapture(stream, &graph);
+                        if (why.empty() && ge != hipSuccess) why = std::string("end capture: ") + hipGetErrorString(ge);
+                        if (why.empty()) { ge = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0); if (ge != hipSuccess) why = std::string("instantiation: ") + hipGetErrorString(ge); }
+                        if (graph) (void)hipGraphDestroy(graph);
+                    }
+                    if (!why.empty()) {
                         (void)hipGetLastError();
                         use_graphs = false;
-                        log(Severity::warn, std::string("hipGraph instantiation failed (") + hipGetErrorString(ie) + "), passes stay on plain launches");
-                        run_pass(); ++eager_passes;
+                        log(Severity::warn, "hipGraph " + why + " - passes stay on plain launches");
+                        run_pass(); ++eager_passes;          // a real launch error surfaces here, outside the capture
                     } else {
                         graphs[key] = exec;
                         hipAssert(hipGraphLaunch(exec, stream)); ++graph_replays;

@@ -57,4 +57,36 @@ inline std::vector<uint16_t> frag_w2(const uint16_t* w, int C) {
     return f;
 }
 
+// The same for v_mfma_f32_32x32x16_f16 (k_mlp96q.hip).  W [N][K] row-major -> [N/32 row tiles][K/16 k-steps][64 lanes][8]:
+// lane = (row & 31) + 32 * h holds columns ks*16 + 8h .. +7
+inline std::vector<uint16_t> frag32_major(const uint16_t* w, int N, int K) {
+    if (N % 32 || K % 16) throw std::runtime_error("frag32_major: shape");
+    std::vector<uint16_t> f((size_t)N * K);
+    const int KS = K / 16;
+    for (int nt = 0; nt < N / 32; ++nt)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e)
+                    f[(((size_t)nt * KS + ks) * 64 + lane) * 8 + e] = w[(size_t)(nt * 32 + (lane & 31)) * K + ks * 16 + (lane >> 5) * 8 + e];
+    return f;
+}
+
+// Second MLP matrix W2 [C][2C] -> [2C/32 chunks][C/32 n-tiles][2 k-steps][64 lanes][8]: lane (n & 31, h) holds the hidden units of
+// the chunk in the order the GELU'd 32x32 accumulator of the transposed first product presents them: registers 8s .. 8s+7 of a
+// lane are rows 16s + 8(j >> 2) + 4h + (j & 3)
+inline std::vector<uint16_t> frag32_w2(const uint16_t* w, int C) {
+    if (C % 32) throw std::runtime_error("frag32_w2: shape");
+    const int H2 = 2 * C, NT = C / 32, NCH = H2 / 32;
+    std::vector<uint16_t> f((size_t)C * H2);
+    for (int ch = 0; ch < NCH; ++ch)
+        for (int nt = 0; nt < NT; ++nt)
+            for (int s = 0; s < 2; ++s)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int h = lane >> 5, hid = ch * 32 + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3);
+                        f[((((size_t)ch * NT + nt) * 2 + s) * 64 + lane) * 8 + e] = w[(size_t)(nt * 32 + (lane & 31)) * H2 + hid];
+                    }
+    return f;
+}
+
 }  // namespace w2x

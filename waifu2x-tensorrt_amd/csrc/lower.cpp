@@ -308,7 +308,11 @@ struct Lowerer {
             View& slot = p.op.res.t < 0 ? p.op.res : p.op.res2;
             if (slot.t >= 0) return;
             if (auto pg = pending_gate.find(it->second.v.t); pg != pending_gate.end()) {   // gated skip connection
-                if (&slot == &p.op.res) p.op.res_scale = pg->second; else apply_gate(it->second.v.t);
+                // the kernels gate the FIRST residual operand on 8-half pieces (launch_gemm refuses res_scale onto a 4-channel output,
+                // the direct 3x3 kernels take no gated operand at all): anything else gets the in-place pass, so that a graph that
+                // lowers also runs
+                if (&slot == &p.op.res && stored_c(C) % 8 == 0 && !(p.op.amode == A_CONV && p.op.kh == 3)) p.op.res_scale = pg->second;
+                else apply_gate(it->second.v.t);
             }
             slot = it->second.v;
             done.insert(u); p.cur = u->out[0];
@@ -434,7 +438,8 @@ struct Lowerer {
         }
         o.Mrows = p.outH * p.outW; o.aW = p.outW;
         if (auto pg = pending_gate.find(x.v.t); pg != pending_gate.end()) {   // gated input: 1x1 / 2x2 kernels scale it on load
-            if (o.kh <= 2) o.se_scale = pg->second; else apply_gate(x.v.t);
+            // (gates ride on 8-half pieces of the operand rows: launch_gemm refuses a_scale on 4-channel or unaligned maps)
+            if (o.kh <= 2 && plan.tensors[x.v.t].C % 8 == 0) o.se_scale = pg->second; else apply_gate(x.v.t);
         }
         p.bias.assign(o.N, 0.f);
         if (n->in.size() > 2 && !n->in[2].empty()) {
