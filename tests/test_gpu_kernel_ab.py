@@ -18,7 +18,7 @@ def test_fused_mlp_kernels_agree_and_are_deterministic(tmp_path):
     csrc = os.path.join(ROOT, "waifu2x-tensorrt_amd", "csrc")
     exe = str(tmp_path / "mlp_ab")
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", csrc, os.path.join(ROOT, "tools", "ab", "mlp_ab.hip"),
-                    os.path.join(ROOT, "tools", "ab", "k_mlp_staged.hip"), os.path.join(csrc, "k_mlp2.hip"), os.path.join(csrc, "k_mlp96p.hip"), "-o", exe], check=True, timeout=900)
+                    os.path.join(ROOT, "tools", "ab", "k_mlp_staged.hip"), os.path.join(csrc, "k_mlp2.hip"), os.path.join(csrc, "k_mlp96q.hip"), "-o", exe], check=True, timeout=900)
     out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=600).stdout
     cases = re.findall(r"C=(\d+) M=(\d+) stats=(\d): max\|dy\|=([0-9.]+) .*max rel stats diff=([0-9.e+-]+)", out)
     assert len(cases) >= 18, out
@@ -51,3 +51,27 @@ def test_fused_attention96_schedules_agree_with_each_other_and_with_fp32(tmp_pat
         assert float(dy) <= 8e-3 and int(nan) == 0, out      # |y| is O(3): one fp16 ULP there is 2e-3; the two differ in summation order only
     for a, b in host:
         assert float(b) <= 1.2e-2 and float(b) <= float(a) + 4e-3, out
+
+
+@pytest.mark.gpu
+def test_fused_mlp96_tile_shapes_agree_with_each_other_and_with_fp32(tmp_path):
+    """tools/ab/mlp96_ab.hip: the C = 96 MLP that ships (csrc/k_mlp96q.hip: v_mfma_f32_32x32x16_f16, rows through buffer resources,
+    biases through LDS) against the round-2 kernel on 16x16x32 tiles (tools/ab/k_mlp96p.hip) - ragged row counts, with and without
+    the LayerNorm-statistics output, both against a plain fp32 host evaluation with the exact erf GELU; the shipped kernel must
+    reproduce itself bit for bit at the headline row count."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    csrc = os.path.join(ROOT, "waifu2x-tensorrt_amd", "csrc")
+    exe = str(tmp_path / "mlp96_ab")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", csrc, "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fno-honor-nans",
+                    os.path.join(ROOT, "tools", "ab", "mlp96_ab.hip"), os.path.join(ROOT, "tools", "ab", "k_mlp96p.hip"), os.path.join(csrc, "k_mlp96q.hip"), "-o", exe],
+                   check=True, timeout=900)
+    out = subprocess.run([exe, "timing"], check=True, capture_output=True, text=True, timeout=600).stdout
+    print(out)
+    ab = re.findall(r"16x16 vs 32x32 max\|dy\|=([0-9.]+) .*?nan=(\d+), max rel stats diff=([0-9.e+-]+)", out)
+    host = re.findall(r"fp32 host evaluation: 16x16 max\|d\|=([0-9.]+) 32x32 max\|d\|=([0-9.]+)", out)
+    assert len(ab) >= 9 and len(host) >= 6, out
+    for dy, nan, ds in ab:
+        assert float(dy) <= 8e-3 and int(nan) == 0 and float(ds) <= 5e-2, out   # |y| is O(4): one fp16 ULP there is 4e-3; summation order only
+    for a, b in host:
+        assert float(b) <= 6e-3 and float(b) <= float(a) + 2e-3, out
+    assert re.search(r"32x32 kernel run twice: 0 elements differ", out), out

@@ -43,7 +43,7 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&ya, M * C * 2)); CK(hipMalloc(&yb, M * C * 2)); CK(hipMalloc(&sa, M * 8 + 8)); CK(hipMalloc(&sb, M * 8 + 8));
         CK(hipMemset(ya, 0xFF, M * C * 2)); CK(hipMemset(yb, 0xFF, M * C * 2));
         pa.w1_frag = up(frag_major(w1.data(), 2 * C, C)); pa.w2_frag = up(frag_w2(w2.data(), C));
-        pb.w1_frag = up(frag32_major(w1.data(), 2 * C, C)); pb.w2_frag = up(frag32_w2(w2.data(), C));
+        pb.w1_frag = up(frag32_major(w1.data(), 2 * C, C)); pb.w2_frag = up(frag32_w2(w2.data(), C)); pb.frag32 = true;
         pa.y = ya; pa.stats_out = stats ? sa : nullptr;
         pb.y = yb; pb.stats_out = stats ? sb : nullptr;
         CK(launch_mlp96p(pa, 0));

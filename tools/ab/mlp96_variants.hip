@@ -75,7 +75,7 @@ int main(int argc, char** argv) {
     for (auto& v : b2) v = frand() * 0.1f;
     MlpParams p; p.M = M; p.C = C;
     p.x = up(x); p.w1 = up(w1); p.w2 = up(w2); p.b1 = up(b1); p.b2 = up(b2);
-    p.w1_frag = up(frag32_major(w1.data(), 2 * C, C)); p.w2_frag = up(frag32_w2(w2.data(), C));
+    p.w1_frag = up(frag32_major(w1.data(), 2 * C, C)); p.w2_frag = up(frag32_w2(w2.data(), C)); p.frag32 = true;
     uint16_t* yv[NVAR];
     std::vector<uint16_t> h0(M * C), hv(M * C);
     for (int v = 0; v < NVAR; ++v) {

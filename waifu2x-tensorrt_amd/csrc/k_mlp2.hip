@@ -332,17 +332,17 @@ hipError_t launch_mlp2_c(const MlpParams& p, hipStream_t s) {
 
 }  // namespace
 
-bool mlp96p_supported(const MlpParams& p);                        // k_mlp96p.hip: C = 96 with both matrices resident in LDS
-hipError_t launch_mlp96p(const MlpParams& p, hipStream_t s);
+bool mlp96q_supported(const MlpParams& p);                        // k_mlp96q.hip: C = 96 with both matrices resident in LDS
+hipError_t launch_mlp96q(const MlpParams& p, hipStream_t s);
 
 hipError_t launch_mlp2(const MlpParams& p, hipStream_t s) {
-    // C = 96: the resident-weight kernel (k_mlp96p.hip); W2X_MLP96_CHUNKED=1 (read once per process) keeps this file's chunked
-    // schedule for A/B runs.  C = 192 (weights 288 KiB): shared-weight schedule, 32 rows per wave, 4 waves per workgroup.
+    // C = 96: the resident-weight kernel on 32x32 tiles (k_mlp96q.hip; the engine stores its weights in that kernel's fragment order,
+    // fragorder.h frag32_*).  This file's chunked schedule at C = 96 (frag_major / frag_w2 order) remains for tools/ab/mlp_ab.hip.
+    // C = 192 (weights 288 KiB): shared-weight schedule, 32 rows per wave, 4 waves per workgroup.
     // Measured alternatives: 8 waves per workgroup (a chunk staged once per 256 rows, one workgroup per CU) 2.0 ms of C = 192 MLP time
     // per frame against 1.77; in round 1 6 / 12 waves per workgroup 2.45 / 1.86 ms of MLP time per frame against 1.58; a per-wave
     // register ring straight from L2 (TT = 4) and 64 rows per wave with shared weights were slower as well.
-    static const bool chunked96 = getenv("W2X_MLP96_CHUNKED") != nullptr;
-    if (p.C == 96 && !chunked96 && mlp96p_supported(p)) return launch_mlp96p(p, s);
+    if (p.C == 96 && p.frag32) return mlp96q_supported(p) ? launch_mlp96q(p, s) : hipErrorInvalidValue;
     if (p.C == 96) return launch_mlp2_c<96, 2, 4>(p, s);
     if (p.C == 192) return launch_mlp2_c<192, 2, 4>(p, s);
     return hipErrorInvalidValue;

@@ -34,7 +34,10 @@
 // tools/ab/mlp96_variants.sh measured 0.345 ms per launch against 0.312 with the rows served from cache and 0.202 with the
 // products and the GELU removed (5 TB/s): the memory phase and the compute phase were adding up.
 #ifndef W2X_MLP_PREFETCH
-#define W2X_MLP_PREFETCH 1
+#define W2X_MLP_PREFETCH 0   // measured (profiles/r3_mlp96/): 0.3018 ms per launch without, 0.3085 with (request after the last chunk), 0.331 with the
+#endif                       // request three chunks earlier: with three waves per SIMD the other two cover a wave's fetch, and the SIMD is busy issuing
+#ifndef W2X_MLP_STAGGER
+#define W2X_MLP_STAGGER 0   // units of s_sleep 127 (about 8 K cycles) between the start of a SIMD's first, second and third wave; measured +9 % time
 #endif
 #ifndef W2X_MLP_PFCH
 #define W2X_MLP_PFCH 5      // the chunk (0..5) after whose first-layer products the request goes out: earlier = further ahead, 24 registers held longer
@@ -169,6 +172,11 @@ __global__ __launch_bounds__(NTHR, 3) void mlp96q_kernel(const MlpParams p, int 
         }
         if (tid < 3 * C) ((float*)(smem + BIAS_OFF))[tid] = tid < 2 * C ? p.b1[tid] : p.b2[tid - 2 * C];
     }
+#if W2X_MLP_STAGGER
+    // The three waves of a SIMD (wv, wv + 4, wv + 8) leave the barrier together and run the same program: left alone they stay in
+    // phase - all in their matrix products, then all in their GELU - and the two pipes take turns.  Start them a third of a tile apart.
+    for (int k = 0; k < (wv >> 2) * W2X_MLP_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
+#endif
     const float* B1s = (const float*)(smem + BIAS_OFF) + h * 4;
     const float* B2s = B1s + 2 * C;
     __syncthreads();
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(NTHR, 3) void mlp96q_kernel(const MlpParams p, int 
 
 }  // namespace
 
-bool mlp96q_supported(const MlpParams& p) { return p.C == C && p.w1_frag && p.w2_frag; }
+bool mlp96q_supported(const MlpParams& p) { return p.C == C && p.w1_frag && p.w2_frag && p.frag32; }
 
 hipError_t launch_mlp96q(const MlpParams& p, hipStream_t s) {
     static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds

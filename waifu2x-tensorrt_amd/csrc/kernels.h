@@ -70,6 +70,8 @@ struct MlpParams {               // y = x + W2 gelu(W1 LN(x) + b1) + b2 on conti
     // fragment-major copies for k_mlp2.hip (engine.cpp): w1 as [hidden tile][k-step][lane][8]; w2 as
     // [chunk of 32 hidden][n-tile][lane][8] with the k order of the GELU'd accumulators (slots 0..3: hidden 4g+j, 4..7: 16+4g+j)
     const void* w1_frag = nullptr; const void* w2_frag = nullptr;
+    // true: the fragment copies are in the 32x32x16 order of k_mlp96q.hip (fragorder.h frag32_major / frag32_w2; C = 96 in the engine)
+    bool frag32 = false;
 };
 
 struct SwinAttnParams {          // y = x + proj(W-MSA(LN(x))) on token maps [B][H][W][C], window 6x6
