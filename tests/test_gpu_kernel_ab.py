@@ -69,7 +69,7 @@ def test_fused_mlp96_tile_shapes_agree_with_each_other_and_with_fp32(tmp_path):
     print(out)
     ab = re.findall(r"16x16 vs 32x32 max\|dy\|=([0-9.]+) .*?nan=(\d+), max rel stats diff=([0-9.e+-]+)", out)
     host = re.findall(r"fp32 host evaluation: 16x16 max\|d\|=([0-9.]+) 32x32 max\|d\|=([0-9.]+)", out)
-    assert len(ab) >= 9 and len(host) >= 6, out
+    assert len(ab) >= 8 and len(host) >= 6, out
     for dy, nan, ds in ab:
         assert float(dy) <= 8e-3 and int(nan) == 0 and float(ds) <= 5e-2, out   # |y| is O(4): one fp16 ULP there is 4e-3; summation order only
     for a, b in host:

@@ -24,18 +24,6 @@
 
 #include <cstdlib>
 
-// C = 192 geometry (tools/ab/mlp192_variants.sh times the alternatives): token tiles of 16 rows per wave, waves per workgroup, and
-// the workgroups per CU the register budget is set for
-#ifndef W2X_MLP192_TT
-#define W2X_MLP192_TT 2
-#endif
-#ifndef W2X_MLP192_NW
-#define W2X_MLP192_NW 4
-#endif
-#ifndef W2X_MLP192_WPS
-#define W2X_MLP192_WPS 2
-#endif
-
 namespace w2x {
 namespace {
 
@@ -141,19 +129,14 @@ struct Mlp2Cfg {
     // in the slab and serve the residual add - x is read from HBM once.  Otherwise the buffers alias the slabs (x lives in
     // registers by then) and the residual rows are fetched a second time.
     static constexpr bool KEEP = C == 96;
-    static constexpr int WORK = KEEP ? NWV * SLAB + 2 * WBUF : (NWV * SLAB > 2 * WBUF ? NWV * SLAB : 2 * WBUF);
-    // b1 [2C] | b2 [C] as fp32 behind the work area: the per-chunk bias reads are LDS reads.  As global loads they shared the vector
-    // memory counter with the LDS-DMA staging of the NEXT chunk, and the wait for a chunk's two bias vectors (s_waitcnt vmcnt(0), in
-    // order) was a wait for that staging: the double buffering did not overlap anything.
-    static constexpr int BIAS_OFF = WORK;
-    static constexpr int SMEM = WORK + 3 * C * 4;
+    static constexpr int SMEM = KEEP ? NWV * SLAB + 2 * WBUF : (NWV * SLAB > 2 * WBUF ? NWV * SLAB : 2 * WBUF);
     static_assert(NF % NWV == 0 && NF % RING == 0 && 2 * KS >= RING, "fragments per wave / ring slots");
     static_assert(RW * PPR % 64 == 0, "flat piece count");
 };
 
 template <int C, int TT, int NW>
 // (the second launch bound is hipcc's minimum number of waves per SIMD, not blocks per CU)
-__global__ __launch_bounds__(NW * 64, (C == 96 ? 3 : W2X_MLP192_WPS) * NW / 4) void mlp2_kernel(const MlpParams p) {
+__global__ __launch_bounds__(NW * 64, (C == 96 ? 3 : 2)) void mlp2_kernel(const MlpParams p) {
     using K = Mlp2Cfg<C, TT, NW>;
     constexpr int RW = K::RW, LDX = K::LDX, PPR = K::PPR, KS = K::KS, NT = K::NT, NCH = K::NCH, NP = K::NP, NF = K::NF, RING = K::RING;
     constexpr int NFW = NF / K::NWV;
@@ -189,9 +172,6 @@ __global__ __launch_bounds__(NW * 64, (C == 96 ? 3 : W2X_MLP192_WPS) * NW / 4) v
         return *(const half8*)(WBb + (size_t)(ch & 1) * K::WBUF + (size_t)f * 1024 + lane * 16);
     };
     if (K::KEEP) stage(0);                     // separate buffers: under the row loads and the LayerNorm
-    for (int i = tid; i < 3 * C; i += K::NWV * 64) ((float*)(smem + K::BIAS_OFF))[i] = i < 2 * C ? p.b1[i] : p.b2[i - 2 * C];   // (first read after two barriers)
-    const float* B1s = (const float*)(smem + K::BIAS_OFF) + g * 4;
-    const float* B2s = B1s + 2 * C;
 
     // ---- x rows: flat coalesced load -> slab
     {
@@ -248,7 +228,7 @@ __global__ __launch_bounds__(NW * 64, (C == 96 ? 3 : W2X_MLP192_WPS) * NW / 4) v
     float4v acc2[TT][NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const float4v b2v = *(const float4v*)(B2s + j * 16);
+        const float4v b2v = *(const float4v*)(p.b2 + j * 16 + g * 4);
 #pragma unroll
         for (int i = 0; i < TT; ++i) acc2[i][j] = b2v;
     }
@@ -259,8 +239,8 @@ __global__ __launch_bounds__(NW * 64, (C == 96 ? 3 : W2X_MLP192_WPS) * NW / 4) v
         // GEMM1 (transposed): acc1[ht][tt] = W1[32ch + 16ht ..][:] * Xn[16tt ..][:]^T   (rows = hidden, columns = tokens), from b1
         float4v acc1[2][TT];
         {
-            const float4v be = *(const float4v*)(B1s + ch * 32);
-            const float4v bo = *(const float4v*)(B1s + ch * 32 + 16);
+            const float4v be = *(const float4v*)(p.b1 + ch * 32 + g * 4);
+            const float4v bo = *(const float4v*)(p.b1 + ch * 32 + 16 + g * 4);
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt) { acc1[0][tt] = be; acc1[1][tt] = bo; }
         }
@@ -364,7 +344,7 @@ hipError_t launch_mlp2(const MlpParams& p, hipStream_t s) {
     // register ring straight from L2 (TT = 4) and 64 rows per wave with shared weights were slower as well.
     if (p.C == 96 && p.frag32) return mlp96q_supported(p) ? launch_mlp96q(p, s) : hipErrorInvalidValue;
     if (p.C == 96) return launch_mlp2_c<96, 2, 4>(p, s);
-    if (p.C == 192) return launch_mlp2_c<192, W2X_MLP192_TT, W2X_MLP192_NW>(p, s);
+    if (p.C == 192) return launch_mlp2_c<192, 2, 4>(p, s);
     return hipErrorInvalidValue;
 }
 

@@ -62,9 +62,12 @@ static launch_fn variants[] = {launch_mlp96_v0, launch_mlp96_v1,
 template <class T> T* up(const std::vector<T>& v) { T* d; CK(hipMalloc(&d, v.size() * sizeof(T) + 256)); CK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)); return d; }
 static float frand() { return (float)rand() / RAND_MAX * 2.f - 1.f; }
 
+#ifndef CW
+#define CW 96        // 192: variants of csrc/k_mlp2.hip (tools/ab/mlp192_variants.sh), weights in the 16x16x32 fragment order
+#endif
 int main(int argc, char** argv) {
-    const int C = 96;
-    const long M = argc > 1 ? atol(argv[1]) : 2592000L;
+    const int C = CW;
+    const long M = argc > 1 ? atol(argv[1]) : (C == 96 ? 2592000L : 648000L);
     srand(7);
     std::vector<uint16_t> x(M * C), w1(2 * C * C), w2(C * 2 * C);
     std::vector<float> b1(2 * C), b2(C);
@@ -75,7 +78,8 @@ int main(int argc, char** argv) {
     for (auto& v : b2) v = frand() * 0.1f;
     MlpParams p; p.M = M; p.C = C;
     p.x = up(x); p.w1 = up(w1); p.w2 = up(w2); p.b1 = up(b1); p.b2 = up(b2);
-    p.w1_frag = up(frag32_major(w1.data(), 2 * C, C)); p.w2_frag = up(frag32_w2(w2.data(), C)); p.frag32 = true;
+    if (C == 96) { p.w1_frag = up(frag32_major(w1.data(), 2 * C, C)); p.w2_frag = up(frag32_w2(w2.data(), C)); p.frag32 = true; }
+    else { p.w1_frag = up(frag_major(w1.data(), 2 * C, C)); p.w2_frag = up(frag_w2(w2.data(), C)); }
     uint16_t* yv[NVAR];
     std::vector<uint16_t> h0(M * C), hv(M * C);
     for (int v = 0; v < NVAR; ++v) {

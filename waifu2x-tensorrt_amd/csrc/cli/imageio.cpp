@@ -70,6 +70,8 @@ Bitmap read_png(const std::vector<uint8_t>& d, const std::string& path) {
     uLongf rawlen = raw.size();
     if (uncompress(raw.data(), &rawlen, idat.data(), idat.size()) != Z_OK || rawlen != raw.size()) throw std::runtime_error(path + ": PNG data does not inflate");
     Bitmap b; b.rows = h; b.cols = w; b.bgr.resize((size_t)w * h * 3);
+    const bool has_alpha = ctype == 4 || ctype == 6;               // kept for the writer (the network sees colour only)
+    if (has_alpha) b.alpha.resize((size_t)w * h);
     size_t at = 0;
     for (int k = 0; k < npass; ++k) {
         const Pass& ps = interlace ? adam7[k] : whole;
@@ -95,8 +97,10 @@ Bitmap read_png(const std::vector<uint8_t>& d, const std::string& path) {
                 else if (ctype == 0 || ctype == 4) r = g = bl = cur[(size_t)x * bpp];
                 else if (ctype == 3) { const size_t kk = (size_t)(packed ? sample : cur[x]) * 3; if (kk + 3 > plte.size()) throw std::runtime_error(path + ": palette index out of range"); r = plte[kk]; g = plte[kk + 1]; bl = plte[kk + 2]; }
                 else { r = cur[(size_t)x * bpp]; g = cur[(size_t)x * bpp + bps]; bl = cur[(size_t)x * bpp + 2 * bps]; }
-                uint8_t* o = &b.bgr[((size_t)(ps.y0 + y * ps.dy) * w + ps.x0 + x * ps.dx) * 3];
+                const size_t px = (size_t)(ps.y0 + y * ps.dy) * w + ps.x0 + x * ps.dx;
+                uint8_t* o = &b.bgr[px * 3];
                 o[0] = bl; o[1] = g; o[2] = r;
+                if (has_alpha) b.alpha[px] = cur[(size_t)x * bpp + (size_t)(ch - 1) * bps];
             }
             prev.swap(cur);
         }
@@ -113,20 +117,80 @@ void chunk(std::vector<uint8_t>& out, const char* type, const std::vector<uint8_
 }
 
 void write_png(const std::string& path, const Bitmap& b) {
-    std::vector<uint8_t> raw(((size_t)b.cols * 3 + 1) * b.rows);
+    const bool rgba = !b.alpha.empty();
+    const int ch = rgba ? 4 : 3;
+    std::vector<uint8_t> raw(((size_t)b.cols * ch + 1) * b.rows);
     for (int y = 0; y < b.rows; ++y) {
-        uint8_t* line = &raw[((size_t)b.cols * 3 + 1) * y];
+        uint8_t* line = &raw[((size_t)b.cols * ch + 1) * y];
         line[0] = 0;   // filter "none": the payload is deflated at level 1 for speed (a 4K frame is 100 MB)
         const uint8_t* s = &b.bgr[(size_t)y * b.cols * 3];
-        for (int x = 0; x < b.cols; ++x) { line[1 + 3 * x] = s[3 * x + 2]; line[2 + 3 * x] = s[3 * x + 1]; line[3 + 3 * x] = s[3 * x]; }
+        for (int x = 0; x < b.cols; ++x) {
+            uint8_t* o = line + 1 + (size_t)ch * x;
+            o[0] = s[3 * x + 2]; o[1] = s[3 * x + 1]; o[2] = s[3 * x];
+            if (rgba) o[3] = b.alpha[(size_t)y * b.cols + x];
+        }
     }
     uLongf clen = compressBound(raw.size());
     std::vector<uint8_t> comp(clen);
     if (compress2(comp.data(), &clen, raw.data(), raw.size(), 1) != Z_OK) throw std::runtime_error("PNG deflate failed");
     comp.resize(clen);
     std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a}, ihdr;
-    put32(ihdr, b.cols); put32(ihdr, b.rows); ihdr.insert(ihdr.end(), {8, 2, 0, 0, 0});
+    put32(ihdr, b.cols); put32(ihdr, b.rows); ihdr.insert(ihdr.end(), {8, (uint8_t)(rgba ? 6 : 2), 0, 0, 0});
     chunk(out, "IHDR", ihdr); chunk(out, "IDAT", comp); chunk(out, "IEND", {});
+    std::ofstream f(path, std::ios::binary);
+    if (!f.write((const char*)out.data(), out.size())) throw std::runtime_error("cannot write " + path);
+}
+
+// ---- device-independent bitmaps (BMP files and the frames of an uncompressed AVI): rows of BGR(A) padded to 4 bytes, bottom-up unless
+// the height is negative
+uint32_t le32(const uint8_t* p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | p[1] << 8); }
+void putle32(std::vector<uint8_t>& v, uint32_t x) { v.push_back(x); v.push_back(x >> 8); v.push_back(x >> 16); v.push_back(x >> 24); }
+void putle16(std::vector<uint8_t>& v, uint16_t x) { v.push_back((uint8_t)x); v.push_back((uint8_t)(x >> 8)); }
+size_t dib_stride(int w, int bits) { return ((size_t)w * bits + 31) / 32 * 4; }
+
+Bitmap read_bmp(const std::vector<uint8_t>& d, const std::string& path) {
+    if (d.size() < 54 || d[0] != 'B' || d[1] != 'M') throw std::runtime_error(path + ": not a BMP file");
+    const uint32_t off = le32(&d[10]), hdr = le32(&d[14]);
+    if (hdr < 40) throw std::runtime_error(path + ": unsupported BMP header");
+    const int w = (int)le32(&d[18]), hs = (int)le32(&d[22]), bits = le16(&d[28]);
+    const uint32_t comp = le32(&d[30]);
+    const int h = hs < 0 ? -hs : hs;
+    if (w <= 0 || h <= 0 || (bits != 24 && bits != 32) || !(comp == 0 || (comp == 3 && bits == 32))) throw std::runtime_error(path + ": unsupported BMP (24 / 32-bit uncompressed only)");
+    if (comp == 3 && (d.size() < 54 + 12 || le32(&d[54]) != 0x00FF0000u || le32(&d[58]) != 0x0000FF00u || le32(&d[62]) != 0x000000FFu)) throw std::runtime_error(path + ": unsupported BMP channel masks");
+    const size_t stride = dib_stride(w, bits);
+    if ((size_t)off + stride * h > d.size()) throw std::runtime_error(path + ": truncated BMP");
+    Bitmap b; b.rows = h; b.cols = w; b.bgr.resize((size_t)w * h * 3);
+    bool any_alpha = false;
+    std::vector<uint8_t> alpha;
+    if (bits == 32) alpha.resize((size_t)w * h);
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* src = &d[off + stride * (size_t)(hs < 0 ? y : h - 1 - y)];
+        uint8_t* o = &b.bgr[(size_t)y * w * 3];
+        if (bits == 24) memcpy(o, src, (size_t)w * 3);
+        else for (int x = 0; x < w; ++x) { o[3 * x] = src[4 * x]; o[3 * x + 1] = src[4 * x + 1]; o[3 * x + 2] = src[4 * x + 2]; alpha[(size_t)y * w + x] = src[4 * x + 3]; any_alpha |= src[4 * x + 3] != 0; }
+    }
+    if (any_alpha) b.alpha.swap(alpha);      // (32-bit files with an all-zero fourth byte carry no alpha: BI_RGB leaves it undefined)
+    return b;
+}
+
+void write_bmp(const std::string& path, const Bitmap& b) {
+    const bool a = !b.alpha.empty();
+    const int bits = a ? 32 : 24;
+    const size_t stride = dib_stride(b.cols, bits), img = stride * b.rows;
+    if (54 + img > 0xFFFFFFFFull) throw std::runtime_error("image too large for a BMP file");
+    std::vector<uint8_t> out;
+    out.reserve(54 + img);
+    out.push_back('B'); out.push_back('M'); putle32(out, (uint32_t)(54 + img)); putle32(out, 0); putle32(out, 54);
+    putle32(out, 40); putle32(out, (uint32_t)b.cols); putle32(out, (uint32_t)b.rows); putle16(out, 1); putle16(out, (uint16_t)bits); putle32(out, 0);
+    putle32(out, (uint32_t)img); putle32(out, 2835); putle32(out, 2835); putle32(out, 0); putle32(out, 0);
+    out.resize(54 + img, 0);
+    for (int y = 0; y < b.rows; ++y) {
+        uint8_t* o = &out[54 + stride * (size_t)(b.rows - 1 - y)];
+        const uint8_t* s = &b.bgr[(size_t)y * b.cols * 3];
+        if (!a) memcpy(o, s, (size_t)b.cols * 3);
+        else for (int x = 0; x < b.cols; ++x) { o[4 * x] = s[3 * x]; o[4 * x + 1] = s[3 * x + 1]; o[4 * x + 2] = s[3 * x + 2]; o[4 * x + 3] = b.alpha[(size_t)y * b.cols + x]; }
+    }
     std::ofstream f(path, std::ios::binary);
     if (!f.write((const char*)out.data(), out.size())) throw std::runtime_error("cannot write " + path);
 }
@@ -157,17 +221,147 @@ void write_ppm(const std::string& path, const Bitmap& b) {
 
 }  // namespace
 
-bool is_builtin_still(const std::string& path) { const std::string e = lower_ext(path); return e == ".png" || e == ".ppm"; }
+bool is_builtin_still(const std::string& path) { const std::string e = lower_ext(path); return e == ".png" || e == ".ppm" || e == ".bmp"; }
 
 Bitmap read_image(const std::string& path) {
     const std::vector<uint8_t> d = slurp(path);
     if (d.size() >= 2 && d[0] == 'P' && d[1] == '6') return read_ppm(d, path);
+    if (d.size() >= 2 && d[0] == 'B' && d[1] == 'M') return read_bmp(d, path);
     return read_png(d, path);
 }
 
 void write_image(const std::string& path, const Bitmap& b) {
-    if ((size_t)b.rows * b.cols * 3 != b.bgr.size()) throw std::runtime_error("bitmap size mismatch");
-    if (lower_ext(path) == ".ppm") write_ppm(path, b); else write_png(path, b);
+    if ((size_t)b.rows * b.cols * 3 != b.bgr.size() || (!b.alpha.empty() && b.alpha.size() != (size_t)b.rows * b.cols)) throw std::runtime_error("bitmap size mismatch");
+    const std::string e = lower_ext(path);
+    if (e == ".ppm") write_ppm(path, b); else if (e == ".bmp") write_bmp(path, b); else write_png(path, b);
+}
+
+// ---- uncompressed AVI (RIFF AVI 1.0): RIFF 'AVI ' { LIST 'hdrl' { 'avih', LIST 'strl' { 'strh', 'strf' } }, LIST 'movi' { '00db' frame ... }, 'idx1' }
+AviReader::~AviReader() { if (f_) fclose(f_); }
+
+bool AviReader::open(const std::string& path, std::string* why) {
+    auto no = [&](const char* w) { if (why) *why = w; if (f_) { fclose(f_); f_ = nullptr; } return false; };
+    f_ = fopen(path.c_str(), "rb");
+    if (!f_) return no("cannot open the file");
+    uint8_t h[12];
+    if (fread(h, 1, 12, f_) != 12 || memcmp(h, "RIFF", 4) || memcmp(h + 8, "AVI ", 4)) return no("not a RIFF AVI file");
+    const long riff_end = 8 + (long)le32(h + 4);
+    bool have_fmt = false, video = false;
+    uint32_t scale = 1, rate = 30, usec = 0;
+    int bits = 0; uint32_t comp = 1; int hs = 0;
+    // walk the top-level chunks up to the 'movi' list; 'hdrl' is descended into
+    std::vector<long> ends = {riff_end};
+    while (ftell(f_) + 8 <= riff_end) {
+        uint8_t c[8];
+        if (fread(c, 1, 8, f_) != 8) break;
+        const uint32_t len = le32(c + 4);
+        const long body = ftell(f_);
+        if (!memcmp(c, "LIST", 4)) {
+            uint8_t t[4];
+            if (fread(t, 1, 4, f_) != 4) break;
+            if (!memcmp(t, "movi", 4)) { movi_end_ = body + (long)len; break; }
+            if (!memcmp(t, "hdrl", 4) || !memcmp(t, "strl", 4)) continue;      // descend
+            fseek(f_, body + (long)((len + 1) & ~1u), SEEK_SET);
+            continue;
+        }
+        std::vector<uint8_t> b(len < 4096 ? len : 4096);
+        if (!b.empty() && fread(b.data(), 1, b.size(), f_) != b.size()) break;
+        if (!memcmp(c, "avih", 4) && b.size() >= 40) { usec = le32(&b[0]); info_.frames = (int)le32(&b[16]); }
+        else if (!memcmp(c, "strh", 4) && b.size() >= 36) { video = !memcmp(&b[0], "vids", 4) && !have_fmt; if (video) { scale = le32(&b[20]); rate = le32(&b[24]); if (le32(&b[32])) info_.frames = (int)le32(&b[32]); } }
+        else if (!memcmp(c, "strf", 4) && video && !have_fmt && b.size() >= 40) { info_.width = (int)le32(&b[4]); hs = (int)le32(&b[8]); bits = le16(&b[14]); comp = le32(&b[16]); have_fmt = true; }
+        fseek(f_, body + (long)((len + 1) & ~1u), SEEK_SET);
+    }
+    if (!have_fmt || !movi_end_) return no("no video stream / no movi list");
+    if (comp != 0 || bits != 24) return no("the video stream is not uncompressed 24-bit (BI_RGB)");
+    info_.height = hs < 0 ? -hs : hs; bottom_up_ = hs > 0;
+    if (info_.width <= 0 || info_.height <= 0) return no("bad frame size");
+    info_.fps = scale && rate ? (double)rate / scale : usec ? 1e6 / usec : 30.0;
+    if (info_.frames <= 0) info_.frames = 1;
+    row_.resize(dib_stride(info_.width, 24));
+    return true;
+}
+
+bool AviReader::read(uint8_t* bgr) {
+    if (!f_) return false;
+    const size_t stride = row_.size(), need = stride * info_.height;
+    while (ftell(f_) + 8 <= movi_end_) {
+        uint8_t c[8];
+        if (fread(c, 1, 8, f_) != 8) return false;
+        const uint32_t len = le32(c + 4);
+        const long body = ftell(f_);
+        if (!memcmp(c, "LIST", 4)) { fseek(f_, 4, SEEK_CUR); continue; }            // 'rec ' groups: descend
+        const bool frame = c[0] == '0' && c[1] == '0' && c[2] == 'd' && (c[3] == 'b' || c[3] == 'c');
+        if (frame && len >= need) {
+            for (int y = 0; y < info_.height; ++y) {
+                if (fread(row_.data(), 1, stride, f_) != stride) return false;
+                memcpy(bgr + (size_t)(bottom_up_ ? info_.height - 1 - y : y) * info_.width * 3, row_.data(), (size_t)info_.width * 3);
+            }
+            fseek(f_, body + (long)((len + 1) & ~1u), SEEK_SET);
+            return true;
+        }
+        fseek(f_, body + (long)((len + 1) & ~1u), SEEK_SET);                             // audio, JUNK, empty (dropped) frames
+    }
+    return false;
+}
+
+AviWriter::~AviWriter() { if (f_) { try { close(); } catch (...) {} } }
+
+void AviWriter::open(const std::string& path, int width, int height, double fps) {
+    f_ = fopen(path.c_str(), "wb");
+    if (!f_) throw std::runtime_error("cannot write " + path);
+    w_ = width; h_ = height; stride_ = dib_stride(width, 24); frames_ = 0; offsets_.clear();
+    buf_.assign(stride_ * height, 0);
+    // frame rate as a fraction with a millihertz grid (23.976 -> 23976 / 1000)
+    scale_ = 1000; rate_ = (uint32_t)(fps * 1000.0 + 0.5); if (!rate_) { rate_ = 30000; }
+    std::vector<uint8_t> hd;
+    auto four = [&](const char* s) { hd.insert(hd.end(), s, s + 4); };
+    four("RIFF"); putle32(hd, 0); four("AVI ");
+    four("LIST"); putle32(hd, 4 + 8 + 56 + 12 + 8 + 56 + 8 + 40); four("hdrl");
+    four("avih"); putle32(hd, 56);
+    putle32(hd, (uint32_t)(1e6 * scale_ / rate_ + 0.5)); putle32(hd, 0); putle32(hd, 0); putle32(hd, 0x10 /* has index */); putle32(hd, 0 /* frames: patched */); putle32(hd, 0);
+    putle32(hd, 1); putle32(hd, (uint32_t)buf_.size()); putle32(hd, (uint32_t)w_); putle32(hd, (uint32_t)h_); for (int i = 0; i < 4; ++i) putle32(hd, 0);
+    four("LIST"); putle32(hd, 4 + 8 + 56 + 8 + 40); four("strl");
+    four("strh"); putle32(hd, 56);
+    four("vids"); four("DIB "); putle32(hd, 0); putle32(hd, 0); putle32(hd, 0); putle32(hd, scale_); putle32(hd, rate_); putle32(hd, 0); putle32(hd, 0 /* length: patched */);
+    putle32(hd, (uint32_t)buf_.size()); putle32(hd, 0xFFFFFFFFu); putle32(hd, 0); putle16(hd, 0); putle16(hd, 0); putle16(hd, (uint16_t)w_); putle16(hd, (uint16_t)h_);
+    four("strf"); putle32(hd, 40);
+    putle32(hd, 40); putle32(hd, (uint32_t)w_); putle32(hd, (uint32_t)h_); putle16(hd, 1); putle16(hd, 24); putle32(hd, 0); putle32(hd, (uint32_t)buf_.size()); for (int i = 0; i < 4; ++i) putle32(hd, 0);
+    four("LIST"); putle32(hd, 0); four("movi");
+    movi_at_ = (long)hd.size() - 4;                 // position of the 'movi' fourcc: index offsets count from here
+    if (fwrite(hd.data(), 1, hd.size(), f_) != hd.size()) throw std::runtime_error("cannot write " + path);
+}
+
+void AviWriter::write(const uint8_t* bgr) {
+    if (!f_) throw std::runtime_error("AVI writer is not open");
+    const long at = ftell(f_);
+    if ((unsigned long long)at + 8 + buf_.size() + 16ull * (frames_ + 1) + 8 > 0xFFFFF000ull)
+        throw std::runtime_error("the built-in uncompressed AVI writer ends at 4 GB per file (RIFF AVI 1.0): use ffmpeg for longer streams");
+    for (int y = 0; y < h_; ++y) memcpy(&buf_[stride_ * (size_t)(h_ - 1 - y)], bgr + (size_t)y * w_ * 3, (size_t)w_ * 3);
+    uint8_t c[8] = {'0', '0', 'd', 'b'};
+    const uint32_t len = (uint32_t)buf_.size();
+    c[4] = (uint8_t)len; c[5] = (uint8_t)(len >> 8); c[6] = (uint8_t)(len >> 16); c[7] = (uint8_t)(len >> 24);
+    if (fwrite(c, 1, 8, f_) != 8 || fwrite(buf_.data(), 1, buf_.size(), f_) != buf_.size()) throw std::runtime_error("write failed (uncompressed AVI)");
+    if (len & 1) fputc(0, f_);
+    offsets_.push_back((uint32_t)(at - movi_at_));
+    ++frames_;
+}
+
+void AviWriter::close() {
+    if (!f_) return;
+    FILE* f = f_; f_ = nullptr;
+    const long movi_end = ftell(f);
+    std::vector<uint8_t> ix;
+    ix.insert(ix.end(), {'i', 'd', 'x', '1'}); putle32(ix, 16 * frames_);
+    for (uint32_t k = 0; k < frames_; ++k) { ix.insert(ix.end(), {'0', '0', 'd', 'b'}); putle32(ix, 0x10); putle32(ix, offsets_[k]); putle32(ix, (uint32_t)buf_.size()); }
+    bool ok = fwrite(ix.data(), 1, ix.size(), f) == ix.size();
+    const long end = ftell(f);
+    auto patch = [&](long pos, uint32_t v) { uint8_t b[4] = {(uint8_t)v, (uint8_t)(v >> 8), (uint8_t)(v >> 16), (uint8_t)(v >> 24)}; ok = ok && !fseek(f, pos, SEEK_SET) && fwrite(b, 1, 4, f) == 4; };
+    patch(4, (uint32_t)(end - 8));                                  // RIFF size
+    patch(12 + 12 + 8 + 16, frames_);                               // avih.dwTotalFrames
+    patch(12 + 12 + 8 + 56 + 12 + 8 + 32, frames_);                 // strh.dwLength
+    patch(movi_at_ - 4, (uint32_t)(movi_end - movi_at_));           // LIST movi size
+    ok = !fclose(f) && ok;
+    if (!ok) throw std::runtime_error("cannot finish the AVI file");
 }
 
 }  // namespace w2x::cli

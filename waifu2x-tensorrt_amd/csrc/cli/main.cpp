@@ -1,16 +1,20 @@
 // w2x: the reference's command line (src/main.cpp) on top of w2x::Img2Img.
 //   w2x --model swin_unet/art --scale 4 --noise 3 --batchSize 4 --tileSize 256 build
 //   w2x --model swin_unet/art --scale 4 --noise 3 --batchSize 4 --tileSize 256 render -i in.png -o outdir [--tta] [--blend 1/16]
-// Stills (.png/.ppm) are read and written by the built-in codecs; other formats and videos are piped through ffmpeg as
-// raw bgr24 when ffmpeg/ffprobe are on PATH (videoio/capture.cpp:96-99, writer.cpp:24-33 do the same).
-// Extension: --devices N drives N engines from N host threads - video frames go round-robin, a single image is split into
-// tile-column strips (Img2Img::renderStrip), every engine writing its own columns of the shared output buffer.
+// Stills (.png / .ppm / .bmp) and uncompressed .avi files are read and written by the built-in codecs (imageio.h); other formats and
+// videos are piped through ffmpeg as raw bgr24 when ffmpeg/ffprobe are on PATH (videoio/capture.cpp:96-99, writer.cpp:24-33 do the same).
+// A PNG / BMP with an alpha channel keeps it: the alpha plane goes through the same engine as a gray image (upstream TODO, README.md:88).
+// Extension: --devices N drives N engines - a single image is split into tile-column strips (Img2Img::renderStrip), every engine
+// writing its own columns of the shared output buffer; a video is cut into chunks of frames that go round-robin to one persistent
+// worker thread per engine (renderSequence over that engine's page-locked buffers), with one reader and one in-order writer thread.
 #include <cstdio>
 #include <cstdlib>
 #include <filesystem>
 #include <iostream>
+#include <atomic>
 #include <condition_variable>
 #include <csignal>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -55,6 +59,101 @@ std::vector<std::string> find_inputs(const cli::Options& o) {
     }
     std::sort(files.begin(), files.end());
     return files;
+}
+
+// ---- frame streams: raw bgr24 frames from / to an ffmpeg pipe or a built-in uncompressed AVI
+struct FrameSource { virtual ~FrameSource() {} virtual bool read(uint8_t* bgr) = 0; };
+struct FrameSink { virtual ~FrameSink() {} virtual bool write(const uint8_t* bgr) = 0; virtual bool close() = 0; };
+
+struct PipeSource : FrameSource {
+    FILE* f; size_t bytes;
+    PipeSource(const std::string& cmd, size_t b) : f(popen(cmd.c_str(), "r")), bytes(b) { if (!f) throw std::runtime_error("cannot start ffmpeg"); }
+    ~PipeSource() override { if (f) pclose(f); }
+    bool read(uint8_t* bgr) override { return fread(bgr, 1, bytes, f) == bytes; }
+};
+struct PipeSink : FrameSink {
+    FILE* f; size_t bytes;
+    PipeSink(const std::string& cmd, size_t b) : f(popen(cmd.c_str(), "w")), bytes(b) { if (!f) throw std::runtime_error("cannot start ffmpeg"); }
+    ~PipeSink() override { if (f) pclose(f); }
+    bool write(const uint8_t* bgr) override { return fwrite(bgr, 1, bytes, f) == bytes; }
+    bool close() override { FILE* g = f; f = nullptr; return g && pclose(g) == 0; }
+};
+struct AviSource : FrameSource {
+    cli::AviReader rd;
+    bool read(uint8_t* bgr) override { return rd.read(bgr); }
+};
+struct AviSink : FrameSink {
+    cli::AviWriter wr;
+    bool write(const uint8_t* bgr) override { try { wr.write(bgr); return true; } catch (const std::exception& e) { std::cerr << e.what() << "\n"; return false; } }
+    bool close() override { try { wr.close(); return true; } catch (const std::exception& e) { std::cerr << e.what() << "\n"; return false; } }
+};
+
+// The frame loop of main.cpp:263-269 over N engines.  Chunk c (CH consecutive frames) belongs to engine c % N; every engine owns SLOTS
+// chunk slots of page-locked frame buffers (allocHost: the copies of renderSequence run by DMA beside the kernels).  One reader thread
+// fills slots in stream order, one persistent worker per engine renders its chunks with renderSequence (upload / compute / download of
+// consecutive frames overlapped), one writer thread drains the slots in stream order - decoding, N renders and encoding all overlap,
+// and frames leave in the order they came (the reference serialises read -> render -> write per frame).
+bool run_frame_pipeline(std::vector<std::unique_ptr<Img2Img>>& engines, FrameSource& src, FrameSink& dst, int width, int height, int scale,
+                        const std::function<void(int)>& on_frames) {
+    const int N = (int)engines.size(), CH = 4, SLOTS = 2;
+    const size_t inBytes = (size_t)width * height * 3, outBytes = inBytes * scale * scale;
+    struct Slot { std::vector<uint8_t*> in, out; int frames = 0; int state = 0; };   // 0 free, 1 read, 2 rendered
+    std::vector<std::vector<Slot>> slots(N, std::vector<Slot>(SLOTS));
+    auto release = [&] { for (int e = 0; e < N; ++e) for (Slot& sl : slots[e]) { for (uint8_t* p : sl.in) engines[e]->freeHost(p); for (uint8_t* p : sl.out) engines[e]->freeHost(p); sl.in.clear(); sl.out.clear(); } };
+    for (int e = 0; e < N; ++e)
+        for (Slot& sl : slots[e])
+            for (int k = 0; k < CH; ++k) {
+                sl.in.push_back((uint8_t*)engines[e]->allocHost(inBytes)); sl.out.push_back((uint8_t*)engines[e]->allocHost(outBytes));
+                if (!sl.in.back() || !sl.out.back()) { release(); throw std::runtime_error("cannot allocate page-locked frame buffers"); }
+            }
+    std::mutex mu; std::condition_variable cv;
+    bool failed = false;
+    long total_chunks = -1;                         // known once the reader has hit the end of the stream
+    auto slot_of = [&](long c) -> Slot& { return slots[c % N][(c / N) % SLOTS]; };
+    std::thread reader([&] {
+        for (long c = 0;; ++c) {
+            Slot& sl = slot_of(c);
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return sl.state == 0 || failed; }); if (failed) return; }
+            int got = 0;
+            for (; got < CH; ++got) if (!src.read(sl.in[got])) break;
+            { std::lock_guard<std::mutex> lk(mu); sl.frames = got; if (got) sl.state = 1; if (got < CH) total_chunks = c + (got ? 1 : 0); }
+            cv.notify_all();
+            if (got < CH) return;
+        }
+    });
+    std::vector<std::thread> workers;
+    for (int e = 0; e < N; ++e) workers.emplace_back([&, e] {
+        for (long c = e;; c += N) {
+            Slot& sl = slot_of(c);
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return sl.state == 1 || failed || (total_chunks >= 0 && c >= total_chunks); }); if (failed || sl.state != 1) return; }
+            const int got = sl.frames;
+            std::vector<Image> si(got), di(got);
+            for (int k = 0; k < got; ++k) {
+                si[k] = Image{sl.in[k], height, width, (size_t)width * 3};
+                di[k] = Image{sl.out[k], height * scale, width * scale, (size_t)width * scale * 3};
+            }
+            const bool ok = engines[e]->renderSequence(si.data(), di.data(), got);
+            { std::lock_guard<std::mutex> lk(mu); if (!ok) failed = true; sl.state = 2; }
+            cv.notify_all();
+            if (!ok) return;
+        }
+    });
+    std::thread writer([&] {
+        for (long c = 0;; ++c) {
+            Slot& sl = slot_of(c);
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return sl.state == 2 || failed || (total_chunks >= 0 && c >= total_chunks); }); if (failed || sl.state != 2) return; }
+            const int n = sl.frames;
+            for (int k = 0; k < n; ++k) if (!dst.write(sl.out[k])) { std::lock_guard<std::mutex> lk(mu); failed = true; }
+            { std::lock_guard<std::mutex> lk(mu); sl.state = 0; }
+            cv.notify_all();
+            on_frames(n);
+        }
+    });
+    reader.join();
+    for (auto& t : workers) t.join();
+    writer.join();
+    release();
+    return !failed;
 }
 
 }  // namespace
@@ -113,107 +212,68 @@ int main(int argc, char** argv) {
                 cli::Bitmap in = cli::read_image(file), out;
                 out.rows = in.rows * o.scale; out.cols = in.cols * o.scale; out.bgr.resize((size_t)out.rows * out.cols * 3);
                 Image src{in.bgr.data(), in.rows, in.cols, (size_t)in.cols * 3}, dst{out.bgr.data(), out.rows, out.cols, (size_t)out.cols * 3};
-                bool ok = true;
-                if (o.devices == 1) ok = engines[0]->render(src, dst);
-                else {   // tile-column strips: each engine composes and downloads its own columns of `out`
+                auto render_still = [&](const Image& s0, Image& d0) {
+                    if (o.devices == 1) return engines[0]->render(s0, d0);
+                    // tile-column strips: each engine composes and downloads its own columns of the output
                     std::vector<std::thread> th; std::vector<char> oks(o.devices, 1);
-                    for (int d = 0; d < o.devices; ++d) th.emplace_back([&, d] { Image s2 = src, d2 = dst; oks[d] = engines[d]->renderStrip(s2, d2, d, o.devices); });
+                    for (int d = 0; d < o.devices; ++d) th.emplace_back([&, d] { Image s2 = s0, d2 = d0; oks[d] = engines[d]->renderStrip(s2, d2, d, o.devices); });
                     for (auto& t : th) t.join();
-                    for (char k : oks) ok = ok && k;
-                }
+                    bool all = true;
+                    for (char k : oks) all = all && k;
+                    return all;
+                };
+                const bool ok = render_still(src, dst);
                 if (!ok) return -1;
-                cli::write_image(cli::output_path(o, file, true), out);
+                if (!in.alpha.empty()) {   // the alpha plane as a gray image through the same engine; its green channel is the new alpha
+                    cli::Bitmap ga, go;
+                    ga.rows = in.rows; ga.cols = in.cols; ga.bgr.resize(in.bgr.size());
+                    for (size_t i = 0; i < in.alpha.size(); ++i) ga.bgr[3 * i] = ga.bgr[3 * i + 1] = ga.bgr[3 * i + 2] = in.alpha[i];
+                    go.bgr.resize(out.bgr.size());
+                    Image as{ga.bgr.data(), in.rows, in.cols, (size_t)in.cols * 3}, ad{go.bgr.data(), out.rows, out.cols, (size_t)out.cols * 3};
+                    if (!render_still(as, ad)) return -1;
+                    out.alpha.resize((size_t)out.rows * out.cols);
+                    for (size_t i = 0; i < out.alpha.size(); ++i) out.alpha[i] = go.bgr[3 * i + 1];
+                }
+                std::string outFile = cli::output_path(o, file, true);
+                if (fs::path(file).extension() == ".bmp" || fs::path(file).extension() == ".BMP") outFile = fs::path(outFile).replace_extension(".bmp").string();   // built-in formats stay what they were, except ...
+                if (fs::path(outFile).extension() == ".ppm") outFile = fs::path(outFile).replace_extension(".png").string();
+                cli::write_image(outFile, out);
                 ++frameIndex;
             } else {
-                if (!have_ffmpeg) throw std::runtime_error(file + ": needs ffmpeg and ffprobe on PATH (built in: .png, .ppm)");
-                const Probe pr = ffprobe(file);
-                frameIndex = 0; frameCount = pr.frames;
-                const bool single = pr.frames == 1;
-                const std::string outFile = cli::output_path(o, file, single);
-                const size_t inBytes = (size_t)pr.width * pr.height * 3, outBytes = inBytes * o.scale * o.scale;
-                FILE* rd = popen(("ffmpeg -v error -i " + shell_quote(file) + " -f rawvideo -pix_fmt bgr24 -").c_str(), "r");
-                std::string wcmd = "ffmpeg -v error -y -f rawvideo -pix_fmt bgr24 -s " + std::to_string(pr.width * o.scale) + "x" + std::to_string(pr.height * o.scale) +
-                                   " -r " + std::to_string(single ? 1.0 : pr.fps) + " -i - ";
-                if (!single) wcmd += "-c:v " + o.codec + " -pix_fmt " + o.pixFmt + " -crf " + std::to_string(o.crf) + " ";
-                FILE* wr = popen((wcmd + shell_quote(outFile)).c_str(), "w");
-                if (!rd || !wr) { if (rd) pclose(rd); if (wr) pclose(wr); throw std::runtime_error("cannot start ffmpeg for " + file); }
-                if (o.devices == 1) {
-                    // one device: chunks of frames through renderSequence (upload / compute / download overlapped, buffers
-                    // page-locked once).  The ffmpeg pipes run on their own threads over two chunk slots, so decoding chunk
-                    // n+1 and encoding chunk n-1 overlap with rendering chunk n (the reference serialises them, main.cpp:263-269).
-                    const int CH = 4, SLOTS = 2;
-                    // frame buffers from the engine's page-locked allocator: their copies run by DMA beside the kernels
-                    struct Slot { std::vector<uint8_t*> in, out; int frames = 0; int state = 0; };   // 0 free, 1 read, 2 rendered
-                    std::vector<Slot> slots(SLOTS);
-                    for (Slot& sl : slots)
-                        for (int k = 0; k < CH; ++k) {
-                            sl.in.push_back((uint8_t*)engines[0]->allocHost(inBytes)); sl.out.push_back((uint8_t*)engines[0]->allocHost(outBytes));
-                            if (!sl.in.back() || !sl.out.back()) throw std::runtime_error("cannot allocate page-locked frame buffers");
-                        }
-                    std::mutex mu; std::condition_variable cv;
-                    bool failed = false;
-                    std::thread reader([&] {          // slot i: free -> read; a slot with 0 frames marks the end of the stream
-                        for (int i = 0;; i = (i + 1) % SLOTS) {
-                            Slot& sl = slots[i];
-                            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return sl.state == 0 || failed; }); if (failed) return; }
-                            int got = 0;
-                            for (; got < CH; ++got) if (fread(sl.in[got], 1, inBytes, rd) != inBytes) break;
-                            { std::lock_guard<std::mutex> lk(mu); sl.frames = got; sl.state = 1; }
-                            cv.notify_all();
-                            if (got < CH) return;
-                        }
-                    });
-                    std::thread writer([&] {          // slot i: rendered -> free
-                        for (int i = 0;; i = (i + 1) % SLOTS) {
-                            Slot& sl = slots[i];
-                            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return sl.state == 2 || failed; }); if (failed) return; }
-                            const int n = sl.frames;
-                            for (int k = 0; k < n; ++k) if (fwrite(sl.out[k], 1, outBytes, wr) != outBytes) { std::lock_guard<std::mutex> lk(mu); failed = true; }
-                            { std::lock_guard<std::mutex> lk(mu); sl.state = 0; }
-                            cv.notify_all();
-                            if (n < CH) return;
-                        }
-                    });
-                    for (int i = 0;; i = (i + 1) % SLOTS) {
-                        Slot& sl = slots[i];
-                        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return sl.state == 1 || failed; }); if (failed) break; }
-                        const int got = sl.frames;
-                        std::vector<Image> si(got), di(got);
-                        for (int k = 0; k < got; ++k) {
-                            si[k] = Image{sl.in[k], pr.height, pr.width, (size_t)pr.width * 3};
-                            di[k] = Image{sl.out[k], pr.height * o.scale, pr.width * o.scale, (size_t)pr.width * o.scale * 3};
-                        }
-                        const bool ok = got == 0 || engines[0]->renderSequence(si.data(), di.data(), got);
-                        { std::lock_guard<std::mutex> lk(mu); if (!ok) failed = true; sl.state = 2; frameIndex += got; }
-                        cv.notify_all();
-                        if (got) on_progress(1, 1, 0.0);
-                        if (!ok || got < CH) break;
-                    }
-                    reader.join(); writer.join();
-                    for (Slot& sl : slots) for (int k = 0; k < CH; ++k) { engines[0]->freeHost(sl.in[k]); engines[0]->freeHost(sl.out[k]); }
-                    pclose(rd); pclose(wr);
-                    if (failed) return -1;
-                    ++fileIndex;
-                    continue;
+                // a video (or a still in a format only ffmpeg reads): uncompressed AVI files through the built-in reader, the rest through ffmpeg
+                std::unique_ptr<FrameSource> source; std::unique_ptr<FrameSink> sink;
+                int width = 0, height = 0, frames = 1; double fps = 30.0;
+                std::string why;
+                auto avi = std::make_unique<AviSource>();
+                const bool is_avi = fs::path(file).extension() == ".avi" || fs::path(file).extension() == ".AVI";
+                if (is_avi && avi->rd.open(file, &why)) {
+                    width = avi->rd.info().width; height = avi->rd.info().height; frames = avi->rd.info().frames; fps = avi->rd.info().fps;
+                    source = std::move(avi);
+                } else {
+                    if (!have_ffmpeg) throw std::runtime_error(file + ": needs ffmpeg and ffprobe on PATH (built in: .png, .ppm, .bmp, uncompressed 24-bit .avi" + (why.empty() ? "" : "; " + why) + ")");
+                    const Probe pr = ffprobe(file);
+                    width = pr.width; height = pr.height; frames = pr.frames; fps = pr.fps;
+                    source.reset(new PipeSource("ffmpeg -v error -i " + shell_quote(file) + " -f rawvideo -pix_fmt bgr24 -", (size_t)width * height * 3));
                 }
-                // frames round-robin over the devices, written in order
-                const int N = o.devices;
-                std::vector<std::vector<uint8_t>> ins(N, std::vector<uint8_t>(inBytes)), outs(N, std::vector<uint8_t>(outBytes));
-                bool eof = false;
-                while (!eof) {
-                    int got = 0;
-                    for (; got < N; ++got) if (fread(ins[got].data(), 1, inBytes, rd) != inBytes) { eof = true; break; }
-                    std::vector<std::thread> th; std::vector<char> oks(N, 1);
-                    for (int d = 0; d < got; ++d) th.emplace_back([&, d] {
-                        Image s2{ins[d].data(), pr.height, pr.width, (size_t)pr.width * 3}, d2{outs[d].data(), pr.height * o.scale, pr.width * o.scale, (size_t)pr.width * o.scale * 3};
-                        oks[d] = engines[d]->render(s2, d2);
-                    });
-                    for (auto& t : th) t.join();
-                    bool bad = false;
-                    for (int d = 0; d < got && !bad; ++d) { bad = !oks[d] || fwrite(outs[d].data(), 1, outBytes, wr) != outBytes; ++frameIndex; }
-                    if (bad) { pclose(rd); pclose(wr); return -1; }
+                frameIndex = 0; frameCount = frames;
+                const bool single = frames == 1;
+                std::string outFile = cli::output_path(o, file, single);
+                const size_t outBytes = (size_t)width * height * 3 * o.scale * o.scale;
+                if (have_ffmpeg) {
+                    std::string wcmd = "ffmpeg -v error -y -f rawvideo -pix_fmt bgr24 -s " + std::to_string(width * o.scale) + "x" + std::to_string(height * o.scale) +
+                                       " -r " + std::to_string(single ? 1.0 : fps) + " -i - ";
+                    if (!single) wcmd += "-c:v " + o.codec + " -pix_fmt " + o.pixFmt + " -crf " + std::to_string(o.crf) + " ";
+                    sink.reset(new PipeSink(wcmd + shell_quote(outFile), outBytes));
+                } else {   // no encoder here: the upscaled stream as an uncompressed AVI
+                    outFile = fs::path(outFile).replace_extension(".avi").string();
+                    on_message(Severity::info, "ffmpeg is not on PATH: writing uncompressed video to " + outFile);
+                    auto as = std::make_unique<AviSink>();
+                    as->wr.open(outFile, width * o.scale, height * o.scale, fps);
+                    sink = std::move(as);
                 }
-                pclose(rd); pclose(wr);
+                const bool ok = run_frame_pipeline(engines, *source, *sink, width, height, o.scale, [&](int n) { frameIndex += n; if (n) on_progress(1, 1, 0.0); });
+                const bool closed = sink->close();
+                if (!ok || !closed) return -1;
             }
             ++fileIndex;
         }

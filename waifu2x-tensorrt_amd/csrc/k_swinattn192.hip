@@ -441,6 +441,23 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
 #undef W2X_LOAD_X2
     __syncthreads();      // every wave's head outputs are in Os; nobody reads the slabs any more
 
+    // The residual rows (the same pixels again, for y = x + ...) are requested here, in front of the projection: its weight fragments
+    // were requested long ago (loads return in order, so the products below wait for nothing new), the head loop's registers are
+    // free, and the fetch travels under the 90 products of the projection.  (Round 2 requested them after the projection and waited.)
+    const int li_r = tid & (LPR - 1), rsub_r = tid / LPR;
+    half8 xres[NPASS];
+    unsigned my_off[NPASS];
+#ifndef W2X_A192_XRES_LATE
+    {
+        const unsigned lane_off = li_r < PPR ? li_r * 16u : kNoRow;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            my_off[ps] = __builtin_elementwise_add_sat((unsigned)Pix[ps * RPP + rsub_r][0], lane_off);
+            xres[ps] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(X, my_off[ps], 0, 0));
+        }
+    }
+#endif
+
     // ---- proj, transposed: out^T = Wproj Os^T + b (rows = output channels, columns = tokens), so a lane ends with 4 consecutive
     // channels of one token (bias as the initial accumulator, 8-byte LDS stores).  Wave w owns output channels 48w .. 48w+47 for all
     // five row tiles; the tile goes over Xs in token order.
@@ -467,15 +484,15 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
 
     // ---- row pieces: + residual x, scatter store, LayerNorm statistics for the next op
     {
-        const int li = tid & (LPR - 1), rsub = tid / LPR;
+        const int li = li_r, rsub = rsub_r;
+#ifdef W2X_A192_XRES_LATE
         const unsigned lane_off = li < PPR ? li * 16u : kNoRow;
-        half8 xres[NPASS];
-        unsigned my_off[NPASS];
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             my_off[ps] = __builtin_elementwise_add_sat((unsigned)Pix[ps * RPP + rsub][0], lane_off);
             xres[ps] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(X, my_off[ps], 0, 0));
         }
+#endif
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int r = ps * RPP + rsub;

@@ -41,6 +41,9 @@
 #ifndef W2X_A96_BUF
 #define W2X_A96_BUF 1
 #endif
+#ifndef W2X_A96_XRES_EARLY
+#define W2X_A96_XRES_EARLY 2   // where the residual rows are requested: 0 in front of the projection (round 2), 1 after the last unit's q / k / v products
+#endif                         // (two registers spill), 2 after its score products.  Measured per launch: 0.524 / 0.534 / 0.518 ms (round 2: 0.550)
 
 namespace w2x {
 namespace {
@@ -326,6 +329,15 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
         sl[2] = zero4;
         b2l = lb[512 + bl];
     }
+    // The residual rows (the same pixels again, now for y = x + ...): requested when the last unit's q / k / v products are done - its
+    // weight registers are free from there on - so that the fetch travels under that unit's softmax and the left-over queries instead
+    // of in front of the projection's weight loads (loads return in order: the first projection product would wait for these rows).
+    half8 xres[NPASS];
+#define W2X_FETCH_XRES() {                                                                                          \
+        const int li_ = tid & (LPR - 1), rsub_ = tid / LPR;                                                         \
+        const unsigned lane_off_ = li_ < PPR ? li_ * 16u : kNoRow;                                                  \
+        _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps)                                                        \
+            xres[ps] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(X, __builtin_elementwise_add_sat((unsigned)Pix[ps * RPP + rsub_][0], lane_off_), 0, 0)); }
     half8 vk01[NU]; half4 vk2[NU];   // v fragments of every unit (key tiles 0 | 1, left-over keys), also for the left-over queries' O^T at the end
     half8 pl01; half4 pl2;           // left-over queries' probabilities
 
@@ -384,6 +396,9 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
         }
         if (u == 1) { W2X_LOAD_W(hC) }   // the second head's fragments take over the registers (reloading each register right after its
                                          // last use inside the loop above measured no faster and cost a spill)
+#if W2X_A96_XRES_EARLY == 1
+        if (u == NU - 1) W2X_FETCH_XRES()
+#endif
         half4 qf[2], kf[3];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
@@ -405,6 +420,9 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
             s[1][kt] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf[kt], qf[1], s[1][kt], 0, 0, 0);
             sl[kt] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf[kt], qz, sl[kt], 0, 0, 0);
         }
+#if W2X_A96_XRES_EARLY == 2
+        if (u == NU - 1) W2X_FETCH_XRES()
+#endif
         // ---- softmax over the keys (column = query): lane-local maximum of 9, then the 4 lanes of the column
         const float t0 = s[0][2][0] + b2[0], t1 = s[1][2][0] + b2[1];
         float mx0 = max9(s[0][0], s[0][1], t0), mx1 = max9(s[1][0], s[1][1], t1);
@@ -453,18 +471,10 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
     }
     __syncthreads();      // every head's outputs are in Os; nobody reads the slabs any more
 
-    // the residual rows are fetched now, under the projection
-    half8 xres[NPASS];
-    unsigned my_off[NPASS];
-    {
-        const int li = tid & (LPR - 1), rsub = tid / LPR;
-        const unsigned lane_off = li < PPR ? li * 16u : kNoRow;
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            my_off[ps] = __builtin_elementwise_add_sat((unsigned)Pix[ps * RPP + rsub][0], lane_off);
-            xres[ps] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(X, my_off[ps], 0, 0));
-        }
-    }
+#if !W2X_A96_XRES_EARLY
+    W2X_FETCH_XRES()      // the residual rows are fetched under the projection
+#endif
+#undef W2X_FETCH_XRES
     // ---- proj, transposed: out^T = Wproj Os^T + b (rows = output channels, columns = tokens), so a lane ends with 4 consecutive
     // channels of one token.  10 units of (16-token tile, 3 channel tiles); weights as fragments from L2, bias as the initial
     // accumulator; the tile goes over Xs in token order.
@@ -499,6 +509,10 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
     // ---- row pieces: + residual x, scatter store, LayerNorm statistics for the next op
     {
         const int li = tid & (LPR - 1), rsub = tid / LPR;
+        const unsigned lane_off = li < PPR ? li * 16u : kNoRow;
+        unsigned my_off[NPASS];
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) my_off[ps] = __builtin_elementwise_add_sat((unsigned)Pix[ps * RPP + rsub][0], lane_off);
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int r = ps * RPP + rsub;
