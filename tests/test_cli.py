@@ -82,10 +82,10 @@ def test_builtin_png_and_ppm_codecs_round_trip(tmp_path):
     assert np.array_equal(np.array(Image.open(tmp_path / "b.png")), a)
     variants = {"gray": Image.fromarray(a[..., 0]), "rgba": Image.fromarray(np.dstack([a, a[..., :1]])),
                 "pal16": Image.fromarray(a).quantize(16), "pal256": Image.fromarray(a).quantize(256), "bilevel": Image.fromarray(a[..., 0] > 127)}
-    for name, im in variants.items():       # gray, alpha (dropped like the reference), 4/8-bit palette, 1-bit
+    for name, im in variants.items():       # gray, alpha (kept: written back as RGBA), 4/8-bit palette, 1-bit
         im.save(tmp_path / f"{name}.png")
         assert run("convert", "-i", str(tmp_path / f"{name}.png"), "-o", str(tmp_path / f"{name}_o.png")).returncode == 0, name
-        assert np.array_equal(np.array(Image.open(tmp_path / f"{name}_o.png")), np.array(Image.open(tmp_path / f"{name}.png").convert("RGB"))), name
+        assert np.array_equal(np.array(Image.open(tmp_path / f"{name}_o.png")), np.array(Image.open(tmp_path / f"{name}.png").convert("RGBA" if name == "rgba" else "RGB"))), name
     # 16-bit samples (gray, RGB, RGB + alpha; rows filtered with Sub so the two-byte pixel stride is exercised): the decoder keeps
     # the high byte, as cv::imread(IMREAD_COLOR) does for the reference (libpng strip_16)
     import struct, zlib
@@ -106,7 +106,7 @@ def test_builtin_png_and_ppm_codecs_round_trip(tmp_path):
         png16(tmp_path / f"deep{ch}.png", a16)
         assert run("convert", "-i", str(tmp_path / f"deep{ch}.png"), "-o", str(tmp_path / f"deep{ch}_o.png")).returncode == 0, ch
         want = (a16 >> 8).astype(np.uint8)
-        want = np.repeat(want, 3, axis=2) if ch == 1 else want[..., :3]
+        want = np.repeat(want, 3, axis=2) if ch == 1 else want          # (16-bit RGBA keeps its alpha plane's high byte as well)
         assert np.array_equal(np.array(Image.open(tmp_path / f"deep{ch}_o.png")), want), ch
     # Adam7-interlaced files (PIL cannot write them: built here from the seven sub-images, filter None)
     def png_adam7(path, arr8):               # arr8: [h, w, 3] uint8
@@ -126,6 +126,56 @@ def test_builtin_png_and_ppm_codecs_round_trip(tmp_path):
         assert np.array_equal(np.array(Image.open(tmp_path / "ilace_o.png")), ai), shape
     r = run("convert", "-i", str(tmp_path / "missing.png"), "-o", str(tmp_path / "x.png"))
     assert r.returncode != 0 and "cannot open" in r.stderr
+
+
+def _avi_frames(path):
+    """Independent reader of an uncompressed 24-bit AVI (RIFF walk in Python) -> (frames [n, h, w, 3] BGR top-down, fps)."""
+    import struct
+    d = open(path, "rb").read()
+    assert d[:4] == b"RIFF" and d[8:12] == b"AVI "
+    assert struct.unpack_from("<I", d, 4)[0] == len(d) - 8
+    w = h = None; frames = []; fps = None
+    def walk(pos, end):
+        nonlocal w, h, fps
+        while pos + 8 <= end:
+            cid, n = d[pos:pos + 4], struct.unpack_from("<I", d, pos + 4)[0]
+            body = pos + 8
+            if cid == b"LIST":
+                walk(body + 4, body + n)
+            elif cid == b"strh":
+                scale, rate = struct.unpack_from("<II", d, body + 20); fps = rate / scale
+            elif cid == b"strf":
+                w, h, _, bits, comp = struct.unpack_from("<iiHHI", d, body + 4); assert bits == 24 and comp == 0 and h > 0
+            elif cid == b"00db":
+                stride = (w * 3 + 3) // 4 * 4
+                rows = np.frombuffer(d, np.uint8, stride * h, body).reshape(h, stride)[::-1, :w * 3]
+                frames.append(rows.reshape(h, w, 3).copy())
+            elif cid == b"idx1":
+                assert n == 16 * len(frames)
+            pos = body + (n + 1) // 2 * 2
+    walk(12, len(d))
+    return np.stack(frames), fps
+
+
+def test_builtin_bmp_and_uncompressed_avi_codecs(tmp_path):
+    """BMP (24-bit, 32-bit with alpha, odd widths: rows padded to 4 bytes, bottom-up) and the uncompressed AVI container through
+    `w2x convert` (stills) and the codec classes as the CLI uses them; PIL reads what the writer wrote and the reader reads what PIL wrote."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(4)
+    for shape in ((37, 53), (5, 1), (8, 2), (3, 7)):
+        a = rng.integers(0, 256, (*shape, 3), dtype=np.uint8)
+        Image.fromarray(a).save(tmp_path / "p.bmp")                                   # PIL's writer -> our reader
+        assert run("convert", "-i", str(tmp_path / "p.bmp"), "-o", str(tmp_path / "p.png")).returncode == 0
+        assert np.array_equal(np.array(Image.open(tmp_path / "p.png")), a), shape
+        assert run("convert", "-i", str(tmp_path / "p.png"), "-o", str(tmp_path / "q.bmp")).returncode == 0   # our writer -> PIL's reader
+        assert np.array_equal(np.array(Image.open(tmp_path / "q.bmp").convert("RGB")), a), shape
+    rgba = rng.integers(0, 256, (21, 30, 4), dtype=np.uint8)
+    Image.fromarray(rgba).save(tmp_path / "a.png")
+    assert run("convert", "-i", str(tmp_path / "a.png"), "-o", str(tmp_path / "a.bmp")).returncode == 0      # 32-bit BGRA
+    assert run("convert", "-i", str(tmp_path / "a.bmp"), "-o", str(tmp_path / "a2.png")).returncode == 0
+    assert np.array_equal(np.array(Image.open(tmp_path / "a2.png")), rgba)
+    r = run("convert", "-i", str(tmp_path / "a.png"), "-o", str(tmp_path / "clip.avi"))
+    assert r.returncode != 0                                                           # a still is not a video container
 
 
 @pytest.mark.gpu
@@ -236,3 +286,85 @@ def test_cli_video_path_matches_the_library(pkg, tmp_path):
     for k in range(N):
         assert np.array_equal(got[k], eng.render(np.ascontiguousarray(frames[k]))), k
     eng.close()
+
+
+def _write_avi(path, frames, fps=25):
+    """Uncompressed 24-bit AVI the way `ffmpeg -c:v rawvideo -pix_fmt bgr24 x.avi` lays it out (bottom-up DIB rows, JUNK padding before
+    movi, an audio-less single stream), written independently of the CLI's own writer."""
+    import struct
+    n, h, w, _ = frames.shape
+    stride = (w * 3 + 3) // 4 * 4
+    def chunk(cid, body): return cid + struct.pack("<I", len(body)) + body + (b"\0" if len(body) & 1 else b"")
+    def lst(t, body): return b"LIST" + struct.pack("<I", len(body) + 4) + t + body
+    avih = struct.pack("<14I", int(1e6 / fps), 0, 0, 0x10, n, 0, 1, stride * h, w, h, 0, 0, 0, 0)
+    strh = b"vids" + b"\0\0\0\0" + struct.pack("<IHHIIIIIIIIhhhh", 0, 0, 0, 0, 1, fps, 0, n, stride * h, 0xFFFFFFFF, 0, 0, 0, w, h)
+    strf = struct.pack("<IiiHHIIiiII", 40, w, h, 1, 24, 0, stride * h, 0, 0, 0, 0)
+    movi = b""
+    for f in frames:
+        rows = np.zeros((h, stride), np.uint8); rows[:, :w * 3] = f.reshape(h, w * 3)
+        movi += chunk(b"00db", rows[::-1].tobytes())
+    body = b"AVI " + lst(b"hdrl", chunk(b"avih", avih) + lst(b"strl", chunk(b"strh", strh) + chunk(b"strf", strf))) + chunk(b"JUNK", b"\0" * 12) + lst(b"movi", movi)
+    open(path, "wb").write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [1, 2, 3])
+def test_cli_video_loop_on_uncompressed_avi_matches_the_library(pkg, tmp_path, devices):
+    """The frame loop of main.cpp:263-269 end to end WITHOUT ffmpeg and without stand-in scripts: an uncompressed AVI in (built-in reader),
+    chunks of four frames round-robin over 1 / 2 / 3 engines (one persistent renderSequence worker each, page-locked slots; the box has
+    one GPU, W2X_DEVICE_MAP puts the logical devices on it), an in-order writer, an uncompressed AVI out.  11 frames = two full chunks
+    and a ragged one, so with 2 and 3 engines the last chunks finish out of order and must still be written in order: every output
+    frame equals Img2Img.render of its input frame, byte for byte."""
+    import synth_models as sm
+    models = tmp_path / "models"
+    path = sm.model_path(str(tmp_path), "swin_unet/art", 4, 3)
+    sm.export_onnx(sm.make_model("swin_unet/art", 4, seed=5, small=True), path, 2, 64, dynamic=True)
+    W, H, N = 99, 70, 11                                                # odd width: padded DIB rows on both sides
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)         # BGR
+    _write_avi(tmp_path / "clip.avi", frames, fps=24)
+    out = tmp_path / "out"; out.mkdir()
+    common = ["--models", str(models), "--model", "swin_unet/art", "--scale", "4", "--noise", "3", "--batchSize", "2", "--tileSize", "64"]
+    env = dict(os.environ, W2X_DEVICE_MAP=",".join(["0"] * devices))
+    env["PATH"] = os.pathsep.join(p for p in env["PATH"].split(os.pathsep) if not os.path.exists(os.path.join(p, "ffmpeg")))   # the built-in path even where ffmpeg exists
+    r = subprocess.run([W2X, *common, "build"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([W2X, *common, "render", "-i", str(tmp_path / "clip.avi"), "-o", str(out), "--devices", str(devices)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "writing uncompressed video" in r.stderr
+    got, fps = _avi_frames(out / "clip(swin_unet_art)(noise3)(scale4).avi")
+    assert got.shape == (N, H * 4, W * 4, 3) and fps == 24
+    eng = pkg.Img2Img()
+    assert eng.load(path, pkg.RenderConfig(batchSize=2, height=64, width=64, scaling=4)), eng.last_error()
+    for k in range(N):
+        assert np.array_equal(got[k], eng.render(np.ascontiguousarray(frames[k]))), k
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_cli_keeps_the_alpha_channel_of_a_still(pkg, tmp_path):
+    """README.md:88 lists alpha as a TODO upstream.  Here an RGBA PNG comes out as an RGBA PNG: colour through the engine as usual, the
+    alpha plane through the same engine as a gray image (its green channel is the new alpha)."""
+    Image = pytest.importorskip("PIL.Image")
+    import synth_models as sm
+    models = tmp_path / "models"
+    path = sm.model_path(str(tmp_path), "cunet/art", 2, 1)
+    sm.export_onnx(sm.make_model("cunet/art", 2, seed=6), path, 2, 64, dynamic=True)
+    rng = np.random.default_rng(5)
+    rgba = rng.integers(0, 256, (80, 100, 4), dtype=np.uint8)
+    yy, xx = np.mgrid[0:80, 0:100]
+    rgba[..., 3] = np.clip(255 - np.hypot(yy - 40, xx - 50) * 5, 0, 255).astype(np.uint8)     # a soft disc
+    Image.fromarray(rgba).save(tmp_path / "in.png")
+    common = ["--models", str(models), "--model", "cunet/art", "--scale", "2", "--noise", "1", "--batchSize", "2", "--tileSize", "64"]
+    assert subprocess.run([W2X, *common, "build"], capture_output=True, text=True).returncode == 0
+    out = tmp_path / "o"; out.mkdir()
+    r = subprocess.run([W2X, *common, "render", "-i", str(tmp_path / "in.png"), "-o", str(out)], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    got = np.array(Image.open(out / "in(cunet_art)(noise1)(scale2).png"))
+    assert got.shape == (160, 200, 4)
+    eng = pkg.Img2Img()
+    assert eng.load(path, pkg.RenderConfig(batchSize=2, height=64, width=64, scaling=2)), eng.last_error()
+    colour = eng.render(np.ascontiguousarray(rgba[..., 2::-1]))
+    alpha = eng.render(np.ascontiguousarray(np.repeat(rgba[..., 3:4], 3, axis=2)))
+    eng.close()
+    assert np.array_equal(got[..., :3], colour[..., ::-1]) and np.array_equal(got[..., 3], alpha[..., 1])

@@ -227,3 +227,29 @@ def test_cunet_gates_are_folded_into_their_consumers(pkg, onnx_model, monkeypatc
     monkeypatch.setenv("W2X_NO_SE_FOLD", "1")
     d = pkg.describe_plan(path, 2, 64)
     assert d.count(" scale t") == 4 and "gate" not in d
+
+
+def test_strip_split_redundancy_table(pkg, capsys):
+    """Single-frame mode: strip p owns whole tile columns and recomputes the neighbouring column whose
+    blend band reaches into its pixels, so the tiles rendered over all strips exceed the frame's tiles and the largest strip bounds
+    the speed-up; the strips are balanced by the columns they render (own + recomputed).  The table below (printed, and kept in DESIGN.md section 7) is what an N-GPU run of ONE image can reach at best;
+    streams shard by frame instead (no redundancy)."""
+    import synth_models as sm
+    cfgs = {"configs[1] cunet/art s2 T256 1080p": ("cunet/art", 2, 256, 1920, 1080), "configs[2] swin_unet/art s4 T256 1080p": ("swin_unet/art", 4, 256, 1920, 1080),
+            "configs[3] swin_unet/photo s4 T400 1080p": ("swin_unet/photo", 4, 400, 1920, 1080), "configs[4] swin_unet/art_scan s4 T640 2160p": ("swin_unet/art_scan", 4, 640, 3840, 2160)}
+    want = {"configs[1] cunet/art s2 T256 1080p": {2: (66, 36), 4: (78, 24), 8: (102, 18)}, "configs[2] swin_unet/art s4 T256 1080p": {2: (50, 25), 4: (60, 15), 8: (80, 10)},
+            "configs[3] swin_unet/photo s4 T400 1080p": {2: (21, 12), 4: (27, 9), 8: (33, 6)}, "configs[4] swin_unet/art_scan s4 T640 2160p": {2: (32, 16), 4: (40, 12), 8: (52, 8)}}
+    lines = []
+    for name, (m, s, T, W, H) in cfgs.items():
+        To = sm.output_tile_size(m, s, T)
+        ov = (0.0625, 0.0625)
+        n = pkg.calculate_tiles(W, H, W * s, H * s, T, To, s, ov)[0]
+        for N in (2, 4, 8):
+            parts = [pkg.strip_plan(W, H, W * s, H * s, T, To, s, ov, p, N) for p in range(N)]
+            total, largest = sum(c for _, c, _, _ in parts), max(c for _, c, _, _ in parts)
+            xs = sorted((x0, x1) for _, c, x0, x1 in parts if c)
+            assert xs[0][0] == 0 and xs[-1][1] == W * s and all(a[1] == b[0] for a, b in zip(xs, xs[1:]))     # the strips tile the output columns
+            assert (total, largest) == want[name][N], (name, N, total, largest)
+            lines.append(f"{name}: N={N}: {total} tiles rendered for {n} (+{100 * (total - n) // n} %), largest strip {largest} -> speed-up <= {n / largest:.2f}x")
+    with capsys.disabled():
+        print("\n" + "\n".join(lines))

@@ -233,7 +233,8 @@ Bitmap read_image(const std::string& path) {
 void write_image(const std::string& path, const Bitmap& b) {
     if ((size_t)b.rows * b.cols * 3 != b.bgr.size() || (!b.alpha.empty() && b.alpha.size() != (size_t)b.rows * b.cols)) throw std::runtime_error("bitmap size mismatch");
     const std::string e = lower_ext(path);
-    if (e == ".ppm") write_ppm(path, b); else if (e == ".bmp") write_bmp(path, b); else write_png(path, b);
+    if (e == ".ppm") write_ppm(path, b); else if (e == ".bmp") write_bmp(path, b); else if (e == ".png") write_png(path, b);
+    else throw std::runtime_error(path + ": no built-in still-image writer for this extension (.png, .ppm, .bmp)");
 }
 
 // ---- uncompressed AVI (RIFF AVI 1.0): RIFF 'AVI ' { LIST 'hdrl' { 'avih', LIST 'strl' { 'strh', 'strf' } }, LIST 'movi' { '00db' frame ... }, 'idx1' }

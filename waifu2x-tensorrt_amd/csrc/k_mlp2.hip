@@ -167,8 +167,12 @@ __global__ __launch_bounds__(NW * 64, (C == 96 ? 3 : W2X_MLP192_WPS) * NW / 4) v
 
     const long row0 = ((long)blockIdx.x * K::NWV + wv) * RW;       // first row of this wave
     const long nrows = p.M - row0 < RW ? p.M - row0 : RW;     // may be <= 0: the wave then only runs dead arithmetic
-    const int npieces = nrows > 0 ? (int)nrows * PPR : 0;
-    const _Float16* __restrict__ X = (const _Float16*)p.x + row0 * C;
+    // rows through buffer resources (32-bit byte offsets, bounds-checked: pieces past the last row read zeros, their stores are dropped;
+    // the launcher cuts passes of more than kMaxBufBytes into runs)
+    const unsigned xbytes = (unsigned)(p.M * (C * 2));
+    const __amdgpu_buffer_rsrc_t XB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t YB = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, xbytes, 0x00020000);
+    const unsigned vo = nrows > 0 ? (unsigned)row0 * (C * 2) + lane * 16u : 0xFFFFC000u;   // (no rows: every piece past the end, without wrapping)
     const _Float16* __restrict__ W1 = (const _Float16*)p.w1_frag + lane * 8;   // [NCH*2 row tiles][KS][64][8]
     const _Float16* __restrict__ W2 = (const _Float16*)p.w2_frag + lane * 8;   // [NCH][NT][64][8], k order of the GELU'd accumulators
 
@@ -197,12 +201,7 @@ __global__ __launch_bounds__(NW * 64, (C == 96 ? 3 : W2X_MLP192_WPS) * NW / 4) v
     {
         half8 xr[NP];
 #pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            const int idx = k * 64 + lane;
-            half8 h = {};
-            if (idx < npieces) h = *(const half8*)(X + (size_t)idx * 8);
-            xr[k] = h;
-        }
+        for (int k = 0; k < NP; ++k) xr[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(XB, vo + k * 1024u, 0, 0));
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int idx = k * 64 + lane, r = idx / PPR, c = idx - r * PPR;
@@ -253,6 +252,7 @@ __global__ __launch_bounds__(NW * 64, (C == 96 ? 3 : W2X_MLP192_WPS) * NW / 4) v
         for (int i = 0; i < TT; ++i) acc2[i][j] = b2v;
     }
 
+    half8 xres[NP];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {   // fully unrolled: the ring registers are renamed statically
         if (ch + 1 < NCH) stage(ch + 1);       // into the other buffer (last read before the previous barrier); in flight under this chunk
@@ -271,6 +271,10 @@ __global__ __launch_bounds__(NW * 64, (C == 96 ? 3 : W2X_MLP192_WPS) * NW / 4) v
             for (int tt = 0; tt < TT; ++tt) acc1[ht][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[j % RING], xreg[tt][ks], acc1[ht][tt], 0, 0, 0);
             wr[j % RING] = lds_frag(ch, j + RING);
             W2X_RING_FENCE();
+        }
+        if (!K::KEEP && ch == NCH - 1) {   // the residual rows, requested as soon as the normalised copies have served their last product:
+#pragma unroll                           // they travel under the last GELU and second-layer products (round 2 fetched them in the epilogue and waited)
+            for (int k = 0; k < NP; ++k) xres[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(XB, vo + k * 1024u, 0, 0));
         }
         // GELU in place; lane holds hidden rows 16ht + 4g + j of token column fr -> B fragment of GEMM2 for the
         // k order (ht 0: slots 0..3, ht 1: slots 4..7)
@@ -293,8 +297,8 @@ __global__ __launch_bounds__(NW * 64, (C == 96 ? 3 : W2X_MLP192_WPS) * NW / 4) v
             for (int tt = 0; tt < TT; ++tt) acc2[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[j % RING], a2[tt], acc2[tt][nt], 0, 0, 0);
             if (j + RING < NF) { wr[j % RING] = lds_frag(ch, j + RING); W2X_RING_FENCE(); }
         }
-        __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): this wave's share of the next chunk has landed
-        __syncthreads();
+        if (ch + 1 < NCH) __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): this wave's share of the next chunk has landed
+        __syncthreads();                       // (after the last chunk: every wave is done with the weight buffers the slabs alias)
         if (ch + 1 < NCH) {
 #pragma unroll
             for (int i = 0; i < RING; ++i) wr[i] = lds_frag(ch + 1, i);
@@ -304,14 +308,12 @@ __global__ __launch_bounds__(NW * 64, (C == 96 ? 3 : W2X_MLP192_WPS) * NW / 4) v
     W2X_PHASE_FENCE();
     // ---- epilogue: residual pieces first (KEEP: from the slab, which still holds the raw rows; otherwise a second fetch),
     //      accumulators -> fp16 tile in the slab, then flat pieces
-    half8 xres[NP];
+    if (K::KEEP) {
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        const int idx = k * 64 + lane, r = idx / PPR, c = idx - r * PPR;
-        half8 h = {};
-        if (K::KEEP) h = *(const half8*)(Xw + r * LDX + c * 8);
-        else if (idx < npieces) h = *(const half8*)(X + (size_t)idx * 8);
-        xres[k] = h;
+        for (int k = 0; k < NP; ++k) {
+            const int idx = k * 64 + lane, r = idx / PPR, c = idx - r * PPR;
+            xres[k] = *(const half8*)(Xw + r * LDX + c * 8);
+        }
     }
     W2X_PHASE_FENCE();
     typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -321,12 +323,11 @@ __global__ __launch_bounds__(NW * 64, (C == 96 ? 3 : W2X_MLP192_WPS) * NW / 4) v
         for (int tt = 0; tt < TT; ++tt)
             *(half4*)(Xw + (tt * 16 + fr) * LDX + nt * 16 + g * 4) = (half4){(_Float16)acc2[tt][nt][0], (_Float16)acc2[tt][nt][1], (_Float16)acc2[tt][nt][2], (_Float16)acc2[tt][nt][3]};
     W2X_PHASE_FENCE();
-    _Float16* __restrict__ Y = (_Float16*)p.y + row0 * C;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int idx = k * 64 + lane, r = idx / PPR, c = idx - r * PPR;
         const half8 o = *(const half8*)(Xw + r * LDX + c * 8) + xres[k];     // fp16 + fp16 rounded once == fp32 add rounded to fp16
-        if (idx < npieces) *(half8*)(Y + (size_t)idx * 8) = o;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, o), YB, vo + k * 1024u, 0, 0);
         if (p.stats_out) *(half8*)(Xw + r * LDX + c * 8) = o;
     }
     W2X_PHASE_FENCE();
@@ -345,9 +346,18 @@ hipError_t launch_mlp2_c(const MlpParams& p, hipStream_t s) {
     using K = Mlp2Cfg<C, TT, NW>;
     static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
     if (hipError_t e = ensure_dynamic_lds((const void*)mlp2_kernel<C, TT, NW>, K::SMEM, lds_ok); e != hipSuccess) return e;
-    dim3 grid((unsigned)((p.M + K::BM - 1) / K::BM));
-    hipLaunchKernelGGL((mlp2_kernel<C, TT, NW>), grid, dim3(K::NWV * 64), K::SMEM, s, p);
-    return hipGetLastError();
+    // the kernel addresses x / y with 32-bit byte offsets: longer passes run in pieces of whole workgroups
+    const long max_rows = (long)((0xFFF00000u / (C * 2)) / K::BM) * K::BM;
+    for (long r0 = 0; r0 < p.M; r0 += max_rows) {
+        MlpParams q = p;
+        q.M = p.M - r0 < max_rows ? p.M - r0 : max_rows;
+        q.x = (const char*)p.x + (size_t)r0 * C * 2; q.y = (char*)p.y + (size_t)r0 * C * 2;
+        if (p.stats_out) q.stats_out = p.stats_out + 2 * r0;
+        dim3 grid((unsigned)((q.M + K::BM - 1) / K::BM));
+        hipLaunchKernelGGL((mlp2_kernel<C, TT, NW>), grid, dim3(K::NWV * 64), K::SMEM, s, q);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace

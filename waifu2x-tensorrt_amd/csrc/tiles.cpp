@@ -68,9 +68,22 @@ std::vector<float> tile_weight_mask(int which, int ovx, int ovy, int size) {
 StripPlan strip_plan(const TileGrid& g, int outW, int tileOutW, int part, int parts) {
     StripPlan sp;
     if (parts <= 0 || part < 0 || part >= parts || g.nx <= 0) return sp;
-    const int c0 = (int)((long)part * g.nx / parts), c1 = (int)((long)(part + 1) * g.nx / parts);
-    if (c0 >= c1) return sp;                                  // more parts than tile columns: nothing to do
     const int stride = tileOutW - g.outOvX;                   // output origin of tile column i = i * stride (img2img_render.cpp:54-55)
+    // Every strip but the first also renders the k earlier tile columns whose blend band reaches into its pixels (k = 1 for every
+    // blend setting of the command line, 0 without overlap), so the strips are balanced by the columns they RENDER, nx + (parts - 1) k
+    // in all: strip p ends at column floor((p + 1) (nx + (parts - 1) k) / parts) - p k.  (Equal shares of own columns left the first
+    // strip short and the others a column over: 20 / 30 tiles instead of 25 / 25 for nx = 9, two strips.)
+    const int k = g.outOvX > 0 && stride > 0 ? (g.outOvX + stride - 1) / stride : 0;
+    auto end_col = [&](int p) {
+        const long t = (long)g.nx + (long)(parts - 1) * k;
+        long c = (long)(p + 1) * t / parts - (long)p * k;
+        if (p + 1 == parts) c = g.nx;
+        return (int)std::min<long>(std::max<long>(c, 0), g.nx);
+    };
+    int c0 = 0;
+    for (int p = 0; p < part; ++p) c0 = std::max(c0, end_col(p));
+    const int c1 = std::max(c0, end_col(part));
+    if (c0 >= c1) return sp;                                  // more parts than tile columns: nothing to do
     sp.x0 = c0 * stride;
     sp.x1 = c1 < g.nx ? c1 * stride : outW;
     int cc0 = c0;                                             // first tile column whose extent reaches x0
