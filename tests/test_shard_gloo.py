@@ -86,7 +86,7 @@ def test_two_ranks_split_one_frame_into_tile_column_strips():
     assert all(r[1] == plans for r in res) and all(r[2] for r in res)
     # config 3: 9x5 tiles; rank 0 owns tile columns 0..4, rank 1 columns 5..8 plus column 4 again for the blend band: 25 tiles each
     assert plans[0] == (0, 25, 0, 5 * 896) and plans[1] == (20, 25, 5 * 896, 7680)
-    assert res[0][3] == 4 * 896 and res[1][3] == 7680 - 4 * 896
+    assert res[0][3] == 5 * 896 and res[1][3] == 7680 - 5 * 896
 
 
 def test_bench_refuses_a_rank_count_that_differs_from_gpus():
