@@ -34,12 +34,14 @@ def onnx_model(model_dir):
     import synth_models as sm
     cache = {}
 
-    def get(model, scale, batch, tile, noise=3, small=False, opset=17):
-        key = (model, scale, batch, tile, noise, small, opset)
+    def get(model, scale, batch, tile, noise=3, small=False, opset=17, variant=None, dynamic=True):
+        vkey = tuple(sorted((variant or {}).items()))
+        key = (model, scale, batch, tile, noise, small, opset, vkey, dynamic)
         if key not in cache:
-            root = os.path.join(model_dir, f"b{batch}_t{tile}_{'s' if small else 'f'}_o{opset}")
+            tag = "".join(f"_{k}{v}" for k, v in vkey) + ("" if dynamic else "_static")
+            root = os.path.join(model_dir, f"b{batch}_t{tile}_{'s' if small else 'f'}_o{opset}{tag}")
             path = sm.model_path(root, model, scale, noise)
-            sm.export_onnx(sm.make_model(model, scale, seed=1234 + noise, small=small), path, batch, tile, opset=opset, dynamic=True)
+            sm.export_onnx(sm.make_model(model, scale, seed=1234 + noise, small=small, variant=variant), path, batch, tile, opset=opset, dynamic=dynamic)
             cache[key] = path
         return cache[key]
 

@@ -503,3 +503,35 @@ def test_two_tile_groups_on_two_streams_are_bit_identical_to_one(pkg, onnx_model
         outs.append(rs[0])
         eng.close()
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("name,kw,tile", [
+    ("window 8 (64 tokens)", dict(variant={"ws": 8}), 80),
+    ("4 / 8 heads of 24 / 48", dict(variant={"heads": 4}), 64),
+    ("C = 128 / 256, 8 heads of 16 / 32", dict(variant={"heads": 8, "base_dim": 128}), 64),
+    ("static batch dimension", dict(dynamic=False), 64),
+    ("opset 11", dict(opset=11), 64),
+    ("opset 15", dict(opset=15), 64),
+])
+def test_loader_takes_graphs_it_was_not_written_around(pkg, onnx_model, name, kw, tile):
+    """img2img_build.cpp:81-88 hands any ONNX file to the parser.  The fused kernels cover the release graphs' transformer shapes
+    ((C, head) = (96, 16) / (192, 32), windows of 6 x 6); other shapes must still build and meet the un-fused path's bounds - windows
+    of 8 x 8, other head counts and widths - and the same weights exported with a static batch dimension or at another opset must
+    lower onto the same plan and give the same bytes as the opset-17 dynamic-batch file."""
+    path = onnx_model("swin_unet/art", 4, 2, tile, noise=2, **kw)
+    eng = make_engine(pkg, path, 2, tile, 4)
+    assert any("ONNX graph" in m and "MatMul x" in m for _, m in eng.messages)        # build() lists what the parser was handed
+    rng = np.random.default_rng(17)
+    x = rng.random((2, 3, tile, tile), dtype=np.float32).astype(np.float16).astype(np.float32)
+    y = eng.infer(x)
+    eng.close()
+    if "variant" in kw:
+        r = network_report(f"network[swin_unet/art s4 B2 T{tile} {name}]", y, oracle16(path)(x), onnx_exec.Executor(path).run(x))
+        assert "swinattn" not in pkg.describe_plan(path, 2, tile)                      # these shapes run on the general kernels
+        assert r["max_ulp16"] <= NET_MAX_ULP16_UNFUSED and r["mean_abs"] <= NET_MEAN_ABS and r["max_ulp16_vs_fp32_oracle"] <= NET_MAX_ULP16_VS_FP32 + 0.5, r
+    else:
+        ref_path = onnx_model("swin_unet/art", 4, 2, tile, noise=2)
+        ref = make_engine(pkg, ref_path, 2, tile, 4)
+        assert np.array_equal(y, ref.infer(x)), name
+        ref.close()
+        assert "swinattn" in pkg.describe_plan(path, 2, tile)

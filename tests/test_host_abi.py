@@ -253,3 +253,47 @@ def test_strip_split_redundancy_table(pkg, capsys):
             lines.append(f"{name}: N={N}: {total} tiles rendered for {n} (+{100 * (total - n) // n} %), largest strip {largest} -> speed-up <= {n / largest:.2f}x")
     with capsys.disabled():
         print("\n" + "\n".join(lines))
+
+
+def _export(net, path, shape, opset=17):
+    import torch
+    import torch.onnx._internal.torchscript_exporter.onnx_proto_utils as opu
+    opu._add_onnxscript_fn = lambda model_bytes, custom_opsets: model_bytes
+    import warnings
+    net.eval()
+    with warnings.catch_warnings(), torch.no_grad():
+        warnings.simplefilter("ignore")
+        torch.onnx.export(net, (torch.zeros(*shape),), path, dynamo=False, opset_version=opset, input_names=["x"], output_names=["y"], do_constant_folding=True)
+
+
+def test_graphs_the_loader_does_not_take_fail_naming_the_node(pkg, tmp_path):
+    """img2img_build.cpp:81-88 hands any ONNX file to the parser; what this loader cannot lower must end as a build error that names
+    the node (like TensorRT's parser on an unsupported layer), never as a wrong plan: a zero-padded 3x3 convolution, a transposed
+    convolution with output_padding, a positive Pad, an operator outside the set."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    class Padded(nn.Module):
+        def __init__(self): super().__init__(); self.c = nn.Conv2d(3, 8, 3, 1, 1); self.d = nn.Conv2d(8, 3, 3, 1, 0)
+        def forward(self, x): return self.d(F.leaky_relu(self.c(x), 0.1))
+
+    class OutPad(nn.Module):
+        def __init__(self): super().__init__(); self.c = nn.Conv2d(3, 8, 3, 1, 0); self.t = nn.ConvTranspose2d(8, 3, 3, 2, 0, output_padding=1)
+        def forward(self, x): return self.t(F.leaky_relu(self.c(x), 0.1))
+
+    class PosPad(nn.Module):
+        def __init__(self): super().__init__(); self.c = nn.Conv2d(3, 3, 3, 1, 0)
+        def forward(self, x): return self.c(F.pad(x, (2, 2, 2, 2), mode="reflect"))
+
+    class Odd(nn.Module):
+        def __init__(self): super().__init__(); self.c = nn.Conv2d(3, 3, 3, 1, 0)
+        def forward(self, x): return torch.atan(self.c(x))
+
+    for name, net, needle in (("padded", Padded(), "Conv"), ("outpad", OutPad(), "ConvTranspose"), ("pospad", PosPad(), "Pad"), ("odd", Odd(), "Atan")):
+        path = str(tmp_path / f"{name}.onnx")
+        _export(net, path, (1, 3, 32, 32))
+        with pytest.raises(pkg.W2xError) as ei:
+            pkg.describe_plan(path, 1, 32)
+        msg = str(ei.value)
+        assert needle in msg, (name, msg)

@@ -35,18 +35,14 @@ struct PixCfg {
     static constexpr int OTILE = RW * LDO * 2 + RW * 8;        // per wave: output tile + (out, res) base offsets per row
     static constexpr int IN_BYTES = 4 * RW * LDXI * 2;         // input staging aliases everything (dead before the first stage)
     static constexpr int MAIN = 2 * WBUF + 4 * OTILE;
-    static constexpr int BIAS_OFF = MAIN > IN_BYTES ? MAIN : IN_BYTES;      // bias [<= 16 sub-pixels][CSO] fp32 behind everything
-    static constexpr int SMEM = BIAS_OFF + 16 * CSO * 4;
-    // skip rows: requested all at once when a sub-pixel starts (CSO <= 96: NPO pieces = 24 registers), else in groups when it is complete
-    static constexpr int RGRP = CSO <= 96 ? NPO : (NPO % 6 == 0 ? 6 : NPO % 4 == 0 ? 4 : NPO);
-    static_assert(NTS % G == 0 && NF % 4 == 0 && RW * PPI % 64 == 0 && RW * PPO % 64 == 0 && NPO % RGRP == 0, "tiling");
+    static constexpr int SMEM = MAIN > IN_BYTES ? MAIN : IN_BYTES;
+    static_assert(NTS % G == 0 && NF % 4 == 0 && RW * PPI % 64 == 0 && RW * PPO % 64 == 0, "tiling");
 };
 
 template <int K, int CSO, int G>
 __global__ __launch_bounds__(256, 2) void pixgemm_kernel(const GemmParams p) {
     using C = PixCfg<K, CSO, G>;
     constexpr int TT = C::TT, RW = C::RW, KS = C::KS, NTS = C::NTS, LDO = C::LDO, LDXI = C::LDXI, NFW = C::NFW;
-    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -54,22 +50,16 @@ __global__ __launch_bounds__(256, 2) void pixgemm_kernel(const GemmParams p) {
     const int fr = lane & 15, g = lane >> 4;
     _Float16* WB = (_Float16*)smem;                                          // [2][NF][64][8]
     _Float16* Ot = (_Float16*)(smem + 2 * C::WBUF + wv * C::OTILE);           // [RW][LDO]
-    unsigned* Rb = (unsigned*)(smem + 2 * C::WBUF + wv * C::OTILE + RW * LDO * 2);   // [RW][2] byte offsets of sub-pixel (0,0): out, res (0xFFFFFFFF: no row)
-    float* Bs = (float*)(smem + C::BIAS_OFF);                                 // bias [r * r * CSO]: read per n-tile through LDS
-    _Float16* Xin = (_Float16*)(smem + wv * RW * LDXI * 2);                   // input staging (aliases the weight buffers and tiles)
+    int* Rb = (int*)(smem + 2 * C::WBUF + wv * C::OTILE + RW * LDO * 2);      // [RW][2] element offsets of sub-pixel (0,0): out, res
+    _Float16* Xin = (_Float16*)(smem + wv * RW * LDXI * 2);                   // input staging (aliases the above)
 
     const long M = (long)p.B * p.Mrows;
     const long row0 = ((long)blockIdx.x * 4 + wv) * RW;
     const long nrows = M - row0 < RW ? M - row0 : RW;
+    const int npieces = nrows > 0 ? (int)nrows * C::PPI : 0;
+    const _Float16* __restrict__ X = (const _Float16*)p.a.p + row0 * K;
     const _Float16* __restrict__ Wf = (const _Float16*)p.wt_frag + lane * 8;  // [N/16][KS][64][8]
     const int r = p.r, nsub = r * r, nstage = nsub * NTS / G;
-    // Rows, residual rows and output rows go through buffer resources (32-bit byte offsets, bounds-checked: an offset of 0xFFFFFFFF -
-    // a row that does not exist - reads zeros and drops the store), so no piece needs a predicate; launch_pix() refuses maps of 4 GB
-    // and more (the general kernel takes them).
-    const __amdgpu_buffer_rsrc_t XB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a.p), 0, (unsigned)(M * (K * 2)), 0x00020000);
-    const __amdgpu_buffer_rsrc_t OB = __builtin_amdgcn_make_buffer_rsrc(p.out.p, 0, (unsigned)((size_t)p.B * p.out.Hs * p.out.Ws * CSO * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t RB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res.p ? p.res.p : p.out.p), 0,
-                                                                         p.res.p ? (unsigned)((size_t)p.B * p.res.Hs * p.res.Ws * p.res.Cs * 2) : 0u, 0x00020000);
 
     // ---- stage 0 of the weights is requested first, then the rows
     half8 stg[NFW];
@@ -77,15 +67,19 @@ __global__ __launch_bounds__(256, 2) void pixgemm_kernel(const GemmParams p) {
     for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)(Wf + (size_t)(wv * NFW + i) * 512);
     {
         half8 xr[C::NPI];
-        const unsigned vo = nrows > 0 ? (unsigned)(row0 * (K * 2)) + lane * 16u : 0xFFFF8000u;
 #pragma unroll
-        for (int k = 0; k < C::NPI; ++k) xr[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(XB, vo + k * 1024u, 0, 0));
+        for (int k = 0; k < C::NPI; ++k) {
+            const int idx = k * 64 + lane;
+            half8 h = {};
+            if (idx < npieces) h = *(const half8*)(X + (size_t)idx * 8);
+            xr[k] = h;
+        }
         if (p.a_scale) {   // squeeze-excite gate of the input map: fp16(x * s), the rounding of the in-place pass
 #pragma unroll
             for (int k = 0; k < C::NPI; ++k) {
                 const int idx = k * 64 + lane, rr = idx / C::PPI, c = idx - rr * C::PPI;
                 const float* sc = p.a_scale + (size_t)((row0 + rr) / p.Mrows) * K + c * 8;
-                if (rr < nrows) xr[k] = gate::gate8(xr[k], sc);
+                if (idx < npieces) xr[k] = gate::gate8(xr[k], sc);
             }
         }
 #pragma unroll
@@ -100,28 +94,25 @@ __global__ __launch_bounds__(256, 2) void pixgemm_kernel(const GemmParams p) {
     for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xa[tt][ks] = *(const half8*)(Xin + (tt * 16 + fr) * LDXI + ks * 32 + g * 8);
-    // per-row output / residual byte offsets of sub-pixel (0,0), computed once
-    unsigned my_ob = 0xFFFFFFFFu, my_rb = 0xFFFFFFFFu;
+    // per-row output / residual offsets of sub-pixel (0,0), computed once
+    int my_ob = 0, my_rb = 0;
     if (lane < RW) {
         const long gr = row0 + lane;
         if (gr < M) {
             const int b = (int)(gr / p.Mrows), ml = (int)(gr - (long)b * p.Mrows);
             const int oy = ml / p.aW, ox = ml - oy * p.aW;
-            my_ob = (unsigned)(((size_t)(b * p.out.Hs + oy * r) * p.out.Ws + ox * r) * CSO * 2);
-            if (p.res.p) my_rb = (unsigned)(((size_t)(b * p.res.Hs + oy * r + p.res.y0) * p.res.Ws + ox * r + p.res.x0) * p.res.Cs * 2);
+            my_ob = ((b * p.out.Hs + oy * r) * p.out.Ws + ox * r) * CSO;
+            my_rb = p.res.p ? ((b * p.res.Hs + oy * r + p.res.y0) * p.res.Ws + ox * r + p.res.x0) * p.res.Cs : 0;
         }
     }
     __syncthreads();                               // all rows are in registers: the staging area becomes weight buffers + tiles
     if (lane < RW) { Rb[2 * lane] = my_ob; Rb[2 * lane + 1] = my_rb; }
-    for (int i = tid; i < nsub * CSO; i += 256) Bs[i] = p.bias[i];
 #pragma unroll
     for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[i];
     __syncthreads();
 
-    // The skip rows of a sub-pixel are REQUESTED when its first n-tiles start and consumed when its last ones are done (round 2 loaded
-    // each piece where it was added and waited for it: nsub x NPO exposed HBM round trips per wave); the bias comes from LDS (as a
-    // global load its in-order wait also waited for the next stage's weight fragments requested just before).
-    half8 rres[C::RGRP];
+    _Float16* __restrict__ Og = (_Float16*)p.out.p;
+    const _Float16* __restrict__ Rg = (const _Float16*)p.res.p;
     for (int st = 0; st < nstage; ++st) {
         const _Float16* wcur = WB + (size_t)(st & 1) * (C::WBUF / 2) + lane * 8;
         if (st + 1 < nstage) {
@@ -129,22 +120,10 @@ __global__ __launch_bounds__(256, 2) void pixgemm_kernel(const GemmParams p) {
             for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)(Wf + (size_t)((st + 1) * C::NF + wv * NFW + i) * 512);
         }
         const int sg = st * G / NTS, nt0 = st * G - sg * NTS;     // sub-pixel and first n-tile inside it
-        const int dy = sg / r, dx = sg - dy * r;
-        // (CSO = 192: twelve pieces = 48 registers carried around the stage loop next to 48 of row fragments do not fit; there all twelve are
-        //  requested together when the sub-pixel is complete - one round trip per sub-pixel instead of one per piece)
-        constexpr bool EARLY = CSO <= 96;
-        if (EARLY && nt0 == 0 && p.res.p) {
-            const unsigned rshift = (unsigned)((dy * p.res.Ws + dx) * p.res.Cs * 2);
-#pragma unroll
-            for (int k = 0; k < C::NPO; ++k) {
-                const int idx = k * 64 + lane, rr = idx / C::PPO, c = idx - rr * C::PPO;
-                rres[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(RB, __builtin_elementwise_add_sat(Rb[2 * rr + 1], rshift + c * 16u), 0, 0));
-            }
-        }
 #pragma unroll
         for (int t = 0; t < G; ++t) {
             float4v acc[TT];
-            const float b = Bs[(sg * NTS + nt0 + t) * 16 + fr];
+            const float b = p.bias[(sg * NTS + nt0 + t) * 16 + fr];
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt) acc[tt] = (float4v){b, b, b, b};         // bias = initial accumulator
 #pragma unroll
@@ -164,30 +143,24 @@ __global__ __launch_bounds__(256, 2) void pixgemm_kernel(const GemmParams p) {
         }
         if (nt0 + G == NTS) {                      // sub-pixel sg complete: residual add and store as 16-byte pieces
             W2X_PHASE_FENCE();
-            const unsigned oshift = (unsigned)((dy * p.out.Ws + dx) * CSO * 2), rshift = (unsigned)((dy * p.res.Ws + dx) * p.res.Cs * 2);
-            constexpr int GRP = C::RGRP;                  // late variant: a group of pieces requested together, then added and stored
+            const int dy = sg / r, dx = sg - dy * r;
+            const int oshift = (dy * p.out.Ws + dx) * CSO, rshift = (dy * p.res.Ws + dx) * p.res.Cs;
 #pragma unroll
-            for (int k0 = 0; k0 < C::NPO; k0 += GRP) {
-                if (!EARLY && p.res.p) {
-#pragma unroll
-                    for (int k = k0; k < k0 + GRP; ++k) {
-                        const int idx = k * 64 + lane, rr = idx / C::PPO, c = idx - rr * C::PPO;
-                        rres[k - k0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(RB, __builtin_elementwise_add_sat(Rb[2 * rr + 1], rshift + c * 16u), 0, 0));
-                    }
-                }
-#pragma unroll
-                for (int k = k0; k < k0 + GRP; ++k) {
-                    const int idx = k * 64 + lane, rr = idx / C::PPO, c = idx - rr * C::PPO;
+            for (int k = 0; k < C::NPO; ++k) {
+                const int idx = k * 64 + lane, rr = idx / C::PPO, c = idx - rr * C::PPO;
+                if (rr < nrows) {
                     half8 o = *(const half8*)(Ot + rr * LDO + c * 8);
-                    if (p.res.p) {
-                        half8 rv = rres[EARLY ? k : k - k0];
-                        if (p.res_scale && rr < nrows) rv = gate::gate8(rv, p.res_scale + (size_t)((row0 + rr) / p.Mrows) * p.res.Cs + c * 8);   // gated skip connection
+                    if (Rg) {
+                        half8 rv = *(const half8*)(Rg + (size_t)Rb[2 * rr + 1] + rshift + c * 8);
+                        if (p.res_scale) {   // gated skip connection
+                            rv = gate::gate8(rv, p.res_scale + (size_t)((row0 + rr) / p.Mrows) * p.res.Cs + c * 8);
+                        }
                         o += rv;                                   // fp16 + fp16 rounded once == fp32 add rounded to fp16
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, o), OB, __builtin_elementwise_add_sat(Rb[2 * rr], oshift + c * 16u), 0, 0);
+                    *(half8*)(Og + (size_t)Rb[2 * rr] + oshift + c * 8) = o;
                 }
-                W2X_PHASE_FENCE();
             }
+            W2X_PHASE_FENCE();
         }
         if (st + 1 < nstage) {
 #pragma unroll
@@ -452,11 +425,6 @@ bool pixgemm_supported(const GemmParams& p) {
     if (p.N != p.r * p.r * p.out.Cs) return false;
     if (p.K == 96 && p.out.Cs == 4 && p.r == 4 && p.N == 64 && !p.res.p && p.act == 0 && p.amode == 0 && !p.a_scale) return true;   // image head
     if (p.has_clip || p.Cout != p.out.Cs || (p.res.p && p.res.Cs != p.out.Cs)) return false;
-    {   // pixgemm_kernel addresses its three maps with 32-bit byte offsets and keeps the bias of at most 16 sub-pixels in LDS
-        const size_t lim = 0xFFFF0000u;
-        if (p.r > 4 || (size_t)p.B * p.Mrows * p.K * 2 >= lim || (size_t)p.B * p.out.Hs * p.out.Ws * p.out.Cs * 2 >= lim ||
-            (p.res.p && (size_t)p.B * p.res.Hs * p.res.Ws * p.res.Cs * 2 >= lim)) return false;
-    }
     if ((p.K == 64 && p.out.Cs == 64) || (p.K == 128 && p.out.Cs == 128)) return true;
     return (p.K == 192 && (p.out.Cs == 96 || p.out.Cs == 192));
 }

@@ -3,13 +3,14 @@
 # recompile that one object with the flags, relink libw2x.so and run bench.py; prints frame time and the per-kernel milliseconds of a
 # frame.  An argument "base" runs the library as built.  Each variant starts from the stock objects (the previous variant's object is
 # rebuilt without flags first), the last step restores the stock library.
-#   tools/ab/lib_variants.sh base "k_swinattn192.hip:-DW2X_A192_XRES_LATE" base
+#   tools/ab/lib_variants.sh base "k_swinattn192.hip:-DW2X_A192_XRES_LATE" base "k_pixgemm.hip@tools/ab/k_pixgemm_r2.hip"
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT/waifu2x-tensorrt_amd"
 CXX="/opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable"
 extra() { case "$1" in k_mlp2.hip) echo "-mllvm -amdgpu-sched-strategy=max-ilp";; k_mlp96q.hip) echo "-mllvm -amdgpu-sched-strategy=max-ilp -fno-honor-nans";; *) echo "";; esac; }
-build() { $CXX $(extra "$1") $2 -c "csrc/$1" -o "build/${1%.hip}.o" 2>/dev/null && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libw2x.so build/*.o; }
+# build <object's file> <flags> [<alternative source, relative to the repository root>]
+build() { $CXX $(extra "$1") $2 -I csrc -c "${3:-csrc/$1}" -o "build/${1%.hip}.o" 2>/dev/null && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libw2x.so build/*.o; }
 run() { (cd "$ROOT"; python bench.py --no-cpu-baseline --steps ${STEPS:-20} 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
@@ -19,7 +20,8 @@ for arg in "$@"; do
   if [ -n "$last" ]; then build "$last" ""; last=""; fi
   if [ "$arg" = "base" ]; then run "base"; continue; fi
   file=${arg%%:*}; flags=""; case "$arg" in *:*) flags=${arg#*:};; esac
-  build "$file" "$flags" || { echo "build failed: $arg"; continue; }
+  alt=""; case "$file" in *@*) alt="$ROOT/${file#*@}"; file=${file%%@*};; esac       # "k_x.hip@tools/ab/k_x_r2.hip": that object from another source
+  build "$file" "$flags" "$alt" || { echo "build failed: $arg"; continue; }
   last=$file
   run "$arg"
 done

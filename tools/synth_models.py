@@ -259,9 +259,9 @@ class ToImage(nn.Module):
 class SwinUNet(nn.Module):
     """swin_unet/{art,art_scan,photo}: T' = scale (T - 16)."""
 
-    def __init__(self, cin=3, cout=3, base_dim=96, base_layers=2, scale=4, ws=6):
+    def __init__(self, cin=3, cout=3, base_dim=96, base_layers=2, scale=4, ws=6, heads=None):
         super().__init__()
-        C, Hd, L = base_dim, base_dim // 16, base_layers
+        C, Hd, L = base_dim, heads or base_dim // 16, base_layers
         self.scale = scale
         self.patch = nn.Sequential(
             nn.Conv2d(cin, C // 2, 3, 1, 0), nn.LeakyReLU(0.1),
@@ -298,15 +298,18 @@ def output_tile_size(model: str, scale: int, tile: int) -> int:
     return scale * (tile - 16)
 
 
-def make_model(model: str, scale: int, seed: int = 1234, small: bool = False) -> nn.Module:
-    """model in {cunet/art, swin_unet/art, swin_unet/art_scan, swin_unet/photo} (main.cpp:26-33)."""
+def make_model(model: str, scale: int, seed: int = 1234, small: bool = False, variant: dict | None = None) -> nn.Module:
+    """model in {cunet/art, swin_unet/art, swin_unet/art_scan, swin_unet/photo} (main.cpp:26-33).
+    variant (swin_unet only): other transformer shapes than the release graphs' - {"ws": window, "heads": heads of the first level,
+    "base_dim": channels} - for the loader's robustness tests (graphs the builder did not write the kernels for)."""
     torch.manual_seed(seed)
     if model.startswith("cunet"):
         if scale == 4:
             raise ValueError("cunet/art has no scale 4 (main.cpp:142-143)")
         net = UpCUNet() if scale == 2 else CUNet()
     elif model.startswith("swin_unet"):
-        net = SwinUNet(scale=scale, base_dim=48 if small else 96)
+        v = dict(variant or {})
+        net = SwinUNet(scale=scale, base_dim=v.get("base_dim", 48 if small else 96), ws=v.get("ws", 6), heads=v.get("heads"))
     else:
         raise ValueError(model)
     _init(net, seed)

@@ -726,6 +726,7 @@ bool Img2Img::build(const std::string& onnxModelPath, const BuildConfig& config)
     }
     Plan plan;
     try {
+        W2X_LOG(info, "ONNX graph \"" + onnxModelPath + "\": " + onnx_op_histogram(onnxModelPath) + ".");
         plan = lower_for_shape(onnxModelPath, config.optBatchSize, config.optChannels, config.optHeight, config.optWidth, fp32);
     } catch (const std::exception& e) {
         W2X_LOG(error, "Failed to parse ONNX model: " + std::string(e.what()) + ".");

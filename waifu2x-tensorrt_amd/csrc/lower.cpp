@@ -939,6 +939,21 @@ Plan lower_graph(const FoldedGraph& g, bool fp32) {
     return l.run();
 }
 
+// "opset 17 (pytorch), 6712 nodes: Conv x2, MatMul x56, ..." - what the parser was handed (img2img_build.cpp:81-88 hands any ONNX file
+// to TensorRT's parser, which lists the layers it made of it); build() logs it so that a graph this loader was not written for shows
+// what it consists of before any node is refused
+std::string onnx_op_histogram(const std::string& onnx_path) {
+    const Model m = load_onnx(onnx_path);
+    std::map<std::string, int> count;
+    for (const Node& n : m.nodes) ++count[n.op];
+    std::vector<std::pair<int, std::string>> by;
+    for (const auto& kv : count) by.push_back({-kv.second, kv.first});
+    std::sort(by.begin(), by.end());
+    std::string s = "opset " + std::to_string(m.opset) + (m.producer.empty() ? "" : " (" + m.producer + ")") + ", " + std::to_string(m.nodes.size()) + " nodes:";
+    for (const auto& e : by) s += " " + e.second + " x" + std::to_string(-e.first);
+    return s;
+}
+
 Plan build_plan(const std::string& onnx_path, int batch, int channels, int height, int width, bool fp32) {
     Model m = load_onnx(onnx_path);
     FoldedGraph g = fold_graph(m, {batch, channels, height, width});

@@ -12,5 +12,6 @@ Plan lower_graph(const FoldedGraph& g, bool fp32 = false);
 
 // Convenience: load + fold + lower.  input is [B,3,T,T].
 Plan build_plan(const std::string& onnx_path, int batch, int channels, int height, int width, bool fp32 = false);
+std::string onnx_op_histogram(const std::string& onnx_path);
 
 }  // namespace w2x
