@@ -290,6 +290,14 @@ def test_graphs_the_loader_does_not_take_fail_naming_the_node(pkg, tmp_path):
         def __init__(self): super().__init__(); self.c = nn.Conv2d(3, 3, 3, 1, 0)
         def forward(self, x): return torch.atan(self.c(x))
 
+    # transformer shapes outside the kernels' range: rows of 256 channels under a LayerNorm (base width 128), windows of 12 x 12
+    import synth_models as sm
+    for name, kw, needle in (("c128", {"heads": 8, "base_dim": 128}, "LayerNorm over rows of 256 channels"), ("ws12", {"ws": 12}, "144 tokens per window")):
+        path = str(tmp_path / name / "m.onnx")
+        sm.export_onnx(sm.make_model("swin_unet/art", 4, seed=3, variant=kw), path, 1, 64, dynamic=True)
+        with pytest.raises(pkg.W2xError) as ei:
+            pkg.describe_plan(path, 1, 64)
+        assert needle in str(ei.value) and "/swin" in str(ei.value), str(ei.value)
     for name, net, needle in (("padded", Padded(), "Conv"), ("outpad", OutPad(), "ConvTranspose"), ("pospad", PosPad(), "Pad"), ("odd", Odd(), "Atan")):
         path = str(tmp_path / f"{name}.onnx")
         _export(net, path, (1, 3, 32, 32))

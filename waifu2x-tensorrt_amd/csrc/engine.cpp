@@ -462,7 +462,7 @@ struct Img2Img::Impl {
         auto tp = [&](int t) -> uint8_t* { return t < 0 ? nullptr : grp < 0 ? (uint8_t*)tensors[t] : group_ptr(tensors[t], grp); };
         auto shift = [&](const void* ptr, int) -> void* { return group_ptr(ptr, grp); };
         const int b0 = grp < 0 ? 0 : 1;   // (non-zero: re-address the prepared parameters)
-        for (size_t i = 0; i < plan.ops.size(); ++i) {
+        for (size_t i = 0; i < plan.ops.size(); ++i) try {
             const Op& op = plan.ops[i];
             cur_op = (int)i;
             switch (op.kind) {
@@ -571,6 +571,8 @@ struct Img2Img::Impl {
                 }
                 default: throw std::runtime_error("plan: unknown op kind");
             }
+        } catch (const std::exception& e) {     // name the op: "invalid argument" alone says nothing about a 60-op plan
+            throw std::runtime_error("op " + std::to_string(i) + " [" + plan.ops[i].name + "]: " + e.what());
         }
         cur_op = -1;
     }

@@ -224,7 +224,20 @@ hipError_t launch_attn(const AttnParams& p, hipStream_t s) {
     }
     W2X_ATTN_CASE(16, 36) W2X_ATTN_CASE(32, 36) W2X_ATTN_CASE(16, 64) W2X_ATTN_CASE(32, 64) W2X_ATTN_CASE(8, 36)
 #undef W2X_ATTN_CASE
+    // other head sizes (multiples of 8 up to 64): the lane-per-query kernel, which is generic in both parameters
+#define W2X_ATTN_VALU_CASE(HD_, NTOK_)                                                                                 \
+    if (p.ntok == NTOK_ && p.hd == HD_) { hipLaunchKernelGGL((attn_kernel<HD_, NTOK_>), grid, dim3(256), 0, s, p); return hipGetLastError(); }
+    W2X_ATTN_VALU_CASE(8, 64) W2X_ATTN_VALU_CASE(24, 36) W2X_ATTN_VALU_CASE(24, 64) W2X_ATTN_VALU_CASE(48, 36) W2X_ATTN_VALU_CASE(48, 64)
+    W2X_ATTN_VALU_CASE(64, 36) W2X_ATTN_VALU_CASE(64, 64)
+#undef W2X_ATTN_VALU_CASE
     return hipErrorInvalidValue;
+}
+
+// what launch_attn() takes: lower.cpp asks before it emits an OP_ATTN, so that a graph with another window or head size fails at build
+// time naming the node instead of at the first render
+bool attn_supported(int hd, int ntok) {
+    if (ntok != 36 && ntok != 64) return false;
+    return hd == 8 || hd == 16 || hd == 24 || hd == 32 || hd == 48 || hd == 64;
 }
 
 }  // namespace w2x

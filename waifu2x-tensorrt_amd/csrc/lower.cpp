@@ -130,6 +130,10 @@ struct Lowerer {
         const TensorDesc& td = plan.tensors[v.v.t];
         if (v.v.y0 || v.v.x0 || v.v.H != td.H || v.v.W != td.W) fail(n, "LayerNorm over a cropped view is not supported");
         if (p.g.Cout != v.C) fail(n, "LayerNorm width differs from producer row width");
+        // the statistics of a row come out of ONE workgroup tile of the producing kernel (k_gemm.hip / k_f32.hip: tiles of up to 192 columns);
+        // wider token rows would need a separate reduction
+        if (p.g.omode != O_PIXSHUF && !gemm_row_stats_supported(p.g.N))
+            fail(n, "LayerNorm over rows of " + std::to_string(p.g.N) + " channels: the producing kernel emits row statistics for widths 32, 48, 64, 96, 128 and 192 only");
         if (p.g.stats_out < 0) { p.g.stats_out = new_tensor(td.B, td.H, td.W, 2, 4); p.g.ln_eps = v.eps; }
         else if (p.g.ln_eps != v.eps) fail(n, "two LayerNorms with different eps on one tensor");
     }
@@ -582,6 +586,8 @@ struct Lowerer {
         if (!rs || rs->op != "Reshape" || shp(rs->out[0]) != Shape{(int64_t)plan.B * nwin, Ntok, C}) fail(tr, "expected head merge reshape");
         done.insert(tr); done.insert(rs);
 
+        if (plan.elt == 2 && !attn_supported(hd, Ntok))
+            fail(mm1, "attention with " + std::to_string(Ntok) + " tokens per window and heads of " + std::to_string(hd) + " is not covered by the attention kernels (windows of 6x6 / 8x8, head sizes 8..64 in steps of 8)");
         Op op; op.kind = OP_ATTN; op.name = mm1->name.empty() ? "attention" : mm1->name;
         AttnOp& a = op.at;
         a.qkv = x.v.t; a.heads = heads; a.hd = hd; a.ws = ws; a.nwin = nwin; a.scale = scale;
