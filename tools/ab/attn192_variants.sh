@@ -1,0 +1,19 @@
+#!/bin/bash
+# Builds tools/ab/attn192_variants from variants of csrc/k_swinattn192.hip:  tools/ab/attn192_variants.sh "<flags v0>" "<flags v1>" ... ["STAMPS <flags>"]
+# A last argument that starts with STAMPS builds that variant with the per-phase s_memtime stamps and prints the phase table.
+set -eu
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+CXX="/opt/rocm/bin/hipcc -std=c++17 -O3 --offload-arch=gfx950 -I $ROOT/waifu2x-tensorrt_amd/csrc -Wno-unused-function -Wno-unused-variable"
+TMP=$(mktemp -d)
+i=0; objs=""; hflags=""
+for arg in "$@"; do
+  src=$ROOT/waifu2x-tensorrt_amd/csrc/k_swinattn192.hip; fl="$arg"
+  case "$arg" in SRC=*) src=${arg%% *}; src=${src#SRC=}; fl=${arg#SRC=$src}; ;; esac
+  case "$fl" in STAMPS*) fl="${fl#STAMPS} -DW2X_A192_STAMPS"; hflags="-DW2X_A192_STAMPS";; esac
+  $CXX $fl -Dlaunch_swin_attn192=launch_swin_attn96_v$i -c "$src" -o $TMP/v$i.o
+  objs="$objs $TMP/v$i.o"; i=$((i+1))
+done
+$CXX -DNVAR=$i -DCW=192 $hflags -c $ROOT/tools/ab/attn96_variants.hip -o $TMP/main.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 $TMP/main.o $objs -o $ROOT/tools/ab/attn192_variants
+rm -rf $TMP
+echo "built tools/ab/attn192_variants with $i variants"

@@ -51,12 +51,19 @@ using namespace w2x;
 template <class T> T* up(const std::vector<T>& v) { T* d; CK(hipMalloc(&d, v.size() * sizeof(T) + 256)); CK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)); return d; }
 static float frand() { return (float)rand() / (float)RAND_MAX * 2.f - 1.f; }
 
+#ifndef CW
+#define CW 96      // 192: variants of csrc/k_swinattn192.hip (tools/ab/attn192_variants.sh); heads of 32, token maps of 120 x 120
+#endif
+#ifdef W2X_A192_STAMPS
+extern "C" void w2x_sa192_stamps(unsigned long long* out);
+#endif
 int main(int argc, char** argv) {
-    const int C = 96, NH = 6, HD = 16, NTOK = 36;
+    const int C = CW, NH = 6, HD = CW / 6, NTOK = 36;
     const bool timing = argc > 1;
     struct Case { int B, H, W, ry, rx, nmask; };
     std::vector<Case> cases = {{1, 12, 12, 0, 0, 1}, {2, 18, 30, 3, 3, 4}, {3, 54, 54, 3, 3, 4}, {1, 60, 60, 0, 0, 1}};
-    if (timing) cases.push_back({45, 240, 240, 3, 3, 4});
+    if (timing) cases.push_back(C == 96 ? Case{45, 240, 240, 3, 3, 4} : Case{45, 120, 120, 3, 3, 4});
+    if (timing && C == 192) cases.push_back(Case{45, 60, 60, 3, 3, 4});
     for (const Case& cs : cases) {
         srand(cs.B * 1000 + cs.H);
         const int B = cs.B, H = cs.H, W = cs.W, nwx = W / 6, nwin = (H / 6) * nwx;
@@ -86,7 +93,7 @@ int main(int argc, char** argv) {
         for (int i = 0; i < nwin; ++i) maskid[i] = rand() % cs.nmask;
         SwinAttnParams p;
         p.x = up(x); p.H = H; p.W = W; p.ry = cs.ry; p.rx = cs.rx; p.B = B; p.nwin = nwin; p.C = C; p.hd = HD;
-        p.wqkv = up(wqkv); p.bqkv = up(bqkv); p.scale = 0.25f; p.bias32 = up(bias32); p.maskid = up(maskid);
+        p.wqkv = up(wqkv); p.bqkv = up(bqkv); p.scale = 1.f / std::sqrt((float)HD); p.bias32 = up(bias32); p.maskid = up(maskid);
         p.wproj = up(wproj); p.bproj = up(bproj); p.eps = 1e-5f;
         p.wqkv_frag = up(frag_major(wqkv.data(), 3 * C, C)); p.wproj_frag = up(frag_major(wproj.data(), C, C));
         uint16_t* yv[NVAR];
@@ -126,7 +133,7 @@ int main(int argc, char** argv) {
                     for (int k = 0; k < NTOK; ++k) {
                         double a = 0;
                         for (int f = 0; f < HD; ++f) a += (double)qkv[q * 3 * C + h * HD + f] * qkv[k * 3 * C + C + h * HD + f];
-                        sc[k] = a * 0.25 * 1.44269504088896341 + lb[(((size_t)m * NH + h) * NTOK + q) * NTOK + k];
+                        sc[k] = a * (1.0 / std::sqrt((double)HD)) * 1.44269504088896341 + lb[(((size_t)m * NH + h) * NTOK + q) * NTOK + k];
                         mx = std::max(mx, sc[k]);
                     }
                     for (int k = 0; k < NTOK; ++k) { sc[k] = std::exp2(sc[k] - mx); l += sc[k]; }
@@ -154,7 +161,7 @@ int main(int argc, char** argv) {
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
                 if (r) { best[v] = std::min(best[v], (double)ms); sum[v] += ms; }
             }
-            printf("TIMING 45 x 240 x 240 tokens, ms per launch (mean of %d rounds / min):", rounds - 1);
+            printf("TIMING %d x %d x %d tokens, ms per launch (mean of %d rounds / min):", B, H, W, rounds - 1);
             for (int v = 0; v < NVAR; ++v) printf("  v%d %.4f / %.4f", v, sum[v] / (rounds - 1), best[v]);
             printf("\n");
             // run-to-run determinism of the last variant
@@ -163,6 +170,19 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(again.data(), yv[NVAR - 1], npix * C * 2, hipMemcpyDeviceToHost));
             long nd = 0; for (long i = 0; i < npix * C; ++i) nd += again[i] != hv[NVAR - 1][i];
             printf("last variant run twice: %ld elements differ\n", nd);
+#ifdef W2X_A192_STAMPS
+            {   // the LAST variant is the stamped build: wave cycles per phase, averaged over the waves
+                unsigned long long st[8];
+                w2x_sa192_stamps(st);                       // clear what the runs above left
+                p.y = yv[NVAR - 1]; CK(variants[NVAR - 1](p, 0)); CK(hipDeviceSynchronize());
+                w2x_sa192_stamps(st);
+                static const char* names[7] = {"gather + LayerNorm + barrier", "q and k products", "v products", "S + softmax", "O + store", "barrier + proj", "barrier + residual rows"};
+                double tot = 0; for (int k = 0; k < 7; ++k) tot += (double)st[k];
+                printf("STAMPS (s_memtime ticks per wave, %llu waves):", st[7]);
+                for (int k = 0; k < 7; ++k) printf("  %s %.0f (%.0f %%)", names[k], (double)st[k] / st[7], 100.0 * st[k] / tot);
+                printf("  | total %.0f\n", tot / st[7]);
+            }
+#endif
         }
         for (const void* d : {p.x, p.wqkv, (const void*)p.bqkv, (const void*)p.bias32, (const void*)p.maskid, p.wproj, (const void*)p.bproj, p.wqkv_frag, p.wproj_frag}) CK(hipFree((void*)d));
         for (int v = 0; v < NVAR; ++v) CK(hipFree(yv[v]));

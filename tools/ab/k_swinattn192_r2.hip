@@ -441,32 +441,13 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
 #undef W2X_LOAD_X2
     __syncthreads();      // every wave's head outputs are in Os; nobody reads the slabs any more
 
-    // The residual rows (the same pixels again, for y = x + ...) are requested here, in front of the projection: its weight fragments
-    // were requested long ago (loads return in order, so the products below wait for nothing new), the head loop's registers are
-    // free, and the fetch travels under the 90 products of the projection.  (Round 2 requested them after the projection and waited.)
-    // (the projection's bias vectors first: anything requested AFTER the rows would wait for them - loads return in order)
-    float4v bp[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) bp[t] = *(const float4v*)(p.bproj + (wv * 3 + t) * 16 + g * 4);
-    const int li_r = tid & (LPR - 1), rsub_r = tid / LPR;
-    half8 xres[NPASS];
-    unsigned my_off[NPASS];
-#ifndef W2X_A192_XRES_LATE
-    {
-        const unsigned lane_off = li_r < PPR ? li_r * 16u : kNoRow;
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            my_off[ps] = __builtin_elementwise_add_sat((unsigned)Pix[ps * RPP + rsub_r][0], lane_off);
-            xres[ps] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(X, my_off[ps], 0, 0));
-        }
-        asm volatile("" ::: "memory");      // keeps the requests here (the scheduler would sink them to their use behind the projection)
-    }
-#endif
-
     // ---- proj, transposed: out^T = Wproj Os^T + b (rows = output channels, columns = tokens), so a lane ends with 4 consecutive
     // channels of one token (bias as the initial accumulator, 8-byte LDS stores).  Wave w owns output channels 48w .. 48w+47 for all
     // five row tiles; the tile goes over Xs in token order.
     {
+        float4v bp[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) bp[t] = *(const float4v*)(p.bproj + (wv * 3 + t) * 16 + g * 4);
 #pragma unroll
         for (int mt = 0; mt < RT; ++mt) {
             float4v acc[3] = {bp[0], bp[1], bp[2]};
@@ -486,15 +467,15 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
 
     // ---- row pieces: + residual x, scatter store, LayerNorm statistics for the next op
     {
-        const int li = li_r, rsub = rsub_r;
-#ifdef W2X_A192_XRES_LATE
+        const int li = tid & (LPR - 1), rsub = tid / LPR;
         const unsigned lane_off = li < PPR ? li * 16u : kNoRow;
+        half8 xres[NPASS];
+        unsigned my_off[NPASS];
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             my_off[ps] = __builtin_elementwise_add_sat((unsigned)Pix[ps * RPP + rsub][0], lane_off);
             xres[ps] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(X, my_off[ps], 0, 0));
         }
-#endif
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int r = ps * RPP + rsub;
@@ -520,11 +501,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
 }  // namespace
 
 hipError_t launch_swin_attn192(const SwinAttnParams& p, hipStream_t s) {
-#ifdef W2X_A192_STAMPS
-    auto kern = swin_attn192_kernel<true>;    // diagnostic build (tools/ab/attn192_variants.sh): per-phase s_memtime stamps into g_sa192_stamps
-#else
-    auto kern = swin_attn192_kernel<false>;
-#endif
+    auto kern = swin_attn192_kernel<false>;   // <true>: per-phase s_memtime stamps into g_sa192_stamps (diagnostic builds only)
     static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
     if (hipError_t e = ensure_dynamic_lds((const void*)kern, SMEM192, lds_ok); e != hipSuccess) return e;
     // the kernel addresses x / y with 32-bit byte offsets: passes beyond that are cut into runs of whole images (k_swinattn96.hip)
@@ -543,14 +520,5 @@ hipError_t launch_swin_attn192(const SwinAttnParams& p, hipStream_t s) {
     }
     return hipSuccess;
 }
-
-#ifdef W2X_A192_STAMPS
-// reads and clears the phase sums of the stamped build: out[0..6] wave cycles per phase summed over all waves, out[7] waves counted
-extern "C" void w2x_sa192_stamps(unsigned long long* out) {
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sa192_stamps), 8 * sizeof(unsigned long long));
-    const unsigned long long zero[8] = {};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sa192_stamps), zero, sizeof(zero));
-}
-#endif
 
 }  // namespace w2x
