@@ -90,8 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv48_kernel(const GemmParams p, int 
         if (sg + 1 < NSTAGE) {
 #pragma unroll
             for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)frag_src(sg + 1, wv * NFW + i);
-            W2X_PHASE_FENCE();     // the requests stay HERE, under this stage's products (the scheduler sank them to the LDS stores at its end: an L2
-        }                          // round trip exposed in front of every barrier)
+        }
 #pragma unroll
         for (int sl = 0; sl < SK; ++sl) {
             const int s = sg * SK + sl;

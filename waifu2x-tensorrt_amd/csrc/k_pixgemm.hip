@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256, 2) void pixgemm_kernel(const GemmParams p) {
         if (st + 1 < nstage) {
 #pragma unroll
             for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)(Wf + (size_t)((st + 1) * C::NF + wv * NFW + i) * 512);
+            W2X_PHASE_FENCE();     // keeps the requests at the top of the stage (the scheduler would sink them to the LDS stores at its end)
         }
         const int sg = st * G / NTS, nt0 = st * G - sg * NTS;     // sub-pixel and first n-tile inside it
         const int dy = sg / r, dx = sg - dy * r;
@@ -389,6 +390,7 @@ __global__ __launch_bounds__(256, 2) void merge_kernel(const GemmParams p) {
             if (stage + 1 < NSTAGE) {
 #pragma unroll
                 for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)frag_src(stage + 1, wv * NFW + i);
+                W2X_PHASE_FENCE();     // (as in pixgemm_kernel: the requests stay at the top of the stage)
             }
 #pragma unroll
             for (int t = 0; t < G; ++t)
