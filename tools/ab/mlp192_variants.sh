@@ -1,6 +1,7 @@
 #!/bin/bash
 # Builds tools/ab/mlp192_variants from variants of csrc/k_mlp2.hip (C = 192 geometry switches):  tools/ab/mlp192_variants.sh "<flags v0>" "<flags v1>" ...
 # e.g.  tools/ab/mlp192_variants.sh "" "-DW2X_MLP192_TT=1 -DW2X_MLP192_WPS=3"        then run tools/ab/mlp192_variants [rows] on the GPU box
+# FRAG32_MASK=0b10 (environment): bit i set = variant i gets its weights in the 32x32x16 fragment order (the mlp2q kernel)
 set -eu
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 CXX="/opt/rocm/bin/hipcc -std=c++17 -O3 --offload-arch=gfx950 -I $ROOT/waifu2x-tensorrt_amd/csrc -Wno-unused-function -Wno-unused-variable -mllvm -amdgpu-sched-strategy=max-ilp"
@@ -14,7 +15,7 @@ for arg in "$@"; do
   objs="$objs $TMP/v$i.o"; i=$((i+1))
 done
 $CXX -fno-honor-nans -c $ROOT/waifu2x-tensorrt_amd/csrc/k_mlp96q.hip -o $TMP/q.o
-$CXX -DNVAR=$i -DCW=192 -c $ROOT/tools/ab/mlp96_variants.hip -o $TMP/main.o
+$CXX -DNVAR=$i -DCW=192 -DFRAG32_MASK=${FRAG32_MASK:-0} -c $ROOT/tools/ab/mlp96_variants.hip -o $TMP/main.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 $TMP/main.o $TMP/q.o $objs -o $ROOT/tools/ab/mlp192_variants
 rm -rf $TMP
 echo "built tools/ab/mlp192_variants with $i variants"

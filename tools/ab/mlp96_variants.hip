@@ -80,11 +80,19 @@ int main(int argc, char** argv) {
     p.x = up(x); p.w1 = up(w1); p.w2 = up(w2); p.b1 = up(b1); p.b2 = up(b2);
     if (C == 96) { p.w1_frag = up(frag32_major(w1.data(), 2 * C, C)); p.w2_frag = up(frag32_w2(w2.data(), C)); p.frag32 = true; }
     else { p.w1_frag = up(frag_major(w1.data(), 2 * C, C)); p.w2_frag = up(frag_w2(w2.data(), C)); }
+    // C = 192: variants built from the 32x32x16 kernel take the other fragment order - the harness keeps both copies and the launcher
+    // picks by MlpParams::frag32, which variant i sets through the bit mask FRAG32_MASK (-DFRAG32_MASK=0b110: variants 1 and 2)
+    MlpParams p32 = p;
+    p32.w1_frag = up(frag32_major(w1.data(), 2 * C, C)); p32.w2_frag = up(frag32_w2(w2.data(), C)); p32.frag32 = true;
+#ifndef FRAG32_MASK
+#define FRAG32_MASK 0
+#endif
+    auto params_of = [&](int v) -> MlpParams& { return (C == 192 && ((FRAG32_MASK >> v) & 1)) ? p32 : p; };
     uint16_t* yv[NVAR];
     std::vector<uint16_t> h0(M * C), hv(M * C);
     for (int v = 0; v < NVAR; ++v) {
         CK(hipMalloc(&yv[v], M * C * 2)); CK(hipMemset(yv[v], 0xFF, M * C * 2));
-        p.y = yv[v]; CK(variants[v](p, 0)); CK(hipDeviceSynchronize());
+        params_of(v).y = yv[v]; CK(variants[v](params_of(v), 0)); CK(hipDeviceSynchronize());
         CK(hipMemcpy(v ? hv.data() : h0.data(), yv[v], M * C * 2, hipMemcpyDeviceToHost));
         if (v) {
             double md = 0; long nd = 0, nan = 0;
@@ -97,9 +105,9 @@ int main(int argc, char** argv) {
     for (int v = 0; v < NVAR; ++v) { best[v] = 1e9; sum[v] = 0; }
     const int rounds = 7, reps = 5;
     for (int r = 0; r < rounds; ++r) for (int v = 0; v < NVAR; ++v) {
-        p.y = yv[v];
+        params_of(v).y = yv[v];
         CK(hipEventRecord(e0, 0));
-        for (int k = 0; k < reps; ++k) CK(variants[v](p, 0));
+        for (int k = 0; k < reps; ++k) CK(variants[v](params_of(v), 0));
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
         if (r) { best[v] = std::min(best[v], (double)ms); sum[v] += ms; }

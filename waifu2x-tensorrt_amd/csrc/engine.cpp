@@ -397,12 +397,12 @@ struct Img2Img::Impl {
             }
         for (const Op& op : plan.ops)
             if (plan.elt == 2 && op.kind == OP_MLP && mlp_supported(op.m.C)) {
-                if (op.m.C == 96) {   // k_mlp96q.hip: 32x32x16 fragments
-                    const auto& w1 = plan.blobs[op.m.w1].data; const auto& w2 = plan.blobs[op.m.w2].data;
-                    if (w1.size() != (size_t)2 * 96 * 96 * 2 || w2.size() != w1.size()) throw std::runtime_error("plan: MLP weight size");
-                    if (!frag_blobs[op.m.w1]) upload_frag(op.m.w1, frag32_major((const uint16_t*)w1.data(), 2 * 96, 96));
-                    if (!frag_blobs[op.m.w2]) upload_frag(op.m.w2, frag32_w2((const uint16_t*)w2.data(), 96));
-                } else { frag_major_blob(op.m.w1, 2 * op.m.C, op.m.C); frag_w2_blob(op.m.w2, op.m.C); }
+                // both MLP kernels run on 32x32x16 fragments (k_mlp96q.hip, mlp2q_kernel in k_mlp2.hip)
+                const int Cm = op.m.C;
+                const auto& w1 = plan.blobs[op.m.w1].data; const auto& w2 = plan.blobs[op.m.w2].data;
+                if (w1.size() != (size_t)2 * Cm * Cm * 2 || w2.size() != w1.size()) throw std::runtime_error("plan: MLP weight size");
+                if (!frag_blobs[op.m.w1]) upload_frag(op.m.w1, frag32_major((const uint16_t*)w1.data(), 2 * Cm, Cm));
+                if (!frag_blobs[op.m.w2]) upload_frag(op.m.w2, frag32_w2((const uint16_t*)w2.data(), Cm));
             }
         for (const Op& op : plan.ops)
             if (plan.elt == 2 && op.kind == OP_SWINATTN) { frag_major_blob(op.sa.wqkv, 3 * op.sa.C, op.sa.C); frag_major_blob(op.sa.wproj, op.sa.C, op.sa.C); }
@@ -543,7 +543,7 @@ struct Img2Img::Impl {
                     MlpParams p;
                     p.x = tp(m.x); p.y = tp(m.y); p.M = (long)live * d.H * d.W; p.C = m.C;
                     p.w1 = blobs[m.w1]; p.b1 = (const float*)blobs[m.b1]; p.w2 = blobs[m.w2]; p.b2 = (const float*)blobs[m.b2];
-                    p.w1_frag = frag_blobs[m.w1]; p.w2_frag = frag_blobs[m.w2]; p.frag32 = m.C == 96;
+                    p.w1_frag = frag_blobs[m.w1]; p.w2_frag = frag_blobs[m.w2]; p.frag32 = true;
                     p.eps = m.eps; p.stats_out = (float*)tp(m.stats_out); p.eps_out = m.eps_out;
                     if (d.C != m.C || plan.tensors[m.y].C != m.C) throw std::runtime_error("plan: MLP width mismatch");
                     stamp_begin(5, op.flops);

@@ -344,6 +344,187 @@ __global__ __launch_bounds__(NW * 64, (C == 96 ? 3 : W2X_MLP192_WPS) * NW / 4) v
     }
 }
 
+// ---- the same schedule on v_mfma_f32_32x32x16_f16 (round 3; C = 192 in the engine).  Why: k_mlp96q.hip.  A wave still owns 32 token rows; a chunk is
+// 32 hidden units = ONE 32 x 32 accumulator of the transposed first product (12 k-steps of 16 channels), whose registers 8s .. 8s+7 are the B fragment of
+// k-step s of the second product as they stand (W2 stored in that k order: fragorder.h frag32_w2); the second product is 6 tiles of 32 output channels
+// x 2 k-steps.  Same FLOP, same 24 KiB of fragments per chunk, half the matrix instructions, LayerNorm sums with one lane swap.
+typedef float float16v __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void halves_sum2(float& a0, float& a1) {   // sums over the lanes l, l ^ 32 of two values at once (k_mlp96q.hip)
+    float b0, b1;
+    asm volatile(
+        "s_nop 2\n\tv_mov_b32 %2, %0\n\tv_mov_b32 %3, %1\n\ts_nop 0\n\t"
+        "v_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\t"
+        "v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3"
+        : "+v"(a0), "+v"(a1), "=&v"(b0), "=&v"(b1));
+}
+
+template <int C, int NW>
+__global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpParams p) {
+    using K = Mlp2Cfg<C, 2, NW>;
+    constexpr int RW = K::RW, LDX = K::LDX, PPR = K::PPR, NP = K::NP, RING = K::RING;
+    constexpr int KS = C / 16, NT = C / 32, NCH = 2 * C / 32, NF = KS + 2 * NT, NFW = NF / K::NWV;
+    static_assert(NF == K::NF && NF % K::NWV == 0 && NF % RING == 0 && KS >= RING && !K::KEEP, "fragments per chunk");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, h = lane >> 5;
+    _Float16* Xw = (_Float16*)(smem + wv * K::SLAB);          // [RW][LDX]
+    unsigned char* const WBb = smem;                          // two weight buffers of NF fragments [64 lanes][8] (alias the slabs)
+
+    const long row0 = ((long)blockIdx.x * K::NWV + wv) * RW;
+    const long nrows = p.M - row0 < RW ? p.M - row0 : RW;
+    const unsigned xbytes = (unsigned)(p.M * (C * 2));
+    const __amdgpu_buffer_rsrc_t XB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t YB = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, xbytes, 0x00020000);
+    const unsigned vo = nrows > 0 ? (unsigned)row0 * (C * 2) + lane * 16u : 0xFFFFC000u;
+    const _Float16* __restrict__ W1 = (const _Float16*)p.w1_frag + lane * 8;   // frag32_major: [NCH row tiles of 32][KS][64][8]
+    const _Float16* __restrict__ W2 = (const _Float16*)p.w2_frag + lane * 8;   // frag32_w2:    [NCH][NT][2][64][8]
+    auto frag_src = [&](int ch, int f) { return f < KS ? W1 + (size_t)(ch * KS + f) * 512 : W2 + (size_t)(ch * 2 * NT + (f - KS)) * 512; };
+    auto stage = [&](int ch) {
+#pragma unroll
+        for (int i = 0; i < NFW; ++i) {
+            const int f = wv * NFW + i;
+            __builtin_amdgcn_global_load_lds((const void*)frag_src(ch, f), (__attribute__((address_space(3))) void*)(WBb + (size_t)(ch & 1) * K::WBUF + (size_t)f * 1024), 16, 0, 0);
+        }
+    };
+    auto lds_frag = [&](int ch, int j) { return *(const half8*)(WBb + (size_t)(ch & 1) * K::WBUF + (size_t)j * 1024 + lane * 16); };   // consumption order = storage order
+    for (int i = tid; i < 3 * C; i += K::NWV * 64) ((float*)(smem + K::BIAS_OFF))[i] = i < 2 * C ? p.b1[i] : p.b2[i - 2 * C];
+    const float* B1s = (const float*)(smem + K::BIAS_OFF) + h * 4;
+    const float* B2s = B1s + 2 * C;
+
+    // ---- x rows: flat coalesced pieces -> slab -> LayerNorm in fragment layout (lane (r32, h): channels ks*16 + 8h .. +7 of row r32)
+    {
+        half8 xr[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) xr[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(XB, vo + k * 1024u, 0, 0));
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int idx = k * 64 + lane, r = idx / PPR, c = idx - r * PPR;
+            *(half8*)(Xw + r * LDX + c * 8) = xr[k];
+        }
+    }
+    W2X_PHASE_FENCE();
+    half8 xreg[KS];
+    {
+        half8 raw[KS];
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { raw[ks] = *(const half8*)(Xw + r32 * LDX + ks * 16 + h * 8); sum_sq8(raw[ks], s, q); }
+        halves_sum2(s, q);
+        const float mean = s * (1.f / C);
+        const float rstd = __builtin_amdgcn_rsqf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps);
+        const float nm = -mean * rstd;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xreg[ks] = norm8(raw[ks], rstd, nm);
+    }
+    W2X_PHASE_FENCE();
+    __syncthreads();                           // every wave holds its rows in registers: the slab area becomes weight buffers
+    stage(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): this wave's share of chunk 0 has landed
+    __syncthreads();
+
+    half8 wr[RING];
+#pragma unroll
+    for (int i = 0; i < RING; ++i) wr[i] = lds_frag(0, i);
+    float16v acc2[NT];                         // rows = output channels 32nt + 8q + 4h + j in register 4q + j, columns = tokens; from b2
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4v b = *(const float4v*)(B2s + nt * 32 + q * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc2[nt][4 * q + j] = b[j];
+        }
+    half8 xres[NP];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (ch + 1 < NCH) stage(ch + 1);
+        float16v acc1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4v b = *(const float4v*)(B1s + ch * 32 + q * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc1[4 * q + j] = b[j];
+        }
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[j % RING], xreg[j], acc1, 0, 0, 0);
+            wr[j % RING] = lds_frag(ch, j + RING);
+            W2X_RING_FENCE();
+        }
+        if (ch == NCH - 1) {   // the residual rows, requested as soon as the normalised copies have served their last product
+#pragma unroll
+            for (int k = 0; k < NP; ++k) xres[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(XB, vo + k * 1024u, 0, 0));
+        }
+        half8 a2[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const float2v g0 = gelu_fast2((float2v){acc1[8 * s2 + 0], acc1[8 * s2 + 1]});
+            const float2v g1 = gelu_fast2((float2v){acc1[8 * s2 + 2], acc1[8 * s2 + 3]});
+            const float2v g2 = gelu_fast2((float2v){acc1[8 * s2 + 4], acc1[8 * s2 + 5]});
+            const float2v g3 = gelu_fast2((float2v){acc1[8 * s2 + 6], acc1[8 * s2 + 7]});
+            a2[s2] = (half8){(_Float16)g0[0], (_Float16)g0[1], (_Float16)g1[0], (_Float16)g1[1],
+                             (_Float16)g2[0], (_Float16)g2[1], (_Float16)g3[0], (_Float16)g3[1]};
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * NT; ++i) {     // fragment KS + i = (output tile i >> 1, k-step i & 1)
+            const int j = KS + i;
+            acc2[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[j % RING], a2[i & 1], acc2[i >> 1], 0, 0, 0);
+            if (j + RING < NF) { wr[j % RING] = lds_frag(ch, j + RING); W2X_RING_FENCE(); }
+        }
+        if (ch + 1 < NCH) __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        if (ch + 1 < NCH) {
+#pragma unroll
+            for (int i = 0; i < RING; ++i) wr[i] = lds_frag(ch + 1, i);
+        }
+    }
+
+    W2X_PHASE_FENCE();
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *(half4*)(Xw + r32 * LDX + nt * 32 + q * 8 + h * 4) = (half4){(_Float16)acc2[nt][4 * q], (_Float16)acc2[nt][4 * q + 1], (_Float16)acc2[nt][4 * q + 2], (_Float16)acc2[nt][4 * q + 3]};
+    W2X_PHASE_FENCE();
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int idx = k * 64 + lane, r = idx / PPR, c = idx - r * PPR;
+        const half8 o = *(const half8*)(Xw + r * LDX + c * 8) + xres[k];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, o), YB, vo + k * 1024u, 0, 0);
+        if (p.stats_out) *(half8*)(Xw + r * LDX + c * 8) = o;
+    }
+    W2X_PHASE_FENCE();
+    if (p.stats_out && lane < nrows) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int c = 0; c < PPR; ++c) sum_sq8(*(const half8*)(Xw + lane * LDX + c * 8), s, q);
+        const float mean = s * (1.f / C);
+        p.stats_out[2 * (row0 + lane)] = mean;
+        p.stats_out[2 * (row0 + lane) + 1] = __builtin_amdgcn_rsqf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps_out);
+    }
+}
+
+template <int C, int NW>
+hipError_t launch_mlp2q_c(const MlpParams& p, hipStream_t s) {
+    using K = Mlp2Cfg<C, 2, NW>;
+    static unsigned lds_ok = 0;
+    if (hipError_t e = ensure_dynamic_lds((const void*)mlp2q_kernel<C, NW>, K::SMEM, lds_ok); e != hipSuccess) return e;
+    const long max_rows = (long)((0xFFF00000u / (C * 2)) / K::BM) * K::BM;
+    for (long r0 = 0; r0 < p.M; r0 += max_rows) {
+        MlpParams q = p;
+        q.M = p.M - r0 < max_rows ? p.M - r0 : max_rows;
+        q.x = (const char*)p.x + (size_t)r0 * C * 2; q.y = (char*)p.y + (size_t)r0 * C * 2;
+        if (p.stats_out) q.stats_out = p.stats_out + 2 * r0;
+        dim3 grid((unsigned)((q.M + K::BM - 1) / K::BM));
+        hipLaunchKernelGGL((mlp2q_kernel<C, NW>), grid, dim3(K::NWV * 64), K::SMEM, s, q);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 template <int C, int TT, int NW>
 hipError_t launch_mlp2_c(const MlpParams& p, hipStream_t s) {
     using K = Mlp2Cfg<C, TT, NW>;
@@ -377,6 +558,7 @@ hipError_t launch_mlp2(const MlpParams& p, hipStream_t s) {
     // register ring straight from L2 (TT = 4) and 64 rows per wave with shared weights were slower as well.
     if (p.C == 96 && p.frag32) return mlp96q_supported(p) ? launch_mlp96q(p, s) : hipErrorInvalidValue;
     if (p.C == 96) return launch_mlp2_c<96, 2, 4>(p, s);
+    if (p.C == 192 && p.frag32) return launch_mlp2q_c<192, 4>(p, s);       // weights in the 32x32x16 fragment order (the engine)
     if (p.C == 192) return launch_mlp2_c<192, W2X_MLP192_TT, W2X_MLP192_NW>(p, s);
     return hipErrorInvalidValue;
 }
