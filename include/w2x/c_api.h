@@ -53,6 +53,9 @@ int w2x_build(w2x_engine* e, const char* onnx_path, const w2x_build_config* cfg)
 int w2x_load(w2x_engine* e, const char* onnx_path, const w2x_render_config* cfg);
 /* src/dst: interleaved 8-bit BGR, `step` bytes per row; dst must be rows*scaling x cols*scaling. */
 int w2x_render(w2x_engine* e, const uint8_t* src, int rows, int cols, size_t src_step, uint8_t* dst, size_t dst_step);
+/* The same on 16-bit samples (extension; the reference reads and writes 8-bit frames only, capture.cpp:96-99, and lists deeper images as a
+ * TODO, README.md:88): interleaved BGR uint16, steps in BYTES; x = u16 * float(1/65535) into the network, sat(rint(x * 65535)) out. */
+int w2x_render16(w2x_engine* e, const uint16_t* src, int rows, int cols, size_t src_step, uint16_t* dst, size_t dst_step);
 /* Multi-GPU split of ONE frame (no reference counterpart: main.cpp:70-74 is single-device): strip `part` of
  * `parts` = a contiguous range of the reference's column-major tile order (img2img_render.cpp:43-44) plus the output columns
  * it alone composes.  w2x_strip_plan is pure host logic: out[0..3] = first_tile, tile_count, x0, x1 (x in output pixels). */

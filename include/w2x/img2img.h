@@ -23,6 +23,9 @@ struct Image {          // stand-in for cv::Mat of type CV_8UC3
     uint8_t* data = nullptr;
     int rows = 0, cols = 0;
     size_t step = 0;    // bytes per row
+    // Extension (alpha / 16-bit images are a TODO upstream, README.md:88): depth 16 = CV_16UC3, data points at uint16_t samples (BGR), step stays
+    // in bytes.  render() / renderStrip() take 16-bit frames when src and dst agree: u16 -> x * float(1/65535) in, sat(rint(x * 65535)) out.
+    int depth = 8;
 };
 
 class Img2Img {

@@ -162,8 +162,11 @@ def reverse_augmentation(x: np.ndarray, k: int) -> np.ndarray:
 
 
 def blob_from_tiles(tiles_u8_rgb) -> np.ndarray:
-    """blobFromImages, img2img_infer.cpp:5-21: HWC u8 -> NCHW f32, f32 = u8 * float(1/255)."""
-    a = np.stack(tiles_u8_rgb).astype(np.float32) * np.float32(1.0 / 255.0)
+    """blobFromImages, img2img_infer.cpp:5-21: HWC u8 -> NCHW f32, f32 = u8 * float(1/255).
+    (uint16 tiles - the 16-bit extension, no reference counterpart - use float(1/65535) the same way.)"""
+    a = np.stack(tiles_u8_rgb)
+    scale = np.float32(1.0 / 255.0) if a.dtype == np.uint8 else np.float32(1.0 / 65535.0)
+    a = a.astype(np.float32) * scale
     return np.ascontiguousarray(a.transpose(0, 3, 1, 2))
 
 
@@ -171,6 +174,12 @@ def to_u8(canvas_f32: np.ndarray) -> np.ndarray:
     """convertTo(CV_8UC3, 255.0), img2img_render.cpp:342: saturate_cast<uchar>(rint(v*255))."""
     v = np.rint(canvas_f32.astype(np.float32) * np.float32(255.0))
     return np.clip(v, 0, 255).astype(np.uint8)
+
+
+def to_u16(canvas_f32: np.ndarray) -> np.ndarray:
+    """The 16-bit extension's counterpart of to_u8: convertTo(CV_16UC3, 65535.0) = saturate_cast<ushort>(rint(v*65535))."""
+    v = np.rint(canvas_f32.astype(np.float32) * np.float32(65535.0))
+    return np.clip(v, 0, 65535).astype(np.uint16)
 
 
 def render(frame_bgr: np.ndarray, net, *, batch, tile, scaling, overlap, tta=False,
@@ -212,7 +221,7 @@ def render(frame_bgr: np.ndarray, net, *, batch, tile, scaling, overlap, tta=Fal
                 t = apply_augmentation(t, aug)                        # :274
             tiles.append(np.ascontiguousarray(t))
         else:
-            tiles.append(np.zeros((tile, tile, 3), np.uint8))         # :281 zero pad slot
+            tiles.append(np.zeros((tile, tile, 3), frame_bgr.dtype))  # :281 zero pad slot
         if bi != batch - 1:
             continue
         x = blob_from_tiles(tiles)                                    # infer(), img2img_infer.cpp:73
@@ -247,5 +256,5 @@ def render(frame_bgr: np.ndarray, net, *, batch, tile, scaling, overlap, tta=Fal
         tiles = []
         if progress:
             progress(step // batch + 1, batch_count)
-    out = to_u8(canvas)                                               # :342
+    out = to_u8(canvas) if frame_bgr.dtype == np.uint8 else to_u16(canvas)   # :342
     return np.ascontiguousarray(out[..., ::-1])                       # :343 RGB2BGR

@@ -368,3 +368,48 @@ def test_cli_keeps_the_alpha_channel_of_a_still(pkg, tmp_path):
     alpha = eng.render(np.ascontiguousarray(np.repeat(rgba[..., 3:4], 3, axis=2)))
     eng.close()
     assert np.array_equal(got[..., :3], colour[..., ::-1]) and np.array_equal(got[..., 3], alpha[..., 1])
+
+
+@pytest.mark.gpu
+def test_cli_deep_keeps_sixteen_bit_pngs(pkg, tmp_path):
+    """--deep (extension): a 16-bit PNG is read with all 16 bits, rendered as CV_16UC3 and written as a 16-bit PNG - the samples the library's
+    16-bit render() gives; without the flag the same file is cut to 8 bits like cv::imread(IMREAD_COLOR) does for the reference."""
+    Image = pytest.importorskip("PIL.Image")
+    import struct, zlib
+    import synth_models as sm
+    models = tmp_path / "models"
+    path = sm.model_path(str(tmp_path), "cunet/art", 2, 1)
+    sm.export_onnx(sm.make_model("cunet/art", 2, seed=6), path, 2, 64, dynamic=True)
+    rng = np.random.default_rng(8)
+    a16 = rng.integers(0, 65536, (50, 66, 3), dtype=np.uint16)              # RGB
+    def chunk(t, body): return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body))
+    raw = b"".join(b"\x00" + a16[y].astype(">u2").tobytes() for y in range(a16.shape[0]))
+    (tmp_path / "in.png").write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 66, 50, 16, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    common = ["--models", str(models), "--model", "cunet/art", "--scale", "2", "--noise", "1", "--batchSize", "2", "--tileSize", "64"]
+    assert subprocess.run([W2X, *common, "build"], capture_output=True, text=True).returncode == 0
+    eng = pkg.Img2Img()
+    assert eng.load(path, pkg.RenderConfig(batchSize=2, height=64, width=64, scaling=2)), eng.last_error()
+    want16 = eng.render(np.ascontiguousarray(a16[..., ::-1]))[..., ::-1]
+    want8 = eng.render(np.ascontiguousarray((a16 >> 8).astype(np.uint8)[..., ::-1]))[..., ::-1]
+    eng.close()
+    for flag, want in ((["--deep"], want16), ([], want8)):
+        out = tmp_path / ("o16" if flag else "o8"); out.mkdir()
+        r = subprocess.run([W2X, *common, "render", "-i", str(tmp_path / "in.png"), "-o", str(out), *flag], capture_output=True, text=True, timeout=180)
+        assert r.returncode == 0, r.stderr
+        d = open(out / "in(cunet_art)(noise1)(scale2).png", "rb").read()
+        w, h, depth, ctype = struct.unpack(">IIBB", d[16:26])
+        assert (w, h, depth, ctype) == (132, 100, 16 if flag else 8, 2)
+        idat = b"".join(d[p + 8:p + 8 + struct.unpack(">I", d[p:p + 4])[0]] for p in _png_chunks(d) if d[p + 4:p + 8] == b"IDAT")
+        rows = zlib.decompress(idat)
+        bps = 2 if flag else 1
+        stride = 1 + w * 3 * bps
+        got = np.stack([np.frombuffer(rows[y * stride + 1:(y + 1) * stride], ">u2" if flag else np.uint8).reshape(w, 3) for y in range(h)])   # filter 0 rows
+        assert np.array_equal(got.astype(want.dtype), want)
+
+
+def _png_chunks(d):
+    import struct
+    p = 8
+    while p + 12 <= len(d):
+        yield p
+        p += 12 + struct.unpack(">I", d[p:p + 4])[0]

@@ -128,3 +128,35 @@ def test_config1_as_written_fp32_b1_t64_256x256(pkg, onnx_model):
     r = frame_report("configs[0] cunet/art s2 n0 B1 T64 fp32 256x256 (121 tiles) vs the fp32 oracle", out, ref)
     assert r["max_lsb"] <= 1 and r["frac_pixels_off_by_1"] < 1e-3, r
     eng.close()
+
+
+@pytest.mark.parametrize("fp32", [False, True])
+def test_sixteen_bit_frames_byte_exact_and_close_to_the_oracle(pkg, onnx_model, fp32):
+    """Extension (16-bit images are a TODO upstream, README.md:88): CV_16UC3 frames through render() - u16 * float(1/65535) into the network,
+    sat(rint(x * 65535)) out, everything in between as for 8-bit frames.  The oracle pipeline takes uint16 frames the same way, so the identity
+    pipeline.render(frame16, net=eng.infer) == eng.render(frame16) must hold to the last of the 16 bits, and against the oracle's own network the
+    frame may differ by the fp16 network tolerance (3 ULP16 of [0.5, 1) = 96 of 65535) on the fp16 engine, by summation order on the fp32 one."""
+    path = onnx_model("swin_unet/art", 4, 2, 64, noise=1)
+    eng = pkg.Img2Img()
+    prec = pkg.Precision.TF32 if fp32 else pkg.Precision.FP16
+    assert eng.build(path, pkg.BuildConfig.fixed(2, 64, precision=prec)), eng.last_error()
+    assert eng.load(path, pkg.RenderConfig(precision=prec, batchSize=2, height=64, width=64, scaling=4, overlap=(0.0625, 0.0625), tta=not fp32)), eng.last_error()
+    rng = np.random.default_rng(12)
+    frame = rng.integers(0, 65536, (70, 90, 3), dtype=np.uint16)
+    frame[:8, :8] = 0; frame[-8:, -8:] = 65535
+    out = eng.render(frame)
+    assert out.dtype == np.uint16 and out.shape == (280, 360, 3)
+    ref = pipeline.render(frame, eng.infer, batch=2, tile=64, scaling=4, overlap=(0.0625, 0.0625), tta=not fp32, net_dtype=None if fp32 else np.float16, tile_out=eng.output_tile_size)
+    assert_same_bytes(f"16-bit frame, {'fp32' if fp32 else 'fp16'} engine", out, ref)
+    ex = onnx_exec.Executor(path) if fp32 else onnx_exec.Executor(path, act_dtype="float16")
+    want = pipeline.render(frame, ex.run, batch=2, tile=64, scaling=4, overlap=(0.0625, 0.0625), tta=not fp32, net_dtype=None if fp32 else np.float16, tile_out=eng.output_tile_size)
+    d = np.abs(out.astype(np.int64) - want.astype(np.int64))
+    from parity_util import _record
+    _record({"test": f"16-bit frame vs the oracle, {'fp32' if fp32 else 'fp16'} engine", "kind": "frame16", "max_lsb16": int(d.max()), "mean_lsb16": float(d.mean())})
+    assert d.max() <= (2 if fp32 else 96), (d.max(), d.mean())
+    # an 8-bit frame afterwards on the same engine (the graph cache keys on the sample width) and a mixed-depth call is refused
+    f8 = (frame >> 8).astype(np.uint8)
+    assert_same_bytes("8-bit after 16-bit", eng.render(f8), pipeline.render(f8, eng.infer, batch=2, tile=64, scaling=4, overlap=(0.0625, 0.0625), tta=not fp32,
+                                                                             net_dtype=None if fp32 else np.float16, tile_out=eng.output_tile_size))
+    assert eng.render(frame, np.zeros((280, 360, 3), np.uint8)) is False
+    eng.close()

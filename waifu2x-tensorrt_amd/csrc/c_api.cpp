@@ -66,6 +66,15 @@ int w2x_render(w2x_engine* e, const uint8_t* src, int rows, int cols, size_t src
     return e->engine.render(s, d) ? 1 : 0;
 }
 
+int w2x_render16(w2x_engine* e, const uint16_t* src, int rows, int cols, size_t src_step, uint16_t* dst, size_t dst_step) {
+    if (!e) return 0;
+    w2x::Image s; s.data = reinterpret_cast<uint8_t*>(const_cast<uint16_t*>(src)); s.rows = rows; s.cols = cols; s.step = src_step; s.depth = 16;
+    w2x::Image d; d.data = reinterpret_cast<uint8_t*>(dst); d.step = dst_step; d.depth = 16;
+    const int sc = e->engine.scaling();
+    d.rows = rows * sc; d.cols = cols * sc;
+    return e->engine.render(s, d) ? 1 : 0;
+}
+
 int w2x_render_strip(w2x_engine* e, const uint8_t* src, int rows, int cols, size_t src_step, uint8_t* dst, size_t dst_step, int part, int parts) {
     if (!e) return 0;
     w2x::Image s; s.data = const_cast<uint8_t*>(src); s.rows = rows; s.cols = cols; s.step = src_step;

@@ -56,6 +56,7 @@ std::string usage() {
            "  --device INT [0]            GPU device ID\n"
            "  --precision TEXT [fp16]     {fp16,tf32}\n"
            "  --devices INT [1]           (extension) number of GPUs: video frames round-robin, one image as tile-column strips\n"
+           "  --deep                      (extension) 16-bit PNGs keep 16 bits per sample through the engine and in the output\n"
            "  --models DIR [models]       (extension) root of the model directory tree\n\n"
            "Subcommands:\n"
            "  render                      Render image(s)/video(s)\n"
@@ -94,6 +95,7 @@ Options parse(int argc, const char* const* argv) {
         else if (k == "--models") o.models = value(i);
         else if (k == "--precision") { o.precision = value(i); std::transform(o.precision.begin(), o.precision.end(), o.precision.begin(), ::tolower); }
         else if (k == "--print-config") o.printConfig = true;
+        else if (k == "--deep") o.deep = true;
         else if (k == "-i" || k == "--input") {
             o.inputs.push_back(value(i));
             while (i + 1 < a.size() && a[i + 1].rfind("-", 0) != 0 && a[i + 1] != "render" && a[i + 1] != "build" && a[i + 1] != "convert") o.inputs.push_back(a[++i]);

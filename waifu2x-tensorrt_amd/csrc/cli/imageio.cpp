@@ -29,7 +29,7 @@ void put32(std::vector<uint8_t>& v, uint32_t x) { v.push_back(x >> 24); v.push_b
 
 int paeth(int a, int b, int c) { int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); return pa <= pb && pa <= pc ? a : pb <= pc ? b : c; }
 
-Bitmap read_png(const std::vector<uint8_t>& d, const std::string& path) {
+Bitmap read_png(const std::vector<uint8_t>& d, const std::string& path, bool keep16) {
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     if (d.size() < 33 || memcmp(d.data(), sig, 8)) throw std::runtime_error(path + ": not a PNG file");
     int w = 0, h = 0, depth = 0, ctype = 0, interlace = 0;
@@ -69,7 +69,9 @@ Bitmap read_png(const std::vector<uint8_t>& d, const std::string& path) {
     std::vector<uint8_t> raw(total);
     uLongf rawlen = raw.size();
     if (uncompress(raw.data(), &rawlen, idat.data(), idat.size()) != Z_OK || rawlen != raw.size()) throw std::runtime_error(path + ": PNG data does not inflate");
-    Bitmap b; b.rows = h; b.cols = w; b.bgr.resize((size_t)w * h * 3);
+    const bool deep = keep16 && wide;                              // --deep: the low bytes stay
+    Bitmap b; b.rows = h; b.cols = w;
+    if (deep) b.bgr16.resize((size_t)w * h * 3); else b.bgr.resize((size_t)w * h * 3);
     const bool has_alpha = ctype == 4 || ctype == 6;               // kept for the writer (the network sees colour only)
     if (has_alpha) b.alpha.resize((size_t)w * h);
     size_t at = 0;
@@ -98,8 +100,14 @@ Bitmap read_png(const std::vector<uint8_t>& d, const std::string& path) {
                 else if (ctype == 3) { const size_t kk = (size_t)(packed ? sample : cur[x]) * 3; if (kk + 3 > plte.size()) throw std::runtime_error(path + ": palette index out of range"); r = plte[kk]; g = plte[kk + 1]; bl = plte[kk + 2]; }
                 else { r = cur[(size_t)x * bpp]; g = cur[(size_t)x * bpp + bps]; bl = cur[(size_t)x * bpp + 2 * bps]; }
                 const size_t px = (size_t)(ps.y0 + y * ps.dy) * w + ps.x0 + x * ps.dx;
-                uint8_t* o = &b.bgr[px * 3];
-                o[0] = bl; o[1] = g; o[2] = r;
+                if (deep) {     // big-endian 16-bit samples
+                    auto s16 = [&](int k) { const uint8_t* q = &cur[(size_t)x * bpp + (size_t)k * 2]; return (uint16_t)(q[0] << 8 | q[1]); };
+                    uint16_t* o = &b.bgr16[px * 3];
+                    if (ctype == 0 || ctype == 4) o[0] = o[1] = o[2] = s16(0); else { o[2] = s16(0); o[1] = s16(1); o[0] = s16(2); }
+                } else {
+                    uint8_t* o = &b.bgr[px * 3];
+                    o[0] = bl; o[1] = g; o[2] = r;
+                }
                 if (has_alpha) b.alpha[px] = cur[(size_t)x * bpp + (size_t)(ch - 1) * bps];
             }
             prev.swap(cur);
@@ -117,17 +125,23 @@ void chunk(std::vector<uint8_t>& out, const char* type, const std::vector<uint8_
 }
 
 void write_png(const std::string& path, const Bitmap& b) {
-    const bool rgba = !b.alpha.empty();
-    const int ch = rgba ? 4 : 3;
-    std::vector<uint8_t> raw(((size_t)b.cols * ch + 1) * b.rows);
+    const bool rgba = !b.alpha.empty(), deep = !b.bgr16.empty();
+    const int ch = rgba ? 4 : 3, bps = deep ? 2 : 1;
+    std::vector<uint8_t> raw(((size_t)b.cols * ch * bps + 1) * b.rows);
     for (int y = 0; y < b.rows; ++y) {
-        uint8_t* line = &raw[((size_t)b.cols * ch + 1) * y];
+        uint8_t* line = &raw[((size_t)b.cols * ch * bps + 1) * y];
         line[0] = 0;   // filter "none": the payload is deflated at level 1 for speed (a 4K frame is 100 MB)
-        const uint8_t* s = &b.bgr[(size_t)y * b.cols * 3];
         for (int x = 0; x < b.cols; ++x) {
-            uint8_t* o = line + 1 + (size_t)ch * x;
-            o[0] = s[3 * x + 2]; o[1] = s[3 * x + 1]; o[2] = s[3 * x];
-            if (rgba) o[3] = b.alpha[(size_t)y * b.cols + x];
+            uint8_t* o = line + 1 + (size_t)ch * bps * x;
+            if (!deep) {
+                const uint8_t* s = &b.bgr[((size_t)y * b.cols + x) * 3];
+                o[0] = s[2]; o[1] = s[1]; o[2] = s[0];
+                if (rgba) o[3] = b.alpha[(size_t)y * b.cols + x];
+            } else {        // big-endian samples; an 8-bit alpha plane is widened by x 257
+                const uint16_t* s = &b.bgr16[((size_t)y * b.cols + x) * 3];
+                for (int k = 0; k < 3; ++k) { o[2 * k] = (uint8_t)(s[2 - k] >> 8); o[2 * k + 1] = (uint8_t)s[2 - k]; }
+                if (rgba) o[6] = o[7] = b.alpha[(size_t)y * b.cols + x];
+            }
         }
     }
     uLongf clen = compressBound(raw.size());
@@ -135,7 +149,7 @@ void write_png(const std::string& path, const Bitmap& b) {
     if (compress2(comp.data(), &clen, raw.data(), raw.size(), 1) != Z_OK) throw std::runtime_error("PNG deflate failed");
     comp.resize(clen);
     std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a}, ihdr;
-    put32(ihdr, b.cols); put32(ihdr, b.rows); ihdr.insert(ihdr.end(), {8, (uint8_t)(rgba ? 6 : 2), 0, 0, 0});
+    put32(ihdr, b.cols); put32(ihdr, b.rows); ihdr.insert(ihdr.end(), {(uint8_t)(deep ? 16 : 8), (uint8_t)(rgba ? 6 : 2), 0, 0, 0});
     chunk(out, "IHDR", ihdr); chunk(out, "IDAT", comp); chunk(out, "IEND", {});
     std::ofstream f(path, std::ios::binary);
     if (!f.write((const char*)out.data(), out.size())) throw std::runtime_error("cannot write " + path);
@@ -223,16 +237,18 @@ void write_ppm(const std::string& path, const Bitmap& b) {
 
 bool is_builtin_still(const std::string& path) { const std::string e = lower_ext(path); return e == ".png" || e == ".ppm" || e == ".bmp"; }
 
-Bitmap read_image(const std::string& path) {
+Bitmap read_image(const std::string& path, bool keep16) {
     const std::vector<uint8_t> d = slurp(path);
     if (d.size() >= 2 && d[0] == 'P' && d[1] == '6') return read_ppm(d, path);
     if (d.size() >= 2 && d[0] == 'B' && d[1] == 'M') return read_bmp(d, path);
-    return read_png(d, path);
+    return read_png(d, path, keep16);
 }
 
 void write_image(const std::string& path, const Bitmap& b) {
-    if ((size_t)b.rows * b.cols * 3 != b.bgr.size() || (!b.alpha.empty() && b.alpha.size() != (size_t)b.rows * b.cols)) throw std::runtime_error("bitmap size mismatch");
+    const size_t n = (size_t)b.rows * b.cols;
+    if (!((b.bgr.size() == n * 3 && b.bgr16.empty()) || (b.bgr16.size() == n * 3 && b.bgr.empty())) || (!b.alpha.empty() && b.alpha.size() != n)) throw std::runtime_error("bitmap size mismatch");
     const std::string e = lower_ext(path);
+    if (!b.bgr16.empty() && e != ".png") throw std::runtime_error(path + ": 16-bit samples can only be written as PNG");
     if (e == ".ppm") write_ppm(path, b); else if (e == ".bmp") write_bmp(path, b); else if (e == ".png") write_png(path, b);
     else throw std::runtime_error(path + ": no built-in still-image writer for this extension (.png, .ppm, .bmp)");
 }

@@ -14,9 +14,14 @@
 
 namespace w2x::cli {
 
-struct Bitmap { int rows = 0, cols = 0; std::vector<uint8_t> bgr; std::vector<uint8_t> alpha; };   // rows * cols * 3, packed; alpha: rows * cols or empty
+struct Bitmap {
+    int rows = 0, cols = 0;
+    std::vector<uint8_t> bgr;       // rows * cols * 3, packed (empty when bgr16 is used)
+    std::vector<uint8_t> alpha;     // rows * cols, or empty
+    std::vector<uint16_t> bgr16;    // 16-bit samples of a 16-bit PNG read with keep16 (--deep); then bgr is empty
+};
 
-Bitmap read_image(const std::string& path);                 // throws std::runtime_error
+Bitmap read_image(const std::string& path, bool keep16 = false);   // throws std::runtime_error; keep16: 16-bit PNG samples stay 16-bit (Bitmap::bgr16)
 void write_image(const std::string& path, const Bitmap& b);  // by extension: .png, .ppm, .bmp
 bool is_builtin_still(const std::string& path);              // .png / .ppm / .bmp
 

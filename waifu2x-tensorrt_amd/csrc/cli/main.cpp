@@ -209,9 +209,17 @@ int main(int argc, char** argv) {
         for (const std::string& file : files) {
             if (cli::is_builtin_still(file)) {
                 frameIndex = 0; frameCount = 1;
-                cli::Bitmap in = cli::read_image(file), out;
-                out.rows = in.rows * o.scale; out.cols = in.cols * o.scale; out.bgr.resize((size_t)out.rows * out.cols * 3);
-                Image src{in.bgr.data(), in.rows, in.cols, (size_t)in.cols * 3}, dst{out.bgr.data(), out.rows, out.cols, (size_t)out.cols * 3};
+                cli::Bitmap in = cli::read_image(file, o.deep), out;
+                out.rows = in.rows * o.scale; out.cols = in.cols * o.scale;
+                const bool deep = !in.bgr16.empty();                   // --deep on a 16-bit PNG: CV_16UC3 through the engine (extension)
+                Image src, dst;
+                if (deep) {
+                    out.bgr16.resize((size_t)out.rows * out.cols * 3);
+                    src = Image{(uint8_t*)in.bgr16.data(), in.rows, in.cols, (size_t)in.cols * 6, 16}; dst = Image{(uint8_t*)out.bgr16.data(), out.rows, out.cols, (size_t)out.cols * 6, 16};
+                } else {
+                    out.bgr.resize((size_t)out.rows * out.cols * 3);
+                    src = Image{in.bgr.data(), in.rows, in.cols, (size_t)in.cols * 3}; dst = Image{out.bgr.data(), out.rows, out.cols, (size_t)out.cols * 3};
+                }
                 auto render_still = [&](const Image& s0, Image& d0) {
                     if (o.devices == 1) return engines[0]->render(s0, d0);
                     // tile-column strips: each engine composes and downloads its own columns of the output

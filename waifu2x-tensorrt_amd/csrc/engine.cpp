@@ -200,6 +200,7 @@ struct Img2Img::Impl {
     int final_op = -1;
 
     // frame-level buffers (grown on demand, reused across frames like the reference's input/output GpuMats, img2img.h:37-38)
+    bool deep = false;                   // the frame in d_frame / d_out has 16-bit samples (Image::depth == 16)
     uint8_t* d_frame = nullptr; size_t frame_cap = 0;
     uint8_t* d_out = nullptr; size_t out_cap = 0;
     void* d_slab = nullptr; size_t slab_cap = 0;
@@ -241,7 +242,7 @@ struct Img2Img::Impl {
     // enqueueV3 (img2img_infer.cpp:80); here a pass is ~40 launches, which the host cannot issue fast enough for small tiles.
     // A pass is captured the second time it is met (the first run stays eager so that one-time attribute calls are out of the
     // way) and replayed from then on.  The key holds everything the captured launches bake in.
-    using GraphKey = std::tuple<const void*, const void*, const void*, const void*, int, int, int>;   // frame, slots, slab out, arena, rows, cols, live
+    using GraphKey = std::tuple<const void*, const void*, const void*, const void*, int, int, int, int>;   // frame, slots, slab out, arena, rows, cols, live, 16-bit samples
     std::map<GraphKey, hipGraphExec_t> graphs;
     std::map<GraphKey, int> graph_seen;
     long graph_replays = 0, eager_passes = 0;
@@ -606,7 +607,7 @@ struct Img2Img::Impl {
             void* const slab_out = (uint8_t*)d_slab + (size_t)bi * B * slot_bytes;
             auto run_pass = [&] {
                 GatherParams gp;
-                gp.frame = d_frame; gp.rows = rows; gp.cols = cols; gp.step = (size_t)cols * 3;
+                gp.frame = d_frame; gp.rows = rows; gp.cols = cols; gp.step = (size_t)cols * 3 * (deep ? 2 : 1); gp.deep = deep ? 1 : 0;
                 gp.out = tensors[plan.in_tensor]; gp.slots = d_slots + (size_t)bi * B; gp.B = B; gp.T = T; gp.fp32 = plan.elt == 4;
                 const int NG = groups;
                 struct NgReset { int& r; ~NgReset() { r = 1; } } ng_reset{ng_now};   // also when a launch throws mid-pass
@@ -646,7 +647,7 @@ struct Img2Img::Impl {
             };
             if (!graphable) run_pass();
             else {
-                const GraphKey key{d_frame, d_slots + (size_t)bi * B, slab_out, arena_base, rows, cols, live};
+                const GraphKey key{d_frame, d_slots + (size_t)bi * B, slab_out, arena_base, rows, cols, live, deep ? 1 : 0};
                 auto it = graphs.find(key);
                 if (it != graphs.end()) { hipAssert(hipGraphLaunch(it->second, stream)); ++graph_replays; }
                 else if (graph_seen.size() >= 4096 && !graph_seen.count(key)) { graph_seen.clear(); run_pass(); ++eager_passes; }   // sizes that keep changing: bounded bookkeeping
@@ -685,7 +686,7 @@ struct Img2Img::Impl {
             }
         }
         ComposeParams cp;
-        cp.tiles = d_slab; cp.fp32 = plan.elt == 4; cp.dst = d_out; cp.dst_step = (size_t)cols * cfg.scaling * 3;
+        cp.tiles = d_slab; cp.fp32 = plan.elt == 4; cp.dst = d_out; cp.dst_step = (size_t)cols * cfg.scaling * 3 * (deep ? 2 : 1); cp.deep = deep ? 1 : 0;
         cp.outW = cols * cfg.scaling; cp.outH = rows * cfg.scaling; cp.To = To;
         cp.nx = grid.nx; cp.ny = grid.ny; cp.stride_x = To - grid.outOvX; cp.stride_y = To - grid.outOvY;
         const bool overlapping = cfg.overlapX != 0 || cfg.overlapY != 0;                      // :244
@@ -881,16 +882,19 @@ bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, cons
     const RenderConfig& cfg = impl->cfg;
     const Plan& plan = impl->plan;
     const int rows = src.rows, cols = src.cols, s = cfg.scaling;
-    if (!src.data || rows <= 0 || cols <= 0 || src.step < (size_t)cols * 3) { W2X_LOG_AS(who, error, "Input image is empty or has an invalid step."); return false; }
-    if (!dst.data || dst.rows != rows * s || dst.cols != cols * s || dst.step < (size_t)dst.cols * 3) {
+    if ((src.depth != 8 && src.depth != 16) || dst.depth != src.depth) { W2X_LOG_AS(who, error, "Input and output images must both be 8-bit or both 16-bit."); return false; }
+    const size_t bps = src.depth / 8;                          // bytes per sample
+    if (!src.data || rows <= 0 || cols <= 0 || src.step < (size_t)cols * 3 * bps) { W2X_LOG_AS(who, error, "Input image is empty or has an invalid step."); return false; }
+    if (!dst.data || dst.rows != rows * s || dst.cols != cols * s || dst.step < (size_t)dst.cols * 3 * bps) {
         W2X_LOG_AS(who, error, "Output image has invalid size: expected " + std::to_string(cols * s) + "x" + std::to_string(rows * s) + ".");
         return false;
     }
     hipStream_t stream = impl->stream;
     // img2img_render.cpp:226 upload
-    impl->ensure(impl->d_frame, impl->frame_cap, (size_t)rows * cols * 3);
-    impl->ensure(impl->d_out, impl->out_cap, (size_t)rows * s * cols * s * 3);
-    hipAssert(hipMemcpy2DAsync(impl->d_frame, (size_t)cols * 3, src.data, src.step, (size_t)cols * 3, rows, hipMemcpyHostToDevice, stream));
+    impl->ensure(impl->d_frame, impl->frame_cap, (size_t)rows * cols * 3 * bps);
+    impl->ensure(impl->d_out, impl->out_cap, (size_t)rows * s * cols * s * 3 * bps);
+    impl->deep = bps == 2;
+    hipAssert(hipMemcpy2DAsync(impl->d_frame, (size_t)cols * 3 * bps, src.data, src.step, (size_t)cols * 3 * bps, rows, hipMemcpyHostToDevice, stream));
     // :232-240
     TileGrid grid = calculate_tiles(cols, rows, cols * s, rows * s, plan.T, plan.T, plan.Tout, plan.Tout, s, cfg.overlapX, cfg.overlapY);
     if (grid.count <= 0) { W2X_LOG_AS(who, error, "Tile grid is empty."); return false; }
@@ -916,7 +920,7 @@ bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, cons
     impl->run_frame(rows, cols, grid, true, sp);
     hipAssert(hipEventRecord(impl->ev1, stream));
     // :344 download ; the reference leaves the sync commented out (:345, quirk Q10) - we wait before handing dst back
-    hipAssert(hipMemcpy2DAsync(dst.data + (size_t)sp.x0 * 3, dst.step, impl->d_out + (size_t)sp.x0 * 3, (size_t)dst.cols * 3, (size_t)(sp.x1 - sp.x0) * 3, dst.rows, hipMemcpyDeviceToHost, stream));
+    hipAssert(hipMemcpy2DAsync(dst.data + (size_t)sp.x0 * 3 * bps, dst.step, impl->d_out + (size_t)sp.x0 * 3 * bps, (size_t)dst.cols * 3 * bps, (size_t)(sp.x1 - sp.x0) * 3 * bps, dst.rows, hipMemcpyDeviceToHost, stream));
     hipAssert(hipStreamSynchronize(stream));
     hipAssert(hipEventElapsedTime(&impl->last_ms, impl->ev0, impl->ev1));
     impl->last_rows = rows; impl->last_cols = cols; impl->last_grid = grid; impl->last_strip = sp;
@@ -938,6 +942,8 @@ bool Img2Img::renderSequence(const Image* srcs, Image* dsts, int count) try {
     const RenderConfig& cfg = impl->cfg;
     const Plan& plan = impl->plan;
     const int rows = srcs[0].rows, cols = srcs[0].cols, s = cfg.scaling;
+    for (int i = 0; i < count; ++i) if (srcs[i].depth != 8 || dsts[i].depth != 8) { W2X_LOG(error, "renderSequence takes 8-bit frames (16-bit images go through render())."); return false; }
+    impl->deep = false;
     for (int i = 0; i < count; ++i) {
         if (!srcs[i].data || srcs[i].rows != rows || srcs[i].cols != cols || srcs[i].step < (size_t)cols * 3 || rows <= 0 || cols <= 0) { W2X_LOG(error, "Input images must be non-empty and of one size."); return false; }
         if (!dsts[i].data || dsts[i].rows != rows * s || dsts[i].cols != cols * s || dsts[i].step < (size_t)cols * s * 3) { W2X_LOG(error, "Output image has invalid size: expected " + std::to_string(cols * s) + "x" + std::to_string(rows * s) + "."); return false; }

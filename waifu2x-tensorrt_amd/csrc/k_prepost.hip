@@ -53,7 +53,7 @@ template <typename P>
 __global__ __launch_bounds__(256) void gather_kernel(const GatherParams p) {
     const int T = p.T;
     const long total = (long)p.B * T * T;
-    const float inv255 = (float)(1.0 / 255.0);
+    const float inv255 = (float)(1.0 / 255.0), inv65535 = (float)(1.0 / 65535.0);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int b = (int)(i / ((long)T * T));
         int rem = (int)(i - (long)b * T * T);
@@ -65,8 +65,13 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherParams p) {
             aug_src(sl.aug, T - 1, y, x, sy, sx);
             int fy = min(max(sl.y + sy, 0), p.rows - 1);
             int fx = min(max(sl.x + sx, 0), p.cols - 1);
-            const uint8_t* px = p.frame + (size_t)fy * p.step + (size_t)fx * 3;
-            v = make_px<P>((float)px[2] * inv255, (float)px[1] * inv255, (float)px[0] * inv255);
+            if (!p.deep) {
+                const uint8_t* px = p.frame + (size_t)fy * p.step + (size_t)fx * 3;
+                v = make_px<P>((float)px[2] * inv255, (float)px[1] * inv255, (float)px[0] * inv255);
+            } else {   // 16-bit samples (extension, README.md:88 lists it as a TODO upstream): the same conversion with 65535
+                const uint16_t* px = (const uint16_t*)(p.frame + (size_t)fy * p.step) + (size_t)fx * 3;
+                v = make_px<P>((float)px[2] * inv65535, (float)px[1] * inv65535, (float)px[0] * inv65535);
+            }
         }
         *((P*)p.out + i) = v;
     }
@@ -80,7 +85,7 @@ __device__ __forceinline__ unsigned quantize_bgr(float r, float g, float b) {
     return B | G << 8 | R << 16;
 }
 template <typename P>
-__device__ __forceinline__ unsigned compose_pixel(const ComposeParams& p, const P* tiles, int X, int Y) {
+__device__ __forceinline__ void compose_pixel_sums(const ComposeParams& p, const P* tiles, int X, int Y, float& r0, float& r1, float& r2) {
     const int To = p.To, n = To - 1;
     const int steps = p.tta ? 8 : 1;
     // candidate tile columns/rows: origin = idx*stride, extent To (clipped to the canvas)
@@ -123,7 +128,13 @@ __device__ __forceinline__ unsigned compose_pixel(const ComposeParams& p, const 
             acc0 += v0; acc1 += v1; acc2 += v2;
         }
     }
-    return quantize_bgr(acc0, acc1, acc2);
+    r0 = acc0; r1 = acc1; r2 = acc2;
+}
+template <typename P>
+__device__ __forceinline__ unsigned compose_pixel(const ComposeParams& p, const P* tiles, int X, int Y) {
+    float a0, a1, a2;
+    compose_pixel_sums<P>(p, tiles, X, Y, a0, a1, a2);
+    return quantize_bgr(a0, a1, a2);
 }
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -150,6 +161,17 @@ __global__ __launch_bounds__(256) void compose_kernel(const ComposeParams p) {
         int a0 = X - To + 1; a0 = a0 <= 0 ? 0 : (a0 + p.stride_x - 1) / p.stride_x;
         int b0 = X + 3 - To + 1; b0 = b0 <= 0 ? 0 : (b0 + p.stride_x - 1) / p.stride_x;
         const int a1 = min(p.nx - 1, X / p.stride_x), b1 = min(p.nx - 1, (X + 3) / p.stride_x);
+        if (p.deep) {   // 16-bit output (extension): the same sums, rint(x * 65535) saturated, BGR
+            uint16_t* d16 = (uint16_t*)(p.dst + (size_t)Y * p.dst_step) + (size_t)X * 3;
+            for (int k = 0; k < np; ++k) {
+                float r, g, b;
+                compose_pixel_sums<P>(p, tiles, X + k, Y, r, g, b);
+                d16[3 * k] = (uint16_t)min(max(__float2int_rn(b * 65535.f), 0), 65535);
+                d16[3 * k + 1] = (uint16_t)min(max(__float2int_rn(g * 65535.f), 0), 65535);
+                d16[3 * k + 2] = (uint16_t)min(max(__float2int_rn(r * 65535.f), 0), 65535);
+            }
+            continue;
+        }
         const bool fast = kHalf && np == 4 && !p.tta && a0 == b0 && a1 == b1 && (((size_t)d) & 3) == 0;
         if (fast) {
             int j0 = Y - To + 1; j0 = j0 <= 0 ? 0 : (j0 + p.stride_y - 1) / p.stride_y;

@@ -103,7 +103,8 @@ struct SeParams {
 struct TileSlot { int x, y, aug, valid; };   // input rect origin (may be negative), augmentation 0..7, 0 = zero-pad slot
 
 struct GatherParams {
-    const uint8_t* frame = nullptr; int rows = 0, cols = 0; size_t step = 0;  // u8 BGR interleaved
+    const uint8_t* frame = nullptr; int rows = 0, cols = 0; size_t step = 0;  // u8 BGR interleaved (deep: u16 samples; step in bytes)
+    int deep = 0;
     void* out = nullptr;            // fp16 (fp32 engines: fp32) [B][T][T][4]
     int fp32 = 0;
     const TileSlot* slots = nullptr;
@@ -113,7 +114,8 @@ struct GatherParams {
 struct ComposeParams {
     const void* tiles = nullptr;    // fp16 (fp32 engines: fp32) [slots][To][To][4], slot = tile*steps + aug
     int fp32 = 0;
-    uint8_t* dst = nullptr; size_t dst_step = 0;    // u8 BGR
+    uint8_t* dst = nullptr; size_t dst_step = 0;    // u8 BGR (deep: u16 samples; step in bytes)
+    int deep = 0;
     int outW = 0, outH = 0;
     int To = 0;
     int nx = 0, ny = 0;

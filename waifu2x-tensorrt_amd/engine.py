@@ -103,6 +103,7 @@ def lib():
     L.w2x_build.argtypes = [vp, C.c_char_p, C.POINTER(_BuildConfig)]; L.w2x_build.restype = C.c_int
     L.w2x_load.argtypes = [vp, C.c_char_p, C.POINTER(_RenderConfig)]; L.w2x_load.restype = C.c_int
     L.w2x_render.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t]; L.w2x_render.restype = C.c_int
+    L.w2x_render16.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t]; L.w2x_render16.restype = C.c_int
     L.w2x_render_strip.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_int]; L.w2x_render_strip.restype = C.c_int
     L.w2x_render_sequence.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t, C.c_int]; L.w2x_render_sequence.restype = C.c_int
     L.w2x_alloc_host.argtypes = [vp, C.c_size_t]; L.w2x_alloc_host.restype = vp
@@ -132,7 +133,7 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "w2x_create", "w2x_destroy", "w2x_set_message_callback", "w2x_set_progress_callback", "w2x_build", "w2x_load",
-    "w2x_render", "w2x_infer", "w2x_output_tile_size", "w2x_plan_flops", "w2x_pass_tiles", "w2x_last_render_ms", "w2x_bench_resident", "w2x_profile_frame", "w2x_op_times",
+    "w2x_render", "w2x_render16", "w2x_infer", "w2x_output_tile_size", "w2x_plan_flops", "w2x_pass_tiles", "w2x_last_render_ms", "w2x_bench_resident", "w2x_profile_frame", "w2x_op_times",
     "w2x_render_strip", "w2x_strip_plan", "w2x_render_sequence", "w2x_alloc_host", "w2x_free_host", "w2x_pin_host", "w2x_unpin_host", "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_describe_plan_precision", "w2x_write_engine_file", "w2x_validate_engine_file", "w2x_sha256_hex", "w2x_version"]
 
 
@@ -198,19 +199,20 @@ class Img2Img:
 
     def render(self, src: np.ndarray, dst: np.ndarray | None = None):
         """render(src, dst) -> bool like the reference; render(src) -> dst array or raises."""
-        if src.dtype != np.uint8 or src.ndim != 3 or src.shape[2] != 3 or src.strides[2] != 1 or src.strides[1] != 3:
-            raise ValueError("src must be a uint8 [rows, cols, 3] BGR array with packed pixels")
+        bps = src.dtype.itemsize                  # uint8 frames, or uint16 ones (extension: w2x_render16)
+        if src.dtype not in (np.uint8, np.uint16) or src.ndim != 3 or src.shape[2] != 3 or src.strides[2] != bps or src.strides[1] != 3 * bps:
+            raise ValueError("src must be a uint8 (or uint16) [rows, cols, 3] BGR array with packed pixels")
         ret_array = dst is None
         if dst is None:
             s = getattr(self, "_scaling", 0)
-            dst = np.empty((src.shape[0] * s, src.shape[1] * s, 3), np.uint8)
+            dst = np.empty((src.shape[0] * s, src.shape[1] * s, 3), src.dtype)
         s = getattr(self, "_scaling", 0)
-        if s and (dst.dtype != np.uint8 or dst.shape != (src.shape[0] * s, src.shape[1] * s, 3) or dst.strides[2] != 1 or dst.strides[1] != 3):
+        if s and (dst.dtype != src.dtype or dst.shape != (src.shape[0] * s, src.shape[1] * s, 3) or dst.strides[2] != bps or dst.strides[1] != 3 * bps):
             # the C ABI only sees pointers and steps, so the cv::Mat-style size check lives here
             self._on_msg(int(Severity.error), f"[render@0] Output image has invalid size: expected {src.shape[1] * s}x{src.shape[0] * s}.".encode(), None)
             return False
-        ok = bool(self._L.w2x_render(self._h, src.ctypes.data, src.shape[0], src.shape[1], src.strides[0],
-                                     dst.ctypes.data, dst.strides[0]))
+        fn = self._L.w2x_render if bps == 1 else self._L.w2x_render16
+        ok = bool(fn(self._h, src.ctypes.data, src.shape[0], src.shape[1], src.strides[0], dst.ctypes.data, dst.strides[0]))
         if ret_array:
             if not ok:
                 raise W2xError(self.last_error() or "render failed")
