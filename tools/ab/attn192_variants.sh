@@ -1,6 +1,7 @@
 #!/bin/bash
 # Builds tools/ab/attn192_variants from variants of csrc/k_swinattn192.hip:  tools/ab/attn192_variants.sh "<flags v0>" "<flags v1>" ... ["STAMPS <flags>"]
 # A last argument that starts with STAMPS builds that variant with the per-phase s_memtime stamps and prints the phase table.
+# A baseline from an earlier revision: git show 38f61ee:waifu2x-tensorrt_amd/csrc/<kernel>.hip > tools/ab/<kernel>_r2.hip, then "SRC=$PWD/tools/ab/<kernel>_r2.hip".
 set -eu
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 CXX="/opt/rocm/bin/hipcc -std=c++17 -O3 --offload-arch=gfx950 -I $ROOT/waifu2x-tensorrt_amd/csrc -Wno-unused-function -Wno-unused-variable"

@@ -10,7 +10,7 @@
 #ifndef W2X_GELU_DEG
 #define W2X_GELU_DEG 4   // coefficients of q(u): 6 -> 3.1e-7, 5 -> 7.1e-7, 4 -> 8.7e-6 absolute error of GELU (tools/fit_gelu.py).  4: a third of
                          // the fp16 rounding of the smallest hidden values that matter, network parity unchanged (2.0 ULP16 on every full-width
-                         // graph, same mean error), MLP kernels 5-7 % faster (tools/ab/gelu_degree_ab.sh)
+                         // graph, same mean error), MLP kernels 5-7 % faster (round 2, profiles/r2_final/gelu_degree_ab.txt; now: tools/ab/lib_variants.sh "k_mlp2.hip:-DW2X_GELU_DEG=6")
 #endif
 
 #include <algorithm>

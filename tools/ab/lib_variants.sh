@@ -4,6 +4,8 @@
 # frame.  An argument "base" runs the library as built.  Each variant starts from the stock objects (the previous variant's object is
 # rebuilt without flags first), the last step restores the stock library.
 #   tools/ab/lib_variants.sh base "k_swinattn192.hip:-DW2X_A192_XRES_LATE" base "k_pixgemm.hip@tools/ab/k_pixgemm_r2.hip"
+# (an earlier revision of a kernel as the alternative source: git show <rev>:waifu2x-tensorrt_amd/csrc/k_pixgemm.hip > tools/ab/k_pixgemm_r2.hip
+#  before the call - round 2's files are revision 38f61ee; the round-3 records under profiles/r3_kernels/ were taken that way)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT/waifu2x-tensorrt_amd"

@@ -2,6 +2,7 @@
 # Builds tools/ab/mlp192_variants from variants of csrc/k_mlp2.hip (C = 192 geometry switches):  tools/ab/mlp192_variants.sh "<flags v0>" "<flags v1>" ...
 # e.g.  tools/ab/mlp192_variants.sh "" "-DW2X_MLP192_TT=1 -DW2X_MLP192_WPS=3"        then run tools/ab/mlp192_variants [rows] on the GPU box
 # FRAG32_MASK=0b10 (environment): bit i set = variant i gets its weights in the 32x32x16 fragment order (the mlp2q kernel)
+# A baseline from an earlier revision: git show 38f61ee:waifu2x-tensorrt_amd/csrc/<kernel>.hip > tools/ab/<kernel>_r2.hip, then "SRC=$PWD/tools/ab/<kernel>_r2.hip".
 set -eu
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 CXX="/opt/rocm/bin/hipcc -std=c++17 -O3 --offload-arch=gfx950 -I $ROOT/waifu2x-tensorrt_amd/csrc -Wno-unused-function -Wno-unused-variable -mllvm -amdgpu-sched-strategy=max-ilp"
