@@ -37,8 +37,8 @@ struct PixCfg {
     static constexpr int MAIN = 2 * WBUF + 4 * OTILE;
     static constexpr int BIAS_OFF = MAIN > IN_BYTES ? MAIN : IN_BYTES;      // bias [<= 16 sub-pixels][CSO] fp32 behind everything
     static constexpr int SMEM = BIAS_OFF + 16 * CSO * 4;
-    // skip rows: requested all at once when a sub-pixel starts (CSO <= 96: NPO pieces = 24 registers), else in groups when it is complete
-    static constexpr int RGRP = CSO <= 96 ? NPO : (NPO % 6 == 0 ? 6 : NPO % 4 == 0 ? 4 : NPO);
+    // skip rows: requested all at once when a sub-pixel starts (CSO <= 128: NPO pieces, up to 32 registers), else in groups when it is complete
+    static constexpr int RGRP = CSO <= 128 ? NPO : (NPO % 6 == 0 ? 6 : NPO % 4 == 0 ? 4 : NPO);
     static_assert(NTS % G == 0 && NF % 4 == 0 && RW * PPI % 64 == 0 && RW * PPO % 64 == 0 && NPO % RGRP == 0, "tiling");
 };
 
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void pixgemm_kernel(const GemmParams p) {
         const int dy = sg / r, dx = sg - dy * r;
         // (CSO = 192: twelve pieces = 48 registers carried around the stage loop next to 48 of row fragments do not fit; there all twelve are
         //  requested together when the sub-pixel is complete - one round trip per sub-pixel instead of one per piece)
-        constexpr bool EARLY = CSO <= 96;
+        constexpr bool EARLY = CSO <= 128;
         if (EARLY && nt0 == 0 && p.res.p) {
             const unsigned rshift = (unsigned)((dy * p.res.Ws + dx) * p.res.Cs * 2);
 #pragma unroll
@@ -389,8 +389,8 @@ __global__ __launch_bounds__(256, 2) void merge_kernel(const GemmParams p) {
             const _Float16* wcur = WB + (size_t)(stage & 1) * (WBUF / 2) + lane * 8;
             if (stage + 1 < NSTAGE) {
 #pragma unroll
-                for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)frag_src(stage + 1, wv * NFW + i);
-                W2X_PHASE_FENCE();     // (as in pixgemm_kernel: the requests stay at the top of the stage)
+                for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)frag_src(stage + 1, wv * NFW + i);   // (pinning these at the top of the stage as in
+                                                                                                               // pixgemm_kernel measured 3-7 % SLOWER here)
             }
 #pragma unroll
             for (int t = 0; t < G; ++t)
