@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256, 2) void conv48_kernel(const GemmParams p, int 
     const int b = blockIdx.x / tpi, trem = blockIdx.x - b * tpi;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
     const int oy0 = ty * TH, ox0 = tx * TW;
+    const _Float16* __restrict__ Ag = (const _Float16*)p.a.p + ((size_t)(b * p.a.Hs + p.a.y0 + oy0) * p.a.Ws + p.a.x0 + ox0) * CIN;
     const _Float16* __restrict__ Wf = (const _Float16*)p.wt_frag + lane * 8;        // [NT][KSTEPS][64][8]
     auto frag_src = [&](int sg, int f) { const int sl = f / NT, nt = f - sl * NT; return Wf + (size_t)(nt * KSTEPS + sg * SK + sl) * 512; };   // fragment f = (local k-step, n-tile) of stage sg
 
@@ -52,27 +53,13 @@ __global__ __launch_bounds__(256, 2) void conv48_kernel(const GemmParams p, int 
 #pragma unroll
     for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)frag_src(0, wv * NFW + i);
 
-    // ---- halo tile, all 48 channels (valid convolution: input extent = output extent + 2; pixels beyond it are zeros).  Every piece of the
-    // tile is requested before the first one is stored (round 2's loop fetched, waited and stored piece by piece: ten memory round trips in a
-    // row per workgroup - most of its life); pieces outside the map go through the buffer resource's bounds check (offset 0xFFFFFFFF reads zeros).
+    // ---- halo tile, all 48 channels (valid convolution: input extent = output extent + 2; pixels beyond it are zeros)
     const int hrows = min(HR, Ho + 2 - oy0), hcols = min(HC, Wo + 2 - ox0);
-    {
-        constexpr int NPIECE = HR * HC * PPP, NIT = (NPIECE + 255) / 256;
-        const size_t map_bytes = (size_t)p.B * p.a.Hs * p.a.Ws * CIN * 2;          // conv48_supported() keeps this below 4 GB
-        const __amdgpu_buffer_rsrc_t AB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a.p), 0, (unsigned)map_bytes, 0x00020000);
-        const unsigned base = (unsigned)((((size_t)(b * p.a.Hs + p.a.y0 + oy0) * p.a.Ws + p.a.x0 + ox0) * CIN) * 2);
-        half8 hv[NIT];
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int i = k * 256 + tid, pix = i / PPP, c8 = i - pix * PPP, hr = pix / HC, hc = pix - hr * HC;
-            const unsigned off = (i < NPIECE && hr < hrows && hc < hcols) ? base + (unsigned)((hr * p.a.Ws + hc) * CIN + c8 * 8) * 2u : 0xFFFFFFFFu;
-            hv[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(AB, off, 0, 0));
-        }
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int i = k * 256 + tid, pix = i / PPP, c8 = i - pix * PPP;
-            if (i < NPIECE) *(half8*)(Hl + pix * LDP + c8 * 8) = hv[k];
-        }
+    for (int i = tid; i < HR * HC * PPP; i += 256) {
+        const int pix = i / PPP, c8 = i - pix * PPP, hr = pix / HC, hc = pix - hr * HC;
+        half8 h = {};
+        if (hr < hrows && hc < hcols) h = *(const half8*)(Ag + ((size_t)hr * p.a.Ws + hc) * CIN + c8 * 8);
+        *(half8*)(Hl + pix * LDP + c8 * 8) = h;
     }
 #pragma unroll
     for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[i];
@@ -157,7 +144,6 @@ bool conv48_supported(const GemmParams& p) {
     if (p.act == 1 && !(p.alpha >= 0.f && p.alpha <= 1.f)) return false;
     if (p.a.Cs != CIN || p.N != N || p.K != 9 * CIN || p.out.Cs != N || p.aW <= 0 || p.Mrows % p.aW) return false;
     const int Ho = p.Mrows / p.aW, Wo = p.aW;
-    if ((size_t)p.B * p.a.Hs * p.a.Ws * CIN * 2 >= ((size_t)1 << 32) - 65536) return false;   // the halo tile is fetched through a 32-bit buffer resource
     return p.a.y0 + Ho + 2 <= p.a.Hs && p.a.x0 + Wo + 2 <= p.a.Ws && p.out.Hs >= Ho && p.out.Ws >= Wo;
 }
 

@@ -23,46 +23,28 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 
 #define W2X_PHASE_FENCE() asm volatile("" ::: "memory")
 
-// How many stages ahead the weight fragments of pixgemm_kernel are requested (each stage in flight holds NFW x 4 registers per lane).  A
-// stage is 24 products per wave - 0.2 us - against an L2 round trip of 1 us and more under load, and a workgroup walks 12 to 24 stages
-// with a barrier each: one stage ahead (round 2) left most of every round trip exposed.
-// 0 = per shape: three ahead for 192 -> 4 x 96 (210 registers), two for the others (192 -> 4 x 192 would spill, cunet's shapes would lose a wave per SIMD).
-// m-tiles per wave of the 192 -> 4 x 192 projection: with two, a wave's skip rows (48 registers) cannot travel with its row fragments (48) and
-// are fetched when a sub-pixel is complete - two exposed round trips to memory per sub-pixel at two waves per SIMD; with one (16 rows per wave,
-// 64 per workgroup, three workgroups per CU) they are requested a sub-pixel ahead like everywhere else.
-#ifndef W2X_PIX192_TT
-#define W2X_PIX192_TT 1
-#endif
-#ifndef W2X_PIX_AHEAD
-#define W2X_PIX_AHEAD 0
-#endif
-
-template <int K, int CSO, int G, int TT_ = 2>
+template <int K, int CSO, int G>
 struct PixCfg {
-    static constexpr int TT = TT_, RW = 16 * TT, BM = 4 * RW;  // m-tiles / rows per wave, rows per workgroup
+    static constexpr int TT = 2, RW = 16 * TT, BM = 4 * RW;   // rows per wave / workgroup
     static constexpr int KS = K / 32, NTS = CSO / 16;          // k-steps, n-tiles per sub-pixel
     static constexpr int LDO = CSO + 8, LDXI = K + 8;          // LDS row strides (halves): output tile, input staging
     static constexpr int PPI = K / 8, PPO = CSO / 8;           // 16-byte pieces per input row / output pixel
     static constexpr int NPI = RW * PPI / 64, NPO = RW * PPO / 64;
     static constexpr int NF = G * KS, NFW = NF / 4;            // fragments per stage / per wave
-    static constexpr bool GATES = K != 192;                    // squeeze-excite gates on the operands exist in cunet's shapes only (pixgemm_supported); without
-                                                               // their branches the stage loop's waits for memory come out exact
-    static constexpr int AHEAD = W2X_PIX_AHEAD ? W2X_PIX_AHEAD : (K == 192 && CSO == 96 ? 3 : 2);
     static constexpr int WBUF = NF * 1024;
     static constexpr int OTILE = RW * LDO * 2 + RW * 8;        // per wave: output tile + (out, res) base offsets per row
     static constexpr int IN_BYTES = 4 * RW * LDXI * 2;         // input staging aliases everything (dead before the first stage)
     static constexpr int MAIN = 2 * WBUF + 4 * OTILE;
     static constexpr int BIAS_OFF = MAIN > IN_BYTES ? MAIN : IN_BYTES;      // bias [<= 16 sub-pixels][CSO] fp32 behind everything
-    static constexpr int SMEM_MAX = BIAS_OFF + 16 * CSO * 4;   // a launch asks for BIAS_OFF + its own sub-pixels x CSO x 4
-    // skip rows: requested all at once when a sub-pixel starts (up to 8 pieces = 32 registers), else in groups when it is complete
-    static constexpr bool EARLY = NPO <= 8;
-    static constexpr int RGRP = EARLY ? NPO : (NPO % 6 == 0 ? 6 : NPO % 4 == 0 ? 4 : NPO);
+    static constexpr int SMEM = BIAS_OFF + 16 * CSO * 4;
+    // skip rows: requested all at once when a sub-pixel starts (CSO <= 128: NPO pieces, up to 32 registers), else in groups when it is complete
+    static constexpr int RGRP = CSO <= 128 ? NPO : (NPO % 6 == 0 ? 6 : NPO % 4 == 0 ? 4 : NPO);
     static_assert(NTS % G == 0 && NF % 4 == 0 && RW * PPI % 64 == 0 && RW * PPO % 64 == 0 && NPO % RGRP == 0, "tiling");
 };
 
-template <int K, int CSO, int G, int TT_>
-__global__ __launch_bounds__(256, TT_ == 1 ? 3 : 2) void pixgemm_kernel(const GemmParams p) {
-    using C = PixCfg<K, CSO, G, TT_>;
+template <int K, int CSO, int G>
+__global__ __launch_bounds__(256, 2) void pixgemm_kernel(const GemmParams p) {
+    using C = PixCfg<K, CSO, G>;
     constexpr int TT = C::TT, RW = C::RW, KS = C::KS, NTS = C::NTS, LDO = C::LDO, LDXI = C::LDXI, NFW = C::NFW;
     typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 
@@ -90,16 +72,15 @@ __global__ __launch_bounds__(256, TT_ == 1 ? 3 : 2) void pixgemm_kernel(const Ge
                                                                          p.res.p ? (unsigned)((size_t)p.B * p.res.Hs * p.res.Ws * p.res.Cs * 2) : 0u, 0x00020000);
 
     // ---- stage 0 of the weights is requested first, then the rows
-    constexpr int D = C::AHEAD;                    // stages in flight; stage st travels in register set st % D
-    half8 stg[D][NFW];
+    half8 stg[NFW];
 #pragma unroll
-    for (int i = 0; i < NFW; ++i) stg[0][i] = *(const half8*)(Wf + (size_t)(wv * NFW + i) * 512);
+    for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)(Wf + (size_t)(wv * NFW + i) * 512);
     {
         half8 xr[C::NPI];
         const unsigned vo = nrows > 0 ? (unsigned)(row0 * (K * 2)) + lane * 16u : 0xFFFF8000u;
 #pragma unroll
         for (int k = 0; k < C::NPI; ++k) xr[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(XB, vo + k * 1024u, 0, 0));
-        if (C::GATES && p.a_scale) {   // squeeze-excite gate of the input map: fp16(x * s), the rounding of the in-place pass
+        if (p.a_scale) {   // squeeze-excite gate of the input map: fp16(x * s), the rounding of the in-place pass
 #pragma unroll
             for (int k = 0; k < C::NPI; ++k) {
                 const int idx = k * 64 + lane, rr = idx / C::PPI, c = idx - rr * C::PPI;
@@ -134,40 +115,26 @@ __global__ __launch_bounds__(256, TT_ == 1 ? 3 : 2) void pixgemm_kernel(const Ge
     if (lane < RW) { Rb[2 * lane] = my_ob; Rb[2 * lane + 1] = my_rb; }
     for (int i = tid; i < nsub * CSO; i += 256) Bs[i] = p.bias[i];
 #pragma unroll
-    for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[0][i];
-    // (requests past the last stage repeat it instead of being skipped: with a fixed number of loads in flight on every path the compiler's
-    //  wait for the oldest set leaves the younger ones outstanding - behind a branch it waited for all of them)
-#pragma unroll
-    for (int d = 1; d < D; ++d)
-#pragma unroll
-        for (int i = 0; i < NFW; ++i) stg[d][i] = *(const half8*)(Wf + (size_t)(min(d, nstage - 1) * C::NF + wv * NFW + i) * 512);
+    for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[i];
     __syncthreads();
 
     // The skip rows of a sub-pixel are REQUESTED when its first n-tiles start and consumed when its last ones are done (round 2 loaded
     // each piece where it was added and waited for it: nsub x NPO exposed HBM round trips per wave); the bias comes from LDS (as a
     // global load its in-order wait also waited for the next stage's weight fragments requested just before).
     half8 rres[C::RGRP];
-    // One trip of the outer loop = one sub-pixel; its SPS stages are unrolled, so the register set of a stage (SPS is a multiple of D), the
-    // stage that requests the skip rows and the one that stores are compile-time facts and every path issues the same loads in the same
-    // order - which is what lets the waits for memory be exact counts.
-    constexpr int SPS = NTS / G;
-    static_assert(SPS % D == 0, "a sub-pixel's stages must be whole rounds of the register sets");
-    for (int sg = 0; sg < nsub; ++sg) {
-#pragma unroll
-      for (int u = 0; u < SPS; ++u) {
-        const int st = sg * SPS + u;
+    for (int st = 0; st < nstage; ++st) {
         const _Float16* wcur = WB + (size_t)(st & 1) * (C::WBUF / 2) + lane * 8;
-        {                                           // set u carried stage st, which reached LDS at the end of stage st - 1
+        if (st + 1 < nstage) {
 #pragma unroll
-            for (int i = 0; i < NFW; ++i) stg[u % D][i] = *(const half8*)(Wf + (size_t)(min(st + D, nstage - 1) * C::NF + wv * NFW + i) * 512);
+            for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)(Wf + (size_t)((st + 1) * C::NF + wv * NFW + i) * 512);
             W2X_PHASE_FENCE();     // keeps the requests at the top of the stage (the scheduler would sink them to the LDS stores at its end)
         }
-        const int nt0 = u * G;                      // first n-tile of the stage inside its sub-pixel
+        const int sg = st * G / NTS, nt0 = st * G - sg * NTS;     // sub-pixel and first n-tile inside it
         const int dy = sg / r, dx = sg - dy * r;
         // (CSO = 192: twelve pieces = 48 registers carried around the stage loop next to 48 of row fragments do not fit; there all twelve are
         //  requested together when the sub-pixel is complete - one round trip per sub-pixel instead of one per piece)
-        constexpr bool EARLY = C::EARLY;
-        if (EARLY && u == 0) {                      // (no skip connection: the resource is empty and the loads return zeros without touching memory)
+        constexpr bool EARLY = CSO <= 128;
+        if (EARLY && nt0 == 0 && p.res.p) {
             const unsigned rshift = (unsigned)((dy * p.res.Ws + dx) * p.res.Cs * 2);
 #pragma unroll
             for (int k = 0; k < C::NPO; ++k) {
@@ -196,13 +163,13 @@ __global__ __launch_bounds__(256, TT_ == 1 ? 3 : 2) void pixgemm_kernel(const Ge
                     Ot[(tt * 16 + g * 4 + j) * LDO + (nt0 + t) * 16 + fr] = (_Float16)v;
                 }
         }
-        if (u == SPS - 1) {                        // sub-pixel sg complete: residual add and store as 16-byte pieces
+        if (nt0 + G == NTS) {                      // sub-pixel sg complete: residual add and store as 16-byte pieces
             W2X_PHASE_FENCE();
             const unsigned oshift = (unsigned)((dy * p.out.Ws + dx) * CSO * 2), rshift = (unsigned)((dy * p.res.Ws + dx) * p.res.Cs * 2);
             constexpr int GRP = C::RGRP;                  // late variant: a group of pieces requested together, then added and stored
 #pragma unroll
             for (int k0 = 0; k0 < C::NPO; k0 += GRP) {
-                if (!EARLY) {
+                if (!EARLY && p.res.p) {
 #pragma unroll
                     for (int k = k0; k < k0 + GRP; ++k) {
                         const int idx = k * 64 + lane, rr = idx / C::PPO, c = idx - rr * C::PPO;
@@ -215,7 +182,7 @@ __global__ __launch_bounds__(256, TT_ == 1 ? 3 : 2) void pixgemm_kernel(const Ge
                     half8 o = *(const half8*)(Ot + rr * LDO + c * 8);
                     if (p.res.p) {
                         half8 rv = rres[EARLY ? k : k - k0];
-                        if (C::GATES && p.res_scale && rr < nrows) rv = gate::gate8(rv, p.res_scale + (size_t)((row0 + rr) / p.Mrows) * p.res.Cs + c * 8);   // gated skip connection
+                        if (p.res_scale && rr < nrows) rv = gate::gate8(rv, p.res_scale + (size_t)((row0 + rr) / p.Mrows) * p.res.Cs + c * 8);   // gated skip connection
                         o += rv;                                   // fp16 + fp16 rounded once == fp32 add rounded to fp16
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, o), OB, __builtin_elementwise_add_sat(Rb[2 * rr], oshift + c * 16u), 0, 0);
@@ -223,23 +190,22 @@ __global__ __launch_bounds__(256, TT_ == 1 ? 3 : 2) void pixgemm_kernel(const Ge
                 W2X_PHASE_FENCE();
             }
         }
-        {                                           // (after the last stage: a copy nobody reads)
+        if (st + 1 < nstage) {
 #pragma unroll
-            for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)((st + 1) & 1) * (C::WBUF / 2) + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[(u + 1) % D][i];
+            for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)((st + 1) & 1) * (C::WBUF / 2) + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[i];
         }
         __syncthreads();
-      }
     }
 }
 
-template <int K, int CSO, int G, int TT = 2>
+template <int K, int CSO, int G>
 hipError_t launch_pix(const GemmParams& p, hipStream_t s) {
-    using C = PixCfg<K, CSO, G, TT>;
+    using C = PixCfg<K, CSO, G>;
     static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
-    if (hipError_t e = ensure_dynamic_lds((const void*)pixgemm_kernel<K, CSO, G, TT>, C::SMEM_MAX, lds_ok); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)pixgemm_kernel<K, CSO, G>, C::SMEM, lds_ok); e != hipSuccess) return e;
     const long M = (long)p.B * p.Mrows;
     dim3 grid((unsigned)((M + C::BM - 1) / C::BM));
-    hipLaunchKernelGGL((pixgemm_kernel<K, CSO, G, TT>), grid, dim3(256), C::BIAS_OFF + p.r * p.r * CSO * 4, s, p);
+    hipLaunchKernelGGL((pixgemm_kernel<K, CSO, G>), grid, dim3(256), C::SMEM, s, p);
     return hipGetLastError();
 }
 
@@ -333,7 +299,6 @@ struct MergeCfg {
     static constexpr int K = 4 * CIN, NT = N / 16, KST = K / 32, NQ = K / SUB, QPK = 2 * CIN / SUB, KSS = SUB / 32;   // sub-chunks total / per ky, k-steps per sub-chunk
     static constexpr int TT = 2, RW = 32, G = 2, NF = G * KSS, NFW = NF / 4, LDS_ROW = (SUB > N ? SUB : N) + 8, PPC = SUB / 8, NPI = RW * PPC / 64;
     static constexpr int PPO = N / 8, NPO = RW * PPO / 64;
-    static constexpr bool GATES = CIN == 64 || CIN == 128;     // cunet's shapes (pixgemm_supported)
     static constexpr int WBUF = NF * 1024, SLAB = RW * LDS_ROW * 2 + RW * 8, SMEM = 2 * WBUF + 4 * SLAB;
     static_assert(NF % 4 == 0 && NT % G == 0 && (2 * CIN) % SUB == 0 && RW * PPC % 64 == 0 && RW * PPO % 64 == 0, "tiling");
 };
@@ -402,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void merge_kernel(const GemmParams p) {
                 half8 h = {};
                 if (off >= 0) {
                     h = *(const half8*)(Xg + (size_t)off + shift + c * 8);
-                    if (C::GATES && p.a_scale) h = gate::gate8(h, p.a_scale + Gb[rr] + (inner + c * 8) % CIN);   // squeeze-excite gate of the input map
+                    if (p.a_scale) h = gate::gate8(h, p.a_scale + Gb[rr] + (inner + c * 8) % CIN);   // squeeze-excite gate of the input map
                 }
                 xr[k] = h;
             }
@@ -478,7 +443,6 @@ hipError_t launch_merge(const GemmParams& p, hipStream_t s) {
 // true if this launch can take the streaming kernel (everything else stays on gemm_kernel)
 bool pixgemm_supported(const GemmParams& p) {
     static const bool off = getenv("W2X_NO_PIXGEMM") != nullptr;   // A/B switch
-    if ((p.a_scale || p.res_scale) && p.a.Cs != 64 && p.a.Cs != 128) return false;   // gated operands: compiled into cunet's shapes only (PixCfg / MergeCfg GATES)
     if (!off && p.wt_frag && p.amode == 2 && p.kh == 2 && p.kw == 2 && p.stride == 2 && p.omode == 0 && !p.ln && (p.act == 0 || p.act == 1) && !p.has_clip &&
         !p.stats_out && !p.pool_out && !p.res.p && !p.res2.p && p.out.Cs == p.N && p.Kw == p.K && p.K == 4 * p.a.Cs && (long)p.out.Hs * p.out.Ws == p.Mrows && p.out.Ws == p.aW &&
         (((p.a.Cs == 96 || p.a.Cs == 192) && p.N == 192) || (p.a.Cs == 64 && p.N == 64) || (p.a.Cs == 128 && p.N == 128))) return true;   // patch merge / cunet down convolution
@@ -508,7 +472,7 @@ hipError_t launch_pixgemm(const GemmParams& p, hipStream_t s) {
         return hipGetLastError();
     }
     if (p.K == 192 && p.out.Cs == 96) return launch_pix<192, 96, 2>(p, s);
-    if (p.K == 192 && p.out.Cs == 192) return launch_pix<192, 192, 2, W2X_PIX192_TT>(p, s);
+    if (p.K == 192 && p.out.Cs == 192) return launch_pix<192, 192, 2>(p, s);
     if (p.K == 64 && p.out.Cs == 64) return launch_pix<64, 64, 2>(p, s);
     if (p.K == 128 && p.out.Cs == 128) return launch_pix<128, 128, 2>(p, s);
     return hipErrorInvalidValue;
