@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--mode", choices=["frames", "strips"], default="frames",
                     help="frames: every rank renders K whole frames (weak scaling, the headline); strips: rank r renders strip r of N of the same frame K times (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frame", choices=["synthetic", "flat", "noise"], default="synthetic",
+                    help="diagnostic: frame content (flat = one grey level, noise = uniform random bytes); `value` is quoted on synthetic")
     ap.add_argument("--op-times", action="store_true", help="print HIP-event time per plan op (one frame) to stderr")
     ap.add_argument("--work", default=os.environ.get("W2X_BENCH_WORK", "/tmp/w2x_bench"))
     a = ap.parse_args()
@@ -165,6 +167,10 @@ def main():
     strips = a.mode == "strips"
     my_frames = [0] if strips else shard.frames_for_rank(a.steps * world, rank, world)   # frame f -> rank f mod N; each rank renders K frames
     frame = synthetic_frame(my_frames[0])
+    if a.frame == "flat":
+        frame = np.full_like(frame, 127)
+    elif a.frame == "noise":
+        frame = np.random.default_rng(my_frames[0]).integers(0, 256, frame.shape, dtype=np.uint8)
     out = np.empty((FRAME_H * SCALE, FRAME_W * SCALE, 3), np.uint8)
     part, parts = (rank, world) if strips else (0, 1)
 
@@ -273,7 +279,7 @@ def main():
             "metric": "upscaled MPix/s, 1080p->4K swin_unet/art fp16",
             "value": round(fps * OUT_MPIX, 2), "unit": "MPix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(wall_max * 1e3 / a.steps, 3), "higher_is_better": True, "scaling": "strong" if strips else "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
+            "dtype": "f16", "data": "synthetic" if a.frame == "synthetic" else "synthetic (" + a.frame + " frame: diagnostic)",
             "config": {"workload": "configs[2]: swin_unet/art scale4 noise3 batch4 tile256 fp16, 1920x1080 frame, blend=0.0625 "
                                    f"({frame_tiles} tiles, 12 batches); synthetic-weight graph of that architecture, frame resident in HBM",
                        "frames_per_s": round(fps, 3), "device_ms_per_frame": round(ms, 3), "frames_per_rank": a.steps,

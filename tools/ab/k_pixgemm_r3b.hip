@@ -323,14 +323,13 @@ __global__ __launch_bounds__(256, 2) void toimage_kernel(const GemmParams p) {
     }
 }
 
-// The slab variant of merge_kernel below, which cunet's down convolutions (64 -> 64, 128 -> 128, LeakyReLU, the input optionally gated by its
-// squeeze-excite block) keep: with the gates' table reads in the unrolled nest the direct-fragment kernel needs 168 / 256 registers there
-// against this one's 110 / 158 (4 / 3 waves per SIMD).  Output pixel (y, x) reads the input pixels (2y+ky, 2x+kx): for each ky one
+// Conv 2x2 stride 2: the Swin patch merge (Cin 96 / 192 -> 192) and cunet's down convolutions (64 -> 64, 128 -> 128, LeakyReLU, the
+// input optionally gated by its squeeze-excite block).  Output pixel (y, x) reads the input pixels (2y+ky, 2x+kx): for each ky one
 // contiguous run of 2*Cin halves, so K = 4*Cin is walked in sub-chunks of SUB contiguous channels.  A wave owns 32 output
 // pixels and all N output columns (accumulators stay in registers over the whole K), rows of a sub-chunk pass through the
 // wave's LDS slab into A fragments, weights stream through LDS in stages of two n-tiles shared by the four waves.
 template <int CIN, int N, int SUB>
-struct MergeSlabCfg {
+struct MergeCfg {
     static constexpr int K = 4 * CIN, NT = N / 16, KST = K / 32, NQ = K / SUB, QPK = 2 * CIN / SUB, KSS = SUB / 32;   // sub-chunks total / per ky, k-steps per sub-chunk
     static constexpr int TT = 2, RW = 32, G = 2, NF = G * KSS, NFW = NF / 4, LDS_ROW = (SUB > N ? SUB : N) + 8, PPC = SUB / 8, NPI = RW * PPC / 64;
     static constexpr int PPO = N / 8, NPO = RW * PPO / 64;
@@ -340,8 +339,8 @@ struct MergeSlabCfg {
 };
 
 template <int CIN, int N, int SUB>
-__global__ __launch_bounds__(256, 2) void merge_slab_kernel(const GemmParams p) {
-    using C = MergeSlabCfg<CIN, N, SUB>;
+__global__ __launch_bounds__(256, 2) void merge_kernel(const GemmParams p) {
+    using C = MergeCfg<CIN, N, SUB>;
     constexpr int NT = C::NT, KST = C::KST, NQ = C::NQ, QPK = C::QPK, KSS = C::KSS;
     constexpr int TT = C::TT, RW = C::RW, G = C::G, NFW = C::NFW, LDS_ROW = C::LDS_ROW, PPC = C::PPC, NPI = C::NPI;
     constexpr int WBUF = C::WBUF, SLAB = C::SLAB;
@@ -464,170 +463,13 @@ __global__ __launch_bounds__(256, 2) void merge_slab_kernel(const GemmParams p) 
     }
 }
 
-// Conv 2x2 stride 2: the Swin patch merge (Cin 96 / 192 -> 192) and cunet's down convolutions (64 -> 64, 128 -> 128, LeakyReLU, the
-// input optionally gated by its squeeze-excite block).  Output pixel (y, x) reads the input pixels (2y+ky, 2x+kx): for each ky one
-// contiguous run of 2*Cin halves, so K = 4*Cin is walked in sub-chunks of SUB contiguous channels.  A wave owns 32 output
-// pixels and all N output columns (accumulators stay in registers over the whole K); weights stream through LDS in stages of two
-// n-tiles shared by the four waves, requested W2X_MERGE_AHEAD stages ahead.
-// The A fragments of a sub-chunk are loaded STRAIGHT from the map (lane (fr, g) of k-step ks takes the 16 bytes at channel 32 ks + 8 g of
-// its row: four lanes cover 64 contiguous bytes of a row, the next k-step the other half of the 128-byte line) into one of two
-// register sets, and the next sub-chunk's are requested when this one's first stage starts.  Round 2 / early round 3 passed the rows
-// through registers and the wave's LDS slab first (48 more registers - no room to request anything ahead, ten registers spilled at
-// Cin = 192) and waited for every sub-chunk's rows with nothing else to do: 2 - 4 exposed round trips to memory per workgroup.
-// The loop nest is fully unrolled (at most 24 stages), so which register set a stage uses and which loads are in flight at each wait
-// are compile-time facts.
-#ifndef W2X_MERGE_AHEAD
-#define W2X_MERGE_AHEAD 2
-#endif
-template <int CIN, int N, int SUB>
-struct MergeCfg {
-    static constexpr int K = 4 * CIN, NT = N / 16, KST = K / 32, NQ = K / SUB, QPK = 2 * CIN / SUB, KSS = SUB / 32;   // sub-chunks total / per ky, k-steps per sub-chunk
-    static constexpr int TT = 2, RW = 32, G = 2, NF = G * KSS, NFW = NF / 4, LDS_ROW = N + 8;
-    static constexpr int PPO = N / 8, NPO = RW * PPO / 64;
-    static constexpr int SPQ = NT / G, NSTAGE = NQ * SPQ;      // weight stages per sub-chunk / in all
-    static constexpr int AHEAD = W2X_MERGE_AHEAD;
-    static constexpr bool GATES = CIN == 64 || CIN == 128;     // cunet's shapes (pixgemm_supported)
-    static constexpr int WBUF = NF * 1024, SLAB = RW * LDS_ROW * 2, SMEM = 2 * WBUF + 4 * SLAB;
-    static_assert(NF % 4 == 0 && NT % G == 0 && (2 * CIN) % SUB == 0 && RW * PPO % 64 == 0, "tiling");
-};
-
-template <int CIN, int N, int SUB>
-__global__ __launch_bounds__(256, 2) void merge_kernel(const GemmParams p) {
-    using C = MergeCfg<CIN, N, SUB>;
-    constexpr int NT = C::NT, KST = C::KST, NQ = C::NQ, QPK = C::QPK, KSS = C::KSS, SPQ = C::SPQ, NSTAGE = C::NSTAGE, D = C::AHEAD;
-    constexpr int TT = C::TT, RW = C::RW, G = C::G, NFW = C::NFW, LDS_ROW = C::LDS_ROW;
-    constexpr int WBUF = C::WBUF, SLAB = C::SLAB;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 15, g = lane >> 4;
-    _Float16* WB = (_Float16*)smem;
-    _Float16* Sl = (_Float16*)(smem + 2 * WBUF + wv * SLAB);              // [RW][LDS_ROW]: the output tile
-    const long M = (long)p.B * p.Mrows;
-    const long row0 = ((long)blockIdx.x * 4 + wv) * RW;
-    const long nrows = M - row0 < RW ? M - row0 : RW;
-    const _Float16* __restrict__ Wf = (const _Float16*)p.wt_frag + lane * 8;   // [NT][KST][64][8]
-    auto frag_src = [&](int stage, int f) {   // stage = q * SPQ + s; fragment f = t * KSS + ks  ->  n-tile s*G + t, k-step q*KSS + ks
-        const int q = stage / SPQ, s2 = stage - q * SPQ, t = f / KSS, ks = f - t * KSS;
-        return Wf + (size_t)((s2 * G + t) * KST + q * KSS + ks) * 512;
-    };
-    // the map goes through a buffer resource (32-bit byte offsets, pixgemm_supported refuses 4 GB and more): a row that does not exist is
-    // offset 0xFFFFFFFF (saturating adds keep it there) and reads zeros
-    const __amdgpu_buffer_rsrc_t XB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a.p), 0, (unsigned)((size_t)p.B * p.a.Hs * p.a.Ws * CIN * 2), 0x00020000);
-
-    float bias_r[NT];                              // requested first: the oldest loads, so no later wait is held up by them
-#pragma unroll
-    for (int t = 0; t < NT; ++t) bias_r[t] = p.bias[t * 16 + fr];
-    half8 stg[D][NFW];
-#pragma unroll
-    for (int i = 0; i < NFW; ++i) stg[0][i] = *(const half8*)frag_src(0, wv * NFW + i);
-    unsigned rbase[TT]; int gb[TT];                // this lane's rows tt * 16 + fr: byte offset of channel 8 g of input pixel (2y, 2x); gate table row
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) {
-        const long gr = row0 + tt * 16 + fr;
-        rbase[tt] = 0xFFFFFFFFu; gb[tt] = 0;
-        if (gr < M) {
-            const int b = (int)(gr / p.Mrows), ml = (int)(gr - (long)b * p.Mrows);
-            const int oy = ml / p.aW, ox = ml - oy * p.aW;
-            rbase[tt] = (unsigned)((((size_t)(b * p.a.Hs + oy * 2 + p.a.y0) * p.a.Ws + ox * 2 + p.a.x0) * CIN + g * 8) * 2);
-            gb[tt] = b * CIN;
-        }
-    }
-    half8 xa[2][TT][KSS];                          // A fragments of sub-chunk q in set q & 1
-    auto xload = [&](int q) {
-        const int ky = q / QPK, inner = (q - ky * QPK) * SUB;
-        const unsigned shift = (unsigned)((ky * p.a.Ws * CIN + inner) * 2);
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-            for (int ks = 0; ks < KSS; ++ks)
-                xa[q & 1][tt][ks] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(XB, __builtin_elementwise_add_sat(rbase[tt], shift + ks * 64u), 0, 0));
-    };
-    xload(0);
-#pragma unroll
-    for (int d = 1; d < D; ++d)
-        if (d < NSTAGE) {
-#pragma unroll
-            for (int i = 0; i < NFW; ++i) stg[d][i] = *(const half8*)frag_src(d, wv * NFW + i);
-        }
-#pragma unroll
-    for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[0][i];
-    float4v acc[TT][NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt) acc[tt][t] = (float4v){bias_r[t], bias_r[t], bias_r[t], bias_r[t]};
-    __syncthreads();
-
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-#pragma unroll
-        for (int s2 = 0; s2 < SPQ; ++s2) {
-            const int stage = q * SPQ + s2;        // a constant after unrolling
-            const _Float16* wcur = WB + (size_t)(stage & 1) * (WBUF / 2) + lane * 8;
-            if (stage + D < NSTAGE) {              // set stage % D carried this stage, which reached LDS at the end of the previous one
-#pragma unroll
-                for (int i = 0; i < NFW; ++i) stg[stage % D][i] = *(const half8*)frag_src(stage + D, wv * NFW + i);
-            }
-            if (s2 == 0 && q + 1 < NQ) xload(q + 1);
-            W2X_PHASE_FENCE();                     // the requests stay at the top of the stage
-            if (C::GATES && s2 == 0 && p.a_scale) {   // squeeze-excite gate of the input map: fp16(x * s), the rounding of the in-place pass
-                const int ky = q / QPK, inner = (q - ky * QPK) * SUB;
-#pragma unroll
-                for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-                    for (int ks = 0; ks < KSS; ++ks) xa[q & 1][tt][ks] = gate::gate8(xa[q & 1][tt][ks], p.a_scale + gb[tt] + (inner + ks * 32 + g * 8) % CIN);
-            }
-#pragma unroll
-            for (int t = 0; t < G; ++t)
-#pragma unroll
-                for (int ks = 0; ks < KSS; ++ks) {
-                    const half8 wb = *(const half8*)(wcur + (size_t)(t * KSS + ks) * 512);
-#pragma unroll
-                    for (int tt = 0; tt < TT; ++tt) acc[tt][s2 * G + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[q & 1][tt][ks], wb, acc[tt][s2 * G + t], 0, 0, 0);
-                }
-            if (stage + 1 < NSTAGE) {
-#pragma unroll
-                for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)((stage + 1) & 1) * (WBUF / 2) + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[(stage + 1) % D][i];
-            }
-            __syncthreads();
-        }
-    }
-    // ---- output tile through the slab, flat 16-byte stores (rows of the output are contiguous)
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v = acc[tt][t][j];
-                if (p.act == 1) v = v > 0.f ? v : v * p.alpha;
-                Sl[(tt * 16 + g * 4 + j) * LDS_ROW + t * 16 + fr] = (_Float16)v;
-            }
-    W2X_PHASE_FENCE();
-    _Float16* __restrict__ Og = (_Float16*)p.out.p + row0 * N;
-    const int npieces = nrows > 0 ? (int)nrows * C::PPO : 0;
-#pragma unroll
-    for (int k = 0; k < C::NPO; ++k) {
-        const int idx = k * 64 + lane, rr = idx / C::PPO, c = idx - rr * C::PPO;
-        if (idx < npieces) *(half8*)(Og + (size_t)idx * 8) = *(const half8*)(Sl + rr * LDS_ROW + c * 8);
-    }
-}
-
 template <int CIN, int N, int SUB>
 hipError_t launch_merge(const GemmParams& p, hipStream_t s) {
+    constexpr int SM = MergeCfg<CIN, N, SUB>::SMEM;
     static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
+    if (hipError_t e = ensure_dynamic_lds((const void*)merge_kernel<CIN, N, SUB>, SM, lds_ok); e != hipSuccess) return e;
     const long M = (long)p.B * p.Mrows;
-    const dim3 grid((unsigned)((M + 127) / 128));
-    if constexpr (CIN == 64 || CIN == 128) {                       // cunet's shapes
-        constexpr int SM = MergeSlabCfg<CIN, N, SUB>::SMEM;
-        if (hipError_t e = ensure_dynamic_lds((const void*)merge_slab_kernel<CIN, N, SUB>, SM, lds_ok); e != hipSuccess) return e;
-        hipLaunchKernelGGL((merge_slab_kernel<CIN, N, SUB>), grid, dim3(256), SM, s, p);
-    } else {
-        constexpr int SM = MergeCfg<CIN, N, SUB>::SMEM;
-        if (hipError_t e = ensure_dynamic_lds((const void*)merge_kernel<CIN, N, SUB>, SM, lds_ok); e != hipSuccess) return e;
-        hipLaunchKernelGGL((merge_kernel<CIN, N, SUB>), grid, dim3(256), SM, s, p);
-    }
+    hipLaunchKernelGGL((merge_kernel<CIN, N, SUB>), dim3((unsigned)((M + 127) / 128)), dim3(256), SM, s, p);
     return hipGetLastError();
 }
 

@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <filesystem>
 #include <fstream>
@@ -321,7 +323,10 @@ struct Img2Img::Impl {
             std::vector<Block> free_list;
             std::vector<size_t> off(nt, 0);
             size_t arena = 0;
-            auto align = [](size_t v) { return (v + 3071) / 3072 * 3072; };   // 256 bytes x 12: offsets stay 256-byte aligned when the arena is cut into 2, 3 or 4 group parts (run_network)
+            // 256 bytes x 12: offsets stay 256-byte aligned when the arena is cut into 2, 3 or 4 group parts (run_network).
+            // W2X_ARENA_ALIGN (a multiple of 3072) is a placement experiment: tools/ab/arena_placement.sh
+            static const size_t unit = [] { const char* e = getenv("W2X_ARENA_ALIGN"); const size_t v = e ? strtoull(e, nullptr, 10) : 0; return v >= 3072 && v % 3072 == 0 ? v : (size_t)3072; }();
+            auto align = [](size_t v) { return (v + unit - 1) / unit * unit; };
             auto alloc = [&](size_t bytes) -> size_t {
                 bytes = align(bytes);
                 int best = -1;
@@ -343,13 +348,16 @@ struct Img2Img::Impl {
                 for (int t = 0; t < nt; ++t) if (!placed[t] && first[t] == step && last[t] >= 0) { off[t] = alloc((size_t)plan.tensors[t].bytes()); placed[t] = 1; }
                 for (int t = 0; t < nt; ++t) if (placed[t] == 1 && last[t] == step) { release(off[t], (size_t)plan.tensors[t].bytes()); placed[t] = 2; }
             }
-            for (int t = 0; t < nt; ++t) if (!placed[t]) { off[t] = alloc((size_t)plan.tensors[t].bytes()); placed[t] = 1; }   // unused tensors
+            // (tensors no op touches - the q / k / v, score and hidden maps inside the fused attention and MLP ops - get no memory: at config 3 they
+            //  were 19 of the arena's 20.7 GiB until round 3)
+            if (getenv("W2X_DUMP_ARENA"))
+                for (int t = 0; t < nt; ++t) if (last[t] >= 0) fprintf(stderr, "[arena] t%d ops %d..%d offset %zu (%.1f MiB) bytes %zu\n", t, first[t], last[t], off[t], off[t] / 1048576.0, (size_t)plan.tensors[t].bytes());
             hipAssert(hipMalloc(&arena_base, arena + 1024));   // slack: vector reads past a table's last row; the group parts rounded up to 256 bytes
             hipAssert(hipMemsetAsync(arena_base, 0, arena + 1024, stream));
             arena_bytes = arena;
             pool_blocks.assign(nt, 0);
         tensors.assign(nt, nullptr);
-            for (int t = 0; t < nt; ++t) tensors[t] = (uint8_t*)arena_base + off[t];
+            for (int t = 0; t < nt; ++t) tensors[t] = placed[t] ? (uint8_t*)arena_base + off[t] : nullptr;
         }
         blobs.assign(plan.blobs.size(), nullptr);
         for (size_t i = 0; i < plan.blobs.size(); ++i) {
