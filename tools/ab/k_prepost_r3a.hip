@@ -144,32 +144,23 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // output bytes leave as three dwords; the per-pixel arithmetic and its order are those of compose_pixel, so the bytes are the
 // same.  Everything else takes the per-pixel path.  (The output is 100 MB of u8 per 4K frame: single-byte stores and 8-byte loads
 // were the kernel's bound; four pixels per thread on the per-pixel path alone lose the loads' coalescing and measured slower.)
-// Launch shape (round 3): blockIdx.x / threadIdx.x pick the four-pixel column group, blockIdx.y a band of kComposeRows rows that the
-// thread walks.  Everything that depends on the column only (covering tile columns, whether the group takes the fast path, the ramp
-// weights of its four pixels) is computed once per thread, what depends on the row is the same for a whole workgroup (scalar
-// registers) - the flat grid-stride loop it replaces paid a 64-bit division and six 32-bit ones per four pixels, and the kernel ran at
-// 3.1 TB/s with its integer unit busier than its memory pipe.
-constexpr int kComposeRows = 8, kComposeThreads = 128;
 template <typename P>
-__global__ __launch_bounds__(kComposeThreads) void compose_kernel(const ComposeParams p) {
+__global__ __launch_bounds__(256) void compose_kernel(const ComposeParams p) {
     constexpr bool kHalf = sizeof(P) == 8;                          // the four-pixel fast path reads fp16 tiles
     const int x1 = p.x1 > 0 ? p.x1 : p.outW, sw = x1 - p.x0;
     const int gw = (sw + 3) >> 2;                                   // pixel groups per row
-    const int xg = blockIdx.x * kComposeThreads + threadIdx.x;
-    if (xg >= gw) return;
+    const long total = (long)gw * p.outH;
     const P* tiles = (const P*)p.tiles;
     const int To = p.To, n = To - 1;
-    const int X = p.x0 + 4 * xg;
-    const int np = min(4, x1 - X);
-    // tile columns covering the first and the last pixel of the group
-    int a0 = X - To + 1; a0 = a0 <= 0 ? 0 : (a0 + p.stride_x - 1) / p.stride_x;
-    int b0 = X + 3 - To + 1; b0 = b0 <= 0 ? 0 : (b0 + p.stride_x - 1) / p.stride_x;
-    const int a1 = min(p.nx - 1, X / p.stride_x), b1 = min(p.nx - 1, (X + 3) / p.stride_x);
-    const bool fast_col = kHalf && np == 4 && !p.tta && !p.deep && a0 == b0 && a1 == b1;
-    const int Y0 = blockIdx.y * kComposeRows, Y1 = min(p.outH, Y0 + kComposeRows);
-    for (int Y = Y0; Y < Y1; ++Y) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int Y = (int)(i / gw), X = p.x0 + 4 * (int)(i - (long)Y * gw);
         uint8_t* d = p.dst + (size_t)Y * p.dst_step + (size_t)X * 3;
+        const int np = min(4, x1 - X);
         unsigned px[4] = {0u, 0u, 0u, 0u};
+        // tile columns covering the first and the last pixel of the group
+        int a0 = X - To + 1; a0 = a0 <= 0 ? 0 : (a0 + p.stride_x - 1) / p.stride_x;
+        int b0 = X + 3 - To + 1; b0 = b0 <= 0 ? 0 : (b0 + p.stride_x - 1) / p.stride_x;
+        const int a1 = min(p.nx - 1, X / p.stride_x), b1 = min(p.nx - 1, (X + 3) / p.stride_x);
         if (p.deep) {   // 16-bit output (extension): the same sums, rint(x * 65535) saturated, BGR
             uint16_t* d16 = (uint16_t*)(p.dst + (size_t)Y * p.dst_step) + (size_t)X * 3;
             for (int k = 0; k < np; ++k) {
@@ -181,7 +172,7 @@ __global__ __launch_bounds__(kComposeThreads) void compose_kernel(const ComposeP
             }
             continue;
         }
-        const bool fast = fast_col && (((size_t)d) & 3) == 0;
+        const bool fast = kHalf && np == 4 && !p.tta && a0 == b0 && a1 == b1 && (((size_t)d) & 3) == 0;
         if (fast) {
             int j0 = Y - To + 1; j0 = j0 <= 0 ? 0 : (j0 + p.stride_y - 1) / p.stride_y;
             const int j1 = min(p.ny - 1, Y / p.stride_y);
@@ -332,11 +323,9 @@ hipError_t launch_gather(const GatherParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_compose(const ComposeParams& p, hipStream_t s) {
-    const int gw = (((p.x1 > 0 ? p.x1 : p.outW) - p.x0) + 3) / 4;
-    if (gw <= 0 || p.outH <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((gw + kComposeThreads - 1) / kComposeThreads), (unsigned)((p.outH + kComposeRows - 1) / kComposeRows));
-    if (p.fp32) hipLaunchKernelGGL(compose_kernel<float4v>, grid, dim3(kComposeThreads), 0, s, p);
-    else hipLaunchKernelGGL(compose_kernel<half4>, grid, dim3(kComposeThreads), 0, s, p);
+    const dim3 grid(grid_for((long)((((p.x1 > 0 ? p.x1 : p.outW) - p.x0) + 3) / 4) * p.outH));
+    if (p.fp32) hipLaunchKernelGGL(compose_kernel<float4v>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(compose_kernel<half4>, grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 hipError_t launch_se(const SeParams& p, hipStream_t s) {

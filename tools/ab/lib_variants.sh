@@ -16,7 +16,7 @@ build() { $CXX $(extra "$1") $2 -I csrc -c "${3:-csrc/$1}" -o "build/${1%.hip}.o
 run() { (cd "$ROOT"; python bench.py --no-cpu-baseline --steps ${STEPS:-20} 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-print('$1', '| ms/frame', d['ms_per_step'], '| full path', d['config']['full_path_ms_per_frame'], '|', d['roofline']['kernels_ms_per_frame'])"); }
+print('$1', '| ms/frame', d['ms_per_step'], '| full path', d['config']['full_path_ms_per_frame'], '|', d['roofline']['kernels_ms_per_frame'], '| compose', d['config']['families_ms_per_frame']['compose'])"); }
 last=""
 for arg in "$@"; do
   if [ -n "$last" ]; then build "$last" ""; last=""; fi
