@@ -191,6 +191,9 @@ struct Img2Img::Impl {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t gstream[3] = {nullptr, nullptr, nullptr};   // further tile groups of a pass (run_frame)
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    // Experiment (W2X_STAGGER_OP=k, two groups): the second group starts when the first has finished op k, so that the two streams run
+    // different kernels side by side instead of the same one.  Off by default (-1): DESIGN.md section 3 has the measurement.
+    hipEvent_t ev_stagger = nullptr; int stagger_op = -1;
     int groups = 2;                      // W2X_GROUPS (1..4; W2X_NO_SPLIT = 1): tile groups a pass is cut into
     std::vector<void*> tensors, blobs;   // tensors point into one arena
     std::vector<void*> frag_blobs;       // per blob id: fragment-major copy of a weight matrix (or null)
@@ -283,6 +286,7 @@ struct Img2Img::Impl {
         if (ev0) { (void)hipEventDestroy(ev0); ev0 = nullptr; }
         if (ev1) { (void)hipEventDestroy(ev1); ev1 = nullptr; }
         if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
+        if (ev_stagger) { (void)hipEventDestroy(ev_stagger); ev_stagger = nullptr; }
         for (hipEvent_t& e : ev_join) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         for (hipStream_t& st : gstream) if (st) { (void)hipStreamDestroy(st); st = nullptr; }
         if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
@@ -580,6 +584,7 @@ struct Img2Img::Impl {
                 }
                 default: throw std::runtime_error("plan: unknown op kind");
             }
+            if (grp == 0 && (int)i == stagger_op && ev_stagger) hipAssert(hipEventRecord(ev_stagger, s));   // W2X_STAGGER_OP: the next group starts here
         } catch (const std::exception& e) {     // name the op: "invalid argument" alone says nothing about a 60-op plan
             throw std::runtime_error("op " + std::to_string(i) + " [" + plan.ops[i].name + "]: " + e.what());
         }
@@ -645,8 +650,13 @@ struct Img2Img::Impl {
                 }
                 hipAssert(hipEventRecord(ev_fork, stream));
                 for (int grp = 1; grp < NG; ++grp) hipAssert(hipStreamWaitEvent(gstream[grp - 1], ev_fork, 0));
-                for (int grp = 0; grp < NG; ++grp)
+                static const int stagger_env = [] { const char* e = getenv("W2X_STAGGER_OP"); return e ? atoi(e) : -1; }();
+                stagger_op = NG == 2 && stagger_env >= 0 && stagger_env < (int)plan.ops.size() ? stagger_env : -1;
+                if (stagger_op >= 0 && !ev_stagger) hipAssert(hipEventCreateWithFlags(&ev_stagger, hipEventDisableTiming));
+                for (int grp = 0; grp < NG; ++grp) {
+                    if (grp == 1 && stagger_op >= 0) hipAssert(hipStreamWaitEvent(gstream[0], ev_stagger, 0));
                     run_network((uint8_t*)slab_out + (size_t)first[grp] * slot_bytes, first[grp + 1] - first[grp], grp, grp ? gstream[grp - 1] : stream);
+                }
                 for (int grp = 1; grp < NG; ++grp) {
                     hipAssert(hipEventRecord(ev_join[grp - 1], gstream[grp - 1]));
                     hipAssert(hipStreamWaitEvent(stream, ev_join[grp - 1], 0));

@@ -125,6 +125,11 @@ __device__ __forceinline__ half8 norm8(const half8 v, float rstd, float nm) {
 #define W2X_PHASE_FENCE() asm volatile("" ::: "memory")
 #define W2X_RING_FENCE() asm volatile("" ::: "memory")   // keeps a ring refill where it is written (the scheduler would sink it to its use)
 
+// Timing experiments on mlp2q_kernel (results are wrong; tools/ab/mlp192_variants.sh): bit 0 no barrier per chunk, bit 1 no weight staging after
+// chunk 0 (and no wait for it), bit 2 GELU replaced by the bare conversion, bit 3 no matrix products.
+#ifndef W2X_MLP2Q_EXP
+#define W2X_MLP2Q_EXP 0
+#endif
 template <int C, int TT, int NW>
 struct Mlp2Cfg {
     static constexpr int RW = 16 * TT;           // rows per wave
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
     half8 xres[NP];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-        if (ch + 1 < NCH) stage(ch + 1);
+        if (ch + 1 < NCH && !(W2X_MLP2Q_EXP & 2)) stage(ch + 1);
         float16v acc1;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -449,7 +454,8 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
         }
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[j % RING], xreg[j], acc1, 0, 0, 0);
+            if (!(W2X_MLP2Q_EXP & 8)) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[j % RING], xreg[j], acc1, 0, 0, 0);
+            else acc1[j % 16] += (float)wr[j % RING][0] + (float)xreg[j][0];
             wr[j % RING] = lds_frag(ch, j + RING);
             W2X_RING_FENCE();
         }
@@ -460,21 +466,23 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
         half8 a2[2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            const float2v g0 = gelu_fast2((float2v){acc1[8 * s2 + 0], acc1[8 * s2 + 1]});
-            const float2v g1 = gelu_fast2((float2v){acc1[8 * s2 + 2], acc1[8 * s2 + 3]});
-            const float2v g2 = gelu_fast2((float2v){acc1[8 * s2 + 4], acc1[8 * s2 + 5]});
-            const float2v g3 = gelu_fast2((float2v){acc1[8 * s2 + 6], acc1[8 * s2 + 7]});
+            auto act2 = [](float2v v) { return (W2X_MLP2Q_EXP & 4) ? v : gelu_fast2(v); };
+            const float2v g0 = act2((float2v){acc1[8 * s2 + 0], acc1[8 * s2 + 1]});
+            const float2v g1 = act2((float2v){acc1[8 * s2 + 2], acc1[8 * s2 + 3]});
+            const float2v g2 = act2((float2v){acc1[8 * s2 + 4], acc1[8 * s2 + 5]});
+            const float2v g3 = act2((float2v){acc1[8 * s2 + 6], acc1[8 * s2 + 7]});
             a2[s2] = (half8){(_Float16)g0[0], (_Float16)g0[1], (_Float16)g1[0], (_Float16)g1[1],
                              (_Float16)g2[0], (_Float16)g2[1], (_Float16)g3[0], (_Float16)g3[1]};
         }
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {     // fragment KS + i = (output tile i >> 1, k-step i & 1)
             const int j = KS + i;
-            acc2[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[j % RING], a2[i & 1], acc2[i >> 1], 0, 0, 0);
+            if (!(W2X_MLP2Q_EXP & 8)) acc2[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[j % RING], a2[i & 1], acc2[i >> 1], 0, 0, 0);
+            else acc2[i >> 1][i % 16] += (float)wr[j % RING][0] + (float)a2[i & 1][0];
             if (j + RING < NF) { wr[j % RING] = lds_frag(ch, j + RING); W2X_RING_FENCE(); }
         }
-        if (ch + 1 < NCH) __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
+        if (ch + 1 < NCH && !(W2X_MLP2Q_EXP & 2)) __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (!(W2X_MLP2Q_EXP & 1)) __syncthreads();
         if (ch + 1 < NCH) {
 #pragma unroll
             for (int i = 0; i < RING; ++i) wr[i] = lds_frag(ch + 1, i);
