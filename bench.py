@@ -236,7 +236,7 @@ def main():
         # dominant kernel of the frame: plan ops grouped by the kernel that serves them, by summed HIP-event time
         # (measured on the compute stream by w2x_profile_frame / w2x_op_times)
         symbols = {("swinattn", 96): "swin_attn96_kernel", ("swinattn", 192): "swin_attn192_kernel",
-                   ("mlp", 96): "mlp96q_kernel", ("mlp", 192): "mlp2_kernel<192,2>"}
+                   ("mlp", 96): "mlp96q_kernel", ("mlp", 192): "mlp2q_kernel<192,4>"}
         groups = {}
         for line, t in zip(desc, op_ms):
             m = re.match(r"\s*\d+ (\w+) (.*?)flops=(\d+)", line)

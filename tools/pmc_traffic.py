@@ -15,8 +15,8 @@ def per_kernel(d, counter):
 def symbol(name):
     m = re.search(r"(swin_attn96_kernel|swin_attn192_kernel|mlp96q_kernel|mlp96p_kernel|conv48_kernel|compose_kernel|gather_kernel|toimage_kernel)", name)
     if m: return m.group(1)
-    m = re.search(r"mlp2_kernel<(\d+), (\d+)[^>]*>", name)
-    if m: return f"mlp2_kernel<{m.group(1)},{m.group(2)}>"
+    m = re.search(r"(mlp2q?_kernel)<(\d+), (\d+)[^>]*>", name)
+    if m: return f"{m.group(1)}<{m.group(2)},{m.group(3)}>"
     m = re.search(r"(pixgemm_kernel<[^>]*>|merge_kernel<[^>]*>|stem_kernel<[^>]*>|conv3_kernel<[^>]*>|gemm_kernel<[^>]*>|mlp_kernel<[^>]*>|swin_attn_kernel<[^>]*>)", name)
     return m.group(1) if m else None
 
