@@ -20,7 +20,8 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 
 constexpr int ITER = 2000;
 
-// SHAPE 0: 16x16x32, 1: 32x32x16, 2: 16x16x16, 3: no MFMA.  NV: plain v_fma_f32 per group.  NX: v_exp_f32 per group.
+// SHAPE 0: 16x16x32, 1: 32x32x16, 2: 16x16x16, 3: no MFMA, 4 / 5: 16x16x32 / 32x32x16 with the accumulators in AccVGPRs (does the matrix
+// instruction then leave the vector register file's ports to the VALU work of the other waves?).  NV: plain v_fma_f32 per group.  NX: v_exp_f32 per group.
 template <int SHAPE, int NV, int NX>
 __global__ __launch_bounds__(256) void k(const half8* in, float* out, long long* cyc) {
     const int lane = threadIdx.x & 63;
@@ -46,6 +47,12 @@ __global__ __launch_bounds__(256) void k(const half8* in, float* out, long long*
             } else if (SHAPE == 2) {
                 float4v& c = u == 0 ? c0 : u == 1 ? c1 : u == 2 ? c2 : c3;
                 asm volatile("v_mfma_f32_16x16x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a4), "v"(b4));
+            } else if (SHAPE == 4) {
+                float4v& c = u == 0 ? c0 : u == 1 ? c1 : u == 2 ? c2 : c3;
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+            } else if (SHAPE == 5) {
+                float16v& d = (u & 1) ? d1 : d0;
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
             }
 #pragma unroll
             for (int j = 0; j < NV; ++j) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[j & 7]) : "v"(m), "v"(ad));
@@ -74,7 +81,7 @@ void run(const char* name, const half8* in, float* out, long long* cyc, int ncu)
         CK(hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost));
         std::sort(h.begin(), h.end());
         const double med = (double)h[h.size() / 2] / ITER;          // wave cycles per group
-        const double flopk = SHAPE == 1 ? 2.0 : SHAPE == 2 ? 0.5 : SHAPE == 0 ? 1.0 : 0.0;   // 16 K FLOP units per MFMA
+        const double flopk = (SHAPE == 1 || SHAPE == 5) ? 2.0 : SHAPE == 2 ? 0.5 : (SHAPE == 0 || SHAPE == 4) ? 1.0 : 0.0;   // 16 K FLOP units per MFMA
         printf("%-12s NV=%d NX=%d W=%d: %.1f wave cycles per group -> %.1f SIMD cycles per group", name, NV, NX, W, med, med / W);
         if (flopk > 0) printf(", %.1f per 16 KFLOP", med / W / flopk);
         printf("\n");
@@ -106,5 +113,11 @@ int main() {
     run<0, 4, 1>("16x16x32", in, out, cyc, ncu);
     run<1, 8, 2>("32x32x16", in, out, cyc, ncu);
     run<2, 4, 0>("16x16x16", in, out, cyc, ncu);
+    run<4, 0, 0>("16x16x32 acc", in, out, cyc, ncu);
+    run<4, 4, 0>("16x16x32 acc", in, out, cyc, ncu);
+    run<4, 8, 0>("16x16x32 acc", in, out, cyc, ncu);
+    run<5, 0, 0>("32x32x16 acc", in, out, cyc, ncu);
+    run<5, 8, 0>("32x32x16 acc", in, out, cyc, ncu);
+    run<5, 16, 0>("32x32x16 acc", in, out, cyc, ncu);
     return 0;
 }

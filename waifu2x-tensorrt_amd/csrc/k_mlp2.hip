@@ -130,6 +130,9 @@ __device__ __forceinline__ half8 norm8(const half8 v, float rstd, float nm) {
 #ifndef W2X_MLP2Q_EXP
 #define W2X_MLP2Q_EXP 0
 #endif
+#ifndef W2X_MLP2Q_SPLITACC
+#define W2X_MLP2Q_SPLITACC 0
+#endif
 template <int C, int TT, int NW>
 struct Mlp2Cfg {
     static constexpr int RW = 16 * TT;           // rows per wave
@@ -452,13 +455,23 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc1[4 * q + j] = b[j];
         }
+#if W2X_MLP2Q_SPLITACC
+        float16v acc1b = {};                   // odd k-steps on a second accumulator: two chains of six dependent products instead of one of twelve
+#endif
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
+#if W2X_MLP2Q_SPLITACC
+            if (j & 1) acc1b = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[j % RING], xreg[j], acc1b, 0, 0, 0);
+            else
+#endif
             if (!(W2X_MLP2Q_EXP & 8)) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[j % RING], xreg[j], acc1, 0, 0, 0);
             else acc1[j % 16] += (float)wr[j % RING][0] + (float)xreg[j][0];
             wr[j % RING] = lds_frag(ch, j + RING);
             W2X_RING_FENCE();
         }
+#if W2X_MLP2Q_SPLITACC
+        acc1 += acc1b;
+#endif
         if (ch == NCH - 1) {   // the residual rows, requested as soon as the normalised copies have served their last product
 #pragma unroll
             for (int k = 0; k < NP; ++k) xres[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(XB, vo + k * 1024u, 0, 0));
