@@ -103,12 +103,26 @@ __device__ __forceinline__ float group_sum32(float v) {
     return a + b;
 }
 
+// Build switches (tools/ab/attn192_variants.sh):
+//   W2X_A192_BQ_LDS      the q / k / v bias vectors (576 floats) are copied to LDS when the workgroup starts and read from there.  As global loads
+//                        they were requested where they are used - the q bias as the initial accumulator of the first q product of a head, the v
+//                        bias inside every unit - and each was a round trip to L2 in front of a waiting wave (two waves per SIMD here).
+//   W2X_A192_BIAS_AHEAD  the rel-pos bias (+ mask) values of a unit (27 registers per lane, the initial accumulators of its score products) are
+//                        requested a phase ahead - before the v products for a head's first unit, under the first unit's softmax for the second -
+//                        instead of at the top of the unit.
+#ifndef W2X_A192_BQ_LDS
+#define W2X_A192_BQ_LDS 1
+#endif
+#ifndef W2X_A192_BIAS_AHEAD
+#define W2X_A192_BIAS_AHEAD 1
+#endif
 constexpr int C = 192, HD = 32, NH = 6, NTOK = 36, G = 2, R = G * NTOK, RT = 5, RP = RT * 16;
 constexpr int SLAB = 48, RPX = G * SLAB;       // slab rows per window / in the tile
 constexpr int LDX = C + 8;                     // 200 halves: 400-byte rows, 16-byte pieces rotate over the banks
 constexpr int XS = RPX * LDX, OS = RP * LDX;
 constexpr int NPAD = G * 12;                   // slab rows between the left-over tokens (kept at zero)
-constexpr int SMEM192 = (XS + OS) * 2 + (R + NPAD) * 8;
+constexpr int BQ_OFF = (XS + OS) * 2 + (R + NPAD) * 8;          // q / k / v bias [3 * C] fp32 (W2X_A192_BQ_LDS)
+constexpr int SMEM192 = BQ_OFF + 3 * C * 4;
 constexpr int DUMMY = XS * 2;                  // byte offset of a row nobody reads at that point (first row of Os): target of the stores of idle lanes
 constexpr int LPR = 32, PPR = C / 8, RPP = 256 / LPR, NPASS = R / RPP;   // row passes: 32 lanes per row, 8 rows per pass, 9 passes
 static_assert(R % RPP == 0, "row passes");
@@ -177,6 +191,13 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
         const int H = mat < 3 ? hA : hC;
         return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(WQ, wl16, (unsigned)((M * NH + H) * 12 + ft * 6 + ks) * 1024u, 0));
     };
+#if W2X_A192_BQ_LDS
+    float4v bq_stage = zero4;                   // requested before the ring's first fragments: the oldest load, nothing waits behind it
+    if (tid < 3 * C / 4) bq_stage = *(const float4v*)(p.bqkv + tid * 4);
+    const float* Bq = (const float*)(smem + BQ_OFF);
+#else
+    const float* Bq = p.bqkv;
+#endif
     half8 wr[RING];
 #pragma unroll
     for (int i = 0; i < RING; ++i) wr[i] = wfrag(i);
@@ -202,6 +223,9 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
         }
         Pix[tid] = (int2v){pix < 0 ? (int)kNoRow : (int)((unsigned)pix * (unsigned)(C * 2)), srow};   // offsets are unsigned 32-bit (up to 4 GB per run)
     }
+#if W2X_A192_BQ_LDS
+    if (tid < 3 * C / 4) *(float4v*)(smem + BQ_OFF + tid * 16) = bq_stage;
+#endif
     __syncthreads();
 
     // ---- gather + LayerNorm into the slabs
@@ -250,24 +274,36 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
     // two row swaps), O^T = V^T P^T scaled by 1/l and parked in Os (token order).  The denominators come off the matrix pipe (a
     // ones matrix in place of V^T, see k_swinattn96.hip); the k bias drops out of the softmax, the v bias is added to the
     // normalised output.
-    auto attend = [&](const int w, const int h, const bool ok, const int amask, const half8 (&qf)[3], const half8 (&kf)[3], const half8 (&vf0)[2], const half8 (&vf1)[2], const bool last) {
+    struct UnitBias { float4v s[3][2]; float b2[3]; };        // rel-pos bias (+ mask) of one unit in the score accumulators' layout
+    auto load_bias = [&](const int amask, const int h, UnitBias& ub) {
+        const float* bias = p.bias32 + ((size_t)amask * NH + h) * (3 * 576);
+#pragma unroll
+        for (int qi = 0; qi < 3; ++qi) {
+            const int bl = qi < 2 ? lane : lane2;
+            ub.s[qi][0] = *(const float4v*)(bias + qi * 576 + bl * 4);
+            ub.s[qi][1] = *(const float4v*)(bias + qi * 576 + 256 + bl * 4);
+            ub.b2[qi] = bias[qi * 576 + 512 + bl];        // key tile 2 holds one key per lane: added after the product
+        }
+        asm volatile("" ::: "memory");                     // the requests stay where they are written
+    };
+    // `ub` holds this unit's bias (requested earlier with W2X_A192_BIAS_AHEAD, else here); next_amask >= 0: the next unit of the same head is
+    // requested into `ub` again once the score products have taken this one's values
+    auto attend = [&](const int w, const int h, const bool ok, const int amask, const half8 (&qf)[3], const half8 (&kf)[3], const half8 (&vf0)[2], const half8 (&vf1)[2], const bool last,
+                      UnitBias& ub, const int next_amask) {
         float4v s[3][3];
         float b2[3];
-        {
-            const float* bias = p.bias32 + ((size_t)amask * NH + h) * (3 * 576);
+#if !W2X_A192_BIAS_AHEAD
+        load_bias(amask, h, ub);
+#endif
 #pragma unroll
-            for (int qi = 0; qi < 3; ++qi) {
-                const int bl = qi < 2 ? lane : lane2;
-                s[qi][0] = *(const float4v*)(bias + qi * 576 + bl * 4);
-                s[qi][1] = *(const float4v*)(bias + qi * 576 + 256 + bl * 4);
-                s[qi][2] = zero4;
-                b2[qi] = bias[qi * 576 + 512 + bl];       // key tile 2 holds one key per lane: added after the product
-            }
-        }
+        for (int qi = 0; qi < 3; ++qi) { s[qi][0] = ub.s[qi][0]; s[qi][1] = ub.s[qi][1]; s[qi][2] = zero4; b2[qi] = ub.b2[qi]; }
 #pragma unroll
         for (int qi = 0; qi < 3; ++qi)
 #pragma unroll
             for (int kt = 0; kt < 3; ++kt) s[qi][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt], qf[qi], s[qi][kt], 0, 0, 0);
+#if W2X_A192_BIAS_AHEAD
+        if (next_amask >= 0) load_bias(next_amask, h, ub);
+#endif
         float mx[3];
 #pragma unroll
         for (int qi = 0; qi < 3; ++qi) {
@@ -298,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
                 for (int ks = 0; ks < 6; ++ks) wp[t][ks] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(WP, wl16, (unsigned)((wv * 3 + t) * 6 + ks) * 1024u, 0));
         }
         float inv[3];
-        const float4v bv[2] = {*(const float4v*)(p.bqkv + 2 * C + h * HD + g * 4), *(const float4v*)(p.bqkv + 2 * C + h * HD + 16 + g * 4)};
+        const float4v bv[2] = {*(const float4v*)(Bq + 2 * C + h * HD + g * 4), *(const float4v*)(Bq + 2 * C + h * HD + 16 + g * 4)};
         {
             const _Float16 one = (_Float16)1.f;
             const half8 ones = {one, one, one, one, one, one, one, one};
@@ -346,13 +382,14 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
         }
     };
 
+    UnitBias ubias;
     // ---- head hA on both windows: every weight fragment multiplies six token tiles
 #define W2X_LOAD_X2(DST, KS_)                                                                                                   \
     _Pragma("unroll") for (int w_ = 0; w_ < 2; ++w_) _Pragma("unroll") for (int t_ = 0; t_ < 3; ++t_)                           \
         DST[w_][t_] = *(const half8*)(Xs + (w_ * SLAB + t_ * 16 + fr) * LDX + (KS_) * 32 + g * 8);
     {
         half8 qf[2][3], kf[2][3], vf0[2][2], vf1[2][2];
-        const float4v bq0 = *(const float4v*)(p.bqkv + hA * HD + g * 4), bq1 = *(const float4v*)(p.bqkv + hA * HD + 16 + g * 4);
+        const float4v bq0 = *(const float4v*)(Bq + hA * HD + g * 4), bq1 = *(const float4v*)(Bq + hA * HD + 16 + g * 4);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {      // q^T (bias = initial accumulator) and k^T (no bias): rows = features (A = weights), columns = slab rows (B = x)
             const float4v b0 = m == 0 ? bq0 : zero4, b1 = m == 0 ? bq1 : zero4;
@@ -373,6 +410,9 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
             pack_qk(a[1], m == 0, m == 0 ? qf[1] : kf[1]);
         }
         W2X_STAMP(1)
+#if W2X_A192_BIAS_AHEAD
+        load_bias(amask0, hA, ubias);
+#endif
         {                                  // v: rows = slab rows (A = x), columns = features (B = weights)
             float4v a[2][3][2] = {{{zero4, zero4}, {zero4, zero4}, {zero4, zero4}}, {{zero4, zero4}, {zero4, zero4}, {zero4, zero4}}};
             half8 xf[2][2][3];
@@ -391,8 +431,8 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
             pack_v(a[1], vf0[1], vf1[1]);
         }
         W2X_STAMP(2)
-        attend(0, hA, wok0, amask0, qf[0], kf[0], vf0[0], vf1[0], false);
-        attend(1, hA, wok1, amask1, qf[1], kf[1], vf0[1], vf1[1], false);
+        attend(0, hA, wok0, amask0, qf[0], kf[0], vf0[0], vf1[0], false, ubias, amask1);
+        attend(1, hA, wok1, amask1, qf[1], kf[1], vf0[1], vf1[1], false, ubias, -1);
         W2X_STAMP(3)
     }
     // ---- head hC on window wC
@@ -401,8 +441,8 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
         const _Float16* xs = Xs + wC * SLAB * LDX;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            const float4v b0 = m == 0 ? *(const float4v*)(p.bqkv + hC * HD + g * 4) : zero4;
-            const float4v b1 = m == 0 ? *(const float4v*)(p.bqkv + hC * HD + 16 + g * 4) : zero4;
+            const float4v b0 = m == 0 ? *(const float4v*)(Bq + hC * HD + g * 4) : zero4;
+            const float4v b1 = m == 0 ? *(const float4v*)(Bq + hC * HD + 16 + g * 4) : zero4;
             float4v a[2][3] = {{b0, b0, b0}, {b1, b1, b1}};
             half8 xf[3];
 #pragma unroll
@@ -418,6 +458,9 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
             }
             pack_qk(a, m == 0, m == 0 ? qf : kf);
         }
+#if W2X_A192_BIAS_AHEAD
+        load_bias(wC == 0 ? amask0 : amask1, hC, ubias);
+#endif
         {
             float4v a[3][2] = {{zero4, zero4}, {zero4, zero4}, {zero4, zero4}};
             half8 xf[3];
@@ -434,7 +477,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
             }
             pack_v(a, vf0, vf1);
         }
-        attend(wC, hC, wC == 0 ? wok0 : wok1, wC == 0 ? amask0 : amask1, qf, kf, vf0, vf1, true);
+        attend(wC, hC, wC == 0 ? wok0 : wok1, wC == 0 ? amask0 : amask1, qf, kf, vf0, vf1, true, ubias, -1);
         W2X_STAMP(4)
     }
 #undef W2X_RING_NEXT
