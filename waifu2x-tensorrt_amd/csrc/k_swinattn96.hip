@@ -41,6 +41,10 @@
 #ifndef W2X_A96_BUF
 #define W2X_A96_BUF 1
 #endif
+#ifndef W2X_A96_BQ_LDS
+#define W2X_A96_BQ_LDS 0       // 1: the q / k / v bias vectors are copied to LDS when the workgroup starts and read from there (k_swinattn192.hip gains 3 % from it).
+                               // Measured here: 0.516 against 0.502 ms - at 128 registers the LDS addresses cost three spilled registers and four waves per SIMD already cover the loads
+#endif
 #ifndef W2X_A96_XRES_EARLY
 #define W2X_A96_XRES_EARLY 2   // where the residual rows are requested: 0 in front of the projection (round 2), 1 after the last unit's q / k / v products
 #endif                         // (two registers spill), 2 after its score products.  Measured per launch: 0.524 / 0.534 / 0.518 ms (round 2: 0.550)
@@ -147,7 +151,8 @@ constexpr int SLAB = 48, RPX = G * SLAB;   // slab rows per window (tokens 0..31
 constexpr int LDX = C + 8;                 // 104 halves
 constexpr int XS = RPX * LDX, OS = RP * LDX;
 constexpr int NPAD = G * 12;                // slab rows between the left-over tokens (kept at zero)
-constexpr int SMEM96 = (XS + OS) * 2 + (RP + NPAD) * 8 + 16;
+constexpr int BQ_OFF = (XS + OS) * 2 + (RP + NPAD) * 8 + 16;   // q / k / v bias [3 * C] fp32 (W2X_A96_BQ_LDS)
+constexpr int SMEM96 = BQ_OFF + 3 * C * 4;
 constexpr int DUMMY = XS * 2;              // byte offset of a row nobody reads at that point (first row of Os): target of the stores of lanes / rows without data
 constexpr int LPR = 16, PPR = C / 8, RPP = NTHR / LPR, NPASS = RP / RPP;   // row passes: 16 lanes per row (12 carry data), 16 rows per pass, 5 passes
 static_assert(NPASS == 5, "the row sums are reduced as 3 + 2 passes");
@@ -230,6 +235,11 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
     const _Float16* wlane = Wqkv + lane * 8;
 #define W2X_WFRAG(SEL, H, KS) (*(const half8*)(wlane + (size_t)(((SEL) * NH + (H)) * 3 + (KS)) * 512))
 #define W2X_BQKV(OFF) (*(const float4v*)(p.bqkv + (OFF) + g * 4))
+#endif
+#if W2X_A96_BQ_LDS
+#undef W2X_BQKV
+#define W2X_BQKV(OFF) (*(const float4v*)((const float*)(smem + BQ_OFF) + (OFF) + g * 4))
+    if (tid < 3 * C / 4) *(float4v*)(smem + BQ_OFF + tid * 16) = *(const float4v*)(p.bqkv + tid * 4);   // (first use is two barriers away)
 #endif
 #define W2X_LOAD_W(H)                                                                           \
     _Pragma("unroll") for (int ks = 0; ks < 3; ++ks) {                                          \
