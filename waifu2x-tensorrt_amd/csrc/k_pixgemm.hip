@@ -164,8 +164,8 @@ __global__ __launch_bounds__(256, TT_ == 1 ? 3 : 2) void pixgemm_kernel(const Ge
         }
         const int nt0 = u * G;                      // first n-tile of the stage inside its sub-pixel
         const int dy = sg / r, dx = sg - dy * r;
-        // (CSO = 192: twelve pieces = 48 registers carried around the stage loop next to 48 of row fragments do not fit; there all twelve are
-        //  requested together when the sub-pixel is complete - one round trip per sub-pixel instead of one per piece)
+        // (more than eight pieces per lane - 192 output columns with two m-tiles per wave: twelve pieces = 48 registers next to 48 of row fragments -
+        //  do not fit; such a shape requests them in groups when the sub-pixel is complete.  The shipped 192-column shape runs one m-tile per wave.)
         constexpr bool EARLY = C::EARLY;
         if (EARLY && u == 0) {                      // (no skip connection: the resource is empty and the loads return zeros without touching memory)
             const unsigned rshift = (unsigned)((dy * p.res.Ws + dx) * p.res.Cs * 2);

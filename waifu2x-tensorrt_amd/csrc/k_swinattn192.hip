@@ -110,6 +110,9 @@ __device__ __forceinline__ float group_sum32(float v) {
 //   W2X_A192_BIAS_AHEAD  the rel-pos bias (+ mask) values of a unit (27 registers per lane, the initial accumulators of its score products) are
 //                        requested a phase ahead - before the v products for a head's first unit, under the first unit's softmax for the second -
 //                        instead of at the top of the unit.
+#ifndef W2X_A192_RING
+#define W2X_A192_RING 8        // weight-fragment registers of a wave (the ring described in the kernel)
+#endif
 #ifndef W2X_A192_BQ_LDS
 #define W2X_A192_BQ_LDS 1
 #endif
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
     // right after the last MFMA that used the register of fragment i - across matrix boundaries and across the softmax phases -
     // so a load has RING x 6 (or 3) MFMAs and everything between the products to land.  (Before: two alternating sets of 12
     // registers, 96 VGPRs, which the scheduler partly sank to the consumers anyway.)
-    constexpr int RING = 8, NFRAG = 72;
+    constexpr int RING = W2X_A192_RING, NFRAG = 72;
     // (through buffer resources: the lane part of a fragment address is lane * 16 for every fragment, the rest is scalar arithmetic -
     // as global loads each fragment cost a 64-bit vector add)
     const __amdgpu_buffer_rsrc_t WQ = make_rsrc(Wqkv, 3u * C * C * 2u), WP = make_rsrc(Wproj, (unsigned)C * C * 2u);
