@@ -130,6 +130,12 @@ __device__ __forceinline__ half8 norm8(const half8 v, float rstd, float nm) {
 #ifndef W2X_MLP2Q_EXP
 #define W2X_MLP2Q_EXP 0
 #endif
+// 1: the first chunk's weights get a buffer of their own behind the slabs (78 KB per workgroup, still two per CU) and are staged when the workgroup starts,
+// under the row fetch and the LayerNorm; 0: both buffers alias the slabs, chunk 0 is staged after the rows are in registers and waited for on the spot.
+// Measured equal (0.3025 / 0.0794 against 0.3004 / 0.0790 ms, profiles/r3_kernels/mlp2q_early0.txt): the CU's other workgroup already covers the wait.  Off.
+#ifndef W2X_MLP2Q_EARLY0
+#define W2X_MLP2Q_EARLY0 0
+#endif
 #ifndef W2X_MLP2Q_SPLITACC
 #define W2X_MLP2Q_SPLITACC 0
 #endif
@@ -378,7 +384,10 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r32 = lane & 31, h = lane >> 5;
     _Float16* Xw = (_Float16*)(smem + wv * K::SLAB);          // [RW][LDX]
-    unsigned char* const WBb = smem;                          // two weight buffers of NF fragments [64 lanes][8] (alias the slabs)
+    // two weight buffers of NF fragments [64 lanes][8]: odd chunks in the slab area (the rows are in registers by then), even chunks behind it (EARLY0) or there as well
+    constexpr int BUF0 = W2X_MLP2Q_EARLY0 ? K::NWV * K::SLAB : 0, BUF1 = W2X_MLP2Q_EARLY0 ? 0 : K::WBUF;
+    constexpr int BIASQ = W2X_MLP2Q_EARLY0 ? K::NWV * K::SLAB + K::WBUF : K::BIAS_OFF;
+    auto wbuf = [&](int ch) { return smem + ((ch & 1) ? BUF1 : BUF0); };
 
     const long row0 = ((long)blockIdx.x * K::NWV + wv) * RW;
     const long nrows = p.M - row0 < RW ? p.M - row0 : RW;
@@ -393,12 +402,15 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
 #pragma unroll
         for (int i = 0; i < NFW; ++i) {
             const int f = wv * NFW + i;
-            __builtin_amdgcn_global_load_lds((const void*)frag_src(ch, f), (__attribute__((address_space(3))) void*)(WBb + (size_t)(ch & 1) * K::WBUF + (size_t)f * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)frag_src(ch, f), (__attribute__((address_space(3))) void*)(wbuf(ch) + (size_t)f * 1024), 16, 0, 0);
         }
     };
-    auto lds_frag = [&](int ch, int j) { return *(const half8*)(WBb + (size_t)(ch & 1) * K::WBUF + (size_t)j * 1024 + lane * 16); };   // consumption order = storage order
-    for (int i = tid; i < 3 * C; i += K::NWV * 64) ((float*)(smem + K::BIAS_OFF))[i] = i < 2 * C ? p.b1[i] : p.b2[i - 2 * C];
-    const float* B1s = (const float*)(smem + K::BIAS_OFF) + h * 4;
+    auto lds_frag = [&](int ch, int j) { return *(const half8*)(wbuf(ch) + (size_t)j * 1024 + lane * 16); };   // consumption order = storage order
+#if W2X_MLP2Q_EARLY0
+    stage(0);                                  // the oldest requests of the wave: they land under the row fetch
+#endif
+    for (int i = tid; i < 3 * C; i += K::NWV * 64) ((float*)(smem + BIASQ))[i] = i < 2 * C ? p.b1[i] : p.b2[i - 2 * C];
+    const float* B1s = (const float*)(smem + BIASQ) + h * 4;
     const float* B2s = B1s + 2 * C;
 
     // ---- x rows: flat coalesced pieces -> slab -> LayerNorm in fragment layout (lane (r32, h): channels ks*16 + 8h .. +7 of row r32)
@@ -427,10 +439,15 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
         for (int ks = 0; ks < KS; ++ks) xreg[ks] = norm8(raw[ks], rstd, nm);
     }
     W2X_PHASE_FENCE();
+#if W2X_MLP2Q_EARLY0
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): this wave's share of chunk 0 (requested first) has landed
+    __syncthreads();                           // every wave holds its rows in registers: the slab area becomes the odd chunks' buffer
+#else
     __syncthreads();                           // every wave holds its rows in registers: the slab area becomes weight buffers
     stage(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): this wave's share of chunk 0 has landed
     __syncthreads();
+#endif
 
     half8 wr[RING];
 #pragma unroll
@@ -531,8 +548,9 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
 template <int C, int NW>
 hipError_t launch_mlp2q_c(const MlpParams& p, hipStream_t s) {
     using K = Mlp2Cfg<C, 2, NW>;
+    constexpr int SMEMQ = W2X_MLP2Q_EARLY0 ? K::NWV * K::SLAB + K::WBUF + 3 * C * 4 : K::SMEM;
     static unsigned lds_ok = 0;
-    if (hipError_t e = ensure_dynamic_lds((const void*)mlp2q_kernel<C, NW>, K::SMEM, lds_ok); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)mlp2q_kernel<C, NW>, SMEMQ, lds_ok); e != hipSuccess) return e;
     const long max_rows = (long)((0xFFF00000u / (C * 2)) / K::BM) * K::BM;
     for (long r0 = 0; r0 < p.M; r0 += max_rows) {
         MlpParams q = p;
@@ -540,7 +558,7 @@ hipError_t launch_mlp2q_c(const MlpParams& p, hipStream_t s) {
         q.x = (const char*)p.x + (size_t)r0 * C * 2; q.y = (char*)p.y + (size_t)r0 * C * 2;
         if (p.stats_out) q.stats_out = p.stats_out + 2 * r0;
         dim3 grid((unsigned)((q.M + K::BM - 1) / K::BM));
-        hipLaunchKernelGGL((mlp2q_kernel<C, NW>), grid, dim3(K::NWV * 64), K::SMEM, s, q);
+        hipLaunchKernelGGL((mlp2q_kernel<C, NW>), grid, dim3(K::NWV * 64), SMEMQ, s, q);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     }
     return hipSuccess;
