@@ -639,7 +639,8 @@ bool pixgemm_supported(const GemmParams& p) {
     if ((p.a_scale || p.res_scale) && p.a.Cs != 64 && p.a.Cs != 128) return false;   // gated operands: compiled into cunet's shapes only (PixCfg / MergeCfg GATES)
     if (!off && p.wt_frag && p.amode == 2 && p.kh == 2 && p.kw == 2 && p.stride == 2 && p.omode == 0 && !p.ln && (p.act == 0 || p.act == 1) && !p.has_clip &&
         !p.stats_out && !p.pool_out && !p.res.p && !p.res2.p && p.out.Cs == p.N && p.Kw == p.K && p.K == 4 * p.a.Cs && (long)p.out.Hs * p.out.Ws == p.Mrows && p.out.Ws == p.aW &&
-        (((p.a.Cs == 96 || p.a.Cs == 192) && p.N == 192) || (p.a.Cs == 64 && p.N == 64) || (p.a.Cs == 128 && p.N == 128))) return true;   // patch merge / cunet down convolution
+        (((p.a.Cs == 96 || p.a.Cs == 192) && p.N == 192 && (size_t)p.B * p.a.Hs * p.a.Ws * p.a.Cs * 2 < 0xFFFF0000u) ||   // (merge_kernel reads its map through 32-bit offsets)
+         (p.a.Cs == 64 && p.N == 64) || (p.a.Cs == 128 && p.N == 128))) return true;   // patch merge / cunet down convolution
     // rows = a Linear, or a 1x1 convolution: cunet's 2x2 stride-2 ConvTranspose is lowered to 1x1 + pixel shuffle with LeakyReLU and a
     // cropped skip add (K = 64 / 128)
     const bool rows = p.amode == 0 || (p.amode == 2 && p.kh == 1 && p.kw == 1);
