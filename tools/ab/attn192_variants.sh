@@ -11,7 +11,7 @@ for arg in "$@"; do
   src=$ROOT/waifu2x-tensorrt_amd/csrc/k_swinattn192.hip; fl="$arg"
   case "$arg" in SRC=*) src=${arg%% *}; src=${src#SRC=}; fl=${arg#SRC=$src}; ;; esac
   case "$fl" in STAMPS*) fl="${fl#STAMPS} -DW2X_A192_STAMPS"; hflags="-DW2X_A192_STAMPS";; esac
-  $CXX $fl -Dlaunch_swin_attn192=launch_swin_attn96_v$i -c "$src" -o $TMP/v$i.o
+  $CXX $fl -Dlaunch_swin_attn192=launch_swin_attn96_v$i -Dlaunch_swin_attn192w=launch_swin_attn96_v$i -c "$src" -o $TMP/v$i.o      # (the wide-workgroup file names its launcher ...192w)
   objs="$objs $TMP/v$i.o"; i=$((i+1))
 done
 $CXX -DNVAR=$i -DCW=192 $hflags -c $ROOT/tools/ab/attn96_variants.hip -o $TMP/main.o
