@@ -145,11 +145,18 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // same.  Everything else takes the per-pixel path.  (The output is 100 MB of u8 per 4K frame: single-byte stores and 8-byte loads
 // were the kernel's bound; four pixels per thread on the per-pixel path alone lose the loads' coalescing and measured slower.)
 // Launch shape (round 3): blockIdx.x / threadIdx.x pick the four-pixel column group, blockIdx.y a band of kComposeRows rows that the
-// thread walks.  Everything that depends on the column only (covering tile columns, whether the group takes the fast path, the ramp
+// thread walks (four: more rows per thread leave too few workgroups in flight, fewer repeat the column arithmetic).  Everything that depends on the column only (covering tile columns, whether the group takes the fast path, the ramp
 // weights of its four pixels) is computed once per thread, what depends on the row is the same for a whole workgroup (scalar
 // registers) - the flat grid-stride loop it replaces paid a 64-bit division and six 32-bit ones per four pixels, and the kernel ran at
 // 3.1 TB/s with its integer unit busier than its memory pipe.
-constexpr int kComposeRows = 8, kComposeThreads = 128;
+// (measured at config 3, profiles/r3_kernels/compose_geometry.txt: rows x threads 8 x 128 0.140 ms, 4 x 128 0.119, 16 x 128 0.177, 4 x 64 0.115-0.118, 2 x 64 0.117, 1 x 64 0.125)
+#ifndef W2X_COMPOSE_ROWS
+#define W2X_COMPOSE_ROWS 4
+#endif
+#ifndef W2X_COMPOSE_THREADS
+#define W2X_COMPOSE_THREADS 64
+#endif
+constexpr int kComposeRows = W2X_COMPOSE_ROWS, kComposeThreads = W2X_COMPOSE_THREADS;
 template <typename P>
 __global__ __launch_bounds__(kComposeThreads) void compose_kernel(const ComposeParams p) {
     constexpr bool kHalf = sizeof(P) == 8;                          // the four-pixel fast path reads fp16 tiles
