@@ -476,13 +476,16 @@ __global__ __launch_bounds__(256, 2) void merge_slab_kernel(const GemmParams p) 
 // Cin = 192) and waited for every sub-chunk's rows with nothing else to do: 2 - 4 exposed round trips to memory per workgroup.
 // The loop nest is fully unrolled (at most 24 stages), so which register set a stage uses and which loads are in flight at each wait
 // are compile-time facts.
+#ifndef W2X_MERGE_TT
+#define W2X_MERGE_TT 2        // m-tiles of 16 output pixels per wave (1: 64 pixels per workgroup, three workgroups per CU, twice the weight traffic from L2)
+#endif
 #ifndef W2X_MERGE_AHEAD
 #define W2X_MERGE_AHEAD 2
 #endif
 template <int CIN, int N, int SUB>
 struct MergeCfg {
     static constexpr int K = 4 * CIN, NT = N / 16, KST = K / 32, NQ = K / SUB, QPK = 2 * CIN / SUB, KSS = SUB / 32;   // sub-chunks total / per ky, k-steps per sub-chunk
-    static constexpr int TT = 2, RW = 32, G = 2, NF = G * KSS, NFW = NF / 4, LDS_ROW = N + 8;
+    static constexpr int TT = W2X_MERGE_TT, RW = 16 * TT, G = 2, NF = G * KSS, NFW = NF / 4, LDS_ROW = N + 8;
     static constexpr int PPO = N / 8, NPO = RW * PPO / 64;
     static constexpr int SPQ = NT / G, NSTAGE = NQ * SPQ;      // weight stages per sub-chunk / in all
     static constexpr int AHEAD = W2X_MERGE_AHEAD;
@@ -492,7 +495,7 @@ struct MergeCfg {
 };
 
 template <int CIN, int N, int SUB>
-__global__ __launch_bounds__(256, 2) void merge_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256, W2X_MERGE_TT == 1 ? 3 : 2) void merge_kernel(const GemmParams p) {
     using C = MergeCfg<CIN, N, SUB>;
     constexpr int NT = C::NT, KST = C::KST, NQ = C::NQ, QPK = C::QPK, KSS = C::KSS, SPQ = C::SPQ, NSTAGE = C::NSTAGE, D = C::AHEAD;
     constexpr int TT = C::TT, RW = C::RW, G = C::G, NFW = C::NFW, LDS_ROW = C::LDS_ROW;
@@ -624,9 +627,9 @@ hipError_t launch_merge(const GemmParams& p, hipStream_t s) {
         if (hipError_t e = ensure_dynamic_lds((const void*)merge_slab_kernel<CIN, N, SUB>, SM, lds_ok); e != hipSuccess) return e;
         hipLaunchKernelGGL((merge_slab_kernel<CIN, N, SUB>), grid, dim3(256), SM, s, p);
     } else {
-        constexpr int SM = MergeCfg<CIN, N, SUB>::SMEM;
+        constexpr int SM = MergeCfg<CIN, N, SUB>::SMEM, BMQ = 4 * MergeCfg<CIN, N, SUB>::RW;
         if (hipError_t e = ensure_dynamic_lds((const void*)merge_kernel<CIN, N, SUB>, SM, lds_ok); e != hipSuccess) return e;
-        hipLaunchKernelGGL((merge_kernel<CIN, N, SUB>), grid, dim3(256), SM, s, p);
+        hipLaunchKernelGGL((merge_kernel<CIN, N, SUB>), dim3((unsigned)((M + BMQ - 1) / BMQ)), dim3(256), SM, s, p);
     }
     return hipGetLastError();
 }
