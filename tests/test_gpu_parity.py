@@ -508,6 +508,30 @@ def test_two_tile_groups_on_two_streams_are_bit_identical_to_one(pkg, onnx_model
     assert np.array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("tile,batch,shape,tta", [(64, 2, (150, 170), False), (64, 2, (101, 119), True), (256, 4, (300, 420), False)])
+def test_image_head_folded_into_the_last_mlp_is_bit_identical(pkg, onnx_model, monkeypatch, tile, batch, shape, tta):
+    """The plan's last MLP and the image head behind it (Linear 96 -> 4x4 sub-pixels x 4 channels, Clip, DepthToSpace) run as ONE launch
+    (engine.cpp fuse_head, k_mlp96q.hip): the 96-channel map between them is neither stored nor read back.  W2X_NO_FUSE_HEAD=1 keeps the
+    two launches.  Same sums in the same order, so infer() - whose output tensor lives in the activation arena, where the head's output
+    must not be given the memory of the MLP's input - and render() - which writes into the frame slab - return the same bytes, also
+    through captured graphs and two tile groups; the tile-256 engine makes every wave of the persistent MLP kernel walk several tiles."""
+    path = onnx_model("swin_unet/art", 4, batch, tile, noise=3)
+    frame = smooth_frame(shape[0], shape[1], 12)
+    x = np.random.default_rng(31).random((batch, 3, tile, tile), dtype=np.float32)
+    outs = []
+    for nofuse in (True, False):
+        if nofuse: monkeypatch.setenv("W2X_NO_FUSE_HEAD", "1")
+        else: monkeypatch.delenv("W2X_NO_FUSE_HEAD")
+        eng = make_engine(pkg, path, batch, tile, 4, tta=tta)
+        ys = [eng.infer(x) for _ in range(2)]
+        rs = [eng.render(frame) for _ in range(3)]
+        assert np.array_equal(ys[0], ys[1]) and np.array_equal(rs[0], rs[1]) and np.array_equal(rs[0], rs[2])
+        outs.append((ys[0], rs[0]))
+        eng.close()
+    assert np.array_equal(outs[0][0], outs[1][0]), np.abs(outs[0][0] - outs[1][0]).max()
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("name,kw,tile", [
     ("window 8 (64 tokens)", dict(variant={"ws": 8}), 80),
     ("4 / 8 heads of 24 / 48", dict(variant={"heads": 4}), 64),

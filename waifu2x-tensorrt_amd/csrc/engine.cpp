@@ -203,6 +203,8 @@ struct Img2Img::Impl {
     std::vector<GemmParams> gemm;      // per op (kind == OP_GEMM)
     std::vector<int> pool_tensors;
     int final_op = -1;
+    std::vector<int> tensor_last;      // last op that touches each tensor (upload_plan)
+    std::vector<char> fuse_head;       // op i is a C = 96 MLP whose rows only feed the image head that follows: one launch (k_mlp96q.hip), op i + 1 is skipped
 
     // frame-level buffers (grown on demand, reused across frames like the reference's input/output GpuMats, img2img.h:37-38)
     bool deep = false;                   // the frame in d_frame / d_out has 16-bit samples (Image::depth == 16)
@@ -323,6 +325,19 @@ struct Img2Img::Impl {
             }
             first[plan.in_tensor] = -1;                       // written by the gather kernel before op 0
             last[plan.out_tensor] = nops;                     // read after the last op (infer) / replaced by the frame slab
+            tensor_last = last;
+            // An image head that rides on the MLP launch in front of it (fuse_head, decided below) writes its output WHILE that MLP still reads its input:
+            // the output must be alive from the MLP on, or it would be given the memory of the MLP's input, which dies at the MLP in the un-fused order.
+            fuse_head.assign(nops, 0);
+            if (plan.elt == 2 && !getenv("W2X_NO_FUSE_HEAD"))
+                for (int i = 0; i + 1 < nops; ++i) {
+                    const Op& a = plan.ops[i]; const Op& b = plan.ops[i + 1];
+                    if (a.kind == OP_MLP && b.kind == OP_GEMM && a.m.C == 96 && a.m.stats_out < 0 && b.g.a.t == a.m.y && last[a.m.y] == i + 1 && b.g.amode == A_ROWS && b.g.K == 96 && b.g.N == 64 &&
+                        b.g.r == 4 && b.g.omode == O_PIXSHUF && b.g.res.t < 0 && b.g.res2.t < 0 && b.g.act == ACT_NONE && !b.g.ln && b.g.se_scale < 0 && b.g.res_scale < 0 && b.g.stats_out < 0 && b.g.pool_out < 0) {
+                        fuse_head[i] = 1;
+                        first[b.g.out.t] = std::min(first[b.g.out.t], i);
+                    }
+                }
             struct Block { size_t off, size; };
             std::vector<Block> free_list;
             std::vector<size_t> off(nt, 0);
@@ -452,6 +467,13 @@ struct Img2Img::Impl {
             if (p.a.Cs != 4 && (p.a.Cs % 8)) throw std::runtime_error("plan: unaligned input channels");
         }
         if (final_op < 0) throw std::runtime_error("plan: the output tensor is not produced by a fused op");
+        // The image head (Linear 96 -> 4x4 sub-pixels x 4 channels, Clip) behind the last MLP: its input rows have no other reader, so the MLP launch
+        // runs the head on every tile it produces and neither stores nor re-reads the 96-channel map (W2X_NO_FUSE_HEAD=1 keeps the two launches).
+        for (size_t i = 0; i + 1 < plan.ops.size(); ++i)       // the candidates of the arena pass above, now with the prepared launch parameters
+            if (fuse_head[i]) {
+                const GemmParams& g = gemm[i + 1];
+                if (!(g.wt_frag && g.out.Cs == 4 && g.a.y0 == 0 && g.a.x0 == 0 && g.a.Ws == g.aW && (long)g.a.Hs * g.a.Ws == g.Mrows && g.Mrows % 32 == 0 && g.aW >= 32 && pixgemm_supported(g))) fuse_head[i] = 0;   // (k_mlp96q.hip: a 32-row tile inside one image, at most two token rows)
+            }
         hipAssert(hipStreamSynchronize(stream));
     }
 
@@ -475,11 +497,13 @@ struct Img2Img::Impl {
         auto tp = [&](int t) -> uint8_t* { return t < 0 ? nullptr : grp < 0 ? (uint8_t*)tensors[t] : group_ptr(tensors[t], grp); };
         auto shift = [&](const void* ptr, int) -> void* { return group_ptr(ptr, grp); };
         const int b0 = grp < 0 ? 0 : 1;   // (non-zero: re-address the prepared parameters)
+        bool skip_next = false;           // the op was folded into the previous launch (fuse_head)
         for (size_t i = 0; i < plan.ops.size(); ++i) try {
             const Op& op = plan.ops[i];
             cur_op = (int)i;
             switch (op.kind) {
                 case OP_GEMM: {
+                    if (skip_next) { skip_next = false; break; }
                     GemmParams p = gemm[i];
                     p.B = live;
                     if (b0) {
@@ -559,7 +583,17 @@ struct Img2Img::Impl {
                     p.w1_frag = frag_blobs[m.w1]; p.w2_frag = frag_blobs[m.w2]; p.frag32 = true;
                     p.eps = m.eps; p.stats_out = (float*)tp(m.stats_out); p.eps_out = m.eps_out;
                     if (d.C != m.C || plan.tensors[m.y].C != m.C) throw std::runtime_error("plan: MLP width mismatch");
-                    stamp_begin(5, op.flops);
+                    double flops = op.flops;
+                    if (fuse_head[i] && !check_general) {      // the image head rides on this launch
+                        const GemmParams& g = gemm[i + 1];
+                        void* out = b0 ? shift(g.out.p, plan.ops[i + 1].g.out.t) : g.out.p;
+                        if ((int)i + 1 == final_op && out_override) out = out_override;
+                        p.ti_w = g.wt_frag; p.ti_b = g.bias; p.ti_out = out; p.ti_Hs = g.out.Hs; p.ti_Ws = g.out.Ws; p.ti_Mrows = g.Mrows; p.ti_aW = g.aW;
+                        p.ti_clip = g.has_clip; p.ti_lo = g.clip_lo; p.ti_hi = g.clip_hi;
+                        flops += plan.ops[i + 1].flops;
+                        skip_next = true;
+                    }
+                    stamp_begin(5, flops);
                     hipAssert(launch_mlp(p, s));
                     stamp_end();
                     break;
@@ -868,7 +902,8 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
     }
     impl->cfg = config;
     W2X_LOG(info, "Loaded \"" + enginePath + "\": " + std::to_string(plan.ops.size()) + " ops, " + std::to_string(plan.B) + " tiles per pass, activation arena " +
-                      std::to_string(impl->arena_bytes >> 20) + " MiB.");
+                      std::to_string(impl->arena_bytes >> 20) + " MiB" +
+                      (std::count(impl->fuse_head.begin(), impl->fuse_head.end(), (char)1) ? ", image head folded into the last MLP launch." : "."));
     // :262-269 blend ramps
     impl->ovx = (int)std::lround(plan.T * config.scaling * config.overlapX);
     impl->ovy = (int)std::lround(plan.T * config.scaling * config.overlapY);

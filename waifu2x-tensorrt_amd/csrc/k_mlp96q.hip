@@ -151,6 +151,7 @@ constexpr int SMEM96Q = BIAS_OFF + 3 * C * 4;
 static_assert(RW * PPR % 64 == 0, "flat piece count");
 static_assert(SMEM96Q <= 160 * 1024, "LDS budget");
 
+template <bool TOIMG>
 __global__ __launch_bounds__(NTHR, 3) void mlp96q_kernel(const MlpParams p, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -290,6 +291,14 @@ __global__ __launch_bounds__(NTHR, 3) void mlp96q_kernel(const MlpParams p, int 
             }
         }
         W2X_PHASE_FENCE();
+        half8 wfh[2][3];                          // TOIMG: the head's first six weight fragments, requested here so that they land under the epilogue below
+        if (TOIMG) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) wfh[t][ks] = *(const half8*)((const _Float16*)p.ti_w + lane * 8 + (size_t)(t * 3 + ks) * 512);
+            W2X_RING_FENCE();
+        }
         // ---- epilogue: residual pieces from the slab (raw rows), accumulators -> fp16 tile in the slab, then flat pieces
         half8 xres[NP];
 #pragma unroll
@@ -309,9 +318,65 @@ __global__ __launch_bounds__(NTHR, 3) void mlp96q_kernel(const MlpParams p, int 
         for (int k = 0; k < NP; ++k) {
             const int idx = k * 64 + lane, r = idx / PPR, c = idx - r * PPR;
             const half8 o = *(const half8*)(Xw + r * LDX + c * 8) + xres[k];     // fp16 + fp16 rounded once == fp32 add rounded to fp16
-            if (!(W2X_MLP_EXP & 32)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, o), YB, yo + k * 1024u, 0, 0);
+            if (TOIMG) *(half8*)(Xw + r * LDX + c * 8) = o;                      // the rows go through the image head below instead of to y
+            else if (!(W2X_MLP_EXP & 32)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, o), YB, yo + k * 1024u, 0, 0);
         }
-        if (p.stats_out) {   // an un-fused consumer wants the LayerNorm statistics of the produced rows: put them back into the slab
+        if (TOIMG) {
+            // ---- image head: Linear 96 -> 64 = 4x4 sub-pixels x 4 stored channels, Clip, DepthToSpace(4) - the sums of toimage_kernel (k_pixgemm.hip), transposed:
+            // out^T = W y^T (rows = output columns, columns = tokens), so lane (token fr16, g4) of n-tile t ends with columns 16 t + 4 g4 .. + 3 = the four channels
+            // of sub-pixel (dy, dx) = (t, g4) of its token - a finished pixel, stored as 8 bytes; the four lane groups of a token write 32 contiguous bytes, the 16
+            // tokens of an m-tile 512.  No trip through LDS for the result.  The head's 12 weight fragments come from L2 per tile (12 KiB: LDS is full, and their
+            // 24 registers at a time are only free here, where the accumulators are dead).
+            W2X_PHASE_FENCE();
+            const int fr16 = lane & 15, g4 = lane >> 4;
+            const _Float16* Wt = (const _Float16*)p.ti_w + lane * 8;
+            // A tile lies inside one image (rows per image are a multiple of 32: mlp96q_supported) and spans at most two rows of its token map (row width >= 32)
+            const int row0i = __builtin_amdgcn_readfirstlane((int)row0);
+            const int bimg = row0i / p.ti_Mrows, ml0 = row0i - bimg * p.ti_Mrows;
+            const int oy0 = ml0 / p.ti_aW, ox0 = ml0 - oy0 * p.ti_aW;
+            _Float16* __restrict__ Og = (_Float16*)p.ti_out + (size_t)bimg * p.ti_Hs * p.ti_Ws * 4;
+            const half2v lo2 = {(_Float16)p.ti_lo, (_Float16)p.ti_lo}, hi2 = {(_Float16)p.ti_hi, (_Float16)p.ti_hi};
+#pragma unroll
+            for (int th = 0; th < 2; ++th) {      // two n-tiles at a time
+                half8 wf[2][3];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks) wf[t][ks] = th == 0 ? wfh[t][ks] : *(const half8*)(Wt + (size_t)((2 + t) * 3 + ks) * 512);
+                float4v acc[2][2];                // [n-tile of the pair][m-tile]
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float4v b = *(const float4v*)(p.ti_b + (2 * th + t) * 16 + g4 * 4);
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) acc[t][tt] = b;
+                }
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks) {
+                        const half8 xa = *(const half8*)(Xw + (tt * 16 + fr16) * LDX + ks * 32 + g4 * 8);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) acc[t][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t][ks], xa, acc[t][tt], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    int ox = ox0 + tt * 16 + fr16, oy = oy0;
+                    if (ox >= p.ti_aW) { ox -= p.ti_aW; ++oy; }
+                    const bool ok = row0 + tt * 16 + fr16 < p.M;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        half2v v01 = {(_Float16)acc[t][tt][0], (_Float16)acc[t][tt][1]}, v23 = {(_Float16)acc[t][tt][2], (_Float16)acc[t][tt][3]};
+                        if (p.ti_clip) {          // bounds that fp16 represents exactly (mlp96q_supported): clamping the rounded value in fp16 is clamping it in fp32 and rounding again
+                            v01 = __builtin_elementwise_min(__builtin_elementwise_max(v01, lo2), hi2);
+                            v23 = __builtin_elementwise_min(__builtin_elementwise_max(v23, lo2), hi2);
+                        }
+                        const half4 px = {v01[0], v01[1], v23[0], v23[1]};
+                        if (ok) *(half4*)(Og + ((size_t)(oy * 4 + 2 * th + t) * p.ti_Ws + ox * 4 + g4) * 4) = px;
+                    }
+                }
+            }
+        }
+        if (!TOIMG && p.stats_out) {   // an un-fused consumer wants the LayerNorm statistics of the produced rows: put them back into the slab
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const int idx = k * 64 + lane, r = idx / PPR, c = idx - r * PPR;
@@ -319,7 +384,7 @@ __global__ __launch_bounds__(NTHR, 3) void mlp96q_kernel(const MlpParams p, int 
             }
         }
         W2X_PHASE_FENCE();
-        if (p.stats_out && lane < nrows) {   // LayerNorm statistics of the produced rows for an un-fused consumer
+        if (!TOIMG && p.stats_out && lane < nrows) {   // LayerNorm statistics of the produced rows for an un-fused consumer
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int c = 0; c < PPR; ++c) sum_sq8(*(const half8*)(Xw + lane * LDX + c * 8), s, q);
@@ -334,11 +399,13 @@ __global__ __launch_bounds__(NTHR, 3) void mlp96q_kernel(const MlpParams p, int 
 
 }  // namespace
 
-bool mlp96q_supported(const MlpParams& p) { return p.C == C && p.w1_frag && p.w2_frag && p.frag32; }
+bool mlp96q_supported(const MlpParams& p) { return p.C == C && p.w1_frag && p.w2_frag && p.frag32 && (!p.ti_w || (p.ti_b && p.ti_out && !p.stats_out && p.ti_Mrows > 0 && p.ti_Mrows % RW == 0 && p.ti_aW >= RW && p.M < 0x7FFFFFFF &&
+                                                                 (!p.ti_clip || ((float)(_Float16)p.ti_lo == p.ti_lo && (float)(_Float16)p.ti_hi == p.ti_hi)))); }
 
 hipError_t launch_mlp96q(const MlpParams& p, hipStream_t s) {
     static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
-    if (hipError_t e = ensure_dynamic_lds((const void*)mlp96q_kernel, SMEM96Q, lds_ok); e != hipSuccess) return e;
+    static unsigned lds_ok_t = 0;
+    if (hipError_t e = p.ti_w ? ensure_dynamic_lds((const void*)mlp96q_kernel<true>, SMEM96Q, lds_ok_t) : ensure_dynamic_lds((const void*)mlp96q_kernel<false>, SMEM96Q, lds_ok); e != hipSuccess) return e;
     static int cus[32] = {0};     // compute units per device (one resident workgroup each)
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
@@ -357,7 +424,10 @@ hipError_t launch_mlp96q(const MlpParams& p, hipStream_t s) {
         const long ntiles = (q.M + RW - 1) / RW;
         const int grid = (int)std::min<long>((ntiles + NWV - 1) / NWV, ncu);
         if ((ntiles + (long)grid * NWV) * (long)(RW * C * 2) > 0xFFFFFFFFl) return hipErrorInvalidValue;   // (cannot happen below kMaxBufBytes with <= 1024 CUs)
-        hipLaunchKernelGGL(mlp96q_kernel, dim3(grid), dim3(NTHR), SMEM96Q, s, q, (int)ntiles);
+        if (p.ti_w) {
+            if (r0 != 0) return hipErrorInvalidValue;      // (the head indexes its output by the global row: one run only - 4 GB of x are 22 M rows, a pass has 2.8 M)
+            hipLaunchKernelGGL(mlp96q_kernel<true>, dim3(grid), dim3(NTHR), SMEM96Q, s, q, (int)ntiles);
+        } else hipLaunchKernelGGL(mlp96q_kernel<false>, dim3(grid), dim3(NTHR), SMEM96Q, s, q, (int)ntiles);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     }
     return hipSuccess;

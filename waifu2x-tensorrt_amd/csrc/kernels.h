@@ -72,6 +72,13 @@ struct MlpParams {               // y = x + W2 gelu(W1 LN(x) + b1) + b2 on conti
     const void* w1_frag = nullptr; const void* w2_frag = nullptr;
     // true: the fragment copies are in the 32x32x16 order of k_mlp96q.hip (fragorder.h frag32_major / frag32_w2; C = 96 in the engine)
     bool frag32 = false;
+    // Image head folded into the launch (engine.cpp: the plan's last MLP followed by Linear 96 -> 64 = 4x4 sub-pixels x 4 stored channels, DepthToSpace(4), Clip):
+    // y is not stored; every produced row goes through the head instead, out[b][4 oy + dy][4 ox + dx][0..3] = clip(fp16(y_row W^T + bias)) - the arithmetic of
+    // toimage_kernel (k_pixgemm.hip), bit for bit.  ti_w = null: no head.
+    const void* ti_w = nullptr;    // fp16 fragment-major [4 n-tiles][3 k-steps][64 lanes][8] (the head's GemmParams::wt_frag)
+    const float* ti_b = nullptr;   // fp32 [64]
+    void* ti_out = nullptr; int ti_Hs = 0, ti_Ws = 0, ti_Mrows = 0, ti_aW = 0;   // output map [B][Hs][Ws][4], rows per image, row width of the token map
+    int ti_clip = 0; float ti_lo = 0.f, ti_hi = 0.f;
 };
 
 struct SwinAttnParams {          // y = x + proj(W-MSA(LN(x))) on token maps [B][H][W][C], window 6x6
