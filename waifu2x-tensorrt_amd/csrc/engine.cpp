@@ -472,7 +472,8 @@ struct Img2Img::Impl {
         for (size_t i = 0; i + 1 < plan.ops.size(); ++i)       // the candidates of the arena pass above, now with the prepared launch parameters
             if (fuse_head[i]) {
                 const GemmParams& g = gemm[i + 1];
-                if (!(g.wt_frag && g.out.Cs == 4 && g.a.y0 == 0 && g.a.x0 == 0 && g.a.Ws == g.aW && (long)g.a.Hs * g.a.Ws == g.Mrows && g.Mrows % 32 == 0 && g.aW >= 32 && pixgemm_supported(g))) fuse_head[i] = 0;   // (k_mlp96q.hip: a 32-row tile inside one image, at most two token rows)
+                if (!(g.wt_frag && g.out.Cs == 4 && g.a.y0 == 0 && g.a.x0 == 0 && g.a.Ws == g.aW && (long)g.a.Hs * g.a.Ws == g.Mrows && g.Mrows % 32 == 0 && g.aW >= 32 && pixgemm_supported(g) &&
+                      (!g.has_clip || (f16_to_f32(f32_to_f16(g.clip_lo)) == g.clip_lo && f16_to_f32(f32_to_f16(g.clip_hi)) == g.clip_hi)))) fuse_head[i] = 0;   // (k_mlp96q.hip: a 32-row tile inside one image, at most two token rows; clip bounds that fp16 holds exactly)
             }
         hipAssert(hipStreamSynchronize(stream));
     }

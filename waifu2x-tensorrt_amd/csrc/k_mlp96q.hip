@@ -331,7 +331,7 @@ __global__ __launch_bounds__(NTHR, 3) void mlp96q_kernel(const MlpParams p, int 
             const int fr16 = lane & 15, g4 = lane >> 4;
             const _Float16* Wt = (const _Float16*)p.ti_w + lane * 8;
             // A tile lies inside one image (rows per image are a multiple of 32: mlp96q_supported) and spans at most two rows of its token map (row width >= 32)
-            const int row0i = __builtin_amdgcn_readfirstlane((int)row0);
+            const int row0i = __builtin_amdgcn_readfirstlane((int)(row0 + p.ti_row0));       // row index in the whole pass (launch_mlp96q cuts passes beyond 4 GB into runs)
             const int bimg = row0i / p.ti_Mrows, ml0 = row0i - bimg * p.ti_Mrows;
             const int oy0 = ml0 / p.ti_aW, ox0 = ml0 - oy0 * p.ti_aW;
             _Float16* __restrict__ Og = (_Float16*)p.ti_out + (size_t)bimg * p.ti_Hs * p.ti_Ws * 4;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(NTHR, 3) void mlp96q_kernel(const MlpParams p, int 
 
 }  // namespace
 
-bool mlp96q_supported(const MlpParams& p) { return p.C == C && p.w1_frag && p.w2_frag && p.frag32 && (!p.ti_w || (p.ti_b && p.ti_out && !p.stats_out && p.ti_Mrows > 0 && p.ti_Mrows % RW == 0 && p.ti_aW >= RW && p.M < 0x7FFFFFFF &&
+bool mlp96q_supported(const MlpParams& p) { return p.C == C && p.w1_frag && p.w2_frag && p.frag32 && (!p.ti_w || (p.ti_b && p.ti_out && !p.stats_out && p.ti_Mrows > 0 && p.ti_Mrows % RW == 0 && p.ti_aW >= RW && p.M < 0x7FFFFFFFl &&
                                                                  (!p.ti_clip || ((float)(_Float16)p.ti_lo == p.ti_lo && (float)(_Float16)p.ti_hi == p.ti_hi)))); }
 
 hipError_t launch_mlp96q(const MlpParams& p, hipStream_t s) {
@@ -425,7 +425,7 @@ hipError_t launch_mlp96q(const MlpParams& p, hipStream_t s) {
         const int grid = (int)std::min<long>((ntiles + NWV - 1) / NWV, ncu);
         if ((ntiles + (long)grid * NWV) * (long)(RW * C * 2) > 0xFFFFFFFFl) return hipErrorInvalidValue;   // (cannot happen below kMaxBufBytes with <= 1024 CUs)
         if (p.ti_w) {
-            if (r0 != 0) return hipErrorInvalidValue;      // (the head indexes its output by the global row: one run only - 4 GB of x are 22 M rows, a pass has 2.8 M)
+            q.ti_row0 = r0;
             hipLaunchKernelGGL(mlp96q_kernel<true>, dim3(grid), dim3(NTHR), SMEM96Q, s, q, (int)ntiles);
         } else hipLaunchKernelGGL(mlp96q_kernel<false>, dim3(grid), dim3(NTHR), SMEM96Q, s, q, (int)ntiles);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;

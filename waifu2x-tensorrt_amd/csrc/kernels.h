@@ -79,6 +79,7 @@ struct MlpParams {               // y = x + W2 gelu(W1 LN(x) + b1) + b2 on conti
     const float* ti_b = nullptr;   // fp32 [64]
     void* ti_out = nullptr; int ti_Hs = 0, ti_Ws = 0, ti_Mrows = 0, ti_aW = 0;   // output map [B][Hs][Ws][4], rows per image, row width of the token map
     int ti_clip = 0; float ti_lo = 0.f, ti_hi = 0.f;
+    long ti_row0 = 0;              // (set by the launcher when it cuts a pass into runs: global index of this run's first row)
 };
 
 struct SwinAttnParams {          // y = x + proj(W-MSA(LN(x))) on token maps [B][H][W][C], window 6x6
