@@ -57,11 +57,28 @@ def test_render_options_and_derived_names(tmp_path):
     (BASE + ["render", "-i", ".", "--blend", "0.3"], "--blend"),
     (BASE + ["render", "-i", ".", "--crf", "52"], "--crf"),
     (BASE + ["--precision", "int8", "build"], "--precision"),
+    (BASE + ["render", "-i", ".", "--tta", "--tta-mode", "median"], "--tta-mode"),
+    (BASE + ["render", "-i", ".", "--tta-mode", "reference"], "needs --tta"),
     (BASE + ["build", "--bogus"], "not expected"),
 ])
 def test_invalid_command_lines_are_rejected(args, msg):
     r = run(*args, "--print-config")
     assert r.returncode != 0 and msg in r.stderr, (r.returncode, r.stderr)
+
+
+def test_tta_mode_selects_the_reference_accumulation(tmp_path):
+    """main.cpp:118 has one --tta switch and img2img_render.cpp:313-316 one accumulation (not the mean).  The command line
+    offers both: --tta alone averages, --tta-mode reference (or --tta-compat) asks for the reference's bytes (RenderConfig::ttaBugCompat)."""
+    img = tmp_path / "a.png"; img.write_bytes(b"x")
+    modes = {}
+    for extra in ([], ["--tta-mode", "mean"], ["--tta-mode", "reference"], ["--tta-mode=Reference"], ["--tta-compat"]):
+        r = run(*BASE, "render", "-i", str(img), "--tta", *extra, "--print-config")
+        assert r.returncode == 0, r.stderr
+        c = json.loads(r.stdout)
+        assert c["tta"] and c["suffix"].endswith("(tta)")           # the output name is the reference's either way (main.cpp:205-209)
+        modes[" ".join(extra)] = c["tta_mode"]
+    assert modes == {"": "mean", "--tta-mode mean": "mean", "--tta-mode reference": "reference", "--tta-mode=Reference": "reference", "--tta-compat": "reference"}
+    assert "--tta-mode" in run("--help").stdout
 
 
 def test_help_lists_the_reference_flags():
@@ -405,6 +422,91 @@ def test_cli_deep_keeps_sixteen_bit_pngs(pkg, tmp_path):
         stride = 1 + w * 3 * bps
         got = np.stack([np.frombuffer(rows[y * stride + 1:(y + 1) * stride], ">u2" if flag else np.uint8).reshape(w, 3) for y in range(h)])   # filter 0 rows
         assert np.array_equal(got.astype(want.dtype), want)
+
+
+def _png16(path, a16):
+    """a16: (h, w, 3 or 4) uint16 RGB(A) -> 16-bit PNG, filter 0 rows"""
+    import struct, zlib
+    def chunk(t, body): return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body))
+    h, w, ch = a16.shape
+    raw = b"".join(b"\x00" + a16[y].astype(">u2").tobytes() for y in range(h))
+    open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 2 if ch == 3 else 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+def _read_png_rows(path):
+    import struct, zlib
+    d = open(path, "rb").read()
+    w, h, depth, ctype = struct.unpack(">IIBB", d[16:26])
+    idat = b"".join(d[p + 8:p + 8 + struct.unpack(">I", d[p:p + 4])[0]] for p in _png_chunks(d) if d[p + 4:p + 8] == b"IDAT")
+    rows = zlib.decompress(idat)
+    ch = {2: 3, 6: 4}[ctype]
+    stride = 1 + w * ch * (depth // 8)
+    assert all(rows[y * stride] == 0 for y in range(h))                       # the built-in writer emits filter 0 rows
+    return np.stack([np.frombuffer(rows[y * stride + 1:(y + 1) * stride], ">u2" if depth == 16 else np.uint8).reshape(w, ch) for y in range(h)]), depth
+
+
+@pytest.mark.gpu
+def test_cli_deep_on_a_sixteen_bit_rgba_png(pkg, tmp_path):
+    """--deep on colour types 4 / 6: the colour planes travel as CV_16UC3 (Bitmap::bgr16, Bitmap::bgr stays empty), the alpha plane's high
+    byte goes through the same engine as an 8-bit gray image and comes back widened (x257).  The alpha scratch images were once sized
+    from the empty 8-bit plane (heap overflow): the sizes now come from the geometry."""
+    import synth_models as sm
+    models = tmp_path / "models"
+    path = sm.model_path(str(tmp_path), "cunet/art", 2, 1)
+    sm.export_onnx(sm.make_model("cunet/art", 2, seed=6), path, 2, 64, dynamic=True)
+    rng = np.random.default_rng(18)
+    a16 = rng.integers(0, 65536, (41, 59, 4), dtype=np.uint16)               # RGBA
+    yy, xx = np.mgrid[0:41, 0:59]
+    a16[..., 3] = (np.clip(255 - np.hypot(yy - 20, xx - 30) * 9, 0, 255).astype(np.uint16) * 257)
+    _png16(tmp_path / "in.png", a16)
+    common = ["--models", str(models), "--model", "cunet/art", "--scale", "2", "--noise", "1", "--batchSize", "2", "--tileSize", "64"]
+    assert subprocess.run([W2X, *common, "build"], capture_output=True, text=True).returncode == 0
+    eng = pkg.Img2Img()
+    assert eng.load(path, pkg.RenderConfig(batchSize=2, height=64, width=64, scaling=2)), eng.last_error()
+    colour16 = eng.render(np.ascontiguousarray(a16[..., 2::-1]))[..., ::-1]
+    colour8 = eng.render(np.ascontiguousarray((a16[..., 2::-1] >> 8).astype(np.uint8)))[..., ::-1]
+    alpha8 = eng.render(np.ascontiguousarray(np.repeat((a16[..., 3:4] >> 8).astype(np.uint8), 3, axis=2)))[..., 1]
+    eng.close()
+    for flag, colour in ((["--deep"], colour16), ([], colour8)):
+        out = tmp_path / ("o16" if flag else "o8"); out.mkdir()
+        r = subprocess.run([W2X, *common, "render", "-i", str(tmp_path / "in.png"), "-o", str(out), *flag], capture_output=True, text=True, timeout=180)
+        assert r.returncode == 0, r.stderr
+        got, depth = _read_png_rows(out / "in(cunet_art)(noise1)(scale2).png")
+        assert depth == (16 if flag else 8) and got.shape == (82, 118, 4)
+        assert np.array_equal(got[..., :3].astype(colour.dtype), colour)
+        assert np.array_equal(got[..., 3].astype(np.int64), alpha8.astype(np.int64) * (257 if flag else 1))
+
+
+@pytest.mark.gpu
+def test_cli_tta_reference_mode_gives_the_reference_accumulation(pkg, tmp_path):
+    """`--tta --tta-mode reference` == the oracle pipeline with tta_bug_compat (img2img_render.cpp:305-318 as written, Q1) around the engine's
+    own network, byte for byte; plain `--tta` == the oracle's true mean; and the two differ."""
+    Image = pytest.importorskip("PIL.Image")
+    import synth_models as sm
+    from oracle import pipeline
+    models = tmp_path / "models"
+    path = sm.model_path(str(tmp_path), "swin_unet/art", 4, 3)
+    sm.export_onnx(sm.make_model("swin_unet/art", 4, seed=5, small=True), path, 2, 64, dynamic=True)
+    rng = np.random.default_rng(21)
+    rgb = rng.integers(0, 256, (70, 90, 3), dtype=np.uint8)
+    Image.fromarray(rgb).save(tmp_path / "in.png")
+    common = ["--models", str(models), "--model", "swin_unet/art", "--scale", "4", "--noise", "3", "--batchSize", "2", "--tileSize", "64"]
+    assert run(*common, "build").returncode == 0
+    eng = pkg.Img2Img()
+    assert eng.load(path, pkg.RenderConfig(batchSize=2, height=64, width=64, scaling=4, tta=True)), eng.last_error()
+    bgr = np.ascontiguousarray(rgb[..., ::-1])
+    outs = {}
+    for mode, bug in (("mean", False), ("reference", True)):
+        out = tmp_path / mode; out.mkdir()
+        r = run(*common, "render", "-i", str(tmp_path / "in.png"), "-o", str(out), "--tta", "--tta-mode", mode)
+        assert r.returncode == 0, r.stderr
+        got = np.array(Image.open(out / "in(swin_unet_art)(noise3)(scale4)(tta).png"))[..., ::-1]
+        ref = pipeline.render(bgr, eng.infer, batch=2, tile=64, scaling=4, overlap=(0.0625, 0.0625), tta=True, tta_bug_compat=bug,
+                              net_dtype=np.float16, tile_out=eng.output_tile_size)
+        assert np.array_equal(got, ref), mode
+        outs[mode] = got
+    eng.close()
+    assert not np.array_equal(outs["mean"], outs["reference"])
 
 
 def _png_chunks(d):

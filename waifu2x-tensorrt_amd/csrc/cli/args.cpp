@@ -62,6 +62,8 @@ std::string usage() {
            "  render                      Render image(s)/video(s)\n"
            "      -i,--input PATH ... REQUIRED   --recursive   -o,--output DIR   --nosuffix\n"
            "      --blend FLOAT [1/16] {1/8,1/16,1/32,0}   --tta   --codec TEXT [libx264]   --pix_fmt TEXT [yuv420p]   --crf INT [23] 0..51\n"
+           "      --tta-mode TEXT [mean]  (extension) {mean,reference}: with --tta, `mean` averages the 8 augmentations; `reference`\n"
+           "                              reproduces the bytes of the reference's accumulation (img2img_render.cpp:313-316); --tta-compat = reference\n"
            "  build                       Build model\n"
            "  convert -i IN -o OUT        (extension) re-encode one still image (png/ppm), no GPU\n";
 }
@@ -105,6 +107,8 @@ Options parse(int argc, const char* const* argv) {
         else if (k == "--nosuffix") o.nosuffix = true;
         else if (k == "--blend") o.blend = to_double(k, value(i));
         else if (k == "--tta") o.tta = true;
+        else if (k == "--tta-mode") { o.ttaMode = value(i); std::transform(o.ttaMode.begin(), o.ttaMode.end(), o.ttaMode.begin(), ::tolower); }
+        else if (k == "--tta-compat") o.ttaMode = "reference";
         else if (k == "--codec") o.codec = value(i);
         else if (k == "--pix_fmt") o.pixFmt = value(i);
         else if (k == "--crf") o.crf = to_int(k, value(i));
@@ -135,6 +139,8 @@ Options parse(int argc, const char* const* argv) {
         const double choices[] = {1.0 / 8.0, 1.0 / 16.0, 1.0 / 32.0, 0.0};
         if (std::none_of(std::begin(choices), std::end(choices), [&](double c) { return c == o.blend; })) throw std::runtime_error("--blend: not in {1/8,1/16,1/32,0}");
         if (o.crf < 0 || o.crf > 51) throw std::runtime_error("--crf: Value not in range 0 to 51");
+        member<std::string>("--tta-mode", o.ttaMode, {"mean", "reference"});
+        if (o.ttaMode == "reference" && !o.tta) throw std::runtime_error("--tta-mode reference: needs --tta");
     }
     // cross-checks, main.cpp:142-145
     if (o.model == "cunet/art" && o.scale == 4) throw std::runtime_error("cunet/art does not support scale factor 4.");
@@ -169,7 +175,7 @@ std::string to_json(const Options& o) {
     os << "{\"command\": " << q(o.command) << ", \"model\": " << q(o.model) << ", \"scale\": " << o.scale << ", \"noise\": " << o.noise
        << ", \"batchSize\": " << o.batchSize << ", \"tileSize\": " << o.tileSize << ", \"device\": " << o.device << ", \"devices\": " << o.devices
        << ", \"precision\": " << q(o.precision) << ", \"recursive\": " << (o.recursive ? "true" : "false") << ", \"output\": " << q(o.output)
-       << ", \"nosuffix\": " << (o.nosuffix ? "true" : "false") << ", \"blend\": " << o.blend << ", \"tta\": " << (o.tta ? "true" : "false")
+       << ", \"nosuffix\": " << (o.nosuffix ? "true" : "false") << ", \"blend\": " << o.blend << ", \"tta\": " << (o.tta ? "true" : "false") << ", \"tta_mode\": " << q(o.ttaMode)
        << ", \"codec\": " << q(o.codec) << ", \"pix_fmt\": " << q(o.pixFmt) << ", \"crf\": " << o.crf << ", \"inputs\": [";
     for (size_t i = 0; i < o.inputs.size(); ++i) os << (i ? ", " : "") << q(o.inputs[i]);
     os << "], \"model_path\": " << q(o.command == "convert" ? "" : model_path(o)) << ", \"suffix\": " << q(o.command == "convert" ? "" : output_suffix(o)) << ", \"outputs\": [";

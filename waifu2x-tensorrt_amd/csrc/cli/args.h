@@ -27,6 +27,8 @@ struct Options {
     // extensions
     int devices = 1;                      // --devices N: frames of a video round-robin, a single image as tile-column strips
     std::string models = "models";        // --models DIR: root of models/<model>/... (reference: fixed relative "models/")
+    std::string ttaMode = "mean";         // --tta-mode {mean,reference}: mean = the true average of the 8 augmentations; reference = the bytes the
+                                          // reference's accumulation produces (img2img_render.cpp:313-316) -> RenderConfig::ttaBugCompat
     bool deep = false;                    // --deep: 16-bit PNGs keep 16 bits per sample (read, rendered and written as CV_16UC3; default: cut to 8 like cv::imread)
     bool printConfig = false;             // --print-config: dump the parsed options and derived names as JSON and exit (tests)
     bool help = false;

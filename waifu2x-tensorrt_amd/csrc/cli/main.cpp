@@ -168,13 +168,14 @@ int main(int argc, char** argv) {
         if (o.command == "convert") { cli::write_image(o.output, cli::read_image(o.inputs[0])); return 0; }
 
         const std::string modelPath = cli::model_path(o);
-        size_t fileIndex = 0, fileCount = 0, frameIndex = 0, frameCount = 0;
+        // the progress callback runs on the engines' worker threads while the writer thread advances the frame counter
+        std::atomic<size_t> fileIndex{0}, fileCount{0}, frameIndex{0}, frameCount{0};
         auto on_message = [](Severity s, const std::string& m) {
             static const char* names[] = {"critical", "error", "warning", "info", "debug", "trace"};
             std::cerr << "[" << names[(int)s < 6 ? (int)s : 5] << "] " << m << "\n";
         };
         auto on_progress = [&](int current, int total, double speed) {
-            fprintf(stderr, "[info] Rendered file %zu/%zu, frame %zu/%zu, batch %d/%d @ %.2f it/s\n", fileIndex, fileCount, frameIndex, frameCount, current, total, speed);
+            fprintf(stderr, "[info] Rendered file %zu/%zu, frame %zu/%zu, batch %d/%d @ %.2f it/s\n", fileIndex.load(), fileCount.load(), frameIndex.load(), frameCount.load(), current, total, speed);
         };
         const Precision prec = o.precision == "tf32" ? Precision::TF32 : Precision::FP16;
 
@@ -201,7 +202,7 @@ int main(int argc, char** argv) {
             if (d == 0) engines.back()->setProgressCallback(on_progress);
             RenderConfig c;
             c.deviceId = o.device + d; c.precision = prec; c.batchSize = o.batchSize; c.channels = 3; c.height = c.width = o.tileSize; c.scaling = o.scale;
-            c.overlapX = c.overlapY = o.blend; c.tta = o.tta;
+            c.overlapX = c.overlapY = o.blend; c.tta = o.tta; c.ttaBugCompat = o.ttaMode == "reference";
             if (!engines.back()->load(modelPath, c)) return -1;
         }
         const std::vector<std::string> files = find_inputs(o);
@@ -234,9 +235,10 @@ int main(int argc, char** argv) {
                 if (!ok) return -1;
                 if (!in.alpha.empty()) {   // the alpha plane as a gray image through the same engine; its green channel is the new alpha
                     cli::Bitmap ga, go;
-                    ga.rows = in.rows; ga.cols = in.cols; ga.bgr.resize(in.bgr.size());
+                    // sized from the geometry: with --deep the colour planes live in bgr16 and in.bgr / out.bgr are empty
+                    ga.rows = in.rows; ga.cols = in.cols; ga.bgr.resize((size_t)in.rows * in.cols * 3);
                     for (size_t i = 0; i < in.alpha.size(); ++i) ga.bgr[3 * i] = ga.bgr[3 * i + 1] = ga.bgr[3 * i + 2] = in.alpha[i];
-                    go.bgr.resize(out.bgr.size());
+                    go.bgr.resize((size_t)out.rows * out.cols * 3);
                     Image as{ga.bgr.data(), in.rows, in.cols, (size_t)in.cols * 3}, ad{go.bgr.data(), out.rows, out.cols, (size_t)out.cols * 3};
                     if (!render_still(as, ad)) return -1;
                     out.alpha.resize((size_t)out.rows * out.cols);

@@ -69,6 +69,18 @@ struct DeviceGuard {
     DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
+// "" when `physical` is a device of this process, else the sentence build() / load() log (a raw "invalid device ordinal" names neither the
+// count nor the map that produced the ordinal)
+std::string device_ordinal_problem(int logical, int physical) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); count = 0; }
+    if (count <= 0) return "no HIP device is visible to this process (hipGetDeviceCount = 0): this library has no CPU path";
+    if (physical >= 0 && physical < count) return "";
+    std::string m = "device id " + std::to_string(logical);
+    if (physical != logical) m += " (W2X_DEVICE_MAP -> " + std::to_string(physical) + ")";
+    return m + " does not exist: this process sees " + std::to_string(count) + " HIP device" + (count == 1 ? "" : "s") + " (valid ids 0.." + std::to_string(count - 1) + ")";
+}
+
 std::string precision_name(Precision p) { return p == Precision::FP16 ? "FP16" : "TF32"; }
 
 // img2img_build.cpp:8-27
@@ -762,6 +774,10 @@ void Img2Img::setProgressCallback(ProgressCallback callback) { impl->progressCal
 bool Img2Img::build(const std::string& onnxModelPath, const BuildConfig& config) try {
     // img2img_build.cpp:56-64
     const int dev = physical_device(config.deviceId);
+    if (const std::string why = device_ordinal_problem(config.deviceId, dev); !why.empty()) {
+        W2X_LOG(error, "Failed to set hip device: " + why + ".");
+        return false;
+    }
     std::unique_ptr<DeviceGuard> guard;
     try {
         guard.reset(new DeviceGuard(dev));
@@ -813,6 +829,10 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
     namespace fs = std::filesystem;
     // img2img_load.cpp:127-135
     const int dev = physical_device(config.deviceId);
+    if (const std::string why = device_ordinal_problem(config.deviceId, dev); !why.empty()) {
+        W2X_LOG(error, "Failed to set hip device: " + why + ".");
+        return false;
+    }
     std::unique_ptr<DeviceGuard> guard;
     try {
         guard.reset(new DeviceGuard(dev));
