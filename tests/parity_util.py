@@ -48,10 +48,20 @@ def network_report(name, y, ref16, ref32=None):
            "max_ulp16": float(d.max() / ULP16), "p999_ulp16": float(np.quantile(d, 0.999) / ULP16),
            "max_ulp_of_ref_top_binade": float((d / ulp_ref).max()) if top.any() else 0.0}
     if ref32 is not None:
-        d32 = np.abs(y.astype(np.float64) - ref32.astype(np.float64))
-        o = np.abs(ref16.astype(np.float64) - ref32.astype(np.float64))
+        e32 = y.astype(np.float64) - ref32.astype(np.float64)
+        o32 = ref16.astype(np.float64) - ref32.astype(np.float64)
+        d32, o = np.abs(e32), np.abs(o32)
+        # the engine and the fp16-boundary oracle are two fp16 evaluations of the same fp32 function: each sits within ~2 ULP16 of the fp32
+        # value, their mutual distance is largest where they fall on opposite sides of it.  `straddle_at_worst` = the two signed errors
+        # (ULP16) at the element where |engine - fp16 oracle| is largest.
+        k = np.unravel_index(int(np.argmax(d)), d.shape)
         rec.update({"max_ulp16_vs_fp32_oracle": float(d32.max() / ULP16), "mean_abs_vs_fp32_oracle": float(d32.mean()),
-                    "fp16_oracle_vs_fp32_oracle_max_ulp16": float(o.max() / ULP16)})
+                    "p999_ulp16_vs_fp32_oracle": float(np.quantile(d32, 0.999) / ULP16),
+                    "rms_ulp16_vs_fp32_oracle": float(np.sqrt(np.mean(e32 ** 2)) / ULP16),
+                    "fp16_oracle_vs_fp32_oracle_max_ulp16": float(o.max() / ULP16),
+                    "fp16_oracle_vs_fp32_oracle_p999_ulp16": float(np.quantile(o, 0.999) / ULP16),
+                    "fp16_oracle_vs_fp32_oracle_rms_ulp16": float(np.sqrt(np.mean(o32 ** 2)) / ULP16),
+                    "straddle_at_worst": [round(float(e32[k] / ULP16), 3), round(float(o32[k] / ULP16), 3)]})
     _record(rec)
     return rec
 
@@ -62,6 +72,21 @@ def frame_report(name, out, ref):
            "frac_pixels_off_by_1": float((d == 1).mean()), "frac_pixels_off_by_more": float((d > 1).mean())}
     _record(rec)
     return rec
+
+
+# The engine measured against an IDEAL fp16 engine (asserted next to the absolute bounds): against the fp32 oracle the engine must not be
+# further off than the fp16-boundary oracle is - the oracle's per-operator-fp16 model of an engine with fp32 accumulation - beyond a small
+# allowance for where the two round differently.  Measured (profiles/r3_late/parity.jsonl, every graph family): engine max 1.04-2.33 vs
+# oracle max 1.04-2.40 ULP16, differences -0.13..+0.14.
+REL_MAX_ALLOW = 0.5      # ULP16 on the maxima (a maximum over 1e5-1e7 elements of a quantised quantity moves in steps; measured <= +0.14)
+REL_RMS_FACTOR = 1.10    # on the rms errors
+REL_P999_ULP16 = 2.0     # p99.9 of |engine - fp32 oracle| (measured <= 2.0 on every graph)
+
+
+def assert_as_accurate_as_ideal_fp16(r):
+    assert r["max_ulp16_vs_fp32_oracle"] <= r["fp16_oracle_vs_fp32_oracle_max_ulp16"] + REL_MAX_ALLOW, r
+    assert r["rms_ulp16_vs_fp32_oracle"] <= REL_RMS_FACTOR * r["fp16_oracle_vs_fp32_oracle_rms_ulp16"], r
+    assert r["p999_ulp16_vs_fp32_oracle"] <= REL_P999_ULP16, r
 
 
 BLOCK_MEAN_TOL = 0.12    # u8 LSB: engine frames differ from the oracle's by <= 1 LSB on a few per cent of the pixels (measured block-mean differences <= 0.06)

@@ -17,7 +17,8 @@ import pytest
 
 import synth_models as sm
 from oracle import onnx_exec, pipeline
-from parity_util import BLOCK_MEAN_TOL, ULP16, check_config_fixture, frame_report, network_report, psnr, smooth_frame  # noqa: F401
+from parity_util import (BLOCK_MEAN_TOL, ULP16, assert_as_accurate_as_ideal_fp16, check_config_fixture, frame_report, network_report, psnr,  # noqa: F401
+                         smooth_frame)
 
 pytestmark = pytest.mark.gpu
 
@@ -42,7 +43,10 @@ def make_engine(pkg, path, batch, tile, scale, **kw):
 @pytest.mark.parametrize("model,scale,batch,tile,small", [
     ("cunet/art", 2, 1, 64, False), ("cunet/art", 2, 3, 96, False), ("cunet/art", 1, 2, 64, False),
     ("swin_unet/art", 4, 2, 64, True), ("swin_unet/art", 4, 1, 64, False), ("swin_unet/photo", 2, 2, 88, False),
-    ("swin_unet/art_scan", 1, 1, 64, False), ("swin_unet/art", 4, 1, 112, False)])
+    ("swin_unet/art_scan", 1, 1, 64, False), ("swin_unet/art", 4, 1, 112, False),
+    # the tile size of configs[1] / configs[2] (BASELINE.json): persistent MLP waves walking several tiles, 120^2 / 60^2 attention levels,
+    # the image head folded into the last MLP launch; 2 s of oracle per tile and mode
+    ("swin_unet/art", 4, 1, 256, False), ("cunet/art", 2, 1, 256, False)])
 def test_network_matches_oracle(pkg, onnx_model, model, scale, batch, tile, small):
     """trt::Img2Img::infer (img2img_infer.cpp:41-93): [B,3,T,T] -> [B,3,T',T'] on the same ONNX weights."""
     path = onnx_model(model, scale, batch, tile, small=small)
@@ -59,12 +63,35 @@ def test_network_matches_oracle(pkg, onnx_model, model, scale, batch, tile, smal
     assert r["max_ulp16"] <= (NET_MAX_ULP16_UNFUSED if small else NET_MAX_ULP16) and r["mean_abs"] <= NET_MEAN_ABS, r
     # and against fp32 arithmetic itself: a loss of accuracy that the fp16-boundary oracle happens to share would still fail here
     assert r["max_ulp16_vs_fp32_oracle"] <= NET_MAX_ULP16_VS_FP32 and r["mean_abs_vs_fp32_oracle"] <= NET_MEAN_ABS, r
+    # ... and relative to an ideal fp16 engine: no further from fp32 than the fp16-boundary oracle is
+    assert_as_accurate_as_ideal_fp16(r)
     # batch items are independent: same tile in slot 0 and slot B-1 gives the same bytes
     if batch > 1:
         x2 = np.repeat(x[:1], batch, axis=0)
         y2 = eng.infer(x2)
         assert np.array_equal(y2[0], y2[-1])
     eng.close()
+
+
+def test_network_at_shipping_tile_sizes_against_fixture(pkg, onnx_model):
+    """configs[3]'s tile (T = 400, T' = 1536) against the COMMITTED oracle output (tests/golden/net_swin_s4_t400.npz from
+    make_net_fixture.py: windows of the fp32 and of the fp16-boundary oracle's output for one seeded tile).  Same bounds as above."""
+    from golden.make_net_fixture import tile_input
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "net_swin_s4_t400.npz"))
+    model, scale, noise, tile, seed = str(z["model"]), int(z["scale"]), int(z["noise"]), int(z["tile"]), int(z["seed"])
+    path = onnx_model(model, scale, 1, tile, noise=noise)
+    eng = make_engine(pkg, path, 1, tile, scale)
+    y = eng.infer(tile_input(tile, seed))[0]
+    eng.close()
+    assert not np.isnan(y).any()
+    got = np.stack([y[:, y0:y0 + h, x0:x0 + w] for y0, x0, h, w in z["windows"]])
+    r = network_report(f"network[{model} s{scale} B1 T{tile} full, committed oracle windows]", got, z["ref16"].astype(np.float32), z["ref32"])
+    assert r["max_ulp16"] <= NET_MAX_ULP16 and r["mean_abs"] <= NET_MEAN_ABS and r["max_ulp16_vs_fp32_oracle"] <= NET_MAX_ULP16_VS_FP32, r
+    assert_as_accurate_as_ideal_fp16(r)
+    # whole-output checksum: the per-channel sums of all 3 x 1536^2 values against the fp32 oracle's (mean error per element, in ULP16)
+    drift = np.abs(y.astype(np.float64).sum(axis=(1, 2)) - z["sum32"]) / y[0].size / ULP16
+    print("PARITY " + str({"test": "network T400 whole-output mean drift per channel (ULP16)", "drift": drift.tolist()}), flush=True)
+    assert drift.max() <= 0.1, drift
 
 
 @pytest.mark.parametrize("model,scale,batch,tile,small,ov,tta,shape", [

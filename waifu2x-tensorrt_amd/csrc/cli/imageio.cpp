@@ -27,6 +27,16 @@ std::vector<uint8_t> slurp(const std::string& path) {
 uint32_t be32(const uint8_t* p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
 void put32(std::vector<uint8_t>& v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
 
+// Frame sizes the built-in codecs accept: headers are untrusted, and everything downstream sizes buffers as rows * cols * 3.  2^28 pixels
+// (16384 x 16384) is an 805 MB frame; OpenCV, which decodes for the reference, stops at 2^30 (CV_IO_MAX_IMAGE_PIXELS).
+constexpr int kMaxSide = 1 << 24;
+constexpr long long kMaxPixels = 1ll << 28;
+void check_dims(const std::string& path, long long w, long long h) {
+    if (w <= 0 || h <= 0) throw std::runtime_error(path + ": image without a size (" + std::to_string(w) + " x " + std::to_string(h) + ")");
+    if (w > kMaxSide || h > kMaxSide || w * h > kMaxPixels)
+        throw std::runtime_error(path + ": " + std::to_string(w) + " x " + std::to_string(h) + " pixels is beyond what the built-in codecs take (2^28 pixels); convert through ffmpeg");
+}
+
 int paeth(int a, int b, int c) { int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); return pa <= pb && pa <= pc ? a : pb <= pc ? b : c; }
 
 Bitmap read_png(const std::vector<uint8_t>& d, const std::string& path, bool keep16) {
@@ -39,7 +49,11 @@ Bitmap read_png(const std::vector<uint8_t>& d, const std::string& path, bool kee
         const std::string type((const char*)&d[pos + 4], 4);
         if (pos + 12 + len > d.size()) throw std::runtime_error(path + ": truncated PNG chunk");
         const uint8_t* body = &d[pos + 8];
-        if (type == "IHDR") { w = (int)be32(body); h = (int)be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12]; }
+        if (type == "IHDR") {
+            if (len < 13) throw std::runtime_error(path + ": short IHDR chunk");
+            check_dims(path, be32(body), be32(body + 4));
+            w = (int)be32(body); h = (int)be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12];
+        }
         else if (type == "PLTE") plte.assign(body, body + len);
         else if (type == "IDAT") idat.insert(idat.end(), body, body + len);
         else if (type == "IEND") break;
@@ -66,6 +80,9 @@ Bitmap read_png(const std::vector<uint8_t>& d, const std::string& path, bool kee
     };
     size_t total = 0;
     for (int k = 0; k < npass; ++k) { int pw, ph; size_t st; pass_dims(interlace ? adam7[k] : whole, pw, ph, st); if (pw && ph) total += (st + 1) * ph; }
+    // deflate expands by at most ~1032 : 1: a header that announces more scanline bytes than the IDAT data can hold is refused before anything of
+    // that size is allocated
+    if (idat.empty() || total > idat.size() * 1032 + 64) throw std::runtime_error(path + ": PNG data is shorter than the image the header announces");
     std::vector<uint8_t> raw(total);
     uLongf rawlen = raw.size();
     if (uncompress(raw.data(), &rawlen, idat.data(), idat.size()) != Z_OK || rawlen != raw.size()) throw std::runtime_error(path + ": PNG data does not inflate");
@@ -169,6 +186,7 @@ Bitmap read_bmp(const std::vector<uint8_t>& d, const std::string& path) {
     if (hdr < 40) throw std::runtime_error(path + ": unsupported BMP header");
     const int w = (int)le32(&d[18]), hs = (int)le32(&d[22]), bits = le16(&d[28]);
     const uint32_t comp = le32(&d[30]);
+    check_dims(path, w, hs < 0 ? -(long long)hs : hs);
     const int h = hs < 0 ? -hs : hs;
     if (w <= 0 || h <= 0 || (bits != 24 && bits != 32) || !(comp == 0 || (comp == 3 && bits == 32))) throw std::runtime_error(path + ": unsupported BMP (24 / 32-bit uncompressed only)");
     if (comp == 3 && (d.size() < 54 + 12 || le32(&d[54]) != 0x00FF0000u || le32(&d[58]) != 0x0000FF00u || le32(&d[62]) != 0x000000FFu)) throw std::runtime_error(path + ": unsupported BMP channel masks");
@@ -213,11 +231,14 @@ Bitmap read_ppm(const std::vector<uint8_t>& d, const std::string& path) {
     size_t pos = 0;
     auto token = [&]() {
         while (pos < d.size() && (isspace(d[pos]) || d[pos] == '#')) { if (d[pos] == '#') while (pos < d.size() && d[pos] != '\n') ++pos; else ++pos; }
-        std::string t; while (pos < d.size() && !isspace(d[pos])) t += (char)d[pos++];
+        std::string t; while (pos < d.size() && !isspace(d[pos]) && t.size() < 16) t += (char)d[pos++];
         return t;
     };
     if (token() != "P6") throw std::runtime_error(path + ": not a binary PPM (P6)");
-    const int w = atoi(token().c_str()), h = atoi(token().c_str()), mx = atoi(token().c_str());
+    auto number = [&]() { const std::string t = token(); char* end = nullptr; const long v = strtol(t.c_str(), &end, 10); if (t.empty() || *end) throw std::runtime_error(path + ": bad PPM header"); return v; };
+    const long wl = number(), hl = number(), mx = number();
+    check_dims(path, wl, hl);
+    const int w = (int)wl, h = (int)hl;
     ++pos;
     if (w <= 0 || h <= 0 || mx != 255 || pos + (size_t)w * h * 3 > d.size()) throw std::runtime_error(path + ": unsupported or truncated PPM");
     Bitmap b; b.rows = h; b.cols = w; b.bgr.resize((size_t)w * h * 3);
@@ -290,8 +311,8 @@ bool AviReader::open(const std::string& path, std::string* why) {
     }
     if (!have_fmt || !movi_end_) return no("no video stream / no movi list");
     if (comp != 0 || bits != 24) return no("the video stream is not uncompressed 24-bit (BI_RGB)");
+    if (info_.width <= 0 || hs == 0 || hs == INT32_MIN || info_.width > kMaxSide || (hs < 0 ? -hs : hs) > kMaxSide || (long long)info_.width * (hs < 0 ? -hs : hs) > kMaxPixels) return no("bad frame size");
     info_.height = hs < 0 ? -hs : hs; bottom_up_ = hs > 0;
-    if (info_.width <= 0 || info_.height <= 0) return no("bad frame size");
     info_.fps = scale && rate ? (double)rate / scale : usec ? 1e6 / usec : 30.0;
     if (info_.frames <= 0) info_.frames = 1;
     row_.resize(dib_stride(info_.width, 24));

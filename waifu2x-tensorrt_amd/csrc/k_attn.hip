@@ -235,9 +235,4 @@ hipError_t launch_attn(const AttnParams& p, hipStream_t s) {
 
 // what launch_attn() takes: lower.cpp asks before it emits an OP_ATTN, so that a graph with another window or head size fails at build
 // time naming the node instead of at the first render
-bool attn_supported(int hd, int ntok) {
-    if (ntok != 36 && ntok != 64) return false;
-    return hd == 8 || hd == 16 || hd == 24 || hd == 32 || hd == 48 || hd == 64;
-}
-
 }  // namespace w2x

@@ -9,11 +9,6 @@ hipError_t launch_mlp2(const MlpParams& p, hipStream_t s);                // k_m
 hipError_t launch_swin_attn96(const SwinAttnParams& p, hipStream_t s);    // k_swinattn96.hip
 hipError_t launch_swin_attn192(const SwinAttnParams& p, hipStream_t s);   // k_swinattn192.hip
 
-bool swin_attn_supported(int C, int heads, int hd, int ws) {
-    return ws == 6 && heads * hd == C && ((C == 96 && hd == 16) || (C == 192 && hd == 32));
-}
-bool mlp_supported(int C) { return C == 96 || C == 192; }
-
 hipError_t launch_swin_attn(const SwinAttnParams& p, hipStream_t s) {
     if (!p.wqkv_frag || !p.wproj_frag) return hipErrorInvalidValue;       // the kernels read fragment-major weights only
     if (p.C == 96 && p.hd == 16) return launch_swin_attn96(p, s);

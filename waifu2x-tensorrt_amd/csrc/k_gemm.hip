@@ -356,6 +356,4 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
 }
 
 // widths whose rows fit one workgroup tile of launch_gemm() (bn >= N): only those can carry LayerNorm statistics out of the epilogue
-bool gemm_row_stats_supported(int N) { return N == 32 || N == 48 || N == 64 || N == 96 || N == 128 || N == 192; }
-
 }  // namespace w2x

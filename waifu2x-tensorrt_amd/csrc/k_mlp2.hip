@@ -462,6 +462,11 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
             for (int j = 0; j < 4; ++j) acc2[nt][4 * q + j] = b[j];
         }
     half8 xres[NP];
+#if defined(W2X_MLP2Q_PRIO) && W2X_MLP2Q_PRIO == 1   // s_setprio by phase: 1 = the chunk loop at priority 1, row phases at 0; 2 = the reverse; 3 = only the GELU at 1
+    __builtin_amdgcn_s_setprio(1);
+#elif defined(W2X_MLP2Q_PRIO) && W2X_MLP2Q_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         if (ch + 1 < NCH && !(W2X_MLP2Q_EXP & 2)) stage(ch + 1);
@@ -494,6 +499,9 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
             for (int k = 0; k < NP; ++k) xres[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(XB, vo + k * 1024u, 0, 0));
         }
         half8 a2[2];
+#if defined(W2X_MLP2Q_PRIO) && W2X_MLP2Q_PRIO == 3
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             auto act2 = [](float2v v) { return (W2X_MLP2Q_EXP & 4) ? v : gelu_fast2(v); };
@@ -504,6 +512,9 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
             a2[s2] = (half8){(_Float16)g0[0], (_Float16)g0[1], (_Float16)g1[0], (_Float16)g1[1],
                              (_Float16)g2[0], (_Float16)g2[1], (_Float16)g3[0], (_Float16)g3[1]};
         }
+#if defined(W2X_MLP2Q_PRIO) && W2X_MLP2Q_PRIO == 3
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {     // fragment KS + i = (output tile i >> 1, k-step i & 1)
             const int j = KS + i;
@@ -518,6 +529,11 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
             for (int i = 0; i < RING; ++i) wr[i] = lds_frag(ch + 1, i);
         }
     }
+#if defined(W2X_MLP2Q_PRIO) && W2X_MLP2Q_PRIO == 1
+    __builtin_amdgcn_s_setprio(0);
+#elif defined(W2X_MLP2Q_PRIO) && W2X_MLP2Q_PRIO == 2
+    __builtin_amdgcn_s_setprio(1);
+#endif
 
     W2X_PHASE_FENCE();
     typedef _Float16 half4 __attribute__((ext_vector_type(4)));

@@ -218,6 +218,9 @@ __global__ __launch_bounds__(NTHR, 3) void mlp96q_kernel(const MlpParams p, int 
             *(half8*)(Xw + r * LDX + c * 8) = xr[k];
         }
         W2X_PHASE_FENCE();
+#if defined(W2X_MLP96_PRIO) && W2X_MLP96_PRIO == 6
+        __builtin_amdgcn_s_setprio(1);
+#endif
         // ---- LayerNorm in fragment layout: lane (r32, h) holds channels ks*16 + 8h .. +7 of row r32, so the row sums are the
         //      lane's own KS pieces plus those of lane ^ 32; the normalised pieces are the B operand registers of GEMM1
         half8 xreg[KS];
@@ -243,6 +246,13 @@ __global__ __launch_bounds__(NTHR, 3) void mlp96q_kernel(const MlpParams p, int 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc2[nt][4 * q + j] = b[j];
             }
+#if defined(W2X_MLP96_PRIO) && (W2X_MLP96_PRIO == 1 || W2X_MLP96_PRIO == 5)   // s_setprio by phase: 1 = the chunk loop at priority 1, row phases at 0; 2 = the reverse; 3 = only the GELU at 1;
+        __builtin_amdgcn_s_setprio(1);                                          // 4 = as 1 at priority 3; 5 = only the matrix products at 1 (GELU at 0); 6 = as 1, LayerNorm included
+#elif defined(W2X_MLP96_PRIO) && W2X_MLP96_PRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#elif defined(W2X_MLP96_PRIO) && W2X_MLP96_PRIO == 4
+        __builtin_amdgcn_s_setprio(3);
+#endif
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             // GEMM1 (transposed): acc1 = W1[32ch ..][:] * Xn^T   (rows = hidden units of the chunk, columns = tokens), from b1
@@ -266,6 +276,11 @@ __global__ __launch_bounds__(NTHR, 3) void mlp96q_kernel(const MlpParams p, int 
             // GELU in place; registers 8s .. 8s+7 of a lane are hidden rows 16s + 8(j >> 2) + 4h + (j & 3) of its token column ->
             // B fragment of k-step s of GEMM2 in the k order W2 is stored in (fragorder.h frag32_w2)
             half8 a2[2];
+#if defined(W2X_MLP96_PRIO) && W2X_MLP96_PRIO == 3
+            __builtin_amdgcn_s_setprio(1);
+#elif defined(W2X_MLP96_PRIO) && W2X_MLP96_PRIO == 5
+            __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 if (W2X_MLP_EXP & 2) {
@@ -280,6 +295,11 @@ __global__ __launch_bounds__(NTHR, 3) void mlp96q_kernel(const MlpParams p, int 
                 a2[s2] = (half8){(_Float16)g0[0], (_Float16)g0[1], (_Float16)g1[0], (_Float16)g1[1],
                                  (_Float16)g2[0], (_Float16)g2[1], (_Float16)g3[0], (_Float16)g3[1]};
             }
+#if defined(W2X_MLP96_PRIO) && W2X_MLP96_PRIO == 3
+            __builtin_amdgcn_s_setprio(0);
+#elif defined(W2X_MLP96_PRIO) && W2X_MLP96_PRIO == 5
+            __builtin_amdgcn_s_setprio(1);
+#endif
             // GEMM2 (transposed): acc2[nt] += W2[32nt ..][chunk] * H[tokens][chunk]^T, fragment i = (nt, k-step) = (i >> 1, i & 1)
             const int nch = ch + 1 < NCH ? ch + 1 : 0;          // after the last chunk: the first chunk's fragments for the next tile
 #pragma unroll
@@ -290,6 +310,11 @@ __global__ __launch_bounds__(NTHR, 3) void mlp96q_kernel(const MlpParams p, int 
                 W2X_RING_FENCE();
             }
         }
+#if defined(W2X_MLP96_PRIO) && (W2X_MLP96_PRIO == 1 || W2X_MLP96_PRIO >= 4)
+        __builtin_amdgcn_s_setprio(0);
+#elif defined(W2X_MLP96_PRIO) && W2X_MLP96_PRIO == 2
+        __builtin_amdgcn_s_setprio(1);
+#endif
         W2X_PHASE_FENCE();
         half8 wfh[2][3];                          // TOIMG: the head's first six weight fragments, requested here so that they land under the epilogue below
         if (TOIMG) {

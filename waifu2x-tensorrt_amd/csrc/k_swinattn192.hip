@@ -110,6 +110,13 @@ __device__ __forceinline__ float group_sum32(float v) {
 //   W2X_A192_BIAS_AHEAD  the rel-pos bias (+ mask) values of a unit (27 registers per lane, the initial accumulators of its score products) are
 //                        requested a phase ahead - before the v products for a head's first unit, under the first unit's softmax for the second -
 //                        instead of at the top of the unit.
+//   W2X_A192_STAGGER=n   experiment: the workgroups of the launch's first generation that land on the second wave slot of their SIMD sleep n x 8128
+//                        cycles first, so that the two workgroups of a CU run half a period apart (one in its row phases while the other multiplies)
+//                        instead of in lockstep; later generations inherit the offset.
+//   W2X_A192_PRIO=m      s_setprio by phase.  1: the head loop at priority 1, row phases at 0;  2: priority rises with progress (0 gather,
+//                        1 head loop, 2 projection, 3 final rows) - the older workgroup of a CU wins every arbitration and leaves sooner;
+//                        3: head loop 2, projection 1, row phases 0;  4: only the softmax / O sections of the head loop at 1;  5: only the q / k / v
+//                        products of the head loop at 1 (the softmax / O sections at 0).
 #ifndef W2X_A192_RING
 #define W2X_A192_RING 8        // weight-fragment registers of a wave (the ring described in the kernel)
 #endif
@@ -171,6 +178,12 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
     const _Float16* __restrict__ Wproj = (const _Float16*)p.wproj_frag;  // [12 row tiles][6 k-steps][64 lanes][8]
     const float4v zero4 = {0.f, 0.f, 0.f, 0.f};
     const half8 zero8 = {};
+#ifdef W2X_A192_STAGGER
+    if (blockIdx.x < 2u * 256u) {      // HW_REG_HW_ID bits 3:0 = wave slot on the SIMD
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+        if (slot & 1) for (int i = 0; i < W2X_A192_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     unsigned long long tprev = 0;
     if (STAMPS) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); if (lane == 0) atomicAdd(&g_sa192_stamps[7], 1ull); }
 
@@ -268,6 +281,11 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
     }
     __syncthreads();
     W2X_STAMP(0)
+#if defined(W2X_A192_PRIO) && W2X_A192_PRIO == 3
+    __builtin_amdgcn_s_setprio(2);
+#elif defined(W2X_A192_PRIO) && W2X_A192_PRIO != 4
+    __builtin_amdgcn_s_setprio(1);
+#endif
 
     const float qscale = p.scale * 1.44269504088896341f;   // log2(e) folded into q: softmax uses exp2
     const int lane2 = g * 16 + (fr >> 2);                  // bias-table lane of the query this lane holds in query tile 2
@@ -293,6 +311,11 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
     // requested into `ub` again once the score products have taken this one's values
     auto attend = [&](const int w, const int h, const bool ok, const int amask, const half8 (&qf)[3], const half8 (&kf)[3], const half8 (&vf0)[2], const half8 (&vf1)[2], const bool last,
                       UnitBias& ub, const int next_amask) {
+#if defined(W2X_A192_PRIO) && W2X_A192_PRIO == 4
+        __builtin_amdgcn_s_setprio(1);
+#elif defined(W2X_A192_PRIO) && W2X_A192_PRIO == 5
+        __builtin_amdgcn_s_setprio(0);
+#endif
         float4v s[3][3];
         float b2[3];
 #if !W2X_A192_BIAS_AHEAD
@@ -363,6 +386,11 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
                     *(half4*)(Os + (w * NTOK + query) * LDX + h * HD + ft * 16 + g * 4) = oh;
                 }
             }
+#if defined(W2X_A192_PRIO) && W2X_A192_PRIO == 4
+        __builtin_amdgcn_s_setprio(0);
+#elif defined(W2X_A192_PRIO) && W2X_A192_PRIO == 5
+        __builtin_amdgcn_s_setprio(1);
+#endif
     };
     // accumulators of one window -> operand fragments: q^T / k^T (rows = features): tile tt = [feature tile 0 | feature tile 1];
     // v (rows = slab rows): vf0 = tokens 0..31, vf1 = slab row 32 + 4g = token 32 + g
@@ -485,6 +513,13 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
     }
 #undef W2X_RING_NEXT
 #undef W2X_LOAD_X2
+#if defined(W2X_A192_PRIO) && W2X_A192_PRIO == 2
+    __builtin_amdgcn_s_setprio(2);
+#elif defined(W2X_A192_PRIO) && W2X_A192_PRIO == 3
+    __builtin_amdgcn_s_setprio(1);
+#elif defined(W2X_A192_PRIO)
+    __builtin_amdgcn_s_setprio(0);
+#endif
     __syncthreads();      // every wave's head outputs are in Os; nobody reads the slabs any more
 
     // The residual rows (the same pixels again, for y = x + ...) are requested here, in front of the projection: its weight fragments
@@ -527,6 +562,11 @@ __global__ __launch_bounds__(256, 2) void swin_attn192_kernel(const SwinAttnPara
                 *(half4*)(Xs + (mt * 16 + fr) * LDX + (wv * 3 + t) * 16 + g * 4) = (half4){(_Float16)acc[t][0], (_Float16)acc[t][1], (_Float16)acc[t][2], (_Float16)acc[t][3]};
         }
     }
+#if defined(W2X_A192_PRIO) && W2X_A192_PRIO == 2
+    __builtin_amdgcn_s_setprio(3);
+#elif defined(W2X_A192_PRIO) && W2X_A192_PRIO == 3
+    __builtin_amdgcn_s_setprio(0);
+#endif
     __syncthreads();
     W2X_STAMP(5)
 

@@ -312,6 +312,9 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
     }
     __syncthreads();
 
+#ifdef W2X_A96_PRIO     // s_setprio by phase (k_swinattn192.hip): 1 = head loop at priority 1, row phases at 0; 2 = rising with progress
+    __builtin_amdgcn_s_setprio(1);
+#endif
     const float qscale = p.scale * 1.44269504088896341f;   // log2(e) folded into q: softmax uses exp2
     const float2v qs2 = {qscale, qscale};
     const half4 zeroh4 = {};
@@ -479,6 +482,11 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
         const float2v o1 = __builtin_elementwise_fma((float2v){o[2], o[3]}, i2, (float2v){bv[2], bv[3]});
         if (ul < NU) *(half4*)(Os + (wl_ * NTOK + 32 + ql) * LDX + hl_ * HD + g * 4) = (half4){(_Float16)o0[0], (_Float16)o0[1], (_Float16)o1[0], (_Float16)o1[1]};
     }
+#if defined(W2X_A96_PRIO) && W2X_A96_PRIO == 1
+    __builtin_amdgcn_s_setprio(0);
+#elif defined(W2X_A96_PRIO)
+    __builtin_amdgcn_s_setprio(2);
+#endif
     __syncthreads();      // every head's outputs are in Os; nobody reads the slabs any more
 
 #if !W2X_A96_XRES_EARLY
@@ -514,6 +522,9 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
         for (int t = 0; t < 3; ++t)
             *(half4*)(Xs + (mt * 16 + fr) * LDX + (n3 + t) * 16 + g * 4) = (half4){(_Float16)acc[t][0], (_Float16)acc[t][1], (_Float16)acc[t][2], (_Float16)acc[t][3]};
     }
+#if defined(W2X_A96_PRIO) && W2X_A96_PRIO == 2
+    __builtin_amdgcn_s_setprio(3);
+#endif
     __syncthreads();
 
     // ---- row pieces: + residual x, scatter store, LayerNorm statistics for the next op

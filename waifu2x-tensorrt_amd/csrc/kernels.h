@@ -1,6 +1,8 @@
 // Launch interface of the HIP kernels (gfx950).  Plain C structs, no torch types.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include "support.h"
 #include <cstdint>
 
 namespace w2x {
@@ -157,10 +159,7 @@ hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s);
 hipError_t launch_attn_f32(const AttnParams& p, hipStream_t s);
 hipError_t launch_mlp(const MlpParams& p, hipStream_t s);
 hipError_t launch_swin_attn(const SwinAttnParams& p, hipStream_t s);
-bool swin_attn_supported(int C, int heads, int hd, int ws);
-bool mlp_supported(int C);
-bool gemm_row_stats_supported(int N);                          // k_gemm.hip: row widths whose LayerNorm statistics the epilogue can emit
-bool attn_supported(int hd, int ntok);                          // k_attn.hip: the un-fused attention core
+// swin_attn_supported / mlp_supported / gemm_row_stats_supported / attn_supported: support.h
 hipError_t launch_se(const SeParams& p, hipStream_t s);
 hipError_t launch_scale(void* x, const float* scale, int B, int HW, int Cs, bool fp32, hipStream_t s);
 hipError_t launch_gather(const GatherParams& p, hipStream_t s);

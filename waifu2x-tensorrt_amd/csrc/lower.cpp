@@ -8,7 +8,7 @@
 #include <stdexcept>
 
 #include "common.h"
-#include "kernels.h"
+#include "support.h"
 
 namespace w2x {
 namespace {
@@ -645,7 +645,7 @@ struct Lowerer {
         if (w1.shape != Shape{Cm, C, 1, 1} || w2.shape != Shape{C, Cm, 1, 1}) fail(c1, "unexpected squeeze-excite weights");
         auto it = tensor_producer.find(x.v.t);
         if (it == tensor_producer.end() || plan.ops[it->second].kind != OP_GEMM) fail(n, "squeeze-excite input is not produced by a fused op");
-        const TensorDesc& td = plan.tensors[x.v.t];
+        const TensorDesc td = plan.tensors[x.v.t];      // by value: new_tensor() below grows plan.tensors (found by `make asan`)
         if (x.v.y0 || x.v.x0 || x.v.H != td.H || x.v.W != td.W) fail(n, "squeeze-excite over a cropped view");
         Op& prod = plan.ops[it->second];
         int nblocks = (prod.g.Mrows + 127) / 128;   // kGemmBM rows per workgroup, tiles never straddle batch items
