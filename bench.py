@@ -235,7 +235,7 @@ def main():
         live = n_tiles / eng.pass_tiles          # the zero-pad slots of the last batch are not computed (plan FLOPs are per pass of pass_tiles)
         # dominant kernel of the frame: plan ops grouped by the kernel that serves them, by summed HIP-event time
         # (measured on the compute stream by w2x_profile_frame / w2x_op_times)
-        symbols = {("swinattn", 96): "swin_attn96_kernel", ("swinattn", 192): "swin_attn192_kernel",
+        symbols = {("swinattn", 96): "swin_attn96_kernel", ("swinattn", 192): "swin_attn192_kernel" if os.environ.get("W2X_A192_TWO_PER_CU") else "swin_attn192u_kernel",
                    ("mlp", 96): "mlp96q_kernel", ("mlp", 192): "mlp2q_kernel<192,4>"}
         groups = {}
         for line, t in zip(desc, op_ms):

@@ -8,6 +8,7 @@
  *   w2x_load                      trt::Img2Img::load(path, RenderConfig)      img2img.h:19, img2img_load.cpp:117-291
  *   w2x_render                    trt::Img2Img::render(cv::Mat, cv::Mat&)     img2img.h:20, img2img_render.cpp:224-352
  *   w2x_infer                     trt::Img2Img::infer (private)               img2img.h:25, img2img_infer.cpp:41-93
+ *   w2x_render_sharded            (extension) one frame over N engines         img2img_render.cpp:43-44, 329-330
  *   w2x_calculate_tiles           calculateTiles (file-static)                img2img_render.cpp:7-66
  *   w2x_tile_weights              createTileWeights (file-static)             img2img_load.cpp:29-52
  * Return convention: 1 = true, 0 = false (after the message callback received the error text), like the reference's
@@ -60,6 +61,14 @@ int w2x_render16(w2x_engine* e, const uint16_t* src, int rows, int cols, size_t 
  * `parts` = a contiguous range of the reference's column-major tile order (img2img_render.cpp:43-44) plus the output columns
  * it alone composes.  w2x_strip_plan is pure host logic: out[0..3] = first_tile, tile_count, x0, x1 (x in output pixels). */
 int w2x_render_strip(w2x_engine* e, const uint8_t* src, int rows, int cols, size_t src_step, uint8_t* dst, size_t dst_step, int part, int parts);
+/* ONE frame over `count` engines of this process with every tile computed once (no reference counterpart; SURVEY.md 8e, seam exchange):
+ * engine k renders part k of w2x_shard_plan - a contiguous range of the reference's column-major tile order (img2img_render.cpp:43-44) -
+ * the blend bands of the ny + 1 tiles in front of a range are copied device-to-device from the engine(s) that computed them, and each
+ * engine composes and downloads the canvas cells of its own tiles.  Same bytes as w2x_render.  w2x_shard_plan is pure host logic:
+ * out[0..3] = first_tile, tile_count, halo_first, nrect; out[4 + 4r ..] = x, y, w, h of rectangle r (r < 3) in output pixels. */
+int w2x_render_sharded(w2x_engine* const* engines, int count, const uint8_t* src, int rows, int cols, size_t src_step, uint8_t* dst, size_t dst_step);
+int w2x_shard_plan(int in_w, int in_h, int out_w, int out_h, int tile_in, int tile_out, int scaling, double overlap_x, double overlap_y,
+                   int part, int parts, int* out16);
 /* Frame sequence with the PCIe copies overlapped (no reference counterpart: main.cpp:263-269 renders frame by frame): srcs/dsts are
  * arrays of `count` frame pointers of one size.  The copies run by DMA beside the kernels only for page-locked memory: take the
  * frame buffers from w2x_alloc_host (engine-owned, w2x_free_host or w2x_destroy releases them).  w2x_pin_host page-locks caller

@@ -41,6 +41,12 @@ public:
     // One device's share of a single frame spread over `parts` devices (tile-column strips): composes and writes only
     // the output columns of strip `part` (w2x_strip_plan); identical bytes to render() there.  render() == renderStrip(.., 0, 1).
     bool renderStrip(const Image& src, Image& dst, int part, int parts);
+    // ONE frame over `count` engines with every tile computed exactly once (seam exchange): engine k runs the k-th of `count`
+    // contiguous ranges of the reference's tile order (w2x_shard_plan), the blend bands of the ny + 1 tiles in front of a range are copied
+    // from the engine(s) that computed them (device-to-device on one GPU, hipMemcpyPeerAsync / peer 2-D copies across GPUs, no collective),
+    // and every engine composes and downloads the canvas cells of its own tiles.  All engines must be loaded with the same model and
+    // RenderConfig, live in this process, and are driven from the calling thread; the bytes are render()'s.  engines[0] reports progress.
+    static bool renderSharded(Img2Img* const* engines, int count, const Image& src, Image& dst);
     // A sequence of equally sized frames (the per-frame loop of main.cpp:263-269) with upload, compute and download overlapped on
     // three HIP streams; outputs are the bytes render() gives.  The copies only overlap for page-locked host memory: take the frame
     // buffers from allocHost() (owned by the engine, released by freeHost(), release at destruction at the latest).

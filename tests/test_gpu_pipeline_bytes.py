@@ -160,3 +160,34 @@ def test_sixteen_bit_frames_byte_exact_and_close_to_the_oracle(pkg, onnx_model, 
                                                                              net_dtype=None if fp32 else np.float16, tile_out=eng.output_tile_size))
     assert eng.render(frame, np.zeros((280, 360, 3), np.uint8)) is False
     eng.close()
+
+
+@pytest.mark.parametrize("tta,ov", [(False, 0.0625), (True, 0.0625), (False, 0.125), (False, 0.0), (True, 0.03125)])
+def test_one_frame_over_several_engines_every_tile_once(pkg, onnx_model, monkeypatch, tta, ov):
+    """SURVEY 8e, second option (w2x_render_sharded): N engines in one process, engine k computes the k-th contiguous range of the tile
+    order ONCE, the blend bands of the ny + 1 tiles in front of a range are copied from the engines that computed them, each engine composes
+    the canvas cells of its own tiles - against the oracle's whole frame and against one engine's render(), byte for byte, for 2, 3 and 8
+    engines (more engines than tile rows, ranges that start and end inside a tile column, a range shorter than its halo).  On the one-GPU box
+    the engines share the card (W2X_DEVICE_MAP), so the exchange runs as device-to-device copies; across GPUs it is peer copies (unmeasured)."""
+    monkeypatch.setenv("W2X_DEVICE_MAP", ",".join(["0"] * 8))
+    path = onnx_model("swin_unet/art", 4, 2, 64)
+    frame = smooth_frame(150, 230, 77)                     # 5 x 4 tiles of 64 at blend 1/16
+    engs = []
+    for dev in range(8):
+        e = pkg.Img2Img()
+        assert e.build(path, pkg.BuildConfig.fixed(2, 64, device=dev)), e.last_error()
+        assert e.load(path, pkg.RenderConfig(deviceId=dev, batchSize=2, height=64, width=64, scaling=4, overlap=(ov, ov), tta=tta)), e.last_error()
+        engs.append(e)
+    whole = engs[0].render(frame)
+    ref = oracle_with_engine_net(engs[0], frame, batch=2, tile=64, scale=4, ov=ov, tta=tta)
+    assert_same_bytes(f"render tta{int(tta)} ov{ov}", whole, ref)
+    for n in (2, 3, 8):
+        out = np.full_like(whole, 55)
+        got = pkg.render_sharded(engs[:n], frame, out)
+        assert_same_bytes(f"{n} engines tta{int(tta)} ov{ov}", got, ref)
+    # a second frame of another size through the same engines (slab and slot buffers are reused), then plain render() again
+    frame2 = noisy_frame(70, 300, 5)
+    assert_same_bytes("second frame", pkg.render_sharded(engs[:3], frame2), engs[3].render(frame2))
+    assert np.array_equal(engs[1].render(frame), whole)
+    for e in engs:
+        e.close()

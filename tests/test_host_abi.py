@@ -229,6 +229,64 @@ def test_cunet_gates_are_folded_into_their_consumers(pkg, onnx_model, monkeypatc
     assert d.count(" scale t") == 4 and "gate" not in d
 
 
+@pytest.mark.parametrize("W,H,T,s,Tout,ov", [(1920, 1080, 256, 4, 960, 0.0625), (1920, 1080, 256, 2, 440, 0.0625), (3840, 2160, 640, 4, 2496, 0.0625),
+                                             (1920, 1080, 256, 4, 960, 0.0), (300, 200, 64, 2, 56, 0.125), (1920, 1080, 400, 4, 1536, 0.03125), (100, 1000, 64, 4, 192, 0.0625)])
+@pytest.mark.parametrize("parts", [1, 2, 3, 5, 8, 16, 64])
+def test_shard_plan_partitions_tiles_and_canvas(pkg, W, H, T, s, Tout, ov, parts):
+    """The every-tile-once split of one frame (SURVEY 8e second option, w2x_shard_plan): the parts' tile ranges partition the reference's
+    tile order, their rectangles partition the canvas, and every tile that covers a pixel of a part's rectangles (per the oracle's rects)
+    is one of its own or one of the tiles [halo_first, first) in front of them - what the seam exchange brings."""
+    n, _, outs = P.calculate_tiles(W, H, W * s, H * s, (T, T), (Tout, Tout), s, (ov, ov))
+    canvas = np.zeros((H * s // 4 + 1, W * s // 4 + 1), np.int32)            # coverage counted on a 4-pixel lattice (rect edges are multiples of the stride)
+    nxt = 0
+    sizes = []
+    for part in range(parts):
+        first, cnt, halo, rects = pkg.shard_plan(W, H, W * s, H * s, T, Tout, s, (ov, ov), part, parts)
+        if cnt == 0:
+            assert not rects
+            continue
+        assert first == nxt and 0 <= halo <= first and len(rects) <= 3
+        nxt = first + cnt
+        sizes.append(cnt)
+        for x, y, w, h in rects:
+            assert w > 0 and h > 0 and x >= 0 and y >= 0 and x + w <= W * s and y + h <= H * s
+            canvas[-(-y // 4):-(-(y + h) // 4), -(-x // 4):-(-(x + w) // 4)] += 1
+            for t, r in enumerate(outs):                                     # tiles that reach into the rectangle
+                if r.x < x + w and r.x + r.w > x and r.y < y + h and r.y + r.h > y:
+                    assert halo <= t < first + cnt, (part, t, (x, y, w, h), r.astuple())
+    assert nxt == n
+    assert (canvas[:-(-H * s // 4), :-(-W * s // 4)] == 1).all()
+    assert max(sizes) - min(sizes) <= 1 or parts > n                          # balanced to within a tile
+    if parts == 1:
+        assert pkg.shard_plan(W, H, W * s, H * s, T, Tout, s, (ov, ov), 0, 1) == (0, n, 0, [(0, 0, W * s, H * s)])
+
+
+def test_shard_split_bound_table(pkg, capsys):
+    """What ONE image can gain from N GPUs when every tile is computed once (w2x_render_sharded) next to the whole-column strips of
+    test_strip_split_redundancy_table: the largest part bounds the speed-up; the seam exchange moves two blend bands per tile in front of a part."""
+    import synth_models as sm
+    cfgs = {"configs[1] cunet/art s2 T256 1080p": ("cunet/art", 2, 256, 1920, 1080), "configs[2] swin_unet/art s4 T256 1080p": ("swin_unet/art", 4, 256, 1920, 1080),
+            "configs[3] swin_unet/photo s4 T400 1080p": ("swin_unet/photo", 4, 400, 1920, 1080), "configs[4] swin_unet/art_scan s4 T640 2160p": ("swin_unet/art_scan", 4, 640, 3840, 2160)}
+    want = {"configs[1] cunet/art s2 T256 1080p": {2: 30, 4: 15, 8: 8}, "configs[2] swin_unet/art s4 T256 1080p": {2: 23, 4: 12, 8: 6},
+            "configs[3] swin_unet/photo s4 T400 1080p": {2: 9, 4: 5, 8: 3}, "configs[4] swin_unet/art_scan s4 T640 2160p": {2: 14, 4: 7, 8: 4}}
+    lines = []
+    for name, (m, s, T, W, H) in cfgs.items():
+        To = sm.output_tile_size(m, s, T)
+        ov = (0.0625, 0.0625)
+        n, _, outs = pkg.calculate_tiles(W, H, W * s, H * s, T, To, s, ov)
+        ovpx = int(outs[1][1] and (To - (outs[1][1] - outs[0][1])))          # blend band in output pixels (tile 1 sits below tile 0)
+        for N in (2, 4, 8):
+            parts = [pkg.shard_plan(W, H, W * s, H * s, T, To, s, ov, p, N) for p in range(N)]
+            assert sum(c for _, c, _, _ in parts) == n
+            largest = max(c for _, c, _, _ in parts)
+            assert largest == want[name][N], (name, N, largest)
+            halo = max(f - h for f, c, h, _ in parts)
+            mb = halo * 2 * ovpx * To * 8 / 1e6
+            lines.append(f"{name}: N={N}: {n} tiles, largest part {largest} -> speed-up <= {n / largest:.2f}x; seam exchange <= {halo} tiles x 2 bands = {mb:.1f} MB per part")
+    with capsys.disabled():
+        print("\n" + "\n".join(lines))
+
+
 def test_strip_split_redundancy_table(pkg, capsys):
     """Single-frame mode: strip p owns whole tile columns and recomputes the neighbouring column whose
     blend band reaches into its pixels, so the tiles rendered over all strips exceed the frame's tiles and the largest strip bounds

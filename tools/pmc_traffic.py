@@ -13,7 +13,7 @@ def per_kernel(d, counter):
     return acc
 
 def symbol(name):
-    m = re.search(r"(swin_attn96_kernel|swin_attn192_kernel|mlp96q_kernel|mlp96p_kernel|conv48_kernel|compose_kernel|gather_kernel|toimage_kernel)", name)
+    m = re.search(r"(swin_attn96_kernel|swin_attn192u?_kernel|mlp96q_kernel|mlp96p_kernel|conv48_kernel|compose_kernel|gather_kernel|toimage_kernel)", name)
     if m: return m.group(1)
     m = re.search(r"(mlp2q?_kernel)<(\d+), (\d+)[^>]*>", name)
     if m: return f"{m.group(1)}<{m.group(2)},{m.group(3)}>"

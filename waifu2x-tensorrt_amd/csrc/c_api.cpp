@@ -84,6 +84,17 @@ int w2x_render_strip(w2x_engine* e, const uint8_t* src, int rows, int cols, size
     return e->engine.renderStrip(s, d, part, parts) ? 1 : 0;
 }
 
+int w2x_render_sharded(w2x_engine* const* engines, int count, const uint8_t* src, int rows, int cols, size_t src_step, uint8_t* dst, size_t dst_step) {
+    if (!engines || count <= 0) return 0;
+    std::vector<w2x::Img2Img*> es(count);
+    for (int k = 0; k < count; ++k) { if (!engines[k]) return 0; es[k] = &engines[k]->engine; }
+    w2x::Image s; s.data = const_cast<uint8_t*>(src); s.rows = rows; s.cols = cols; s.step = src_step;
+    w2x::Image d; d.data = dst; d.step = dst_step;
+    const int sc = es[0]->scaling();
+    d.rows = rows * sc; d.cols = cols * sc;
+    return w2x::Img2Img::renderSharded(es.data(), count, s, d) ? 1 : 0;
+}
+
 int w2x_render_sequence(w2x_engine* e, const uint8_t* const* srcs, int rows, int cols, size_t src_step, uint8_t* const* dsts, size_t dst_step, int count) {
     if (!e || count < 0) return 0;
     const int sc = e->engine.scaling();
@@ -105,6 +116,16 @@ int w2x_strip_plan(int in_w, int in_h, int out_w, int out_h, int tile_in, int ti
     w2x::TileGrid g = w2x::calculate_tiles(in_w, in_h, out_w, out_h, tile_in, tile_in, tile_out, tile_out, scaling, overlap_x, overlap_y);
     w2x::StripPlan sp = w2x::strip_plan(g, out_w, tile_out, part, parts);
     out4[0] = sp.first_tile; out4[1] = sp.tile_count; out4[2] = sp.x0; out4[3] = sp.x1;
+    return 1;
+}
+
+int w2x_shard_plan(int in_w, int in_h, int out_w, int out_h, int tile_in, int tile_out, int scaling, double overlap_x, double overlap_y,
+                   int part, int parts, int* out16) {
+    if (!out16) return 0;
+    w2x::TileGrid g = w2x::calculate_tiles(in_w, in_h, out_w, out_h, tile_in, tile_in, tile_out, tile_out, scaling, overlap_x, overlap_y);
+    w2x::ShardPlan sp = w2x::shard_plan(g, out_w, out_h, tile_out, tile_out, part, parts);
+    out16[0] = sp.first_tile; out16[1] = sp.tile_count; out16[2] = sp.halo_first; out16[3] = sp.nrect;
+    for (int r = 0; r < 3; ++r) { out16[4 + 4 * r] = sp.rect[r].x; out16[5 + 4 * r] = sp.rect[r].y; out16[6 + 4 * r] = sp.rect[r].w; out16[7 + 4 * r] = sp.rect[r].h; }
     return 1;
 }
 

@@ -201,6 +201,8 @@ struct Img2Img::Impl {
     RenderConfig cfg;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_shard = nullptr;       // renderSharded(): this engine's tiles are in its slab
+    size_t shard_halo_slots = 0;         // renderSharded(): slab slots in front of this engine's own tiles (the bands copied from the preceding parts)
     hipStream_t gstream[3] = {nullptr, nullptr, nullptr};   // further tile groups of a pass (run_frame)
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     // Experiment (W2X_STAGGER_OP=k, two groups): the second group starts when the first has finished op k, so that the two streams run
@@ -299,6 +301,7 @@ struct Img2Img::Impl {
         frame_cap = out_cap = slab_cap = slots_cap = 0;
         if (ev0) { (void)hipEventDestroy(ev0); ev0 = nullptr; }
         if (ev1) { (void)hipEventDestroy(ev1); ev1 = nullptr; }
+        if (ev_shard) { (void)hipEventDestroy(ev_shard); ev_shard = nullptr; }
         if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
         if (ev_stagger) { (void)hipEventDestroy(ev_stagger); ev_stagger = nullptr; }
         for (hipEvent_t& e : ev_join) if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -649,10 +652,16 @@ struct Img2Img::Impl {
 
     // device part of one frame: gather -> network per batch -> compose.  Frame must already be in d_frame.
     void run_frame(int rows, int cols, const TileGrid& grid, bool report, const StripPlan& sp) {
+        run_passes(rows, cols, sp.tile_count, 0, report);
+        compose_rect(rows, cols, grid, sp.x0, sp.x1, 0, 0, sp.first_tile);
+    }
+
+    // the network passes of `tile_count` tiles (slots d_slots[0 ..]); their outputs go to slab slots slab_slot0, slab_slot0 + 1, ...
+    void run_passes(int rows, int cols, int tile_count, size_t slab_slot0, bool report) {
         const int B = plan.B, T = plan.T, To = plan.Tout;
         const int steps = cfg.tta ? 8 : 1;
         const int userB = plan.userB, S = B / userB;
-        const int batchCount = (int)std::lround(std::ceil((double)(sp.tile_count * steps) / userB));   // img2img_render.cpp:249
+        const int batchCount = (int)std::lround(std::ceil((double)(tile_count * steps) / userB));   // img2img_render.cpp:249
         const int passCount = (batchCount + S - 1) / S;
         const size_t slot_bytes = (size_t)To * To * 4 * plan.elt;
         if (poison) {
@@ -663,8 +672,8 @@ struct Img2Img::Impl {
         const bool graphable = use_graphs && !profiling && !check_general;
         for (int bi = 0; bi < passCount; ++bi) {
             const auto t0 = std::chrono::steady_clock::now();
-            const int live = std::max(0, std::min(B, sp.tile_count * steps - bi * B));
-            void* const slab_out = (uint8_t*)d_slab + (size_t)bi * B * slot_bytes;
+            const int live = std::max(0, std::min(B, tile_count * steps - bi * B));
+            void* const slab_out = (uint8_t*)d_slab + (slab_slot0 + (size_t)bi * B) * slot_bytes;
             auto run_pass = [&] {
                 GatherParams gp;
                 gp.frame = d_frame; gp.rows = rows; gp.cols = cols; gp.step = (size_t)cols * 3 * (deep ? 2 : 1); gp.deep = deep ? 1 : 0;
@@ -750,6 +759,13 @@ struct Img2Img::Impl {
                     log(k + 1, batchCount, 1000.0 * S / std::max(ms, 1e-6));                     // :336-338
             }
         }
+        last_batches = batchCount;
+    }
+
+    // compose: output columns [x0, x1) (x1 = 0: to the right edge) and rows [y0, y1) (y1 = 0: to the bottom) from the slab, whose slot 0 holds
+    // global tile `first_tile`
+    void compose_rect(int rows, int cols, const TileGrid& grid, int x0, int x1, int y0, int y1, long first_tile) {
+        const int To = plan.Tout;
         ComposeParams cp;
         cp.tiles = d_slab; cp.fp32 = plan.elt == 4; cp.dst = d_out; cp.dst_step = (size_t)cols * cfg.scaling * 3 * (deep ? 2 : 1); cp.deep = deep ? 1 : 0;
         cp.outW = cols * cfg.scaling; cp.outH = rows * cfg.scaling; cp.To = To;
@@ -757,11 +773,10 @@ struct Img2Img::Impl {
         const bool overlapping = cfg.overlapX != 0 || cfg.overlapY != 0;                      // :244
         cp.ovx = overlapping ? ovx : 0; cp.ovy = overlapping ? ovy : 0;
         cp.ramp_x = d_rampx; cp.ramp_y = d_rampy; cp.tta = cfg.tta ? 1 : 0; cp.tta_bug_compat = cfg.ttaBugCompat ? 1 : 0;
-        cp.x0 = sp.x0; cp.x1 = sp.x1; cp.first_tile = sp.first_tile;
+        cp.x0 = x0; cp.x1 = x1; cp.y0 = y0; cp.y1 = y1; cp.first_tile = first_tile;
         stamp_begin(4, 0);
         hipAssert(launch_compose(cp, stream));
         stamp_end();
-        last_batches = batchCount;
     }
 };
 
@@ -1002,6 +1017,136 @@ bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, cons
 } catch (const std::exception& e) {
     W2X_LOG_AS(who, error, "Render failed unexpectedly: " + std::string(e.what()) + ".");
     return false;
+}
+
+// ONE frame over several engines, every tile computed once (img2img.h; SURVEY 8e second option; the reference is single-device,
+// main.cpp:70-74).  Engine k takes part k of tiles.cpp shard_plan(): a contiguous range of the reference's column-major tile order
+// (img2img_render.cpp:43-44) and the canvas cells of those tiles.  Phase 1, every engine on its own stream: upload, gather + network
+// passes of its own tiles into its slab, an event.  Phase 2, per engine: behind the events of the engines that computed the ny + 1
+// tiles in front of its range, copy their blend bands into the slab slots in front of its own (the seam exchange: two bands per tile,
+// all four per augmented tile under TTA - a dihedral map sends the right / bottom band to any of the four), compose its cells (the
+// same kernel and the same ascending-tile order as a whole-frame render, img2img_render.cpp:329-330: identical bytes), download them.
+// The calling thread drives all engines; nothing here is a collective.
+bool Img2Img::renderSharded(Img2Img* const* engines, int count, const Image& src, Image& dst) {
+    if (!engines || count <= 0 || !engines[0]) return false;
+    Img2Img* const first = engines[0];
+    Impl* const impl = first->impl.get();                      // (the log macros name `impl`)
+    try {
+        for (int k = 0; k < count; ++k) {
+            if (!engines[k] || !engines[k]->impl->loaded) { W2X_LOG(error, "Render called before a successful load (engine " + std::to_string(k) + ")."); return false; }
+            const Impl& a = *engines[k]->impl;
+            const RenderConfig &c = a.cfg, &c0 = impl->cfg;
+            if (a.plan.T != impl->plan.T || a.plan.Tout != impl->plan.Tout || a.plan.elt != impl->plan.elt || c.scaling != c0.scaling || c.overlapX != c0.overlapX ||
+                c.overlapY != c0.overlapY || c.tta != c0.tta || c.ttaBugCompat != c0.ttaBugCompat || c.batchSize != c0.batchSize) {
+                W2X_LOG(error, "renderSharded: engine " + std::to_string(k) + " was loaded with another model or configuration."); return false;
+            }
+            for (int j = 0; j < k; ++j) if (engines[j] == engines[k]) { W2X_LOG(error, "renderSharded: the same engine twice."); return false; }
+        }
+        const RenderConfig& cfg = impl->cfg;
+        const Plan& plan = impl->plan;
+        const int rows = src.rows, cols = src.cols, s = cfg.scaling;
+        if (src.depth != 8 || dst.depth != 8) { W2X_LOG(error, "renderSharded takes 8-bit frames."); return false; }
+        if (!src.data || rows <= 0 || cols <= 0 || src.step < (size_t)cols * 3) { W2X_LOG(error, "Input image is empty or has an invalid step."); return false; }
+        if (!dst.data || dst.rows != rows * s || dst.cols != cols * s || dst.step < (size_t)dst.cols * 3) {
+            W2X_LOG(error, "Output image has invalid size: expected " + std::to_string(cols * s) + "x" + std::to_string(rows * s) + "."); return false;
+        }
+        const TileGrid grid = calculate_tiles(cols, rows, cols * s, rows * s, plan.T, plan.T, plan.Tout, plan.Tout, s, cfg.overlapX, cfg.overlapY);
+        if (grid.count <= 0) { W2X_LOG(error, "Tile grid is empty."); return false; }
+        for (const Rect& r : grid.out) if (r.w <= 0 || r.h <= 0) { W2X_LOG(error, "Tile grid does not fit the output (scaling does not match the model)."); return false; }
+        std::vector<ShardPlan> sp(count);
+        for (int k = 0; k < count; ++k) sp[k] = shard_plan(grid, cols * s, rows * s, plan.Tout, plan.Tout, k, count);
+        if (count > 1 && sp[0].tile_count == 0 && grid.count >= count) { W2X_LOG(error, "renderSharded: the blend bands are wider than the tile stride; use renderStrip."); return false; }
+        const int steps = cfg.tta ? 8 : 1;
+        const int To = plan.Tout;
+        const size_t px = (size_t)4 * plan.elt, slot_bytes = (size_t)To * To * px;
+        const bool overlapping = cfg.overlapX != 0 || cfg.overlapY != 0;
+        // ---- phase 1: every engine computes its own tiles
+        for (int k = 0; k < count; ++k) {
+            Impl& e = *engines[k]->impl;
+            if (sp[k].tile_count == 0) continue;
+            DeviceGuard guard(e.device);
+            e.deep = false;
+            e.ensure(e.d_frame, e.frame_cap, (size_t)rows * cols * 3);
+            e.ensure(e.d_out, e.out_cap, (size_t)rows * s * cols * s * 3);
+            hipAssert(hipMemcpy2DAsync(e.d_frame, (size_t)cols * 3, src.data, src.step, (size_t)cols * 3, rows, hipMemcpyHostToDevice, e.stream));
+            const int B = e.plan.B, S = e.plan.B / e.plan.userB;
+            const int batchCount = (int)std::lround(std::ceil((double)(sp[k].tile_count * steps) / e.plan.userB));
+            const int stepCount = ((batchCount + S - 1) / S) * B;
+            e.h_slots.resize(stepCount);
+            for (int st = 0; st < stepCount; ++st) {
+                const int ti = st / steps, aug = st % steps;
+                TileSlot sl{0, 0, aug, 0};
+                if (ti < sp[k].tile_count) { sl.x = grid.in[sp[k].first_tile + ti].x; sl.y = grid.in[sp[k].first_tile + ti].y; sl.valid = 1; }
+                e.h_slots[st] = sl;
+            }
+            e.ensure(e.d_slots, e.slots_cap, (size_t)stepCount * sizeof(TileSlot));
+            hipAssert(hipMemcpyAsync(e.d_slots, e.h_slots.data(), (size_t)stepCount * sizeof(TileSlot), hipMemcpyHostToDevice, e.stream));
+            e.shard_halo_slots = (size_t)(sp[k].first_tile - sp[k].halo_first) * steps;
+            e.ensure(e.d_slab, e.slab_cap, (e.shard_halo_slots + (size_t)stepCount) * slot_bytes);
+            hipAssert(hipEventRecord(e.ev0, e.stream));
+            e.run_passes(rows, cols, sp[k].tile_count, e.shard_halo_slots, k == 0);
+            if (!e.ev_shard) hipAssert(hipEventCreateWithFlags(&e.ev_shard, hipEventDisableTiming));
+            hipAssert(hipEventRecord(e.ev_shard, e.stream));
+        }
+        // ---- phase 2: seam exchange, compose, download
+        for (int k = 0; k < count; ++k) {
+            Impl& e = *engines[k]->impl;
+            if (sp[k].tile_count == 0) continue;
+            DeviceGuard guard(e.device);
+            int waited = -1;
+            for (int g = sp[k].halo_first; g < sp[k].first_tile && overlapping; ++g) {
+                int q = k - 1;
+                while (q >= 0 && !(sp[q].tile_count > 0 && g >= sp[q].first_tile && g < sp[q].first_tile + sp[q].tile_count)) --q;
+                if (q < 0) throw std::runtime_error("shard plan: tile " + std::to_string(g) + " has no owner");
+                Impl& o = *engines[q]->impl;
+                if (q != waited) { hipAssert(hipStreamWaitEvent(e.stream, o.ev_shard, 0)); waited = q; }   // (parts are visited in descending order of q per run of g: at most a few waits)
+                const bool same = o.device == e.device;
+                bool peer2d = same;
+                if (!same) {      // strided band copies between devices need peer access; without it whole slots travel by hipMemcpyPeerAsync
+                    int can = 0;
+                    if (hipDeviceCanAccessPeer(&can, e.device, o.device) == hipSuccess && can) {
+                        const hipError_t pe = hipDeviceEnablePeerAccess(o.device, 0);
+                        peer2d = pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled;
+                    }
+                    (void)hipGetLastError();
+                }
+                for (int a = 0; a < steps; ++a) {
+                    const uint8_t* from = (const uint8_t*)o.d_slab + (o.shard_halo_slots + (size_t)(g - sp[q].first_tile) * steps + a) * slot_bytes;
+                    uint8_t* to = (uint8_t*)e.d_slab + ((size_t)(g - sp[k].halo_first) * steps + a) * slot_bytes;
+                    if (!peer2d) { hipAssert(hipMemcpyPeerAsync(to, e.device, from, o.device, slot_bytes, e.stream)); continue; }
+                    int bx = std::min(To, grid.outOvX), by = std::min(To, grid.outOvY);
+                    if (steps > 1) bx = by = std::max(bx, by);                     // a rotation turns a column band into a row band of the same width
+                    const size_t pitch = (size_t)To * px;
+                    auto cols_band = [&](int x0) { if (bx > 0) hipAssert(hipMemcpy2DAsync(to + (size_t)x0 * px, pitch, from + (size_t)x0 * px, pitch, (size_t)bx * px, To, hipMemcpyDeviceToDevice, e.stream)); };
+                    auto rows_band = [&](int y0) { if (by > 0) hipAssert(hipMemcpyAsync(to + (size_t)y0 * pitch, from + (size_t)y0 * pitch, (size_t)by * pitch, hipMemcpyDeviceToDevice, e.stream)); };
+                    cols_band(To - bx); rows_band(To - by);                        // what the cells to the right of / below the tile read
+                    if (steps > 1) { cols_band(0); rows_band(0); }                // an augmented tile is read through its inverse dihedral map
+                }
+            }
+            for (int r = 0; r < sp[k].nrect; ++r) {
+                const Rect& rc = sp[k].rect[r];
+                e.compose_rect(rows, cols, grid, rc.x, rc.x + rc.w, rc.y, rc.y + rc.h, sp[k].halo_first);
+            }
+            hipAssert(hipEventRecord(e.ev1, e.stream));
+            for (int r = 0; r < sp[k].nrect; ++r) {
+                const Rect& rc = sp[k].rect[r];
+                hipAssert(hipMemcpy2DAsync(dst.data + (size_t)rc.y * dst.step + (size_t)rc.x * 3, dst.step, e.d_out + ((size_t)rc.y * dst.cols + rc.x) * 3, (size_t)dst.cols * 3,
+                                           (size_t)rc.w * 3, rc.h, hipMemcpyDeviceToHost, e.stream));
+            }
+        }
+        for (int k = 0; k < count; ++k) {
+            Impl& e = *engines[k]->impl;
+            if (sp[k].tile_count == 0) continue;
+            DeviceGuard guard(e.device);
+            hipAssert(hipStreamSynchronize(e.stream));
+            hipAssert(hipEventElapsedTime(&e.last_ms, e.ev0, e.ev1));
+        }
+        return true;
+    } catch (const std::exception& ex) {
+        for (int k = 0; k < count; ++k) if (engines[k] && engines[k]->impl->stream) { try { DeviceGuard guard(engines[k]->impl->device); (void)hipStreamSynchronize(engines[k]->impl->stream); } catch (...) {} }
+        W2X_LOG(error, "Render failed unexpectedly: " + std::string(ex.what()) + ".");
+        return false;
+    }
 }
 
 // A sequence of equally sized frames (a video, main.cpp:263-269) with the PCIe copies taken off the critical path: frame i+1 is

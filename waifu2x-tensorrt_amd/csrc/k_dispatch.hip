@@ -3,16 +3,22 @@
 // kernel; graphs of other widths keep the un-fused GEMM + OP_ATTN plan.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace w2x {
 
 hipError_t launch_mlp2(const MlpParams& p, hipStream_t s);                // k_mlp2.hip
 hipError_t launch_swin_attn96(const SwinAttnParams& p, hipStream_t s);    // k_swinattn96.hip
-hipError_t launch_swin_attn192(const SwinAttnParams& p, hipStream_t s);   // k_swinattn192.hip
+hipError_t launch_swin_attn192(const SwinAttnParams& p, hipStream_t s);   // k_swinattn192.hip: two workgroups per CU, a head's weights shared by both windows
+hipError_t launch_swin_attn192u(const SwinAttnParams& p, hipStream_t s);  // k_swinattn192u.hip: three workgroups per CU, one (window, head) unit at a time (round 4)
 
 hipError_t launch_swin_attn(const SwinAttnParams& p, hipStream_t s) {
     if (!p.wqkv_frag || !p.wproj_frag) return hipErrorInvalidValue;       // the kernels read fragment-major weights only
     if (p.C == 96 && p.hd == 16) return launch_swin_attn96(p, s);
-    if (p.C == 192 && p.hd == 32) return launch_swin_attn192(p, s);
+    if (p.C == 192 && p.hd == 32) {
+        static const bool two_per_cu = getenv("W2X_A192_TWO_PER_CU") != nullptr;      // A/B switch, read once: the round-3 kernel
+        return two_per_cu ? launch_swin_attn192(p, s) : launch_swin_attn192u(p, s);
+    }
     return hipErrorInvalidValue;
 }
 

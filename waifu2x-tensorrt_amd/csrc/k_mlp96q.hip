@@ -34,8 +34,17 @@
 // tools/ab/mlp96_variants.sh measured 0.345 ms per launch against 0.312 with the rows served from cache and 0.202 with the
 // products and the GELU removed (5 TB/s): the memory phase and the compute phase were adding up.
 #ifndef W2X_MLP_PREFETCH
-#define W2X_MLP_PREFETCH 0   // measured (profiles/r3_mlp96/): 0.3018 ms per launch without, 0.3085 with (request after the last chunk), 0.331 with the
-#endif                       // request three chunks earlier: with three waves per SIMD the other two cover a wave's fetch, and the SIMD is busy issuing
+#define W2X_MLP_PREFETCH 1   // round 3 (profiles/r3_mlp96/): 0.3018 ms per launch without, 0.3085 with (request after the last chunk), 0.331 with the
+#endif                       // request three chunks earlier: with three waves per SIMD the other two cover a wave's fetch, and the SIMD is busy issuing.
+                             // Round 4: on, together with W2X_MLP96_PRIO = 1 - once the chunk loop outranks the row phases a wave's fetch is no longer
+                             // covered by its neighbours' row phases, and asking a tile ahead pays (profiles/r4_kernels/mlp96_prio.txt: 0.345 / 0.339 as it was,
+                             // 0.324 / 0.324 priority alone, 0.318 / 0.320 with the prefetch, 0.334 / 0.337 prefetch alone)
+// W2X_MLP96_PRIO: s_setprio by phase.  1 = the chunk loop (products + GELU) at priority 1, the row phases (fetch, LayerNorm, epilogue, stores) at 0: of the three
+// waves of a SIMD the ones that multiply win the issue arbitration over the ones that move rows (-5 % per launch, above).  Other modes measured and not kept: 2 the
+// reverse (-1.5 %), 3 only the GELU at 1 (-3 %), 4 as 1 at priority 3 (-3 %), 5 only the products at 1 (+2 %), 6 as 1 with the LayerNorm included (-1 %).
+#ifndef W2X_MLP96_PRIO
+#define W2X_MLP96_PRIO 1
+#endif
 #ifndef W2X_MLP_STAGGER
 #define W2X_MLP_STAGGER 0   // units of s_sleep 127 (about 8 K cycles) between the start of a SIMD's first, second and third wave; measured +9 % time
 #endif

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kComposeThreads) void compose_kernel(const ComposeP
     int b0 = X + 3 - To + 1; b0 = b0 <= 0 ? 0 : (b0 + p.stride_x - 1) / p.stride_x;
     const int a1 = min(p.nx - 1, X / p.stride_x), b1 = min(p.nx - 1, (X + 3) / p.stride_x);
     const bool fast_col = kHalf && np == 4 && !p.tta && !p.deep && a0 == b0 && a1 == b1;
-    const int Y0 = blockIdx.y * kComposeRows, Y1 = min(p.outH, Y0 + kComposeRows);
+    const int Y0 = p.y0 + blockIdx.y * kComposeRows, Y1 = min(p.y1 > 0 ? p.y1 : p.outH, Y0 + kComposeRows);
     for (int Y = Y0; Y < Y1; ++Y) {
         uint8_t* d = p.dst + (size_t)Y * p.dst_step + (size_t)X * 3;
         unsigned px[4] = {0u, 0u, 0u, 0u};
@@ -341,7 +341,9 @@ hipError_t launch_gather(const GatherParams& p, hipStream_t s) {
 hipError_t launch_compose(const ComposeParams& p, hipStream_t s) {
     const int gw = (((p.x1 > 0 ? p.x1 : p.outW) - p.x0) + 3) / 4;
     if (gw <= 0 || p.outH <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((gw + kComposeThreads - 1) / kComposeThreads), (unsigned)((p.outH + kComposeRows - 1) / kComposeRows));
+    const int nrows = (p.y1 > 0 ? p.y1 : p.outH) - p.y0;
+    if (nrows <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((gw + kComposeThreads - 1) / kComposeThreads), (unsigned)((nrows + kComposeRows - 1) / kComposeRows));
     if (p.fp32) hipLaunchKernelGGL(compose_kernel<float4v>, grid, dim3(kComposeThreads), 0, s, p);
     else hipLaunchKernelGGL(compose_kernel<half4>, grid, dim3(kComposeThreads), 0, s, p);
     return hipGetLastError();

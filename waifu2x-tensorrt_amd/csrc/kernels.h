@@ -138,6 +138,8 @@ struct ComposeParams {
     // strip rendering (one GPU of several composes only its columns): output columns [x0, x1) and the global index of
     // the tile held by slot 0 (x1 = 0: the whole canvas)
     int x0 = 0, x1 = 0; long first_tile = 0;
+    // shard rendering (renderSharded): additionally output rows [y0, y1) (y1 = 0: all rows)
+    int y0 = 0, y1 = 0;
 };
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);

@@ -93,4 +93,32 @@ StripPlan strip_plan(const TileGrid& g, int outW, int tileOutW, int part, int pa
     return sp;
 }
 
+ShardPlan shard_plan(const TileGrid& g, int outW, int outH, int tileOutW, int tileOutH, int part, int parts) {
+    ShardPlan sp;
+    if (parts <= 0 || part < 0 || part >= parts || g.count <= 0 || g.ny <= 0) return sp;
+    const int sx = tileOutW - g.outOvX, sy = tileOutH - g.outOvY;
+    // a cell sees tiles (i-1..i, j-1..j) only if a tile's blend band does not reach past its neighbour: overlap < stride (every blend setting of
+    // the command line: overlap <= 1/8 of the tile)
+    if (sx <= 0 || sy <= 0 || g.outOvX >= sx || g.outOvY >= sy) return sp;
+    const long t0 = (long)part * g.count / parts, t1 = (long)(part + 1) * g.count / parts;
+    if (t0 >= t1) return sp;                                           // more parts than tiles
+    sp.first_tile = (int)t0; sp.tile_count = (int)(t1 - t0);
+    sp.halo_first = (int)std::max<long>(0, t0 - g.ny - 1);
+    auto x_of = [&](int i) { return i >= g.nx ? outW : i * sx; };
+    auto y_of = [&](int j) { return j >= g.ny ? outH : j * sy; };
+    auto add = [&](int i0, int i1, int j0, int j1) {                   // cells of columns [i0, i1) x rows [j0, j1)
+        if (i0 >= i1 || j0 >= j1) return;
+        sp.rect[sp.nrect++] = Rect{x_of(i0), y_of(j0), x_of(i1) - x_of(i0), y_of(j1) - y_of(j0)};
+    };
+    const int c0 = (int)(t0 / g.ny), r0 = (int)(t0 % g.ny), c1 = (int)(t1 / g.ny), r1 = (int)(t1 % g.ny);
+    if (c0 == c1) add(c0, c0 + 1, r0, r1);                             // inside one column
+    else {
+        int full0 = c0;
+        if (r0 != 0) { add(c0, c0 + 1, r0, g.ny); full0 = c0 + 1; }    // the tail of the first column
+        add(full0, c1, 0, g.ny);                                       // whole columns
+        if (r1 != 0) add(c1, c1 + 1, 0, r1);                           // the head of the last column
+    }
+    return sp;
+}
+
 }  // namespace w2x

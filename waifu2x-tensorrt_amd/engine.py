@@ -111,6 +111,8 @@ def lib():
     L.w2x_pin_host.argtypes = [vp, vp, C.c_size_t]; L.w2x_pin_host.restype = C.c_int
     L.w2x_unpin_host.argtypes = [vp, vp]; L.w2x_unpin_host.restype = None
     L.w2x_strip_plan.argtypes = [C.c_int] * 7 + [C.c_double, C.c_double, C.c_int, C.c_int, vp]; L.w2x_strip_plan.restype = C.c_int
+    L.w2x_render_sharded.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t]; L.w2x_render_sharded.restype = C.c_int
+    L.w2x_shard_plan.argtypes = [C.c_int] * 7 + [C.c_double, C.c_double, C.c_int, C.c_int, vp]; L.w2x_shard_plan.restype = C.c_int
     L.w2x_infer.argtypes = [vp, vp, vp]; L.w2x_infer.restype = C.c_int
     L.w2x_output_tile_size.argtypes = [vp]; L.w2x_output_tile_size.restype = C.c_int
     L.w2x_pass_tiles.argtypes = [vp]; L.w2x_pass_tiles.restype = C.c_int
@@ -134,7 +136,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "w2x_create", "w2x_destroy", "w2x_set_message_callback", "w2x_set_progress_callback", "w2x_build", "w2x_load",
     "w2x_render", "w2x_render16", "w2x_infer", "w2x_output_tile_size", "w2x_plan_flops", "w2x_pass_tiles", "w2x_last_render_ms", "w2x_bench_resident", "w2x_profile_frame", "w2x_op_times",
-    "w2x_render_strip", "w2x_strip_plan", "w2x_render_sequence", "w2x_alloc_host", "w2x_free_host", "w2x_pin_host", "w2x_unpin_host", "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_describe_plan_precision", "w2x_write_engine_file", "w2x_validate_engine_file", "w2x_sha256_hex", "w2x_version"]
+    "w2x_render_strip", "w2x_strip_plan", "w2x_render_sharded", "w2x_shard_plan", "w2x_render_sequence", "w2x_alloc_host", "w2x_free_host", "w2x_pin_host", "w2x_unpin_host", "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_describe_plan_precision", "w2x_write_engine_file", "w2x_validate_engine_file", "w2x_sha256_hex", "w2x_version"]
 
 
 class Img2Img:
@@ -335,6 +337,29 @@ class Img2Img:
         out = np.zeros(4096, np.float64)
         n = self._L.w2x_op_times(self._h, out.ctypes.data, 4096)
         return out[:n].copy()
+
+
+def render_sharded(engines, src: np.ndarray, dst: np.ndarray = None) -> np.ndarray:
+    """ONE frame over several engines of this process, every tile computed once (w2x_render_sharded): engine k takes the k-th contiguous
+    range of the tile order, the seam bands travel device to device, each engine composes and downloads its own cells of `dst`."""
+    s = getattr(engines[0], "_scaling", 0)
+    if src.dtype != np.uint8 or src.ndim != 3 or src.shape[2] != 3 or src.strides[2] != 1 or src.strides[1] != 3:
+        raise ValueError("src must be a uint8 [rows, cols, 3] BGR array with packed pixels")
+    if dst is None:
+        dst = np.empty((src.shape[0] * s, src.shape[1] * s, 3), np.uint8)
+    if dst.dtype != np.uint8 or dst.shape != (src.shape[0] * s, src.shape[1] * s, 3) or dst.strides[2] != 1 or dst.strides[1] != 3:
+        raise ValueError("dst must be a packed uint8 array of the scaled size")
+    handles = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    if not lib().w2x_render_sharded(handles, len(engines), src.ctypes.data, src.shape[0], src.shape[1], src.strides[0], dst.ctypes.data, dst.strides[0]):
+        raise W2xError(engines[0].last_error() or "sharded render failed")
+    return dst
+
+
+def shard_plan(in_w, in_h, out_w, out_h, tile_in, tile_out, scaling, overlap, part, parts):
+    """Host logic of the every-tile-once split of one frame -> (first_tile, tile_count, halo_first, [(x, y, w, h), ...])."""
+    out = np.zeros(16, np.int32)
+    lib().w2x_shard_plan(in_w, in_h, out_w, out_h, tile_in, tile_out, scaling, float(overlap[0]), float(overlap[1]), int(part), int(parts), out.ctypes.data)
+    return int(out[0]), int(out[1]), int(out[2]), [tuple(int(v) for v in out[4 + 4 * r:8 + 4 * r]) for r in range(int(out[3]))]
 
 
 def strip_plan(in_w, in_h, out_w, out_h, tile_in, tile_out, scaling, overlap, part, parts):
