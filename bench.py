@@ -36,9 +36,45 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 MODEL, SCALE, NOISE, BATCH, TILE, BLEND = "swin_unet/art", 4, 3, 4, 256, 0.0625
 FRAME_W, FRAME_H = 1920, 1080
+TTA = False
+# --config N (1-based index into BASELINE.json configs; 3 = the headline the metric is quoted on; configs[0] is the CPU plumbing case of tests/)
+CONFIGS = {
+    2: dict(name="configs[1]", model="cunet/art", scale=2, noise=1, batch=4, tile=256, w=1920, h=1080, tta=False),
+    3: dict(name="configs[2]", model="swin_unet/art", scale=4, noise=3, batch=4, tile=256, w=1920, h=1080, tta=False),
+    4: dict(name="configs[3]", model="swin_unet/photo", scale=4, noise=3, batch=8, tile=400, w=1920, h=1080, tta=True),
+    5: dict(name="configs[4]", model="swin_unet/art_scan", scale=4, noise=3, batch=16, tile=640, w=3840, h=2160, tta=False),
+}
+CONFIG_NAME = "configs[2]"
 MFMA_F16_PEAK_TFLOPS = 2500.0        # dense, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0                # spec; ~6300 achievable (same guide)
 OUT_MPIX = FRAME_W * SCALE * FRAME_H * SCALE / 1e6
+
+
+def select_config(n: int) -> None:
+    global MODEL, SCALE, NOISE, BATCH, TILE, FRAME_W, FRAME_H, TTA, OUT_MPIX, CONFIG_NAME
+    c = CONFIGS[n]
+    MODEL, SCALE, NOISE, BATCH, TILE, FRAME_W, FRAME_H, TTA, CONFIG_NAME = c["model"], c["scale"], c["noise"], c["batch"], c["tile"], c["w"], c["h"], c["tta"], c["name"]
+    OUT_MPIX = FRAME_W * SCALE * FRAME_H * SCALE / 1e6
+
+
+def kernel_source_sha(symbol: str):
+    """sha256 (12 hex digits) of the source file + build recipe that produce a kernel symbol: roofline.traffic comes from rocprofv3 --pmc passes
+    recorded in profiles/pmc_traffic.json; it is only quoted while the kernel it was measured on is the kernel that runs now."""
+    import hashlib
+    files = {"swin_attn96_kernel": "k_swinattn96.hip", "swin_attn192_kernel": "k_swinattn192.hip", "swin_attn192u_kernel": "k_swinattn192u.hip", "mlp96q_kernel": "k_mlp96q.hip",
+             "mlp2q_kernel": "k_mlp2.hip", "mlp2_kernel": "k_mlp2.hip", "conv48_kernel": "k_conv48.hip", "compose_kernel": "k_prepost.hip", "gather_kernel": "k_prepost.hip",
+             "pixgemm_kernel": "k_pixgemm.hip", "merge_kernel": "k_pixgemm.hip", "toimage_kernel": "k_pixgemm.hip", "conv3_kernel": "k_conv3.hip", "conv3h_kernel": "k_conv3h.hip",
+             "stem_kernel": "k_stem.hip", "gemm_kernel": "k_gemm.hip"}
+    f = files.get(symbol.split("<")[0])
+    if not f:
+        return None
+    h = hashlib.sha256()
+    for path in (os.path.join(ROOT, "waifu2x-tensorrt_amd", "csrc", f), os.path.join(ROOT, "waifu2x-tensorrt_amd", "Makefile")):
+        try:
+            h.update(open(path, "rb").read())
+        except OSError:
+            return None
+    return h.hexdigest()[:12]
 
 
 def synthetic_frame(seed: int) -> np.ndarray:
@@ -53,34 +89,115 @@ def synthetic_frame(seed: int) -> np.ndarray:
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
-def cpu_baseline(work: str, threads: int) -> dict:
-    """The oracle (CPU port of the path: fp32 ONNX executor on torch-CPU kernels + numpy tile pipeline) timed on this
-    box's host cores on a bounded sample: 10 tiles of the same workload (same graph exported at batch 1) through the
-    network plus its pre/post work, extrapolated to the 45 tiles of a frame."""
+def cpu_baseline(work: str, tile_out: int) -> dict:
+    """The oracle (CPU port of the path: fp32 ONNX executor on torch-CPU kernels + numpy tile pipeline) timed on this box's host cores on a
+    bounded sample of the same workload: tiles of the same graph (exported at batch 1) through the network plus their pre / post work, extrapolated
+    to the tiles of a frame.  Thread count: 32 and 64 threads (or all usable cores if fewer) are both tried on one tile, the faster setting is used and
+    both timings are reported.  Why not all cores of a 256-CPU box: the graph is ~640 small operators per tile, which stop scaling at a few dozen
+    threads, and with one thread per CPU the pool oversubscribes - measured once with every core (profiles/r4_final/bench_cpu_all_cores_probe.json):
+    0.48 s per tile on 32 threads, 81.4 s on 256.  Three samples, the median is quoted."""
     import torch
     import synth_models as sm
     from oracle import onnx_exec, pipeline
-    torch.set_num_threads(threads)
     path = sm.model_path(os.path.join(work, "cpu_b1"), MODEL, SCALE, NOISE)
     if not os.path.exists(path):
         sm.export_onnx(sm.make_model(MODEL, SCALE, seed=1234 + NOISE), path, 1, TILE, dynamic=True)
     ex = onnx_exec.Executor(path)
     frame = synthetic_frame(0)
-    n, ins, outs = pipeline.calculate_tiles(FRAME_W, FRAME_H, FRAME_W * SCALE, FRAME_H * SCALE, (TILE, TILE), (960, 960), SCALE, (BLEND, BLEND))
-    picks = list(range(0, n, max(1, n // 10)))[:10]
-    w = pipeline.create_tile_weights((64, 64), (960, 960))
-    ex.run(np.zeros((1, 3, TILE, TILE), np.float32))      # warm-up (thread pool, allocator)
-    t0 = time.perf_counter()
-    for k in picks:
+    n, ins, outs = pipeline.calculate_tiles(FRAME_W, FRAME_H, FRAME_W * SCALE, FRAME_H * SCALE, (TILE, TILE), (tile_out, tile_out), SCALE, (BLEND, BLEND))
+    ov = int(round(tile_out * BLEND))
+    w = pipeline.create_tile_weights((ov, ov), (tile_out, tile_out))
+
+    def one_tile(k):
         tile = np.ascontiguousarray(pipeline.pad_roi(frame[..., ::-1], ins[k]))
         y = ex.run(pipeline.blob_from_tiles([tile]))
         o = pipeline.apply_weights(np.ascontiguousarray(y[0].transpose(1, 2, 0)), outs[k], FRAME_W * SCALE, FRAME_H * SCALE, w)
         pipeline.to_u8(o)
-    dt = time.perf_counter() - t0
-    frame_s = dt / len(picks) * n
-    return {"value": round(OUT_MPIX / frame_s, 4), "unit": "MPix/s", "cores": threads, "kind": "port",
-            "sample": f"oracle (torch-CPU fp32 ONNX executor + numpy pipeline) on {len(picks)} tiles T={TILE} ({dt:.1f} s), "
-                      f"extrapolated to {n} tiles/frame ({frame_s:.0f} s/frame)"}
+
+    host = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = host
+    tried = {}
+    for th in sorted({min(32, usable), min(64, usable)}):
+        torch.set_num_threads(th)
+        one_tile(0)                                          # warm-up (thread pool, allocator)
+        t0 = time.perf_counter(); one_tile(n // 2); tried[th] = time.perf_counter() - t0
+    threads = min(tried, key=tried.get)
+    torch.set_num_threads(threads)
+    per = max(2, min(6, int(6.0 / max(tried[threads], 1e-3))))    # tiles per sample: about 6 s each
+    picks = list(range(0, n, max(1, n // (3 * per))))[:3 * per]
+    samples = []
+    for sidx in range(3):
+        mine = picks[sidx::3]
+        t0 = time.perf_counter()
+        for k in mine:
+            one_tile(k)
+        samples.append((time.perf_counter() - t0) / len(mine) * n)
+    frame_s = sorted(samples)[1]
+    return {"value": round(OUT_MPIX / frame_s, 4), "unit": "MPix/s", "cores": threads, "host_cores": host, "usable_cores": usable, "kind": "port",
+            "samples_mpix_per_s": [round(OUT_MPIX / v, 4) for v in samples],
+            "seconds_per_tile_by_threads": {str(k): round(v, 3) for k, v in tried.items()},
+            "sample": f"oracle (torch-CPU fp32 ONNX executor + numpy pipeline), 3 samples of {len(picks) // 3} tiles T={TILE} each on {threads} threads "
+                      f"(host shows {host} CPUs, {usable} usable; one tile took " + ", ".join(f"{v:.2f} s on {k}" for k, v in tried.items()) + f" threads; 81.4 s on all 256 threads of such a box, profiles/r4_final/bench_cpu_all_cores_probe.json), "
+                      f"median extrapolated to {n} tiles/frame ({frame_s:.0f} s/frame)"}
+
+
+def bench_shards(a) -> int:
+    """--mode shards: ONE frame over --gpus N engines of THIS process with every tile computed once (w2x_render_sharded: contiguous tile ranges,
+    seam bands copied device to device, each engine composes and downloads its own canvas cells).  Host frame in -> host frame out per step,
+    strong scaling.  No child ranks: the seam exchange is a device-to-device copy between engines of one process."""
+    import __graft_entry__ as g
+    import synth_models as sm
+    import shard
+    have = len(shard.gpu_nodes())
+    if have < a.gpus and not os.environ.get("W2X_DEVICE_MAP"):
+        raise SystemExit(f"--gpus {a.gpus} but this node shows {have} GPU(s); refusing to report n_gpus != requested")
+    pkg = g.package()
+    work = os.path.join(a.work, "shards")
+    path = sm.model_path(work, MODEL, SCALE, NOISE)
+    if not os.path.exists(path):
+        sm.export_onnx(sm.make_model(MODEL, SCALE, seed=1234 + NOISE), path, BATCH, TILE, dynamic=True)
+    engs = []
+    for d in range(a.gpus):
+        e = pkg.Img2Img()
+        if not e.build(path, pkg.BuildConfig.fixed(BATCH, TILE, device=d)):
+            raise SystemExit("build failed: " + e.last_error())
+        if not e.load(path, pkg.RenderConfig(deviceId=d, batchSize=BATCH, height=TILE, width=TILE, scaling=SCALE, overlap=(BLEND, BLEND), tta=TTA)):
+            raise SystemExit("load failed: " + e.last_error())
+        engs.append(e)
+    frame = synthetic_frame(0)
+    out = engs[0].alloc_host((FRAME_H * SCALE, FRAME_W * SCALE, 3))
+    pf = engs[0].alloc_host(frame.shape); pf[...] = frame
+    whole = engs[0].render(frame)
+    for _ in range(max(a.warmup, 3)):
+        pkg.render_sharded(engs, pf, out)
+    if not np.array_equal(out, whole):
+        raise SystemExit("renderSharded and render disagree")
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        pkg.render_sharded(engs, pf, out)
+    wall = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        engs[0].render(pf, out)
+    wall1 = time.perf_counter() - t0
+    n = pkg.calculate_tiles(FRAME_W, FRAME_H, FRAME_W * SCALE, FRAME_H * SCALE, TILE, engs[0].output_tile_size, SCALE, (BLEND, BLEND))[0]
+    parts = [pkg.shard_plan(FRAME_W, FRAME_H, FRAME_W * SCALE, FRAME_H * SCALE, TILE, engs[0].output_tile_size, SCALE, (BLEND, BLEND), p, a.gpus) for p in range(a.gpus)]
+    fps = a.steps / wall
+    line = {"metric": f"upscaled MPix/s, one {FRAME_W}x{FRAME_H} frame over N engines ({MODEL} fp16)", "value": round(fps * OUT_MPIX, 2), "unit": "MPix/s", "n_gpus": a.gpus,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(wall * 1e3 / a.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{CONFIG_NAME}: {MODEL} scale{SCALE} noise{NOISE} batch{BATCH} tile{TILE} fp16{' +TTA' if TTA else ''}, {FRAME_W}x{FRAME_H} frame, blend={BLEND} ({n} tiles); host frame in -> host frame out",
+                       "mode": "shards", "parallelism": f"one frame in {a.gpus} contiguous tile ranges (renderSharded), every tile computed once, seam bands copied device to device, no collectives; one process drives all engines",
+                       "tiles_per_engine": [c for _, c, _, _ in parts], "speedup_bound": round(n / max(c for _, c, _, _ in parts), 2),
+                       "one_engine_render_ms": round(wall1 * 1e3 / a.steps, 3), "speedup_measured": round(wall1 / wall, 3),
+                       "device_map": os.environ.get("W2X_DEVICE_MAP")}}
+    print(json.dumps(line), flush=True)
+    for e in engs:
+        e.close()
+    return 0
 
 
 def spawn_ranks(a) -> int:
@@ -110,15 +227,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", choices=["frames", "strips"], default="frames",
-                    help="frames: every rank renders K whole frames (weak scaling, the headline); strips: rank r renders strip r of N of the same frame K times (strong scaling)")
+    ap.add_argument("--mode", choices=["frames", "strips", "shards"], default="frames",
+                    help="frames: every rank renders K whole frames (weak scaling, the headline); strips: rank r renders strip r of N of the same frame K times (strong scaling); "
+                         "shards: one process, N engines, one frame in N tile ranges with every tile computed once (strong scaling)")
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=3,
+                    help="BASELINE.json configuration (1-based; 3 = configs[2], the one the metric is quoted on); the others emit the same JSON record for their workload")
+    ap.add_argument("--cpu-baseline", action="store_true", help="time the CPU oracle for --config other than 3 as well (minutes for the 400 / 640 tiles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frame", choices=["synthetic", "flat", "noise"], default="synthetic",
                     help="diagnostic: frame content (flat = one grey level, noise = uniform random bytes); `value` is quoted on synthetic")
     ap.add_argument("--op-times", action="store_true", help="print HIP-event time per plan op (one frame) to stderr")
     ap.add_argument("--work", default=os.environ.get("W2X_BENCH_WORK", "/tmp/w2x_bench"))
     a = ap.parse_args()
+    select_config(a.config)
 
+    if a.mode == "shards":
+        if int(os.environ.get("RANK", "0")) != 0:       # under a launcher: rank 0 drives every engine, the other ranks have nothing to do
+            return
+        raise SystemExit(bench_shards(a))
     if a.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(spawn_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
@@ -157,7 +283,7 @@ def main():
     bc = pkg.BuildConfig.fixed(BATCH, TILE, device=local_rank)
     if not eng.build(path, bc):
         raise SystemExit("build failed: " + eng.last_error())
-    rc = pkg.RenderConfig(deviceId=local_rank, batchSize=BATCH, height=TILE, width=TILE, scaling=SCALE, overlap=(BLEND, BLEND))
+    rc = pkg.RenderConfig(deviceId=local_rank, batchSize=BATCH, height=TILE, width=TILE, scaling=SCALE, overlap=(BLEND, BLEND), tta=TTA)
     if not eng.load(path, rc):
         raise SystemExit("load failed: " + eng.last_error())
     if rank == 0:
@@ -244,7 +370,15 @@ def main():
             kind, rest, flops = m.group(1), m.group(2), int(m.group(3)) * live
             cm = re.search(r"\bC=(\d+)", rest)
             key = (kind, int(cm.group(1))) if kind in ("swinattn", "mlp") and cm else (kind, 0)
+            am = re.search(r"\ba=(\w+) M=(\d+) K=(\d+) N=(\d+)", rest)
             nbytes = 0.0
+            if kind == "gemm" and am and CONFIG_NAME != "configs[2]":
+                # other configs (cunet's convolutions): one group per operand shape, so that the dominant KERNEL is named - 3x3 convolutions over
+                # 32-channel chunks run on conv3_kernel; algorithmic bytes = read the input map once + write the output map once
+                mode, M, K, N = am.group(1), int(am.group(2)), int(am.group(3)), int(am.group(4))
+                taps = 9 if "3x3" in mode else 4 if "2x2" in mode else 1
+                key = (kind, f"{mode} {K // taps}->{N}")
+                nbytes = float(M) * live * (K // taps + N) * 2
             if key[0] == "swinattn":    # read x + write y: tiles * windows * 36 tokens * C * 2 B, each way
                 nbytes = 2.0 * n_tiles * int(re.search(r"nwin=(\d+)", rest).group(1)) * 36 * key[1] * 2
             elif key[0] == "mlp":
@@ -260,28 +394,34 @@ def main():
                 "achieved": round(gbs if hbm_bound else tflops, 2), "peak": HBM_PEAK_GBS if hbm_bound else MFMA_F16_PEAK_TFLOPS,
                 "unit": "GB/s" if hbm_bound else "TFLOP/s",
                 "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tflops / MFMA_F16_PEAK_TFLOPS), 5), "traffic": None,
-                "kernel": symbols.get(dom, "gemm_kernel / pixgemm kernels" if dom[0] == "gemm" else dom[0]),
+                "kernel": symbols.get(dom, ("conv3_kernel" if isinstance(dom[1], str) and dom[1].startswith("conv3x3s1") and int(dom[1].split()[1].split("->")[0]) % 32 == 0 else
+                                            "gemm_kernel / pixgemm kernels") if dom[0] == "gemm" else dom[0]),
+                "plan_ops": dom[1] if isinstance(dom[1], str) else None,
                 "launches_per_frame": dom_n, "avg_launch_us": round(dom_ms * 1e3 / dom_n, 2),
                 "launch_note": "HIP events around each launch with every pass in one piece on one stream (the engine's profiling pass, = W2X_NO_SPLIT=1: a launch covers all live tiles); the timed region of `value` runs each pass as two tile groups on two streams",
                 "algorithmic_gflop_per_launch": round(dom_flop / dom_n / 1e9, 3),
                 "algorithmic_mbyte_per_launch": round(dom_bytes / dom_n / 1e6, 3),
                 "other_roof": {"unit": "TFLOP/s" if hbm_bound else "GB/s", "achieved": round(tflops if hbm_bound else gbs, 2),
                                "frac": round((tflops / MFMA_F16_PEAK_TFLOPS) if hbm_bound else (gbs / HBM_PEAK_GBS), 5)},
-                "kernels_ms_per_frame": {symbols.get(k, k[0]): round(v[0], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])}}
+                "kernels_ms_per_frame": {symbols.get(k, k[0] if not isinstance(k[1], str) else k[0] + " " + k[1]): round(v[0], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])}}
         tr = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/profile_round.sh)
-        if os.path.exists(tr):
+        if os.path.exists(tr) and CONFIG_NAME == "configs[2]":
             try:
                 t = json.load(open(tr)).get(roof["kernel"])
-                if t: roof["traffic"] = t["bytes_per_launch"]; roof["traffic_source"] = t["source"]
+                now = kernel_source_sha(roof["kernel"])
+                if t and t.get("source_sha") and t["source_sha"] == now:
+                    roof["traffic"] = t["bytes_per_launch"]; roof["traffic_source"] = t["source"]; roof["traffic_kernel_source_sha"] = now
+                elif t:          # the counters were taken on another revision of this kernel: not quoted
+                    roof["traffic_note"] = f"profiles/pmc_traffic.json holds {t['bytes_per_launch']} bytes per launch measured on kernel source {t.get('source_sha', 'unrecorded')}; the kernel now built is {now}: not quoted"
             except Exception:
                 pass
         line = {
-            "metric": "upscaled MPix/s, 1080p->4K swin_unet/art fp16",
+            "metric": "upscaled MPix/s, 1080p->4K swin_unet/art fp16" if CONFIG_NAME == "configs[2]" else f"upscaled MPix/s, {FRAME_W}x{FRAME_H} x{SCALE} {MODEL} fp16{' +TTA' if TTA else ''}",
             "value": round(fps * OUT_MPIX, 2), "unit": "MPix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(wall_max * 1e3 / a.steps, 3), "higher_is_better": True, "scaling": "strong" if strips else "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic" if a.frame == "synthetic" else "synthetic (" + a.frame + " frame: diagnostic)",
-            "config": {"workload": "configs[2]: swin_unet/art scale4 noise3 batch4 tile256 fp16, 1920x1080 frame, blend=0.0625 "
-                                   f"({frame_tiles} tiles, 12 batches); synthetic-weight graph of that architecture, frame resident in HBM",
+            "config": {"workload": f"{CONFIG_NAME}: {MODEL} scale{SCALE} noise{NOISE} batch{BATCH} tile{TILE} fp16{' +TTA' if TTA else ''}, {FRAME_W}x{FRAME_H} frame, blend={BLEND} "
+                                   f"({frame_tiles} tiles, {-(-(frame_tiles * (8 if TTA else 1)) // BATCH)} batches); synthetic-weight graph of that architecture, frame resident in HBM",
                        "frames_per_s": round(fps, 3), "device_ms_per_frame": round(ms, 3), "frames_per_rank": a.steps,
                        "parallelism": (f"one frame in {world} tile-column strips (renderStrip), no collectives" if strips else f"frame-sharded x{world}, no collectives") + "; timing barrier over gloo",
                        "mode": a.mode, "rank0_cpus": len(pinned) or None,
@@ -296,8 +436,8 @@ def main():
                        "families_ms_per_frame": {k: round(v[0], 3) for k, v in prof.items() if k != "frame_ms"}},
             "roofline": roof,
         }
-        if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(a.work, threads=min(os.cpu_count() or 1, 32))
+        if not a.no_cpu_baseline and world == 1 and (a.config == 3 or a.cpu_baseline):
+            line["cpu_baseline"] = cpu_baseline(a.work, eng.output_tile_size)
         print(json.dumps(line), file=json_out, flush=True)
     json_out.close()
     eng.close()

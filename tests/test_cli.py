@@ -223,8 +223,9 @@ def test_cli_build_and_render_match_the_library(pkg, tmp_path):
 
 @pytest.mark.gpu
 def test_cli_two_devices_render_a_still_as_strips_and_a_tf32_engine(pkg, tmp_path):
-    """`--devices 2` on a still: one engine per device, each renders its tile-column strip straight into the shared output image
-    (SURVEY 8e); the bytes are those of the single-device frame.  The box has one GPU, so W2X_DEVICE_MAP=0,0 puts both logical
+    """`--devices N` on a still: one engine per device.  --split shards (default): every tile once, seam bands exchanged, each engine composes
+    its cells of the shared output image (Img2Img::renderSharded); --split strips: each renders its tile-column strip, seam column recomputed
+    (SURVEY 8e); the bytes are those of the single-device frame either way.  The box has one GPU, so W2X_DEVICE_MAP=0,0 puts both logical
     devices on it (engine.cpp physical_device).  The same command line with --precision tf32 builds and renders on the fp32 engine."""
     Image = pytest.importorskip("PIL.Image")
     import synth_models as sm
@@ -234,18 +235,20 @@ def test_cli_two_devices_render_a_still_as_strips_and_a_tf32_engine(pkg, tmp_pat
     rgb = np.random.default_rng(2).integers(0, 256, (150, 210, 3), dtype=np.uint8)
     Image.fromarray(rgb).save(tmp_path / "in.png")
     common = ["--models", str(models), "--model", "cunet/art", "--scale", "2", "--noise", "1", "--batchSize", "2", "--tileSize", "64"]
-    env = dict(os.environ, W2X_DEVICE_MAP="0,0")
+    env = dict(os.environ, W2X_DEVICE_MAP="0,0,0")
     def cli(*a):
         return subprocess.run([W2X, *common, *a], capture_output=True, text=True, timeout=180, env=env)
     r = cli("build")
     assert r.returncode == 0, r.stderr
     outs = {}
-    for name, extra in (("one", []), ("two", ["--devices", "2"])):
+    for name, extra in (("one", []), ("two", ["--devices", "2"]), ("two_strips", ["--devices", "2", "--split", "strips"]), ("three", ["--devices", "3"])):
         out = tmp_path / name; out.mkdir()
         r = cli("render", "-i", str(tmp_path / "in.png"), "-o", str(out), *extra)
         assert r.returncode == 0, r.stderr
         outs[name] = np.array(Image.open(out / "in(cunet_art)(noise1)(scale2).png"))
-    assert outs["one"].shape == (300, 420, 3) and np.array_equal(outs["one"], outs["two"])
+    assert outs["one"].shape == (300, 420, 3)
+    for name in ("two", "two_strips", "three"):
+        assert np.array_equal(outs["one"], outs[name]), name
     r = cli("--precision", "tf32", "build")
     assert r.returncode == 0, r.stderr
     out = tmp_path / "tf32"; out.mkdir()

@@ -2,7 +2,8 @@
 MI355X_MICROARCH.md prescribes for gfx950:  bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (both counters are in KiB;
 FETCH_SIZE reports half of a wide streaming read on gfx950; Infinity-Cache hits are counted).
 usage: pmc_traffic.py <dir with pmc_fetch/ and pmc_write/> <out.json> <source tag>"""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def per_kernel(d, counter):
     acc = collections.defaultdict(lambda: [0.0, 0])
@@ -21,6 +22,10 @@ def symbol(name):
     return m.group(1) if m else None
 
 root, out, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+try:
+    from bench import kernel_source_sha      # the kernel source + build recipe the counters were taken on: bench.py quotes the traffic only while they match
+except Exception:
+    kernel_source_sha = lambda s: None
 fetch, write = per_kernel(root + "/pmc_fetch", "FETCH_SIZE"), per_kernel(root + "/pmc_write", "WRITE_SIZE")
 res = {}
 for k in fetch:
@@ -28,6 +33,6 @@ for k in fetch:
     if not s or k not in write: continue
     f, w = fetch[k][0] / fetch[k][1], write[k][0] / write[k][1]
     res[s] = {"bytes_per_launch": round((2 * f + w) * 1024), "fetch_kib_raw": round(f, 1), "write_kib": round(w, 1),
-              "launches_sampled": fetch[k][1], "source": tag}
+              "launches_sampled": fetch[k][1], "source": tag, "source_sha": kernel_source_sha(s)}
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]["bytes_per_launch"]): print(f"{k:40s} {v['bytes_per_launch'] / 1e6:10.1f} MB/launch")

@@ -55,7 +55,8 @@ std::string usage() {
            "  --tileSize INT REQUIRED     {64,128,256,400,640}\n"
            "  --device INT [0]            GPU device ID\n"
            "  --precision TEXT [fp16]     {fp16,tf32}\n"
-           "  --devices INT [1]           (extension) number of GPUs: video frames round-robin, one image as tile-column strips\n"
+           "  --devices INT [1]           (extension) number of GPUs: video frames round-robin, one image as N tile ranges\n"
+           "  --split TEXT [shards]       (extension) {shards,strips}: one image over --devices N: every tile once with the seam bands exchanged / whole tile columns\n"
            "  --deep                      (extension) 16-bit PNGs keep 16 bits per sample through the engine and in the output\n"
            "  --models DIR [models]       (extension) root of the model directory tree\n\n"
            "Subcommands:\n"
@@ -94,6 +95,7 @@ Options parse(int argc, const char* const* argv) {
         else if (k == "--tileSize") { o.tileSize = to_int(k, value(i)); seen_tile = true; }
         else if (k == "--device") o.device = to_int(k, value(i));
         else if (k == "--devices") o.devices = to_int(k, value(i));
+        else if (k == "--split") o.split = value(i);
         else if (k == "--models") o.models = value(i);
         else if (k == "--precision") { o.precision = value(i); std::transform(o.precision.begin(), o.precision.end(), o.precision.begin(), ::tolower); }
         else if (k == "--print-config") o.printConfig = true;
@@ -131,6 +133,7 @@ Options parse(int argc, const char* const* argv) {
     member("--tileSize", o.tileSize, {64, 128, 256, 400, 640});
     if (o.device < 0) throw std::runtime_error("--device: number must be non-negative");
     if (o.devices < 1) throw std::runtime_error("--devices: number must be positive");
+    member<std::string>("--split", o.split, {"shards", "strips"});
     member<std::string>("--precision", o.precision, {"fp16", "tf32"});
     if (o.command == "render") {
         if (o.inputs.empty()) throw std::runtime_error("--input is required");
@@ -173,7 +176,7 @@ std::string to_json(const Options& o) {
     auto q = [](const std::string& s) { std::string r = "\""; for (char c : s) { if (c == '"' || c == '\\') r += '\\'; r += c; } return r + "\""; };
     std::ostringstream os;
     os << "{\"command\": " << q(o.command) << ", \"model\": " << q(o.model) << ", \"scale\": " << o.scale << ", \"noise\": " << o.noise
-       << ", \"batchSize\": " << o.batchSize << ", \"tileSize\": " << o.tileSize << ", \"device\": " << o.device << ", \"devices\": " << o.devices
+       << ", \"batchSize\": " << o.batchSize << ", \"tileSize\": " << o.tileSize << ", \"device\": " << o.device << ", \"devices\": " << o.devices << ", \"split\": " << q(o.split)
        << ", \"precision\": " << q(o.precision) << ", \"recursive\": " << (o.recursive ? "true" : "false") << ", \"output\": " << q(o.output)
        << ", \"nosuffix\": " << (o.nosuffix ? "true" : "false") << ", \"blend\": " << o.blend << ", \"tta\": " << (o.tta ? "true" : "false") << ", \"tta_mode\": " << q(o.ttaMode)
        << ", \"codec\": " << q(o.codec) << ", \"pix_fmt\": " << q(o.pixFmt) << ", \"crf\": " << o.crf << ", \"inputs\": [";

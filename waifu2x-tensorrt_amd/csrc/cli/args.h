@@ -25,7 +25,9 @@ struct Options {
     std::string codec = "libx264", pixFmt = "yuv420p";
     int crf = 23;
     // extensions
-    int devices = 1;                      // --devices N: frames of a video round-robin, a single image as tile-column strips
+    int devices = 1;                      // --devices N: frames of a video round-robin, a single image as N tile ranges (--split)
+    std::string split = "shards";         // --split {shards,strips}: how ONE image is spread over --devices N: shards = every tile once, seam bands exchanged
+                                          // (Img2Img::renderSharded); strips = whole tile columns per device, the seam column recomputed (Img2Img::renderStrip)
     std::string models = "models";        // --models DIR: root of models/<model>/... (reference: fixed relative "models/")
     std::string ttaMode = "mean";         // --tta-mode {mean,reference}: mean = the true average of the 8 augmentations; reference = the bytes the
                                           // reference's accumulation produces (img2img_render.cpp:313-316) -> RenderConfig::ttaBugCompat

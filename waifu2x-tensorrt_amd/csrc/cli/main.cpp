@@ -223,7 +223,14 @@ int main(int argc, char** argv) {
                 }
                 auto render_still = [&](const Image& s0, Image& d0) {
                     if (o.devices == 1) return engines[0]->render(s0, d0);
-                    // tile-column strips: each engine composes and downloads its own columns of the output
+                    // every tile once: engine k takes the k-th contiguous range of the tile order, the seam bands travel device to device, each
+                    // engine composes and downloads its own cells of the output (Img2Img::renderSharded).  16-bit frames and --split strips keep the
+                    // tile-column strips (each engine on its own host thread, the seam column recomputed instead of exchanged).
+                    if (s0.depth == 8 && o.split == "shards") {
+                        std::vector<Img2Img*> es;
+                        for (auto& e : engines) es.push_back(e.get());
+                        return Img2Img::renderSharded(es.data(), (int)es.size(), s0, d0);
+                    }
                     std::vector<std::thread> th; std::vector<char> oks(o.devices, 1);
                     for (int d = 0; d < o.devices; ++d) th.emplace_back([&, d] { Image s2 = s0, d2 = d0; oks[d] = engines[d]->renderStrip(s2, d2, d, o.devices); });
                     for (auto& t : th) t.join();
