@@ -50,7 +50,7 @@ struct Conv3Cfg {
 __device__ __forceinline__ int halo_slot(int x, int pc) { return x * 64 + ((pc + 2 * ((x >> 2) & 3)) & 3) * 16; }
 
 template <bool POOL>
-__global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int Ho, int Wo, int tiles_x, int tiles_y, int nblk) {
+__global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int Ho, int Wo, int tiles_x, int tiles_y, int nblk, int xcd_order) {
     using C = Conv3Cfg;
     constexpr int HR = C::HR, HC = C::HC;
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
@@ -58,8 +58,17 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, g = lane >> 4;
 
-    const int nb = blockIdx.x % nblk, tidx = blockIdx.x / nblk;      // the blocks of a tile run side by side: its halo is fetched from HBM once
+    // The 2 - 4 output blocks of a pixel tile share its halo.  Workgroups are handed to the eight XCDs round-robin (workgroup q -> XCD q % 8), each XCD
+    // with its own L2: as consecutive workgroups the blocks of a tile land on different XCDs and each fetches the halo into its own L2.  XCD-grouped
+    // order (round 4): the r-th workgroup of an XCD (r = q / 8) is block r % nblk of tile (r / nblk) * 8 + xcd, so the blocks of a tile are consecutive
+    // workgroups of ONE XCD and the halo goes through one L2.  (W2X_CONV3_XCD=0 keeps the plain order.)
+    int nb, tidx;
     const int tpi = tiles_x * tiles_y;
+    if (xcd_order) {
+        const int q = blockIdx.x, xcd = q & 7, r = q >> 3;
+        tidx = (r / nblk) * 8 + xcd; nb = r % nblk;
+        if (tidx >= p.B * tpi) return;                                // (the grid is rounded up to whole rounds of eight tiles)
+    } else { nb = blockIdx.x % nblk; tidx = blockIdx.x / nblk; }
     const int b = tidx / tpi, trem = tidx - b * tpi;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
     const int oy0 = ty * C::TH, ox0 = tx * C::TW, n0 = nb * 64;
@@ -217,9 +226,12 @@ hipError_t launch_conv3(const GemmParams& p, hipStream_t s) {
     if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<false>, C::SMEM, lds_ok); e != hipSuccess) return e;
     if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<true>, C::SMEM, lds_ok_pool); e != hipSuccess) return e;
     const int tiles_x = (Wo + C::TW - 1) / C::TW, tiles_y = (Ho + C::TH - 1) / C::TH, nblk = p.N / 64;
-    const dim3 grid((unsigned)(p.B * tiles_x * tiles_y * nblk));
-    if (p.pool_out) hipLaunchKernelGGL(conv3_kernel<true>, grid, dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, nblk);
-    else hipLaunchKernelGGL(conv3_kernel<false>, grid, dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, nblk);
+    static const bool xcd_off = [] { const char* e = getenv("W2X_CONV3_XCD"); return e && e[0] == '0'; }();   // A/B switch, read once
+    const int xcd_order = nblk > 1 && !xcd_off ? 1 : 0;
+    const int ntiles = p.B * tiles_x * tiles_y;
+    const dim3 grid((unsigned)((xcd_order ? (ntiles + 7) / 8 * 8 : ntiles) * nblk));
+    if (p.pool_out) hipLaunchKernelGGL(conv3_kernel<true>, grid, dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, nblk, xcd_order);
+    else hipLaunchKernelGGL(conv3_kernel<false>, grid, dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, nblk, xcd_order);
     return hipGetLastError();
 }
 

@@ -104,6 +104,9 @@ __device__ __forceinline__ float group_sum32(float v) {
 #ifndef W2X_A192U_WPC
 #define W2X_A192U_WPC 3
 #endif
+#ifndef W2X_A192U_EXP
+#define W2X_A192U_EXP 0      // timing experiments (wrong results): 1 = leave after the head loop, 2 = skip the head loop, 3 = rows fetched from one cached 64 KB region
+#endif
 #ifndef W2X_A192U_BIAS_EARLY
 #define W2X_A192U_BIAS_EARLY 1   // measured (profiles/r4_kernels/attn192u_*.txt): 0 -> 0.358 ms per 120 x 120 launch, 1 -> 0.308 - 0.322, 2 -> 0.331 (spills)
 #endif
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256, W2X_A192U_WPC) void swin_attn192u_kernel(const
             const int2v pr = Pix[ps * RPP + rsub];
             srow[ps] = pr[1];
             // rows that do not exist and the eight idle lanes of a row read zeros
-            xr[ps] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(X, __builtin_elementwise_add_sat((unsigned)pr[0], lane_off), 0, 0));
+            xr[ps] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(X, __builtin_elementwise_add_sat(W2X_A192U_EXP == 3 ? (unsigned)pr[0] & 0xFFFFu : (unsigned)pr[0], lane_off), 0, 0));
         }
         static_assert(NPASS == 9, "the row sums are reduced three passes at a time");
         float sm[NPASS], sq[NPASS];
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256, W2X_A192U_WPC) void swin_attn192u_kernel(const
     half4 oh[3][2][3];
 
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < (W2X_A192U_EXP == 2 ? 0 : 3); ++u) {
         const int w = u == 2 ? wC : u, h = u == 2 ? hC : hA;
         const int amask = w == 0 ? amask0 : amask1;
         const _Float16* xs = Xs + w * SLAB * LDX;
@@ -384,6 +387,17 @@ __global__ __launch_bounds__(256, W2X_A192U_WPC) void swin_attn192u_kernel(const
             }
     }
 #undef W2X_RING_NEXT
+#if W2X_A192U_EXP == 1
+    if (p.B >= 0) { if (tid == 0) ((float*)p.y)[blockIdx.x] = (float)oh[0][0][0][0] + (float)oh[1][1][1][1] + (float)oh[2][0][2][2]; return; }
+#endif
+#if W2X_A192U_EXP == 2
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int qi = 0; qi < 3; ++qi) oh[u][ft][qi] = (half4){};
+#endif
 #ifdef W2X_A192U_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
