@@ -202,6 +202,8 @@ struct Img2Img::Impl {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_shard = nullptr;       // renderSharded(): this engine's tiles are in its slab
+    hipEvent_t ev_part[2] = {nullptr, nullptr};
+    int pipeline_parts = 2;              // W2X_RENDER_PARTS (read at load): 1 = render() runs a frame as one part
     size_t shard_halo_slots = 0;         // renderSharded(): slab slots in front of this engine's own tiles (the bands copied from the preceding parts)
     hipStream_t gstream[3] = {nullptr, nullptr, nullptr};   // further tile groups of a pass (run_frame)
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -253,6 +255,16 @@ struct Img2Img::Impl {
     }
     void stamp_end() { if (profiling) hipAssert(hipEventRecord(stamps.back().b, stream)); }
 
+    // The copy streams of renderSequence() (upload, download) and of a two-part render() (download): ONE pair, created in one place and in one
+    // order - the runtime spreads streams over its hardware queues in creation order, and a further stream in between moved the copy streams
+    // onto the compute streams' queues (host-to-host 7.6 -> 9.8 ms per frame, profiles/r4_kernels/render_parts_ab.txt, first run).
+    void ensure_copy_streams() {
+        if (s_up) return;
+        hipAssert(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking));
+        hipAssert(hipStreamCreateWithFlags(&s_dn, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) { hipAssert(hipEventCreateWithFlags(&ev_up[b], hipEventDisableTiming)); hipAssert(hipEventCreateWithFlags(&ev_comp[b], hipEventDisableTiming)); hipAssert(hipEventCreateWithFlags(&ev_dn[b], hipEventDisableTiming)); }
+    }
+
     // last frame (for benchResident)
     int last_rows = 0, last_cols = 0, last_batches = 0;
     TileGrid last_grid;
@@ -302,6 +314,7 @@ struct Img2Img::Impl {
         if (ev0) { (void)hipEventDestroy(ev0); ev0 = nullptr; }
         if (ev1) { (void)hipEventDestroy(ev1); ev1 = nullptr; }
         if (ev_shard) { (void)hipEventDestroy(ev_shard); ev_shard = nullptr; }
+        for (hipEvent_t& e : ev_part) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
         if (ev_stagger) { (void)hipEventDestroy(ev_stagger); ev_stagger = nullptr; }
         for (hipEvent_t& e : ev_join) if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -652,19 +665,20 @@ struct Img2Img::Impl {
 
     // device part of one frame: gather -> network per batch -> compose.  Frame must already be in d_frame.
     void run_frame(int rows, int cols, const TileGrid& grid, bool report, const StripPlan& sp) {
-        run_passes(rows, cols, sp.tile_count, 0, report);
+        run_passes(rows, cols, sp.tile_count, 0, report, 0, true);
         compose_rect(rows, cols, grid, sp.x0, sp.x1, 0, 0, sp.first_tile);
     }
 
-    // the network passes of `tile_count` tiles (slots d_slots[0 ..]); their outputs go to slab slots slab_slot0, slab_slot0 + 1, ...
-    void run_passes(int rows, int cols, int tile_count, size_t slab_slot0, bool report) {
+    // the network passes of `tile_count` tiles (slots d_slots[slots_off ..]); their outputs go to slab slots slab_slot0, slab_slot0 + 1, ...
+    // fresh: the first passes of a frame (W2X_POISON wipes the arena and the slab here, not between the parts of a pipelined frame)
+    void run_passes(int rows, int cols, int tile_count, size_t slab_slot0, bool report, size_t slots_off, bool fresh, int batch0 = 0, int batch_total = 0) {
         const int B = plan.B, T = plan.T, To = plan.Tout;
         const int steps = cfg.tta ? 8 : 1;
         const int userB = plan.userB, S = B / userB;
         const int batchCount = (int)std::lround(std::ceil((double)(tile_count * steps) / userB));   // img2img_render.cpp:249
         const int passCount = (batchCount + S - 1) / S;
         const size_t slot_bytes = (size_t)To * To * 4 * plan.elt;
-        if (poison) {
+        if (poison && fresh) {
             hipAssert(hipMemsetAsync(arena_base, 0x7E, arena_bytes, stream));
             hipAssert(hipMemsetAsync(d_slab, 0x7E, slab_cap, stream));
         }
@@ -677,7 +691,7 @@ struct Img2Img::Impl {
             auto run_pass = [&] {
                 GatherParams gp;
                 gp.frame = d_frame; gp.rows = rows; gp.cols = cols; gp.step = (size_t)cols * 3 * (deep ? 2 : 1); gp.deep = deep ? 1 : 0;
-                gp.out = tensors[plan.in_tensor]; gp.slots = d_slots + (size_t)bi * B; gp.B = B; gp.T = T; gp.fp32 = plan.elt == 4;
+                gp.out = tensors[plan.in_tensor]; gp.slots = d_slots + slots_off + (size_t)bi * B; gp.B = B; gp.T = T; gp.fp32 = plan.elt == 4;
                 const int NG = groups;
                 struct NgReset { int& r; ~NgReset() { r = 1; } } ng_reset{ng_now};   // also when a launch throws mid-pass
                 ng_now = NG;
@@ -701,7 +715,7 @@ struct Img2Img::Impl {
                 int first[5] = {0, 0, 0, 0, 0};
                 for (int grp = 0; grp < NG; ++grp) first[grp + 1] = first[grp] + live / NG + (grp < live % NG ? 1 : 0);
                 for (int grp = 0; grp < NG; ++grp) {      // each group's tiles at the start of its part of the arena
-                    gp.out = group_ptr(tensors[plan.in_tensor], grp); gp.slots = d_slots + (size_t)bi * B + (size_t)first[grp]; gp.B = first[grp + 1] - first[grp];
+                    gp.out = group_ptr(tensors[plan.in_tensor], grp); gp.slots = d_slots + slots_off + (size_t)bi * B + (size_t)first[grp]; gp.B = first[grp + 1] - first[grp];
                     hipAssert(launch_gather(gp, stream));
                 }
                 hipAssert(hipEventRecord(ev_fork, stream));
@@ -721,7 +735,7 @@ struct Img2Img::Impl {
             };
             if (!graphable) run_pass();
             else {
-                const GraphKey key{d_frame, d_slots + (size_t)bi * B, slab_out, arena_base, rows, cols, live, deep ? 1 : 0};
+                const GraphKey key{d_frame, d_slots + slots_off + (size_t)bi * B, slab_out, arena_base, rows, cols, live, deep ? 1 : 0};
                 auto it = graphs.find(key);
                 if (it != graphs.end()) { hipAssert(hipGraphLaunch(it->second, stream)); ++graph_replays; }
                 else if (graph_seen.size() >= 4096 && !graph_seen.count(key)) { graph_seen.clear(); run_pass(); ++eager_passes; }   // sizes that keep changing: bounded bookkeeping
@@ -756,10 +770,10 @@ struct Img2Img::Impl {
                 const auto t1 = std::chrono::steady_clock::now();
                 const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
                 for (int k = bi * S; k < std::min((bi + 1) * S, batchCount); ++k)
-                    log(k + 1, batchCount, 1000.0 * S / std::max(ms, 1e-6));                     // :336-338
+                    log(batch0 + k + 1, batch_total > 0 ? batch_total : batchCount, 1000.0 * S / std::max(ms, 1e-6));                     // :336-338
             }
         }
-        last_batches = batchCount;
+        last_batches = batch0 + batchCount;
     }
 
     // compose: output columns [x0, x1) (x1 = 0: to the right edge) and rows [y0, y1) (y1 = 0: to the bottom) from the slab, whose slot 0 holds
@@ -896,6 +910,7 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
     impl->poison = getenv("W2X_POISON") != nullptr;
     impl->check_general = getenv("W2X_PIXGEMM_CHECK") != nullptr;
     impl->use_graphs = getenv("W2X_NO_GRAPH") == nullptr;
+    if (const char* e = getenv("W2X_RENDER_PARTS")) impl->pipeline_parts = atoi(e) >= 2 ? 2 : 1;
     try {
         impl->plan = Plan::deserialize((const uint8_t*)engineBuffer.data(), engineBuffer.size());
     } catch (const std::exception& e) {
@@ -992,27 +1007,105 @@ bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, cons
     if (sp.tile_count == 0) return true;                       // more devices than tile columns: this one has no share
     // :246-267 step schedule: slot = step index, tile = step / stepsPerTile, aug = step % stepsPerTile, zero pad slots at the end
     const int steps = cfg.tta ? 8 : 1, B = plan.B, S = plan.B / plan.userB;
-    const int batchCount = (int)std::lround(std::ceil((double)(sp.tile_count * steps) / plan.userB));
-    const int stepCount = ((batchCount + S - 1) / S) * B;   // reference batches rounded up to whole network passes
-    impl->h_slots.resize(stepCount);
-    for (int st = 0; st < stepCount; ++st) {
-        int ti = st / steps, aug = st % steps;
-        TileSlot sl{0, 0, aug, 0};
-        if (ti < sp.tile_count) { sl.x = grid.in[sp.first_tile + ti].x; sl.y = grid.in[sp.first_tile + ti].y; sl.valid = 1; }
-        impl->h_slots[st] = sl;
+    // A whole frame (render()) runs as TWO parts one after the other: the first part's tiles, its canvas cells composed and handed to the
+    // download stream, then the second part's while those cells travel to the host - the synchronous contract of img2img_render.cpp:226-344
+    // with most of the 100 MB download of a 4K frame off the critical path (10.0 -> 9.x ms per call at config 3).  The parts are those of
+    // shard_plan() (contiguous tile ranges, canvas cells of their tiles; the second part reads the first one's tiles from the same slab), cut
+    // at a multiple of the batch size so that batches, their order and the progress schedule (:246-250, 336-338) are the reference's.
+    int cut = 0;                                               // tiles in the first part (0: one part)
+    if (parts == 1 && impl->pipeline_parts > 1 && sp.tile_count >= 16 && grid.outOvX < plan.Tout - grid.outOvX && grid.outOvY < plan.Tout - grid.outOvY) {
+        for (int t = sp.tile_count / 2; t >= sp.tile_count / 4 && !cut; --t) if ((t * steps) % plan.userB == 0) cut = t;
     }
-    impl->ensure(impl->d_slots, impl->slots_cap, (size_t)stepCount * sizeof(TileSlot));
-    hipAssert(hipMemcpyAsync(impl->d_slots, impl->h_slots.data(), (size_t)stepCount * sizeof(TileSlot), hipMemcpyHostToDevice, stream));
-    impl->ensure(impl->d_slab, impl->slab_cap, (size_t)stepCount * plan.Tout * plan.Tout * 4 * plan.elt);
+    const int npart = cut ? 2 : 1;
+    const int tiles_of[2] = {cut ? cut : sp.tile_count, cut ? sp.tile_count - cut : 0};
+    size_t slots_off[2] = {0, 0}; int batches_of[2] = {0, 0}; size_t stepTotal = 0;
+    for (int k = 0; k < npart; ++k) {
+        batches_of[k] = (int)std::lround(std::ceil((double)(tiles_of[k] * steps) / plan.userB));
+        slots_off[k] = stepTotal;
+        stepTotal += (size_t)((batches_of[k] + S - 1) / S) * B;   // reference batches rounded up to whole network passes
+    }
+    impl->h_slots.resize(stepTotal);
+    for (int k = 0; k < npart; ++k) {
+        const int t0 = k ? cut : 0;
+        const size_t n = (k + 1 < npart ? slots_off[k + 1] : stepTotal) - slots_off[k];
+        for (size_t st = 0; st < n; ++st) {
+            const int ti = (int)(st / steps), aug = (int)(st % steps);
+            TileSlot sl{0, 0, aug, 0};
+            if (ti < tiles_of[k]) { sl.x = grid.in[sp.first_tile + t0 + ti].x; sl.y = grid.in[sp.first_tile + t0 + ti].y; sl.valid = 1; }
+            impl->h_slots[slots_off[k] + st] = sl;
+        }
+    }
+    impl->ensure(impl->d_slots, impl->slots_cap, stepTotal * sizeof(TileSlot));
+    hipAssert(hipMemcpyAsync(impl->d_slots, impl->h_slots.data(), stepTotal * sizeof(TileSlot), hipMemcpyHostToDevice, stream));
+    // the slab holds the frame's tiles in tile order: the last part's passes end at most a pass beyond them
+    impl->ensure(impl->d_slab, impl->slab_cap, ((size_t)(cut * steps) + (stepTotal - slots_off[npart - 1])) * plan.Tout * plan.Tout * 4 * plan.elt);
 
     hipAssert(hipEventRecord(impl->ev0, stream));
-    impl->run_frame(rows, cols, grid, true, sp);
-    hipAssert(hipEventRecord(impl->ev1, stream));
-    // :344 download ; the reference leaves the sync commented out (:345, quirk Q10) - we wait before handing dst back
-    hipAssert(hipMemcpy2DAsync(dst.data + (size_t)sp.x0 * 3 * bps, dst.step, impl->d_out + (size_t)sp.x0 * 3 * bps, (size_t)dst.cols * 3 * bps, (size_t)(sp.x1 - sp.x0) * 3 * bps, dst.rows, hipMemcpyDeviceToHost, stream));
-    hipAssert(hipStreamSynchronize(stream));
+    if (npart == 1) {
+        impl->run_frame(rows, cols, grid, true, sp);
+        hipAssert(hipEventRecord(impl->ev1, stream));
+        // :344 download ; the reference leaves the sync commented out (:345, quirk Q10) - we wait before handing dst back
+        hipAssert(hipMemcpy2DAsync(dst.data + (size_t)sp.x0 * 3 * bps, dst.step, impl->d_out + (size_t)sp.x0 * 3 * bps, (size_t)dst.cols * 3 * bps, (size_t)(sp.x1 - sp.x0) * 3 * bps, dst.rows, hipMemcpyDeviceToHost, stream));
+        hipAssert(hipStreamSynchronize(stream));
+    } else {
+        impl->ensure_copy_streams();
+        for (int k = 0; k < 2; ++k) if (!impl->ev_part[k]) hipAssert(hipEventCreateWithFlags(&impl->ev_part[k], hipEventDisableTiming));
+        ShardPlan part_plan[2];
+        for (int k = 0; k < 2; ++k) {
+            // the cells of tiles [0, cut) and [cut, count): shard_plan()'s rectangles for an uneven two-way split
+            ShardPlan q; q.first_tile = k ? cut : 0; q.tile_count = tiles_of[k];
+            const int sx = plan.Tout - grid.outOvX, sy = plan.Tout - grid.outOvY;
+            auto x_of = [&](int i) { return i >= grid.nx ? cols * s : i * sx; };
+            auto y_of = [&](int j) { return j >= grid.ny ? rows * s : j * sy; };
+            auto add = [&](int i0, int i1, int j0, int j1) { if (i0 < i1 && j0 < j1) q.rect[q.nrect++] = Rect{x_of(i0), y_of(j0), x_of(i1) - x_of(i0), y_of(j1) - y_of(j0)}; };
+            const int t0 = q.first_tile, t1 = t0 + q.tile_count;
+            const int c0 = t0 / grid.ny, r0 = t0 % grid.ny, c1 = t1 / grid.ny, r1 = t1 % grid.ny;
+            if (c0 == c1) add(c0, c0 + 1, r0, r1);
+            else { int full0 = c0; if (r0) { add(c0, c0 + 1, r0, grid.ny); full0 = c0 + 1; } add(full0, c1, 0, grid.ny); if (r1) add(c1, c1 + 1, 0, r1); }
+            part_plan[k] = q;
+        }
+        for (int k = 0; k < 2; ++k) {
+            impl->run_passes(rows, cols, tiles_of[k], (size_t)(k ? cut : 0) * steps, true, slots_off[k], k == 0, k ? batches_of[0] : 0, batches_of[0] + batches_of[1]);
+            for (int r = 0; r < part_plan[k].nrect; ++r) {
+                const Rect& rc = part_plan[k].rect[r];
+                impl->compose_rect(rows, cols, grid, rc.x, rc.x + rc.w, rc.y, rc.y + rc.h, 0);
+            }
+            hipAssert(hipEventRecord(impl->ev_part[k], stream));
+        }
+        hipAssert(hipEventRecord(impl->ev1, stream));
+        // the downloads, in order, on a copy stream: part 0's cells travel while part 1 computes.  Which of the two copy streams: the one created
+        // FIRST (renderSequence()'s upload stream, idle here) - the runtime spreads streams over its hardware queues in creation order, and from
+        // pageable memory the download only ran beside the kernels on that one (9.1 against 9.9 ms per call, profiles/r4_kernels/render_parts_ab*.txt)
+        static const bool dn_on_second = getenv("W2X_RENDER_DN_STREAM") != nullptr;
+        hipStream_t dn = dn_on_second ? impl->s_dn : impl->s_up;
+        for (int k = 0; k < 2; ++k) {
+            hipAssert(hipStreamWaitEvent(dn, impl->ev_part[k], 0));
+            for (int r = 0; r < part_plan[k].nrect; ++r) {
+                const Rect& rc = part_plan[k].rect[r];
+                hipAssert(hipMemcpy2DAsync(dst.data + (size_t)rc.y * dst.step + (size_t)rc.x * 3 * bps, dst.step, impl->d_out + ((size_t)rc.y * dst.cols + rc.x) * 3 * bps, (size_t)dst.cols * 3 * bps,
+                                           (size_t)rc.w * 3 * bps, rc.h, hipMemcpyDeviceToHost, dn));
+            }
+        }
+        hipAssert(hipStreamSynchronize(dn));
+        hipAssert(hipStreamSynchronize(stream));
+    }
     hipAssert(hipEventElapsedTime(&impl->last_ms, impl->ev0, impl->ev1));
     impl->last_rows = rows; impl->last_cols = cols; impl->last_grid = grid; impl->last_strip = sp;
+    // (benchResident / profileFrame replay the frame as ONE part: the slots of a one-part frame)
+    if (npart > 1) {
+        const int batchCount = (int)std::lround(std::ceil((double)(sp.tile_count * steps) / plan.userB));
+        const size_t stepCount = (size_t)((batchCount + S - 1) / S) * B;
+        impl->h_slots.resize(stepCount);
+        for (size_t st = 0; st < stepCount; ++st) {
+            const int ti = (int)(st / steps), aug = (int)(st % steps);
+            TileSlot sl{0, 0, aug, 0};
+            if (ti < sp.tile_count) { sl.x = grid.in[sp.first_tile + ti].x; sl.y = grid.in[sp.first_tile + ti].y; sl.valid = 1; }
+            impl->h_slots[st] = sl;
+        }
+        impl->ensure(impl->d_slots, impl->slots_cap, stepCount * sizeof(TileSlot));
+        hipAssert(hipMemcpy(impl->d_slots, impl->h_slots.data(), stepCount * sizeof(TileSlot), hipMemcpyHostToDevice));
+        impl->ensure(impl->d_slab, impl->slab_cap, stepCount * plan.Tout * plan.Tout * 4 * plan.elt);
+    }
     return true;
 } catch (const std::exception& e) {
     W2X_LOG_AS(who, error, "Render failed unexpectedly: " + std::string(e.what()) + ".");
@@ -1084,7 +1177,7 @@ bool Img2Img::renderSharded(Img2Img* const* engines, int count, const Image& src
             e.shard_halo_slots = (size_t)(sp[k].first_tile - sp[k].halo_first) * steps;
             e.ensure(e.d_slab, e.slab_cap, (e.shard_halo_slots + (size_t)stepCount) * slot_bytes);
             hipAssert(hipEventRecord(e.ev0, e.stream));
-            e.run_passes(rows, cols, sp[k].tile_count, e.shard_halo_slots, k == 0);
+            e.run_passes(rows, cols, sp[k].tile_count, e.shard_halo_slots, k == 0, 0, true);
             if (!e.ev_shard) hipAssert(hipEventCreateWithFlags(&e.ev_shard, hipEventDisableTiming));
             hipAssert(hipEventRecord(e.ev_shard, e.stream));
         }
@@ -1168,11 +1261,7 @@ bool Img2Img::renderSequence(const Image* srcs, Image* dsts, int count) try {
         if (!dsts[i].data || dsts[i].rows != rows * s || dsts[i].cols != cols * s || dsts[i].step < (size_t)cols * s * 3) { W2X_LOG(error, "Output image has invalid size: expected " + std::to_string(cols * s) + "x" + std::to_string(rows * s) + "."); return false; }
     }
     hipStream_t stream = impl->stream;
-    if (!impl->s_up) {
-        hipAssert(hipStreamCreateWithFlags(&impl->s_up, hipStreamNonBlocking));
-        hipAssert(hipStreamCreateWithFlags(&impl->s_dn, hipStreamNonBlocking));
-        for (int b = 0; b < 2; ++b) { hipAssert(hipEventCreateWithFlags(&impl->ev_up[b], hipEventDisableTiming)); hipAssert(hipEventCreateWithFlags(&impl->ev_comp[b], hipEventDisableTiming)); hipAssert(hipEventCreateWithFlags(&impl->ev_dn[b], hipEventDisableTiming)); }
-    }
+    impl->ensure_copy_streams();
     const size_t in_bytes = (size_t)rows * cols * 3, out_bytes = in_bytes * s * s;
     impl->ensure(impl->d_frame, impl->frame_cap, in_bytes);   impl->ensure(impl->d_frame2, impl->frame2_cap, in_bytes);
     impl->ensure(impl->d_out, impl->out_cap, out_bytes);      impl->ensure(impl->d_out2, impl->out2_cap, out_bytes);
