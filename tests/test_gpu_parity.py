@@ -22,9 +22,16 @@ from parity_util import (BLOCK_MEAN_TOL, ULP16, assert_as_accurate_as_ideal_fp16
 
 pytestmark = pytest.mark.gpu
 
-NET_MAX_ULP16 = 3.0      # fp16 ULPs of [0.5, 1) = 2^-11 each, fused kernels (full-width graphs, cunet); measured 1.0-2.25 (profiles/r2_final/parity.jsonl), north_star asks 1 against TensorRT itself
-NET_MAX_ULP16_UNFUSED = 3.5   # the un-fused operator path (48-channel graphs, W2X_NO_FUSE_ATTN): one more fp16 rounding per operator; measured 2.5-3.0
-NET_MAX_ULP16_VS_FP32 = 3.3   # the same outputs against the FP32 oracle (no model of the engine's rounding points in between); measured 1.0-2.31
+# fp16 ULPs of [0.5, 1) = 2^-11 each.  north_star asks 1 against TensorRT itself (not checkable offline); what is checkable:
+#  * engine vs the FP32 oracle - the engine's own error.  Measured (profiles/r4_final/parity.jsonl, every graph family, T = 64 ... 400): max 1.04-2.52, p99.9 <= 1.57, rms 0.31-0.46;
+#    the oracle's per-operator-fp16 model of an ideal fp16 engine measures max 1.04-2.44, rms 0.31-0.44 against the same fp32 values: the engine is as accurate as that model
+#    (asserted per case by parity_util.assert_as_accurate_as_ideal_fp16: max within +0.5, rms within 10 %, p99.9 <= 2).
+#  * engine vs the fp16-boundary oracle - the DISTANCE BETWEEN TWO fp16 evaluations, each within ~2 ULP16 of the fp32 value: largest where they straddle it
+#    (parity.jsonl `straddle_at_worst`: e.g. [-1.6, +1.4] at the one element that measures 3.00 on swin_unet/art T112) and quantised in whole / half ULPs.  Its bound is
+#    therefore the sum of the two, not a statement about the engine: 3.5 (measured 1.0-3.0).  Round 3 asserted 3.0 on a measured 3.00.
+NET_MAX_ULP16 = 3.5
+NET_MAX_ULP16_UNFUSED = 3.5   # the un-fused operator path (48-channel graphs, W2X_NO_FUSE_ATTN): measured 2.0-3.0
+NET_MAX_ULP16_VS_FP32 = 3.0   # measured <= 2.52 (T = 256: the maximum over 2.7 M outputs)
 NET_MEAN_ABS = 2.2e-4    # measured <= 1.7e-4
 FRAME_MAX_LSB = 1        # u8; measured 1 on every case
 

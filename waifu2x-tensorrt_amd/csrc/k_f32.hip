@@ -28,8 +28,11 @@ __device__ __forceinline__ float act_fn(float v, int act, float alpha) {
     }
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN>
-__global__ __launch_bounds__(256) void gemm32_kernel(const GemmParams p) {
+#ifndef W2X_G32_WPC
+#define W2X_G32_WPC 3      // workgroups per CU the register budget is set for (the half-height epilogue tile leaves LDS for three)
+#endif
+template <int WAVES_M, int WAVES_N, int WM, int WN, int HALVES>
+__global__ __launch_bounds__(256, W2X_G32_WPC) void gemm32_kernel(const GemmParams p) {
     constexpr int KB = 16;                      // k-chunk: four v_mfma_f32_16x16x4_f32 steps
     constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
     constexpr int LDA = KB + 1, LDC = BN + 4;   // floats
@@ -41,7 +44,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmParams p) {
     float* As = (float*)smem;
     float* Bs = As + BM * LDA;
     float* Cs = (float*)smem;                   // aliases As / Bs after the main loop
-    constexpr int AB_BYTES = (BM + BN) * LDA * 4, C_BYTES = BM * LDC * 4;
+    constexpr int AB_BYTES = (BM + BN) * LDA * 4, C_BYTES = BM / HALVES * LDC * 4;
     constexpr int MAIN_BYTES = AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES;
     int* s_aoff = (int*)(smem + MAIN_BYTES);
     int* s_ob = s_aoff + BM;
@@ -156,45 +159,54 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmParams p) {
             }
         }
     }
-    __syncthreads();
-
-    // ---- epilogue phase 1: accumulators -> (LayerNorm algebra, bias, activation) -> fp32 tile in LDS
-    {
-        const int ccol = lane & 15, crow = (lane >> 4) * 4;
+    // ---- epilogue, in HALVES rounds over half-height tiles.  The fp32 output tile in LDS (128 rows x up to 196 floats = 100 KB) used to set the
+    // kernel's LDS size and with it ONE workgroup - one wave per SIMD - per CU (round 2/3: 27 - 47 TFLOP/s on the config-3 graph).  Round 4: a
+    // round takes the row tiles i with i / RH == h of every wave (RH = WM / HALVES), so the tile is 64 rows x LDC: 52 KB with the row tables,
+    // three workgroups per CU.  Rows are independent in everything below except the squeeze-excite column sums, which are carried across the
+    // rounds per thread (same fixed order on every run).
+    constexpr int RH = WM / HALVES, HROWS = WAVES_M * RH * 16;
+    static_assert(WM % HALVES == 0, "row tiles per wave split evenly over the rounds");
+    float pool_sum = 0.f;                                             // column tid of the tile (BN <= 256)
+    float* __restrict__ Og = (float*)p.out.p;
+    const int Cso = p.out.Cs;
+    const bool pix = p.omode == 2;
+    const int ppc = (pix ? Cso : BN) / 4;                  // pieces per (row, sub-pixel) in this tile
+    const int subs = pix ? BN / Cso : 1;
+    int gs = 1; while (gs < ppc) gs <<= 1;
+    const int groups = 256 / gs;
+    const int jp = tid & (gs - 1);
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int col = (wn * WN + j) * 16 + ccol, n = n0 + col;
-            float bias = 0.f, cs = 0.f;
-            if (n < p.N) { bias = p.bias ? p.bias[n] : 0.f; if (p.ln) cs = p.csum[n]; }
+    for (int h = 0; h < HALVES; ++h) {
+        __syncthreads();                                              // the operand tiles (first round) / the previous round's tile are done with
+        // phase 1: accumulators -> (LayerNorm algebra, bias, activation) -> fp32 tile in LDS
+        {
+            const int ccol = lane & 15, crow = (lane >> 4) * 4;
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+            for (int j = 0; j < WN; ++j) {
+                const int col = (wn * WN + j) * 16 + ccol, n = n0 + col;
+                float bias = 0.f, cs = 0.f;
+                if (n < p.N) { bias = p.bias ? p.bias[n] : 0.f; if (p.ln) cs = p.csum[n]; }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int row = (wm * WM + i) * 16 + crow + e;
-                    float v = acc[i][j][e];
-                    if (p.ln) v = s_rstd[row] * (v - s_mean[row] * cs);
-                    v += bias;
-                    Cs[row * LDC + col] = act_fn(v, p.act, p.alpha);
-                }
+                for (int ii = 0; ii < RH; ++ii)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = h * RH + ii;
+                        const int row = (wm * WM + i) * 16 + crow + e, lrow = (wm * RH + ii) * 16 + crow + e;
+                        float v = acc[i][j][e];
+                        if (p.ln) v = s_rstd[row] * (v - s_mean[row] * cs);
+                        v += bias;
+                        Cs[lrow * LDC + col] = act_fn(v, p.act, p.alpha);
+                    }
+            }
         }
-    }
-    __syncthreads();
-
-    // ---- epilogue phase 2: pieces of 4 floats: residual adds, clip, store, LayerNorm statistics, SE pooling
-    {
-        float* __restrict__ Og = (float*)p.out.p;
-        const int Cso = p.out.Cs;
-        const bool pix = p.omode == 2;
-        const int ppc = (pix ? Cso : BN) / 4;                  // pieces per (row, sub-pixel) in this tile
-        const int subs = pix ? BN / Cso : 1;
-        int gs = 1; while (gs < ppc) gs <<= 1;
-        const int groups = 256 / gs;
-        const int items = BM * subs;
-        const int jp = tid & (gs - 1);
+        __syncthreads();
+        // phase 2: pieces of 4 floats: residual adds, clip, store, LayerNorm statistics, SE pooling
+        const int items = HROWS * subs;
         for (int q0 = 0; q0 < items; q0 += groups) {
             int q = q0 + tid / gs;
             if (q >= items) q = items - 1;   // clamp (duplicates are masked by `valid` below)
-            const int i = q / subs, s = q - i * subs;
+            const int li = q / subs, s = q - li * subs;
+            const int i = (li / (RH * 16)) * (WM * 16) + h * (RH * 16) + li % (RH * 16);      // row of the workgroup tile behind local row li
             bool valid = (q0 + tid / gs) < items && jp < ppc && s_aoff[i] >= 0;
             const int ccol = pix ? s * Cso + jp * 4 : jp * 4;     // column inside the LDS tile
             const int ch = pix ? jp * 4 : n0 + jp * 4;            // channel inside the output pixel
@@ -206,7 +218,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmParams p) {
             if (valid) {
                 b = s_ob[i]; Y = s_oy[i] * p.r + dy; X = s_ox[i] * p.r + dx;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = Cs[i * LDC + ccol + e];
+                for (int e = 0; e < 4; ++e) v[e] = Cs[li * LDC + ccol + e];
                 if (p.res.p) {
                     const float4v r = *(const float4v*)((const float*)p.res.p + (size_t)((b * p.res.Hs + Y + p.res.y0) * p.res.Ws + X + p.res.x0) * p.res.Cs + ch);
 #pragma unroll
@@ -222,7 +234,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmParams p) {
                     for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], p.clip_lo), p.clip_hi);
                 }
                 *(float4v*)(Og + (size_t)((b * p.out.Hs + Y) * p.out.Ws + X) * Cso + ch) = (float4v){v[0], v[1], v[2], v[3]};
-                if (p.pool_out) *(float4v*)(Cs + i * LDC + ccol) = (float4v){v[0], v[1], v[2], v[3]};   // final values for the column sums below
+                if (p.pool_out) *(float4v*)(Cs + li * LDC + ccol) = (float4v){v[0], v[1], v[2], v[3]};   // final values for the column sums below
             }
             if (p.stats_out) {   // uniform branch; all lanes take part in the shuffles
                 float sum = v[0] + v[1] + v[2] + v[3];
@@ -241,23 +253,26 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmParams p) {
                 }
             }
         }
-        if (p.pool_out) {   // per-workgroup column sums in row order; se_kernel adds the partials of a batch item in tile order
+        if (p.pool_out) {   // per-workgroup column sums in a fixed order (the rounds' rows, in local row order); se_kernel adds the partials of a batch item in tile order
             __syncthreads();
-            for (int c = tid; c < BN; c += 256) {
-                float sum = 0.f;
-                for (int i = 0; i < BM; ++i) if (s_aoff[i] >= 0) sum += Cs[i * LDC + c];
-                if (n0 + c < p.N) p.pool_out[(size_t)blockIdx.x * Cso + n0 + c] = sum;
+            if (tid < BN) {
+                for (int li = 0; li < HROWS; ++li) {
+                    const int i = (li / (RH * 16)) * (WM * 16) + h * (RH * 16) + li % (RH * 16);
+                    if (s_aoff[i] >= 0) pool_sum += Cs[li * LDC + tid];
+                }
             }
         }
     }
+    if (p.pool_out && tid < BN && n0 + tid < p.N) p.pool_out[(size_t)blockIdx.x * Cso + n0 + tid] = pool_sum;
 }
 
 template <int WAVES_M, int WAVES_N, int WM, int WN>
 hipError_t launch_cfg32(const GemmParams& p, hipStream_t s) {
+    constexpr int HALVES = 2;             // the output tile goes through LDS in two half-height rounds (see the kernel's epilogue)
     constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16, LDA = 17, LDC = BN + 4;
-    constexpr int AB = (BM + BN) * LDA * 4, CB = BM * LDC * 4;
+    constexpr int AB = (BM + BN) * LDA * 4, CB = BM / HALVES * LDC * 4;
     constexpr int SMEM = (AB > CB ? AB : CB) + BM * 6 * 4;
-    auto kern = gemm32_kernel<WAVES_M, WAVES_N, WM, WN>;
+    auto kern = gemm32_kernel<WAVES_M, WAVES_N, WM, WN, HALVES>;
     static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
     if (hipError_t e = ensure_dynamic_lds((const void*)kern, SMEM, lds_ok); e != hipSuccess) return e;
     const dim3 grid(p.B * ((p.Mrows + BM - 1) / BM), (p.N + BN - 1) / BN);
