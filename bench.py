@@ -358,6 +358,7 @@ def main():
         frame_tiles = n_tiles
         if strips:                               # the kernel figures below are rank 0's: its strip's tiles
             n_tiles = pkg.strip_plan(FRAME_W, FRAME_H, FRAME_W * SCALE, FRAME_H * SCALE, TILE, eng.output_tile_size, SCALE, (BLEND, BLEND), 0, world)[1]
+        n_tiles *= 8 if TTA else 1               # network steps: a tile goes through the network once per augmentation
         live = n_tiles / eng.pass_tiles          # the zero-pad slots of the last batch are not computed (plan FLOPs are per pass of pass_tiles)
         # dominant kernel of the frame: plan ops grouped by the kernel that serves them, by summed HIP-event time
         # (measured on the compute stream by w2x_profile_frame / w2x_op_times)

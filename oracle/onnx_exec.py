@@ -183,6 +183,8 @@ class Executor:
             if not a[0].is_floating_point() and not a[1].is_floating_point():
                 return torch.div(a[0], a[1], rounding_mode="trunc")
             return a[0] / a[1]
+        if op == "Mod":      # ONNX Mod: fmod = 0 -> the sign of the divisor (Python / torch.remainder), fmod = 1 -> the sign of the dividend (C fmod)
+            return torch.fmod(a[0], a[1]) if at.get("fmod", 0) else torch.remainder(a[0], a[1])
         if op == "Pow":
             return torch.pow(a[0], a[1])
         if op == "Equal":

@@ -573,6 +573,9 @@ def test_image_head_folded_into_the_last_mlp_is_bit_identical(pkg, onnx_model, m
     ("static batch dimension", dict(dynamic=False), 64),
     ("opset 11", dict(opset=11), 64),
     ("opset 15", dict(opset=15), 64),
+    # the attention traced in torchvision's shifted_window_attention operator order (tools/synth_models.py SwinBlock.attn_tv): a zero Pad to the window
+    # multiple in front, the shift mask built in-graph from slice assignments and two masked_fill, whole-map Slices behind the reverse roll
+    ("torchvision operator order", dict(variant={"tv": 1}), 64),
 ])
 def test_loader_takes_graphs_it_was_not_written_around(pkg, onnx_model, name, kw, tile):
     """img2img_build.cpp:81-88 hands any ONNX file to the parser.  The fused kernels cover the release graphs' transformer shapes
@@ -586,7 +589,7 @@ def test_loader_takes_graphs_it_was_not_written_around(pkg, onnx_model, name, kw
     x = rng.random((2, 3, tile, tile), dtype=np.float32).astype(np.float16).astype(np.float32)
     y = eng.infer(x)
     eng.close()
-    if "variant" in kw:
+    if "variant" in kw and "tv" not in kw["variant"]:
         r = network_report(f"network[swin_unet/art s4 B2 T{tile} {name}]", y, oracle16(path)(x), onnx_exec.Executor(path).run(x))
         assert "swinattn" not in pkg.describe_plan(path, 2, tile)                      # these shapes run on the general kernels
         assert r["max_ulp16"] <= NET_MAX_ULP16_UNFUSED and r["mean_abs"] <= NET_MEAN_ABS and r["max_ulp16_vs_fp32_oracle"] <= NET_MAX_ULP16_VS_FP32 + 0.5, r

@@ -287,6 +287,22 @@ def test_shard_split_bound_table(pkg, capsys):
         print("\n" + "\n".join(lines))
 
 
+def test_torchvision_operator_order_lowers_onto_the_same_plan(pkg, onnx_model):
+    """The release graphs were exported from nunif's swin_unet, whose blocks most likely trace torchvision's shifted_window_attention (neither is available
+    offline).  Its operator order differs from the synthetic graphs' in three places the pattern matcher must see through: F.pad to the window multiple in
+    front (a Pad node with all-zero pads here), the shift mask built inside the traced function (new_zeros, nine slice assignments, view / permute, a
+    difference of two unsqueezes, two masked_fill - all constant at a static shape), and x[:, :H, :W, :] behind the reverse roll (one whole-map Slice per
+    axis).  Same weights exported both ways: the CPU oracle gives identical outputs, and the loader lowers both files onto the same fused plan."""
+    import re
+    from oracle import onnx_exec
+    std, tv = onnx_model("swin_unet/art", 4, 1, 64, noise=2), onnx_model("swin_unet/art", 4, 1, 64, noise=2, variant={"tv": 1})
+    x = np.random.default_rng(3).random((1, 3, 64, 64), dtype=np.float32)
+    assert np.array_equal(onnx_exec.Executor(std).run(x), onnx_exec.Executor(tv).run(x))
+    strip = lambda d: [re.sub(r" \[[^\]]*\]$", "", l) for l in d.splitlines()]
+    a, b = strip(pkg.describe_plan(std, 1, 64)), strip(pkg.describe_plan(tv, 1, 64))
+    assert a == b and sum("swinattn" in l for l in a) == 14 and sum(l.split()[1:2] == ["mlp"] for l in a) == 14
+
+
 def test_strip_split_redundancy_table(pkg, capsys):
     """Single-frame mode: strip p owns whole tile columns and recomputes the neighbouring column whose
     blend band reaches into its pixels, so the tiles rendered over all strips exceed the frame's tiles and the largest strip bounds

@@ -169,9 +169,10 @@ def _shift_mask(H, W, ws, shift):
 class SwinBlock(nn.Module):
     """Swin-V1 block on BHWC maps: x += proj(W-MSA(LN(x))); x += MLP(LN(x)), MLP ratio 2."""
 
-    def __init__(self, dim, heads, ws, shift):
+    def __init__(self, dim, heads, ws, shift, tv=False):
         super().__init__()
         self.dim, self.heads, self.ws, self.shift = dim, heads, ws, shift
+        self.tv = tv        # trace the attention the way torchvision.models.swin_transformer.shifted_window_attention writes it (attn_tv)
         self.norm1 = nn.LayerNorm(dim)
         self.qkv = nn.Linear(dim, dim * 3)
         self.proj = nn.Linear(dim, dim)
@@ -206,17 +207,66 @@ class SwinBlock(nn.Module):
             x = torch.roll(x, shifts=(sh, sh), dims=(1, 2))
         return x
 
+    def attn_tv(self, x):
+        """The same attention in the operator order of torchvision's shifted_window_attention (the function nunif's swin_unet blocks most likely
+        trace through; torchvision is not installed here, this follows its source from memory): a zero F.pad to the window multiple in front (a Pad node
+        with all-zero pads when the map already is one), the shift mask built INSIDE the traced function - new_zeros, slice assignments of the region
+        ids, view / permute, a difference of two unsqueezes, two masked_fill - and a slice back to [:, :H, :W, :] behind the reverse roll."""
+        B, H, W, C = x.shape
+        ws, nh = self.ws, self.heads
+        pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
+        x = F.pad(x, (0, 0, 0, pad_r, 0, pad_b))
+        _, pad_H, pad_W, _ = x.shape
+        sh = [self.shift, self.shift]
+        if ws >= pad_H: sh[0] = 0
+        if ws >= pad_W: sh[1] = 0
+        if sum(sh) > 0:
+            x = torch.roll(x, shifts=(-sh[0], -sh[1]), dims=(1, 2))
+        nW = (pad_H // ws) * (pad_W // ws)
+        x = x.view(B, pad_H // ws, ws, pad_W // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B * nW, ws * ws, C)
+        qkv = F.linear(x, self.qkv.weight, self.qkv.bias)
+        qkv = qkv.reshape(x.size(0), x.size(1), 3, nh, C // nh).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        q = q * (C // nh) ** -0.5
+        attn = q.matmul(k.transpose(-2, -1))
+        N = ws * ws
+        bias = self.rpb_table[self.rpb_index].view(N, N, -1).permute(2, 0, 1).contiguous().unsqueeze(0)
+        attn = attn + bias
+        if sum(sh) > 0:
+            attn_mask = x.new_zeros((pad_H, pad_W))
+            h_slices = ((0, -ws), (-ws, -sh[0]), (-sh[0], None))
+            w_slices = ((0, -ws), (-ws, -sh[1]), (-sh[1], None))
+            count = 0
+            for h in h_slices:
+                for w in w_slices:
+                    attn_mask[h[0]:h[1], w[0]:w[1]] = count
+                    count += 1
+            attn_mask = attn_mask.view(pad_H // ws, ws, pad_W // ws, ws)
+            attn_mask = attn_mask.permute(0, 2, 1, 3).reshape(nW, ws * ws)
+            attn_mask = attn_mask.unsqueeze(1) - attn_mask.unsqueeze(2)
+            attn_mask = attn_mask.masked_fill(attn_mask != 0, float(-100.0)).masked_fill(attn_mask == 0, float(0.0))
+            attn = attn.view(x.size(0) // nW, nW, nh, x.size(1), x.size(1))
+            attn = attn + attn_mask.unsqueeze(1).unsqueeze(0)
+            attn = attn.view(-1, nh, x.size(1), x.size(1))
+        attn = F.softmax(attn, dim=-1)
+        x = attn.matmul(v).transpose(1, 2).reshape(x.size(0), x.size(1), C)
+        x = F.linear(x, self.proj.weight, self.proj.bias)
+        x = x.view(B, pad_H // ws, pad_W // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, pad_H, pad_W, C)
+        if sum(sh) > 0:
+            x = torch.roll(x, shifts=(sh[0], sh[1]), dims=(1, 2))
+        return x[:, :H, :W, :].contiguous()
+
     def forward(self, x):
-        x = x + self.attn(self.norm1(x))
+        x = x + (self.attn_tv if self.tv else self.attn)(self.norm1(x))
         x = x + self.fc2(F.gelu(self.fc1(self.norm2(x))))
         return x
 
 
 class SwinBlocks(nn.Module):
-    def __init__(self, dim, heads, layers, ws):
+    def __init__(self, dim, heads, layers, ws, tv=False):
         super().__init__()
         self.block = nn.Sequential(*[
-            SwinBlock(dim, heads, ws, 0 if i % 2 == 0 else ws // 2) for i in range(layers)])
+            SwinBlock(dim, heads, ws, 0 if i % 2 == 0 else ws // 2, tv) for i in range(layers)])
 
     def forward(self, x):
         return self.block(x)
@@ -259,22 +309,22 @@ class ToImage(nn.Module):
 class SwinUNet(nn.Module):
     """swin_unet/{art,art_scan,photo}: T' = scale (T - 16)."""
 
-    def __init__(self, cin=3, cout=3, base_dim=96, base_layers=2, scale=4, ws=6, heads=None):
+    def __init__(self, cin=3, cout=3, base_dim=96, base_layers=2, scale=4, ws=6, heads=None, tv=False):
         super().__init__()
         C, Hd, L = base_dim, heads or base_dim // 16, base_layers
         self.scale = scale
         self.patch = nn.Sequential(
             nn.Conv2d(cin, C // 2, 3, 1, 0), nn.LeakyReLU(0.1),
             nn.Conv2d(C // 2, C, 3, 1, 0), nn.LeakyReLU(0.1))
-        self.swin1 = SwinBlocks(C, Hd, L, ws)
+        self.swin1 = SwinBlocks(C, Hd, L, ws, tv)
         self.down1 = PatchDown(C, C * 2)
-        self.swin2 = SwinBlocks(C * 2, Hd, L, ws)
+        self.swin2 = SwinBlocks(C * 2, Hd, L, ws, tv)
         self.down2 = PatchDown(C * 2, C * 2)
-        self.swin3 = SwinBlocks(C * 2, Hd, L * 3, ws)
+        self.swin3 = SwinBlocks(C * 2, Hd, L * 3, ws, tv)
         self.up2 = PatchUp(C * 2, C * 2)
-        self.swin4 = SwinBlocks(C * 2, Hd, L, ws)
+        self.swin4 = SwinBlocks(C * 2, Hd, L, ws, tv)
         self.up1 = PatchUp(C * 2, C)
-        self.swin5 = SwinBlocks(C, Hd, L, ws)
+        self.swin5 = SwinBlocks(C, Hd, L, ws, tv)
         self.to_image = ToImage(C, cout, scale)
 
     def forward(self, x):
@@ -301,7 +351,8 @@ def output_tile_size(model: str, scale: int, tile: int) -> int:
 def make_model(model: str, scale: int, seed: int = 1234, small: bool = False, variant: dict | None = None) -> nn.Module:
     """model in {cunet/art, swin_unet/art, swin_unet/art_scan, swin_unet/photo} (main.cpp:26-33).
     variant (swin_unet only): other transformer shapes than the release graphs' - {"ws": window, "heads": heads of the first level,
-    "base_dim": channels} - for the loader's robustness tests (graphs the builder did not write the kernels for)."""
+    "base_dim": channels, "tv": 1 = the attention traced in torchvision's shifted_window_attention operator order} - for the loader's robustness
+    tests (graphs the builder did not write the kernels for)."""
     torch.manual_seed(seed)
     if model.startswith("cunet"):
         if scale == 4:
@@ -309,7 +360,7 @@ def make_model(model: str, scale: int, seed: int = 1234, small: bool = False, va
         net = UpCUNet() if scale == 2 else CUNet()
     elif model.startswith("swin_unet"):
         v = dict(variant or {})
-        net = SwinUNet(scale=scale, base_dim=v.get("base_dim", 48 if small else 96), ws=v.get("ws", 6), heads=v.get("heads"))
+        net = SwinUNet(scale=scale, base_dim=v.get("base_dim", 48 if small else 96), ws=v.get("ws", 6), heads=v.get("heads"), tv=bool(v.get("tv", 0)))
     else:
         raise ValueError(model)
     _init(net, seed)

@@ -2,6 +2,7 @@
 // (/root/reference/src/tensorrt/img2img.h:14-50).  build(): ONNX -> plan file; load(): plan -> HBM; render(): frame ->
 // tiles -> fused HIP kernels -> blended frame.  Everything on the device is HIP; there is no CPU fallback.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -201,6 +202,8 @@ struct Img2Img::Impl {
     RenderConfig cfg;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // W2X_ROCTX=1 (read at load): roctxRangePushA / roctxRangePop around the launches of every plan op, resolved from libroctx64.so at run time (no link dependency)
+    int (*roctx_push)(const char*) = nullptr; int (*roctx_pop)() = nullptr;
     hipEvent_t ev_shard = nullptr;       // renderSharded(): this engine's tiles are in its slab
     hipEvent_t ev_part[2] = {nullptr, nullptr};
     int pipeline_parts = 2;              // W2X_RENDER_PARTS (read at load): 1 = render() runs a frame as one part
@@ -530,6 +533,8 @@ struct Img2Img::Impl {
         for (size_t i = 0; i < plan.ops.size(); ++i) try {
             const Op& op = plan.ops[i];
             cur_op = (int)i;
+            struct Range { Impl* e; bool on; ~Range() { if (on) e->roctx_pop(); } } range{this, roctx_push != nullptr};   // W2X_ROCTX=1: a roctx range per plan op (rocprofv3 --marker-trace)
+            if (range.on) roctx_push((std::to_string(i) + " " + op.name).c_str());
             switch (op.kind) {
                 case OP_GEMM: {
                     if (skip_next) { skip_next = false; break; }
@@ -911,6 +916,14 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
     impl->check_general = getenv("W2X_PIXGEMM_CHECK") != nullptr;
     impl->use_graphs = getenv("W2X_NO_GRAPH") == nullptr;
     if (const char* e = getenv("W2X_RENDER_PARTS")) impl->pipeline_parts = atoi(e) >= 2 ? 2 : 1;
+    if (getenv("W2X_ROCTX") && !impl->roctx_push) {
+        if (void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL)) {
+            impl->roctx_push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+            impl->roctx_pop = (int (*)())dlsym(h, "roctxRangePop");
+            if (!impl->roctx_push || !impl->roctx_pop) impl->roctx_push = nullptr;
+        }
+        if (!impl->roctx_push) W2X_LOG(warn, "W2X_ROCTX is set but libroctx64.so could not be loaded: no marker ranges.");
+    }
     try {
         impl->plan = Plan::deserialize((const uint8_t*)engineBuffer.data(), engineBuffer.size());
     } catch (const std::exception& e) {

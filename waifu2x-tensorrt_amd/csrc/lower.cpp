@@ -257,6 +257,24 @@ struct Lowerer {
         p.op.omode = O_WIN;
         p.op.win_table = window_table(H, W, ws, ry, rx, true);
         p.okind = LVal::MAP; p.nchw = false; p.outH = H; p.outW = W;
+        // torchvision's shifted_window_attention ends with x[:, :H, :W, :] (one Slice per axis): slices that keep the whole [B, H, W, C] map
+        const int64_t dims[4] = {plan.B, H, W, p.op.N};
+        for (;;) {
+            const Node* sl = only_user(p.cur);
+            if (!sl || sl->op != "Slice" || sl->in.size() < 3 || !is_c(sl->in[1]) || !is_c(sl->in[2])) break;
+            const std::vector<int64_t> starts = g.cst(sl->in[1]).i, ends = g.cst(sl->in[2]).i;
+            const std::vector<int64_t> axes = sl->in.size() > 3 && !sl->in[3].empty() ? g.cst(sl->in[3]).i : std::vector<int64_t>{};
+            const std::vector<int64_t> steps = sl->in.size() > 4 && !sl->in[4].empty() ? g.cst(sl->in[4]).i : std::vector<int64_t>{};
+            bool whole = !starts.empty() && starts.size() == ends.size();
+            for (size_t k = 0; k < starts.size() && whole; ++k) {
+                int64_t ax = axes.empty() ? (int64_t)k : axes[k]; if (ax < 0) ax += 4;
+                if (ax < 0 || ax > 3 || (!steps.empty() && steps[k] != 1)) { whole = false; break; }
+                const int64_t D = dims[ax], st = starts[k] < 0 ? starts[k] + D : starts[k], en = ends[k] < 0 ? ends[k] + D : std::min<int64_t>(ends[k], D);
+                whole = st == 0 && en == D;
+            }
+            if (!whole) break;
+            done.insert(sl); p.cur = sl->out[0];
+        }
     }
 
     // lower a pure-view producer (crop) ahead of its position in the node list so it can be used as a residual
@@ -273,6 +291,9 @@ struct Lowerer {
 
     void lower_pad(const Node* n, const LVal& x) {
         std::vector<int64_t> pads = n->has("pads") ? n->aints("pads") : g.cst(n->in[1]).i;
+        // a Pad that pads nothing is the identity whatever it sits on: torchvision's shifted_window_attention pads every token map to the window
+        // multiple (F.pad(x, (0, 0, 0, pad_r, 0, pad_b))), which exports as a Pad node with all-zero pads when the map already is one
+        if (std::all_of(pads.begin(), pads.end(), [](int64_t v) { return v == 0; })) { vals[n->out[0]] = x; done.insert(n); return; }
         if (x.kind != LVal::MAP || !x.nchw || x.ln || pads.size() != 8) fail(n, "only spatial crops of NCHW maps are supported");
         if (pads[0] || pads[1] || pads[4] || pads[5]) fail(n, "padding batch/channel dims");
         if (pads[2] > 0 || pads[3] > 0 || pads[6] > 0 || pads[7] > 0) fail(n, "positive padding is not supported (only negative = crop)");
@@ -861,6 +882,21 @@ struct Lowerer {
             if (op == "Pad") { lower_pad(n, x); continue; }
             if (op != "Slice")   // crops are views; every other consumer of a gated map gets the in-place pass first
                 for (const std::string& in : n->in) { auto iv = vals.find(in); if (iv != vals.end() && iv->second.kind == LVal::MAP) apply_gate(iv->second.v.t); }
+            if (op == "Slice" && x.kind == LVal::MAP && n->in.size() > 2 && is_c(n->in[1]) && is_c(n->in[2])) {
+                // a Slice that keeps everything is the identity in any layout (torchvision's shifted_window_attention ends with x[:, :H, :W, :])
+                std::vector<int64_t> starts = g.cst(n->in[1]).i, ends = g.cst(n->in[2]).i;
+                std::vector<int64_t> axes = n->in.size() > 3 && !n->in[3].empty() ? g.cst(n->in[3]).i : std::vector<int64_t>{};
+                std::vector<int64_t> steps = n->in.size() > 4 && !n->in[4].empty() ? g.cst(n->in[4]).i : std::vector<int64_t>{};
+                const int64_t dims[4] = {plan.B, x.nchw ? x.C : x.v.H, x.nchw ? x.v.H : x.v.W, x.nchw ? x.v.W : x.C};
+                bool whole = !starts.empty() && starts.size() == ends.size();
+                for (size_t k = 0; k < starts.size() && whole; ++k) {
+                    int64_t ax = axes.empty() ? (int64_t)k : axes[k]; if (ax < 0) ax += 4;
+                    if (ax < 0 || ax > 3 || (!steps.empty() && steps[k] != 1)) { whole = false; break; }
+                    const int64_t D = dims[ax], st = starts[k] < 0 ? starts[k] + D : starts[k], en = ends[k] < 0 ? ends[k] + D : std::min<int64_t>(ends[k], D);
+                    whole = st == 0 && en == D;
+                }
+                if (whole) { vals[n->out[0]] = x; done.insert(n); continue; }
+            }
             if (op == "Slice" && x.kind == LVal::MAP && x.nchw && !x.ln && true) {
                 // crop expressed as Slice on H/W
                 std::vector<int64_t> starts = g.cst(n->in[1]).i, ends = g.cst(n->in[2]).i;
