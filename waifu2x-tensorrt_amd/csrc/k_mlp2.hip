@@ -127,6 +127,9 @@ __device__ __forceinline__ half8 norm8(const half8 v, float rstd, float nm) {
 
 // Timing experiments on mlp2q_kernel (results are wrong; tools/ab/mlp192_variants.sh): bit 0 no barrier per chunk, bit 1 no weight staging after
 // chunk 0 (and no wait for it), bit 2 GELU replaced by the bare conversion, bit 3 no matrix products.
+#ifndef W2X_MLP2Q_PIPE
+#define W2X_MLP2Q_PIPE 0     // 1: the chunk loop software-pipelined (first-layer products of chunk c + 1 between the pieces of chunk c's GELU), see mlp2q_kernel
+#endif
 #ifndef W2X_MLP2Q_EXP
 #define W2X_MLP2Q_EXP 0
 #endif
@@ -438,6 +441,113 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xreg[ks] = norm8(raw[ks], rstd, nm);
     }
+#if W2X_MLP2Q_PIPE
+    // ---- software-pipelined chunk loop (round 4).  Per chunk a wave issues 24 matrix instructions (12 first-layer, 12 second-layer) and ~130 vector
+    // instructions (the GELU of 16 values per lane), and as written above they come in separate runs: a 32 x 32 product lets about four vector
+    // instructions issue for free while it occupies the pipe (tools/issue_model.hip: 23.4 ticks alone, 31.6 with eight), but a run of products has none to
+    // hide and the GELU run has no product to hide behind.  Here the FIRST-layer products of chunk c + 1 (they depend on nothing of chunk c) are issued
+    // one by one between the pieces of chunk c's GELU.  What it takes: a second first-layer accumulator (16 registers), and the staged chunks skewed by
+    // half a chunk - buffer c holds W1 of chunk c + 1 and W2 of chunk c (fragments 0 .. KS-1 / KS .. NF-1, consumption order = storage order as before).
+    W2X_PHASE_FENCE();
+    auto skew_src = [&](int c, int f) { return f < KS ? W1 + (size_t)((c + 1) * KS + f) * 512 : W2 + (size_t)(c * 2 * NT + (f - KS)) * 512; };
+    auto stage_skew = [&](int c) {               // c = -1: only W1 of chunk 0; c = NCH - 1: only W2 of the last chunk
+#pragma unroll
+        for (int i = 0; i < NFW; ++i) {
+            const int f = wv * NFW + i;
+            if ((f < KS && c + 1 >= NCH) || (f >= KS && c < 0)) continue;
+            __builtin_amdgcn_global_load_lds((const void*)skew_src(c, f), (__attribute__((address_space(3))) void*)(wbuf(c & 1) + (size_t)f * 1024), 16, 0, 0);
+        }
+    };
+    __syncthreads();                           // every wave holds its rows in registers: the slab area becomes weight buffers
+    stage_skew(-1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
+    __syncthreads();
+    stage_skew(0);                             // lands under the first chunk's first-layer products
+    float16v acc1n;
+    {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4v b = *(const float4v*)(B1s + q * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc1n[4 * q + j] = b[j];
+        }
+        half8 w0[RING];
+#pragma unroll
+        for (int i = 0; i < RING; ++i) w0[i] = lds_frag(-1, i);
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            acc1n = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[j % RING], xreg[j], acc1n, 0, 0, 0);
+            if (j + RING < KS) { w0[j % RING] = lds_frag(-1, j + RING); W2X_RING_FENCE(); }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): this wave's share of buffer 0
+    __syncthreads();
+    half8 wr[RING];
+    float16v acc2[NT];                         // rows = output channels 32nt + 8q + 4h + j in register 4q + j, columns = tokens; from b2
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4v b = *(const float4v*)(B2s + nt * 32 + q * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc2[nt][4 * q + j] = b[j];
+        }
+    half8 xres[NP];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const bool more = ch + 1 < NCH;        // there is a next chunk whose first-layer products run under this chunk's GELU
+        if (more) stage_skew(ch + 1);
+        const int f0 = more ? 0 : KS;          // first fragment consumed from this buffer
+#pragma unroll
+        for (int i = 0; i < RING; ++i) wr[i] = lds_frag(ch, f0 + i);
+        const float16v acc1 = acc1n;
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4v b = *(const float4v*)(B1s + (ch + 1) * 32 + q * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc1n[4 * q + j] = b[j];
+            }
+        }
+        // GELU of chunk ch in eight pieces of one value pair each, a first-layer product of chunk ch + 1 in front of every piece (and of the
+        // four conversions); the scheduling barriers keep the pieces between the products
+        float2v gp[8];
+        half8 a2[2];
+        // ten pieces - pairs 0..3, pack a2[0], pairs 4..7, pack a2[1] - spread over the KS product slots: slot j takes pieces [10 j / KS, 10 (j + 1) / KS)
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            if (more) {
+                acc1n = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[j % RING], xreg[j], acc1n, 0, 0, 0);
+                wr[j % RING] = lds_frag(ch, j + RING);          // (f0 = 0 here: fragments KS .. KS + RING - 1 are the first of the second layer)
+                W2X_RING_FENCE();
+            }
+#pragma unroll
+            for (int e = 10 * j / KS; e < 10 * (j + 1) / KS; ++e) {
+                if (e == 4 || e == 9) {
+                    const int s2 = e == 4 ? 0 : 1;
+                    a2[s2] = (half8){(_Float16)gp[4 * s2][0], (_Float16)gp[4 * s2][1], (_Float16)gp[4 * s2 + 1][0], (_Float16)gp[4 * s2 + 1][1],
+                                     (_Float16)gp[4 * s2 + 2][0], (_Float16)gp[4 * s2 + 2][1], (_Float16)gp[4 * s2 + 3][0], (_Float16)gp[4 * s2 + 3][1]};
+                } else {
+                    const int w = e < 4 ? e : e - 1;             // value pair w = registers 2w, 2w + 1 of the accumulator
+                    gp[w] = gelu_fast2((float2v){acc1[2 * w], acc1[2 * w + 1]});
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ch == NCH - 1) {   // the residual rows, requested as soon as the normalised copies have served their last product
+#pragma unroll
+            for (int k = 0; k < NP; ++k) xres[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(XB, vo + k * 1024u, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * NT; ++i) {     // second layer: fragment KS + i = (output tile i >> 1, k-step i & 1)
+            const int k = (more ? KS : 0) + i; // position in this chunk's consumption order
+            acc2[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[k % RING], a2[i & 1], acc2[i >> 1], 0, 0, 0);
+            if (f0 + k + RING < NF) { wr[k % RING] = lds_frag(ch, f0 + k + RING); W2X_RING_FENCE(); }
+        }
+        if (more) __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+    }
+#else
     W2X_PHASE_FENCE();
 #if W2X_MLP2Q_EARLY0
     __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): this wave's share of chunk 0 (requested first) has landed
@@ -535,6 +645,7 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
     __builtin_amdgcn_s_setprio(1);
 #endif
 
+#endif
     W2X_PHASE_FENCE();
     typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #pragma unroll
