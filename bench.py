@@ -263,11 +263,14 @@ def main():
     # one rank per GPU: run on the CPUs of that GPU's NUMA node (page-locked frame buffers are allocated after this and land there)
     dmap = os.environ.get("W2X_DEVICE_MAP")
     phys = int(dmap.split(",")[local_rank]) if dmap and local_rank < len(dmap.split(",")) else local_rank
-    pinned = shard.pin_to_gpu_numa(phys) if world > 1 or os.environ.get("W2X_PIN_NUMA") else set()
     import torch
     import __graft_entry__ as g
     import synth_models as sm
     pkg = g.package()
+    pinned = set()
+    if world > 1 or os.environ.get("W2X_PIN_NUMA"):
+        # the CPUs of THIS rank's GPU by its PCI address as the HIP runtime reports it (no assumption about ordinal orders); nothing is allocated yet
+        pinned = shard.pin_to_gpu_numa(phys, pci_bus_id=pkg.device_pci_bus_id(local_rank))
 
     dist = None
     if world > 1:
@@ -348,9 +351,13 @@ def main():
     prof = eng.profile_frame()
     desc = pkg.describe_plan(path, eng.pass_tiles, TILE).splitlines()[2:]
     op_ms = eng.op_times()
+    # an op the engine folded into the previous launch (the image head riding on the last C = 96 MLP, engine.cpp fuse_head) has no launch of its own:
+    # its time is inside the previous op's
+    folded = [i for i, (line, t) in enumerate(zip(desc, op_ms)) if t == 0.0 and i > 0 and " gemm " in f" {line} " and " mlp " in f" {desc[i - 1]} "]
     if a.op_times and rank == 0:
-        for line, t in zip(desc, op_ms):
-            print(f"{t:8.3f} ms  {line[:150]}", file=sys.stderr)
+        for i, (line, t) in enumerate(zip(desc, op_ms)):
+            note = "  (no launch of its own: folded into the previous op's launch, whose time includes it)" if i in folded else ""
+            print(f"{t:8.3f} ms  {line[:150]}{note}", file=sys.stderr)
     if rank == 0:
         import re
         fps = a.steps * (1 if strips else world) / wall_max       # strips: the N ranks together produce each frame
@@ -405,6 +412,8 @@ def main():
                 "other_roof": {"unit": "TFLOP/s" if hbm_bound else "GB/s", "achieved": round(tflops if hbm_bound else gbs, 2),
                                "frac": round((tflops / MFMA_F16_PEAK_TFLOPS) if hbm_bound else (gbs / HBM_PEAK_GBS), 5)},
                 "kernels_ms_per_frame": {symbols.get(k, k[0] if not isinstance(k[1], str) else k[0] + " " + k[1]): round(v[0], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])}}
+        if folded:
+            roof["kernels_note"] = "mlp96q_kernel's figure includes the image head (Linear 96 -> 64, Clip, DepthToSpace), which the engine folds into the last C = 96 MLP launch; that plan op has no launch and reports 0 ms"
         tr = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/profile_round.sh)
         if os.path.exists(tr) and CONFIG_NAME == "configs[2]":
             try:

@@ -107,6 +107,9 @@ int w2x_describe_plan_precision(const char* onnx_path, int batch, int tile, int 
  * engine"), writing "ok" or the reason into buf. */
 int w2x_write_engine_file(const char* onnx_path, int batch, int tile, const char* out_path);
 int w2x_validate_engine_file(const char* path, char* buf, size_t cap);
+/* PCI bus id ("0000:c1:00.0") of HIP device `device` of this process (after W2X_DEVICE_MAP), for callers that place their host threads and
+ * page-locked buffers on the GPU's NUMA node (/sys/bus/pci/devices/<id>/local_cpulist); 1 on success. */
+int w2x_device_pci_bus_id(int device, char* buf, size_t cap);
 /* sha256 hex digest (names engine files; utilities/sha256.h:39-94). out: 65 bytes. */
 void w2x_sha256_hex(const void* data, size_t len, char* out);
 const char* w2x_version(void);

@@ -83,6 +83,9 @@ private:
     std::unique_ptr<Impl> impl;
 };
 
+// PCI bus id of HIP device `deviceId` (the logical id RenderConfig::deviceId takes, W2X_DEVICE_MAP applied); false if there is no such device
+bool device_pci_bus_id(int deviceId, char* buf, size_t cap);
+
 }  // namespace w2x
 
 #endif

@@ -129,6 +129,13 @@ def test_gpu_count_and_numa_pinning_come_from_sysfs_without_touching_the_gpu(tmp
     assert shard.pin_to_gpu_numa(5, root, apply=False) == want        # intersected with the cpuset this process may use
     assert shard.pin_to_gpu_numa(8, root, apply=False) == set()       # no such GPU: nothing changes
     assert shard.gpu_nodes(str(tmp_path / "nothing")) == []           # no KFD (this container): zero GPUs, no exception
+    # by PCI address (what bench.py's ranks use: w2x_device_pci_bus_id of their own HIP device): the ordinal plays no part - a runtime that enumerates
+    # the GPUs in another order than the KFD nodes still lands on its own GPU's CPUs; an address sysfs does not know falls back to the KFD order
+    pci = os.path.join(root, "bus", "pci", "devices", "0000:c1:00.0"); os.makedirs(pci)
+    cpus = sorted(allowed)
+    open(os.path.join(pci, "local_cpulist"), "w").write(f"{cpus[0]}\n")
+    assert shard.pin_to_gpu_numa(5, root, apply=False, pci_bus_id="0000:C1:00.0") == {cpus[0]}
+    assert shard.pin_to_gpu_numa(5, root, apply=False, pci_bus_id="0000:ff:00.0") == want
     # really applying it keeps the process runnable (restore afterwards)
     _fake_sysfs(str(tmp_path / "b"), [(0, ",".join(str(c) for c in sorted(allowed)))])
     assert shard.pin_to_gpu_numa(0, str(tmp_path / "b")) == allowed

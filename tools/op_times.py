@@ -23,5 +23,7 @@ print(f"{eng.bench_resident(5):.3f} ms per resident frame, {eng.pass_tiles} tile
 prof = eng.profile_frame()
 print({k: round(v[0], 3) for k, v in prof.items() if k != "frame_ms"})
 desc = pkg.describe_plan(path, eng.pass_tiles, tile, prec).splitlines()[2:]
-for line, t in zip(desc, eng.op_times()):
-    print(f"{t:8.3f} ms  {line[:170]}")
+times = list(eng.op_times())
+for i, (line, t) in enumerate(zip(desc, times)):
+    folded = t == 0.0 and i > 0 and " gemm " in f" {line} " and " mlp " in f" {desc[i - 1]} "      # the image head riding on the last MLP launch (engine.cpp fuse_head)
+    print(f"{t:8.3f} ms  {line[:170]}" + ("  (folded into the previous op's launch)" if folded else ""))

@@ -72,16 +72,26 @@ def parse_cpulist(text: str) -> set[int]:
     return cpus
 
 
-def pin_to_gpu_numa(device: int, sysfs: str = "/sys", apply: bool = True) -> set[int]:
+def pin_to_gpu_numa(device: int, sysfs: str = "/sys", apply: bool = True, pci_bus_id: str | None = None) -> set[int]:
     """Restrict this process to the CPUs local to GPU `device` (its PCIe root's NUMA node), intersected with what the process may
     use already (cgroup cpusets).  Page-locked frame buffers allocated afterwards then sit on the GPU's own NUMA node: with one
     rank per GPU every rank moves 100 MB per 4K frame over PCIe.  Returns the CPU set applied (empty: nothing known, nothing
-    changed)."""
+    changed).  pci_bus_id: the device's PCI address as the HIP runtime of THIS process reports it (w2x_device_pci_bus_id) - then the
+    CPU list comes from /sys/bus/pci/devices/<id>/local_cpulist and does not rest on HIP ordinals following the KFD node order
+    (they do not under *_VISIBLE_DEVICES filters or a reordering runtime); without it the KFD order is assumed."""
     import os
-    nodes = gpu_nodes(sysfs)
-    if not (0 <= device < len(nodes)) or not nodes[device]["cpulist"]:
-        return set()
-    want = parse_cpulist(nodes[device]["cpulist"])
+    cpulist = ""
+    if pci_bus_id:
+        try:
+            cpulist = open(os.path.join(sysfs, "bus", "pci", "devices", pci_bus_id.lower(), "local_cpulist")).read().strip()
+        except OSError:
+            cpulist = ""
+    if not cpulist:
+        nodes = gpu_nodes(sysfs)
+        if not (0 <= device < len(nodes)) or not nodes[device]["cpulist"]:
+            return set()
+        cpulist = nodes[device]["cpulist"]
+    want = parse_cpulist(cpulist)
     try:
         allowed = os.sched_getaffinity(0)
     except (AttributeError, OSError):

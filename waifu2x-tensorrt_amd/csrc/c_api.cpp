@@ -196,6 +196,8 @@ int w2x_write_engine_file(const char* onnx_path, int batch, int tile, const char
     } catch (const std::exception&) { return 0; }
 }
 
+int w2x_device_pci_bus_id(int device, char* buf, size_t cap) { return buf && cap >= 16 && w2x::device_pci_bus_id(device, buf, cap) ? 1 : 0; }
+
 void w2x_sha256_hex(const void* data, size_t len, char* out) {
     std::string h = w2x::sha256_hex(data, len);
     memcpy(out, h.c_str(), 65);

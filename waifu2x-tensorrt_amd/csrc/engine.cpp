@@ -82,6 +82,16 @@ std::string device_ordinal_problem(int logical, int physical) {
     return m + " does not exist: this process sees " + std::to_string(count) + " HIP device" + (count == 1 ? "" : "s") + " (valid ids 0.." + std::to_string(count - 1) + ")";
 }
 
+}  // namespace
+bool device_pci_bus_id(int deviceId, char* buf, size_t cap) {
+    const int dev = physical_device(deviceId);
+    if (!device_ordinal_problem(deviceId, dev).empty()) return false;
+    const bool ok = hipDeviceGetPCIBusId(buf, (int)cap, dev) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}
+namespace {
+
 std::string precision_name(Precision p) { return p == Precision::FP16 ? "FP16" : "TF32"; }
 
 // img2img_build.cpp:8-27

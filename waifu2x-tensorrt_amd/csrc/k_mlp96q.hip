@@ -401,8 +401,11 @@ __global__ __launch_bounds__(NTHR, 3) void mlp96q_kernel(const MlpParams p, int 
                     for (int t = 0; t < 2; ++t) {
                         half2v v01 = {(_Float16)acc[t][tt][0], (_Float16)acc[t][tt][1]}, v23 = {(_Float16)acc[t][tt][2], (_Float16)acc[t][tt][3]};
                         if (p.ti_clip) {          // bounds that fp16 represents exactly (mlp96q_supported): clamping the rounded value in fp16 is clamping it in fp32 and rounding again
-                            v01 = __builtin_elementwise_min(__builtin_elementwise_max(v01, lo2), hi2);
-                            v23 = __builtin_elementwise_min(__builtin_elementwise_max(v23, lo2), hi2);
+                            // max, then min, as instructions: this file is built with -fno-honor-nans, under which the compiler may reorder the pair (equal for
+                            // numbers, not for a NaN: v_pk_max / v_pk_min return the other operand, so max-then-min sends a NaN to clip_lo like toimage_kernel's
+                            // fminf(fmaxf(v, lo), hi), min-then-max would send it to clip_hi)
+                            asm("v_pk_max_f16 %0, %1, %2\n\tv_pk_min_f16 %0, %0, %3" : "=&v"(v01) : "v"(v01), "v"(lo2), "v"(hi2));
+                            asm("v_pk_max_f16 %0, %1, %2\n\tv_pk_min_f16 %0, %0, %3" : "=&v"(v23) : "v"(v23), "v"(lo2), "v"(hi2));
                         }
                         const half4 px = {v01[0], v01[1], v23[0], v23[1]};
                         if (ok) *(half4*)(Og + ((size_t)(oy * 4 + 2 * th + t) * p.ti_Ws + ox * 4 + g4) * 4) = px;

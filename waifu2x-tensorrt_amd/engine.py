@@ -127,6 +127,7 @@ def lib():
     L.w2x_describe_plan_precision.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]; L.w2x_describe_plan_precision.restype = C.c_int
     L.w2x_write_engine_file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p]; L.w2x_write_engine_file.restype = C.c_int
     L.w2x_validate_engine_file.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]; L.w2x_validate_engine_file.restype = C.c_int
+    L.w2x_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_size_t]; L.w2x_device_pci_bus_id.restype = C.c_int
     L.w2x_sha256_hex.argtypes = [vp, C.c_size_t, C.c_char_p]
     L.w2x_version.restype = C.c_char_p
     _lib = L
@@ -136,7 +137,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "w2x_create", "w2x_destroy", "w2x_set_message_callback", "w2x_set_progress_callback", "w2x_build", "w2x_load",
     "w2x_render", "w2x_render16", "w2x_infer", "w2x_output_tile_size", "w2x_plan_flops", "w2x_pass_tiles", "w2x_last_render_ms", "w2x_bench_resident", "w2x_profile_frame", "w2x_op_times",
-    "w2x_render_strip", "w2x_strip_plan", "w2x_render_sharded", "w2x_shard_plan", "w2x_render_sequence", "w2x_alloc_host", "w2x_free_host", "w2x_pin_host", "w2x_unpin_host", "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_describe_plan_precision", "w2x_write_engine_file", "w2x_validate_engine_file", "w2x_sha256_hex", "w2x_version"]
+    "w2x_render_strip", "w2x_strip_plan", "w2x_render_sharded", "w2x_shard_plan", "w2x_render_sequence", "w2x_alloc_host", "w2x_free_host", "w2x_pin_host", "w2x_unpin_host", "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_describe_plan_precision", "w2x_write_engine_file", "w2x_validate_engine_file", "w2x_device_pci_bus_id", "w2x_sha256_hex", "w2x_version"]
 
 
 class Img2Img:
@@ -353,6 +354,12 @@ def render_sharded(engines, src: np.ndarray, dst: np.ndarray = None) -> np.ndarr
     if not lib().w2x_render_sharded(handles, len(engines), src.ctypes.data, src.shape[0], src.shape[1], src.strides[0], dst.ctypes.data, dst.strides[0]):
         raise W2xError(engines[0].last_error() or "sharded render failed")
     return dst
+
+
+def device_pci_bus_id(device: int):
+    """PCI bus id of HIP device `device` of this process (W2X_DEVICE_MAP applied), or None: w2x_device_pci_bus_id.  Initialises the HIP runtime."""
+    buf = C.create_string_buffer(64)
+    return buf.value.decode() if lib().w2x_device_pci_bus_id(int(device), buf, 64) else None
 
 
 def shard_plan(in_w, in_h, out_w, out_h, tile_in, tile_out, scaling, overlap, part, parts):
