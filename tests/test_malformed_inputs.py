@@ -118,6 +118,62 @@ def test_truncated_and_bit_flipped_onnx_files(small_models, tmp_path):
     assert sum(rc == 2 for rc in res.values()) >= 20, "the corpus does not reach the rejection paths"
 
 
+# ---- well-formed protobuf, hostile content: a minimal ONNX writer (wire format of SURVEY.md appendix C; no onnx package offline)
+def _vint(n):
+    n &= (1 << 64) - 1
+    out = bytearray()
+    while True:
+        b = n & 0x7F; n >>= 7
+        out.append(b | (0x80 if n else 0))
+        if not n:
+            return bytes(out)
+
+
+def _ld(field, payload): return _vint(field << 3 | 2) + _vint(len(payload)) + payload
+def _iv(field, v): return _vint(field << 3 | 0) + _vint(v)
+def _tensor(name, dtype, dims, raw): return b"".join(_iv(1, d) for d in dims) + _iv(2, dtype) + _ld(8, name.encode()) + _ld(9, raw)
+def _attr_t(name, tensor): return _ld(1, name.encode()) + _ld(5, tensor) + _iv(20, 4)
+def _attr_i(name, v): return _ld(1, name.encode()) + _iv(3, v) + _iv(20, 2)
+def _node(op, ins, outs, attrs=(), name=""): return b"".join(_ld(1, i.encode()) for i in ins) + b"".join(_ld(2, o.encode()) for o in outs) + _ld(3, (name or op).encode()) + _ld(4, op.encode()) + b"".join(_ld(5, a) for a in attrs)
+def _vinfo(name, dims): return _ld(1, name.encode()) + _ld(2, _ld(1, _iv(1, 1) + _ld(2, b"".join(_ld(1, _iv(1, d)) for d in dims))))
+def _i64s(vals): return np.array(vals, "<i8").tobytes()
+
+
+def _model(nodes, inits=(), in_dims=(1, 3, 64, 64), out_dims=(1, 3, 64, 64), out="y"):
+    g = b"".join(_ld(1, n) for n in nodes) + _ld(2, b"g") + b"".join(_ld(5, t) for t in inits) + _ld(11, _vinfo("x", in_dims)) + _ld(12, _vinfo(out, out_dims))
+    return _iv(1, 8) + _ld(2, b"hostile") + _ld(7, g) + _ld(8, _iv(2, 17))
+
+
+def test_well_formed_but_hostile_onnx_graphs(tmp_path):
+    """Files the protobuf reader accepts whose CONTENT asks for the impossible: constants of 2^40 elements (ConstantOfShape, Expand, Range: the folding pass
+    evaluates whatever does not depend on the input), initialisers whose dims do not match their payload or are negative, a node that reads its own output, an
+    undefined input, a rank-5 graph input, an operator nobody lowers.  Each must be refused with a message; none may allocate what the file dictates."""
+    huge = 1 << 40
+    one = _tensor("", 1, [1], np.float32([1.0]).tobytes())
+    blobs = {
+        "const_of_shape_huge": _model([_node("ConstantOfShape", ["s"], ["c"], [_attr_t("value", one)]), _node("Add", ["x", "c"], ["y"])], [_tensor("s", 7, [1], _i64s([huge]))]),
+        "const_of_shape_negative": _model([_node("ConstantOfShape", ["s"], ["c"]), _node("Add", ["x", "c"], ["y"])], [_tensor("s", 7, [2], _i64s([-5, 7]))]),
+        "expand_huge": _model([_node("Expand", ["one", "s"], ["c"]), _node("Add", ["x", "c"], ["y"])], [_tensor("one", 1, [1], np.float32([1]).tobytes()), _tensor("s", 7, [2], _i64s([1 << 20, 1 << 20]))]),
+        "range_huge": _model([_node("Range", ["a", "b", "d"], ["c"]), _node("Add", ["x", "c"], ["y"])], [_tensor("a", 7, [], _i64s([0])), _tensor("b", 7, [], _i64s([huge])), _tensor("d", 7, [], _i64s([1]))]),
+        "range_zero_step": _model([_node("Range", ["a", "b", "d"], ["c"]), _node("Add", ["x", "c"], ["y"])], [_tensor("a", 7, [], _i64s([0])), _tensor("b", 7, [], _i64s([9])), _tensor("d", 7, [], _i64s([0]))]),
+        "init_dims_exceed_payload": _model([_node("Add", ["x", "w"], ["y"])], [_tensor("w", 1, [1 << 30, 1 << 30], np.float32([1, 2]).tobytes())]),
+        "init_dims_exceed_payload_f16": _model([_node("Add", ["x", "w"], ["y"])], [_tensor("w", 10, [1 << 31, 4], np.float16([1, 2]).tobytes())]),
+        "init_dims_exceed_payload_i32": _model([_node("Add", ["x", "w"], ["y"])], [_tensor("w", 6, [1 << 40], np.int32([1, 2]).tobytes())]),
+        "init_negative_dim": _model([_node("Add", ["x", "w"], ["y"])], [_tensor("w", 1, [-1, 4], np.float32([1, 2, 3, 4]).tobytes())]),
+        "init_dims_overflow": _model([_node("Add", ["x", "w"], ["y"])], [_tensor("w", 1, [1 << 62, 1 << 62, 4], b"")]),
+        "node_reads_itself": _model([_node("Relu", ["y"], ["y"])]),
+        "undefined_input": _model([_node("Add", ["x", "nowhere"], ["y"])]),
+        "rank5_input": _model([_node("Relu", ["x"], ["y"])], in_dims=(1, 3, 4, 64, 64), out_dims=(1, 3, 4, 64, 64)),
+        "zero_sized_input": _model([_node("Relu", ["x"], ["y"])], in_dims=(1, 0, 64, 64), out_dims=(1, 0, 64, 64)),
+        "unknown_operator": _model([_node("NonMaxSuppression", ["x"], ["y"])]),
+        "reshape_to_huge": _model([_node("Reshape", ["x", "s"], ["y"])], [_tensor("s", 7, [4], _i64s([huge, huge, huge, -1]))]),
+        "conv_kernel_huge": _model([_node("Conv", ["x", "w"], ["y"], [_attr_i("group", 1)])], [_tensor("w", 1, [1 << 20, 3, 1 << 20, 3], b"")]),
+        "no_nodes": _model([], out="x"),
+    }
+    res = run_corpus("onnx", write_all(tmp_path, blobs, ".onnx"), extra=(1, 64))
+    assert all(rc == 2 for k, rc in res.items() if k != "no_nodes"), {k: v for k, v in res.items() if v != 2}      # (an empty graph is the identity network: a plan of zero ops)
+
+
 def test_truncated_and_bit_flipped_engine_files(pkg, small_models, tmp_path):
     rng = np.random.default_rng(7)
     blobs = {}

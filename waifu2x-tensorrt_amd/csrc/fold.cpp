@@ -62,10 +62,24 @@ struct Bcast {
     }
 };
 
+// Constants the folding pass materialises come from shapes a FILE dictates (ConstantOfShape, Expand, Range, Tile-like broadcasts ...): bounded, so that a
+// model file cannot make build() allocate terabytes.  2^28 elements = 1 GiB of floats; the largest folded constant of the graphs here (a 640 x 640 tile's
+// window tables and shift masks) is below 2^23.
+constexpr int64_t kMaxFoldedElems = int64_t(1) << 28;
+int64_t checked_numel(const Shape& shape) {
+    int64_t n = 1;
+    for (int64_t d : shape) {
+        if (d < 0) throw std::runtime_error("fold: negative dimension " + std::to_string(d) + " in a constant's shape");
+        if (d != 0 && n > kMaxFoldedElems / d) throw std::runtime_error("fold: a constant of more than 2^28 elements (shape dictated by the model file) is refused");
+        n *= d;
+    }
+    return n;
+}
+
 HTensorP make(int dtype, const Shape& shape) {
     auto t = std::make_shared<HTensor>();
     t->dtype = dtype; t->shape = shape;
-    int64_t n = t->numel();
+    int64_t n = checked_numel(shape);
     if (t->is_float()) t->f.assign(n, 0.f); else t->i.assign(n, 0);
     return t;
 }
@@ -164,10 +178,16 @@ std::vector<int64_t> ints_of(const HTensor& t) {
 Shape reshape_target(const Shape& in, const std::vector<int64_t>& req, bool allowzero) {
     Shape o(req.size());
     int64_t known = 1; int neg = -1;
+    // (the requested dims come from the file: products are formed with an overflow check, a target larger than any tensor here is a size mismatch)
+    auto mul = [&](int64_t d) {
+        if (d < 0) throw std::runtime_error("fold: reshape to a negative dimension");
+        if (d != 0 && known > (int64_t(1) << 48) / d) throw std::runtime_error("fold: reshape size mismatch");
+        known *= d;
+    };
     for (size_t k = 0; k < req.size(); ++k) {
         if (req[k] == -1) { if (neg >= 0) throw std::runtime_error("fold: reshape with two -1"); neg = (int)k; o[k] = 1; }
-        else if (req[k] == 0 && !allowzero) { if (k >= in.size()) throw std::runtime_error("fold: reshape 0-dim out of range"); o[k] = in[k]; known *= o[k]; }
-        else { o[k] = req[k]; known *= o[k]; }
+        else if (req[k] == 0 && !allowzero) { if (k >= in.size()) throw std::runtime_error("fold: reshape 0-dim out of range"); o[k] = in[k]; mul(o[k]); }
+        else { o[k] = req[k]; mul(o[k]); }
     }
     int64_t total = prod(in);
     if (neg >= 0) { if (known == 0 || total % known) throw std::runtime_error("fold: reshape size mismatch"); o[neg] = total / known; }

@@ -101,7 +101,14 @@ HTensorP parse_tensor(Span s, std::string* name_out) {
             default: break;
         }
     }
-    int64_t n = t->numel();
+    // dims come from the file: every one non-negative, the product bounded, and checked against the payload that is actually there BEFORE anything
+    // of that size is allocated
+    int64_t n = 1;
+    for (int64_t d : t->shape) {
+        if (d < 0) throw std::runtime_error("onnx: tensor with a negative dimension");
+        if (d != 0 && n > (int64_t(1) << 40) / d) throw std::runtime_error("onnx: tensor dimensions overflow");
+        n *= d;
+    }
     auto need = [&](size_t have, size_t elt) { if ((int64_t)(have / elt) != n) throw std::runtime_error("onnx: tensor payload size mismatch"); };
     switch (t->dtype) {
         case DT_F32:
@@ -109,12 +116,14 @@ HTensorP parse_tensor(Span s, std::string* name_out) {
             else { need(f32.size(), 1); t->f = std::move(f32); }
             break;
         case DT_F16:
+            if (has_raw) need(raw.e - raw.p, 2); else need(i32.size(), 1);
             t->f.resize(n);
             if (has_raw) { need(raw.e - raw.p, 2); for (int64_t k = 0; k < n; ++k) { uint16_t h; memcpy(&h, raw.p + 2 * k, 2); t->f[k] = half_to_float(h); } }
             else { need(i32.size(), 1); for (int64_t k = 0; k < n; ++k) t->f[k] = half_to_float((uint16_t)i32[k]); }
             t->dtype = DT_F32;
             break;
         case DT_F64:
+            if (has_raw) need(raw.e - raw.p, 8); else need(f64.size(), 1);
             t->f.resize(n);
             if (has_raw) { need(raw.e - raw.p, 8); for (int64_t k = 0; k < n; ++k) { double d; memcpy(&d, raw.p + 8 * k, 8); t->f[k] = (float)d; } }
             else { need(f64.size(), 1); for (int64_t k = 0; k < n; ++k) t->f[k] = (float)f64[k]; }
@@ -125,11 +134,13 @@ HTensorP parse_tensor(Span s, std::string* name_out) {
             else { need(i64.size(), 1); t->i = std::move(i64); }
             break;
         case DT_I32:
+            if (has_raw) need(raw.e - raw.p, 4); else need(i32.size(), 1);
             t->i.resize(n);
             if (has_raw) { need(raw.e - raw.p, 4); for (int64_t k = 0; k < n; ++k) { int32_t v; memcpy(&v, raw.p + 4 * k, 4); t->i[k] = v; } }
             else { need(i32.size(), 1); for (int64_t k = 0; k < n; ++k) t->i[k] = (int32_t)i32[k]; }
             break;
         case DT_BOOL: case DT_U8: case DT_I8:
+            if (has_raw) need(raw.e - raw.p, 1); else need(i32.size(), 1);
             t->i.resize(n);
             if (has_raw) { need(raw.e - raw.p, 1); for (int64_t k = 0; k < n; ++k) t->i[k] = t->dtype == DT_I8 ? (int64_t)(int8_t)raw.p[k] : (int64_t)raw.p[k]; }
             else { need(i32.size(), 1); for (int64_t k = 0; k < n; ++k) t->i[k] = i32[k]; }
