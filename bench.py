@@ -144,8 +144,8 @@ def cpu_baseline(work: str, tile_out: int) -> dict:
                       f"median extrapolated to {n} tiles/frame ({frame_s:.0f} s/frame)"}
 
 
-def bench_shards(a) -> int:
-    """--mode shards: ONE frame over --gpus N engines of THIS process with every tile computed once (w2x_render_sharded: contiguous tile ranges,
+def bench_shards_one_process(a) -> int:
+    """--mode shards1p: ONE frame over --gpus N engines of THIS process with every tile computed once (w2x_render_sharded: contiguous tile ranges,
     seam bands copied device to device, each engine composes and downloads its own canvas cells).  Host frame in -> host frame out per step,
     strong scaling.  No child ranks: the seam exchange is a device-to-device copy between engines of one process."""
     import __graft_entry__ as g
@@ -190,7 +190,7 @@ def bench_shards(a) -> int:
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(wall * 1e3 / a.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{CONFIG_NAME}: {MODEL} scale{SCALE} noise{NOISE} batch{BATCH} tile{TILE} fp16{' +TTA' if TTA else ''}, {FRAME_W}x{FRAME_H} frame, blend={BLEND} ({n} tiles); host frame in -> host frame out",
-                       "mode": "shards", "parallelism": f"one frame in {a.gpus} contiguous tile ranges (renderSharded), every tile computed once, seam bands copied device to device, no collectives; one process drives all engines",
+                       "mode": "shards1p", "parallelism": f"one frame in {a.gpus} contiguous tile ranges (renderSharded), every tile computed once, seam bands copied device to device, no collectives; one process drives all engines",
                        "tiles_per_engine": [c for _, c, _, _ in parts], "speedup_bound": round(n / max(c for _, c, _, _ in parts), 2),
                        "one_engine_render_ms": round(wall1 * 1e3 / a.steps, 3), "speedup_measured": round(wall1 / wall, 3),
                        "device_map": os.environ.get("W2X_DEVICE_MAP")}}
@@ -198,6 +198,90 @@ def bench_shards(a) -> int:
     for e in engs:
         e.close()
     return 0
+
+
+def bench_shards_ranks(a, pkg, eng, dist, rank, local_rank, world, json_out, pinned) -> int:
+    """--mode shards: ONE frame over N ranks, one process per GPU, every tile computed once.  Per step: rank r computes its contiguous range of the tile
+    order into its slab (w2x_shard_compute), the ranks exchange the IPC handles of their slabs (a gloo all_gather of 64 bytes each - also the barrier that says
+    every slab is complete), rank r opens the slabs of the parts in front of it, copies their seam bands device to device, composes its canvas cells and
+    writes them into the frame all ranks share (a /dev/shm mapping), and a closing barrier keeps a rank from starting the next frame while a neighbour still
+    reads its slab.  No collective on the data path."""
+    import shard
+    frame = synthetic_frame(0)
+    oh, ow = FRAME_H * SCALE, FRAME_W * SCALE
+    shm = f"/dev/shm/w2x_shards_{os.environ.get('MASTER_PORT', '0')}.u8"      # the frame all ranks write their cells into (one launch = one port)
+    if rank == 0:
+        with open(shm, "wb") as f:
+            f.truncate(oh * ow * 3)
+    shard.barrier(dist)
+    out = np.memmap(shm, np.uint8, "r+", shape=(oh, ow, 3))
+    opened = {}                                   # handle bytes -> device pointer in this process
+
+    def step():
+        if not eng.shard_compute(frame, rank, world):
+            raise SystemExit("shard_compute failed: " + eng.last_error())
+        ptr, handle = eng.shard_slab_handle()
+        if dist is not None:
+            handles = [None] * world
+            dist.all_gather_object(handles, handle)
+        else:
+            handles = [handle]
+        slabs = [0] * world
+        for q in range(rank):                     # only parts in front of this one can hold tiles it needs
+            if handles[q] not in opened:
+                opened[handles[q]] = pkg.ipc_open(handles[q], local_rank)
+                if not opened[handles[q]]:
+                    raise SystemExit(f"rank {rank}: hipIpcOpenMemHandle of rank {q}'s slab failed")
+            slabs[q] = opened[handles[q]]
+        # every logical device of a W2X_DEVICE_MAP rehearsal is the same card; on a real node rank q's slab lives on device q
+        if not eng.shard_finish(out, rank, world, slabs, devices=list(range(world))):
+            raise SystemExit("shard_finish failed: " + eng.last_error())
+        shard.barrier(dist)
+
+    for _ in range(max(a.warmup, 2)):
+        step()
+    shard.barrier(dist)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    wall = shard.max_over_ranks(time.perf_counter() - t0, dist)
+    rc = 0
+    if rank == 0:
+        whole = eng.render(frame)
+        same = bool(np.array_equal(np.asarray(out), whole))
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            eng.render(frame, whole)
+        wall1 = time.perf_counter() - t0
+        n = pkg.calculate_tiles(FRAME_W, FRAME_H, ow, oh, TILE, eng.output_tile_size, SCALE, (BLEND, BLEND))[0]
+        parts = [pkg.shard_plan(FRAME_W, FRAME_H, ow, oh, TILE, eng.output_tile_size, SCALE, (BLEND, BLEND), p, world) for p in range(world)]
+        fps = a.steps / wall
+        line = {"metric": f"upscaled MPix/s, one {FRAME_W}x{FRAME_H} frame over N ranks ({MODEL} fp16)", "value": round(fps * OUT_MPIX, 2), "unit": "MPix/s", "n_gpus": world,
+                "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(wall * 1e3 / a.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f16", "data": "synthetic",
+                "config": {"workload": f"{CONFIG_NAME}: {MODEL} scale{SCALE} noise{NOISE} batch{BATCH} tile{TILE} fp16{' +TTA' if TTA else ''}, {FRAME_W}x{FRAME_H} frame, blend={BLEND} ({n} tiles); host frame in -> host frame out (a /dev/shm mapping shared by the ranks)",
+                           "mode": "shards", "parallelism": f"one frame in {world} contiguous tile ranges, one process per GPU, every tile computed once; seam bands copied device to device out of the neighbours' slabs (hipIpc handles exchanged over gloo), no data-path collective",
+                           "tiles_per_rank": [c for _, c, _, _ in parts], "speedup_bound": round(n / max(c for _, c, _, _ in parts), 2),
+                           "one_rank_render_ms": round(wall1 * 1e3 / a.steps, 3), "speedup_measured": round(wall1 / wall, 3), "bytes_equal_render": same,
+                           "rank0_cpus": len(pinned) or None, "device_map": os.environ.get("W2X_DEVICE_MAP")}}
+        print(json.dumps(line), file=json_out, flush=True)
+        if not same:
+            print("[w2x] the sharded frame differs from render()", file=sys.stderr)
+            rc = 1
+    shard.barrier(dist)
+    for p_ in opened.values():
+        pkg.ipc_close(p_)
+    del out
+    if rank == 0:
+        try:
+            os.unlink(shm)
+        except OSError:
+            pass
+    json_out.close()
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    return rc
 
 
 def spawn_ranks(a) -> int:
@@ -227,9 +311,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", choices=["frames", "strips", "shards"], default="frames",
+    ap.add_argument("--mode", choices=["frames", "strips", "shards", "shards1p"], default="frames",
                     help="frames: every rank renders K whole frames (weak scaling, the headline); strips: rank r renders strip r of N of the same frame K times (strong scaling); "
-                         "shards: one process, N engines, one frame in N tile ranges with every tile computed once (strong scaling)")
+                         "shards: one frame in N tile ranges with every tile computed once, one process per GPU, the seam bands copied out of the neighbours' slabs through IPC handles "
+                         "(strong scaling); shards1p: the same with one process driving N engines")
     ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=3,
                     help="BASELINE.json configuration (1-based; 3 = configs[2], the one the metric is quoted on); the others emit the same JSON record for their workload")
     ap.add_argument("--cpu-baseline", action="store_true", help="time the CPU oracle for --config other than 3 as well (minutes for the 400 / 640 tiles)")
@@ -241,10 +326,10 @@ def main():
     a = ap.parse_args()
     select_config(a.config)
 
-    if a.mode == "shards":
+    if a.mode == "shards1p":
         if int(os.environ.get("RANK", "0")) != 0:       # under a launcher: rank 0 drives every engine, the other ranks have nothing to do
             return
-        raise SystemExit(bench_shards(a))
+        raise SystemExit(bench_shards_one_process(a))
     if a.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(spawn_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
@@ -293,6 +378,8 @@ def main():
         for _, m in eng.messages[-2:]:
             print("[w2x] " + m, file=sys.stderr)
 
+    if a.mode == "shards":
+        raise SystemExit(bench_shards_ranks(a, pkg, eng, dist, rank, local_rank, world, json_out, pinned))
     strips = a.mode == "strips"
     my_frames = [0] if strips else shard.frames_for_rank(a.steps * world, rank, world)   # frame f -> rank f mod N; each rank renders K frames
     frame = synthetic_frame(my_frames[0])

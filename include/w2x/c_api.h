@@ -69,6 +69,17 @@ int w2x_render_strip(w2x_engine* e, const uint8_t* src, int rows, int cols, size
 int w2x_render_sharded(w2x_engine* const* engines, int count, const uint8_t* src, int rows, int cols, size_t src_step, uint8_t* dst, size_t dst_step);
 int w2x_shard_plan(int in_w, int in_h, int out_w, int out_h, int tile_in, int tile_out, int scaling, double overlap_x, double overlap_y,
                    int part, int parts, int* out16);
+/* The same split with ONE PROCESS PER GPU: rank r calls w2x_shard_compute (its own tiles into its slab, complete on return), exports w2x_shard_slab with
+ * w2x_ipc_export (a 64-byte handle, hipIpcGetMemHandle) and hands it to its peers by whatever channel the caller has (bench.py: gloo all_gather - the
+ * exchange is also the barrier); w2x_shard_finish takes the w2x_ipc_open'ed slabs of the parts in front of `part` (slabs[q] for q < part that own tiles;
+ * other entries are ignored; devices[q] = the logical device the slab lives on, or NULL), copies the seam bands device to device, composes and writes this
+ * part's canvas cells of dst (dst rows x cols = the OUTPUT size).  No collective on the data path. */
+int w2x_shard_compute(w2x_engine* e, const uint8_t* src, int rows, int cols, size_t src_step, int part, int parts);
+const void* w2x_shard_slab(w2x_engine* e, size_t* bytes);
+int w2x_shard_finish(w2x_engine* e, uint8_t* dst, int out_rows, int out_cols, size_t dst_step, int part, int parts, const void* const* slabs, const int* devices);
+int w2x_ipc_export(const void* device_ptr, uint8_t* out64);
+void* w2x_ipc_open(const uint8_t* handle64, int device);
+void w2x_ipc_close(void* p);
 /* Frame sequence with the PCIe copies overlapped (no reference counterpart: main.cpp:263-269 renders frame by frame): srcs/dsts are
  * arrays of `count` frame pointers of one size.  The copies run by DMA beside the kernels only for page-locked memory: take the
  * frame buffers from w2x_alloc_host (engine-owned, w2x_free_host or w2x_destroy releases them).  w2x_pin_host page-locks caller

@@ -47,6 +47,13 @@ public:
     // and every engine composes and downloads the canvas cells of its own tiles.  All engines must be loaded with the same model and
     // RenderConfig, live in this process, and are driven from the calling thread; the bytes are render()'s.  engines[0] reports progress.
     static bool renderSharded(Img2Img* const* engines, int count, const Image& src, Image& dst);
+    // The same with ONE PROCESS PER GPU (bench.py / torch.distributed.run ranks): rank r runs shardCompute(src, r, N) - its own tiles into its slab,
+    // complete on return -, exports shardSlab() with ipc_export(), and once every rank has published its handle (the caller's barrier: the exchange
+    // itself) shardFinish(dst, r, N, slabs, devices) with the ipc_open()ed slabs of the parts in front of it (entries of later / own parts are ignored):
+    // seam bands copied device to device, its canvas cells composed and written to dst.
+    bool shardCompute(const Image& src, int part, int parts);
+    const void* shardSlab(size_t* bytes = nullptr) const;
+    bool shardFinish(Image& dst, int part, int parts, const void* const* slabs, const int* devices);
     // A sequence of equally sized frames (the per-frame loop of main.cpp:263-269) with upload, compute and download overlapped on
     // three HIP streams; outputs are the bytes render() gives.  The copies only overlap for page-locked host memory: take the frame
     // buffers from allocHost() (owned by the engine, released by freeHost(), release at destruction at the latest).
@@ -83,6 +90,11 @@ private:
     std::unique_ptr<Impl> impl;
 };
 
+// Device memory across processes (hipIpc*): export a device pointer of this process as a 64-byte handle; open another process's handle on logical device
+// `deviceId` (nullptr on failure); close it again.
+bool ipc_export(const void* device_ptr, uint8_t out[64]);
+void* ipc_open(const uint8_t handle[64], int deviceId);
+void ipc_close(void* p);
 // PCI bus id of HIP device `deviceId` (the logical id RenderConfig::deviceId takes, W2X_DEVICE_MAP applied); false if there is no such device
 bool device_pci_bus_id(int deviceId, char* buf, size_t cap);
 

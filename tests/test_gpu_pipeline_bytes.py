@@ -11,6 +11,8 @@ sides see identical network outputs and everything around the network must agree
 
 This is the tier's bar for integer / byte work.  Network outputs of a tile do not depend on its batch slot or on the tiles it shares
 a pass with (asserted bit-exactly in test_gpu_parity.py), which is what lets infer() stand in for the passes render() runs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -191,3 +193,23 @@ def test_one_frame_over_several_engines_every_tile_once(pkg, onnx_model, monkeyp
     assert np.array_equal(engs[1].render(frame), whole)
     for e in engs:
         e.close()
+
+
+def test_one_frame_over_two_processes_through_ipc_handles(pkg, tmp_path):
+    """The same split with ONE PROCESS PER GPU (bench.py --mode shards: the launch contract's ranks): rank r computes its tile range into its slab
+    (w2x_shard_compute), the ranks exchange hipIpc handles of their slabs over gloo, rank r copies the seam bands out of its predecessors' slabs and writes
+    its canvas cells into a frame the ranks share; bench.py itself compares that frame with rank 0's render() and exits non-zero on a difference.  Two ranks
+    sharing the box's GPU (W2X_DEVICE_MAP); three and four ranks were rehearsed by hand (profiles/r4_final/bench_shards_*ranks_one_gpu.json) - every rank
+    exports and builds the headline model, which is most of this test's minute and a half."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for n in (2,):
+        env = dict(os.environ, W2X_DEVICE_MAP=",".join(["0"] * n), W2X_BENCH_WORK=str(tmp_path / f"w{n}"))
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "shards", "--gpus", str(n), "--steps", "2", "--warmup", "1"],
+                           capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == n and line["config"]["mode"] == "shards" and line["config"]["bytes_equal_render"] is True
+        assert sum(line["config"]["tiles_per_rank"]) == 45

@@ -95,6 +95,21 @@ int w2x_render_sharded(w2x_engine* const* engines, int count, const uint8_t* src
     return w2x::Img2Img::renderSharded(es.data(), count, s, d) ? 1 : 0;
 }
 
+int w2x_shard_compute(w2x_engine* e, const uint8_t* src, int rows, int cols, size_t src_step, int part, int parts) {
+    if (!e) return 0;
+    w2x::Image s; s.data = const_cast<uint8_t*>(src); s.rows = rows; s.cols = cols; s.step = src_step;
+    return e->engine.shardCompute(s, part, parts) ? 1 : 0;
+}
+const void* w2x_shard_slab(w2x_engine* e, size_t* bytes) { return e ? e->engine.shardSlab(bytes) : nullptr; }
+int w2x_shard_finish(w2x_engine* e, uint8_t* dst, int rows, int cols, size_t dst_step, int part, int parts, const void* const* slabs, const int* devices) {
+    if (!e) return 0;
+    w2x::Image d; d.data = dst; d.rows = rows; d.cols = cols; d.step = dst_step;
+    return e->engine.shardFinish(d, part, parts, slabs, devices) ? 1 : 0;
+}
+int w2x_ipc_export(const void* device_ptr, uint8_t* out64) { return out64 && w2x::ipc_export(device_ptr, out64) ? 1 : 0; }
+void* w2x_ipc_open(const uint8_t* handle64, int device) { return handle64 ? w2x::ipc_open(handle64, device) : nullptr; }
+void w2x_ipc_close(void* p) { w2x::ipc_close(p); }
+
 int w2x_render_sequence(w2x_engine* e, const uint8_t* const* srcs, int rows, int cols, size_t src_step, uint8_t* const* dsts, size_t dst_step, int count) {
     if (!e || count < 0) return 0;
     const int sc = e->engine.scaling();

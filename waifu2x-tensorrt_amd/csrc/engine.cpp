@@ -218,6 +218,7 @@ struct Img2Img::Impl {
     hipEvent_t ev_part[2] = {nullptr, nullptr};
     int pipeline_parts = 2;              // W2X_RENDER_PARTS (read at load): 1 = render() runs a frame as one part
     size_t shard_halo_slots = 0;         // renderSharded(): slab slots in front of this engine's own tiles (the bands copied from the preceding parts)
+    int shard_rows = 0, shard_cols = 0;  // shardCompute(): the frame shardFinish() completes
     hipStream_t gstream[3] = {nullptr, nullptr, nullptr};   // further tile groups of a pass (run_frame)
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     // Experiment (W2X_STAGGER_OP=k, two groups): the second group starts when the first has finished op k, so that the two streams run
@@ -1143,6 +1144,101 @@ bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, cons
 // all four per augmented tile under TTA - a dihedral map sends the right / bottom band to any of the four), compose its cells (the
 // same kernel and the same ascending-tile order as a whole-frame render, img2img_render.cpp:329-330: identical bytes), download them.
 // The calling thread drives all engines; nothing here is a collective.
+// what a part needs to know about the part(s) in front of it: where their slab is and how it is laid out
+struct ShardPeer { const void* slab = nullptr; size_t halo_slots = 0; int device = -1; hipEvent_t ev = nullptr; int first_tile = 0, tile_count = 0; };
+
+// phase 1 of a sharded frame on this engine: upload, slots of its own tiles, their network passes into the slab behind the slots reserved for the
+// preceding parts' bands; records ev0 and ev_shard on the compute stream (no host synchronisation)
+static void shard_phase1(Img2Img::Impl& e, const Image& src, const TileGrid& grid, const ShardPlan& sp, bool report) {
+    const int rows = src.rows, cols = src.cols, s = e.cfg.scaling, steps = e.cfg.tta ? 8 : 1;
+    const size_t slot_bytes = (size_t)e.plan.Tout * e.plan.Tout * 4 * e.plan.elt;
+    e.deep = false;
+    e.ensure(e.d_frame, e.frame_cap, (size_t)rows * cols * 3);
+    e.ensure(e.d_out, e.out_cap, (size_t)rows * s * cols * s * 3);
+    hipAssert(hipMemcpy2DAsync(e.d_frame, (size_t)cols * 3, src.data, src.step, (size_t)cols * 3, rows, hipMemcpyHostToDevice, e.stream));
+    const int B = e.plan.B, S = e.plan.B / e.plan.userB;
+    const int batchCount = (int)std::lround(std::ceil((double)(sp.tile_count * steps) / e.plan.userB));
+    const int stepCount = ((batchCount + S - 1) / S) * B;
+    e.h_slots.resize(stepCount);
+    for (int st = 0; st < stepCount; ++st) {
+        const int ti = st / steps, aug = st % steps;
+        TileSlot sl{0, 0, aug, 0};
+        if (ti < sp.tile_count) { sl.x = grid.in[sp.first_tile + ti].x; sl.y = grid.in[sp.first_tile + ti].y; sl.valid = 1; }
+        e.h_slots[st] = sl;
+    }
+    e.ensure(e.d_slots, e.slots_cap, (size_t)stepCount * sizeof(TileSlot));
+    hipAssert(hipMemcpyAsync(e.d_slots, e.h_slots.data(), (size_t)stepCount * sizeof(TileSlot), hipMemcpyHostToDevice, e.stream));
+    e.shard_halo_slots = (size_t)(sp.first_tile - sp.halo_first) * steps;
+    e.ensure(e.d_slab, e.slab_cap, (e.shard_halo_slots + (size_t)stepCount) * slot_bytes);
+    hipAssert(hipEventRecord(e.ev0, e.stream));
+    e.run_passes(rows, cols, sp.tile_count, e.shard_halo_slots, report, 0, true);
+    if (!e.ev_shard) hipAssert(hipEventCreateWithFlags(&e.ev_shard, hipEventDisableTiming));
+    hipAssert(hipEventRecord(e.ev_shard, e.stream));
+}
+
+// phase 2 on this engine (part k): the seam exchange - behind the owners' events (where there are events: engines of this process; slabs of other
+// processes are complete when their handles arrive) copy the blend bands of the tiles [halo_first, first_tile) out of the owners' slabs - then compose and
+// download this part's rectangles (asynchronously: the caller synchronises the stream)
+static void shard_phase2(Img2Img::Impl& e, int k, const std::vector<ShardPlan>& sp, const std::vector<ShardPeer>& peers, const TileGrid& grid, int rows, int cols, Image& dst) {
+    const int steps = e.cfg.tta ? 8 : 1, To = e.plan.Tout;
+    const size_t px = (size_t)4 * e.plan.elt, slot_bytes = (size_t)To * To * px;
+    const bool overlapping = e.cfg.overlapX != 0 || e.cfg.overlapY != 0;
+    int waited = -1;
+    for (int g = sp[k].halo_first; g < sp[k].first_tile && overlapping; ++g) {
+        int q = k - 1;
+        while (q >= 0 && !(sp[q].tile_count > 0 && g >= sp[q].first_tile && g < sp[q].first_tile + sp[q].tile_count)) --q;
+        if (q < 0 || !peers[q].slab) throw std::runtime_error("shard plan: tile " + std::to_string(g) + " has no owner");
+        const ShardPeer& o = peers[q];
+        if (q != waited) { if (o.ev) hipAssert(hipStreamWaitEvent(e.stream, o.ev, 0)); waited = q; }
+        const bool same = o.device == e.device;
+        bool peer2d = same;
+        if (!same) {      // strided band copies between devices need peer access; without it whole slots travel by hipMemcpyPeerAsync
+            int can = 0;
+            if (o.device >= 0 && hipDeviceCanAccessPeer(&can, e.device, o.device) == hipSuccess && can) {
+                const hipError_t pe = hipDeviceEnablePeerAccess(o.device, 0);
+                peer2d = pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled;
+            }
+            (void)hipGetLastError();
+        }
+        for (int a = 0; a < steps; ++a) {
+            const uint8_t* from = (const uint8_t*)o.slab + (o.halo_slots + (size_t)(g - sp[q].first_tile) * steps + a) * slot_bytes;
+            uint8_t* to = (uint8_t*)e.d_slab + ((size_t)(g - sp[k].halo_first) * steps + a) * slot_bytes;
+            if (!peer2d) {
+                if (o.device >= 0) hipAssert(hipMemcpyPeerAsync(to, e.device, from, o.device, slot_bytes, e.stream));
+                else hipAssert(hipMemcpyAsync(to, from, slot_bytes, hipMemcpyDefault, e.stream));
+                continue;
+            }
+            int bx = std::min(To, grid.outOvX), by = std::min(To, grid.outOvY);
+            if (steps > 1) bx = by = std::max(bx, by);                     // a rotation turns a column band into a row band of the same width
+            const size_t pitch = (size_t)To * px;
+            auto cols_band = [&](int x0) { if (bx > 0) hipAssert(hipMemcpy2DAsync(to + (size_t)x0 * px, pitch, from + (size_t)x0 * px, pitch, (size_t)bx * px, To, hipMemcpyDeviceToDevice, e.stream)); };
+            auto rows_band = [&](int y0) { if (by > 0) hipAssert(hipMemcpyAsync(to + (size_t)y0 * pitch, from + (size_t)y0 * pitch, (size_t)by * pitch, hipMemcpyDeviceToDevice, e.stream)); };
+            cols_band(To - bx); rows_band(To - by);                        // what the cells to the right of / below the tile read
+            if (steps > 1) { cols_band(0); rows_band(0); }                // an augmented tile is read through its inverse dihedral map
+        }
+    }
+    for (int r = 0; r < sp[k].nrect; ++r) {
+        const Rect& rc = sp[k].rect[r];
+        e.compose_rect(rows, cols, grid, rc.x, rc.x + rc.w, rc.y, rc.y + rc.h, sp[k].halo_first);
+    }
+    hipAssert(hipEventRecord(e.ev1, e.stream));
+    for (int r = 0; r < sp[k].nrect; ++r) {
+        const Rect& rc = sp[k].rect[r];
+        hipAssert(hipMemcpy2DAsync(dst.data + (size_t)rc.y * dst.step + (size_t)rc.x * 3, dst.step, e.d_out + ((size_t)rc.y * dst.cols + rc.x) * 3, (size_t)dst.cols * 3,
+                                   (size_t)rc.w * 3, rc.h, hipMemcpyDeviceToHost, e.stream));
+    }
+}
+
+// frame / output checks shared by the sharded entries; "" when fine
+static std::string shard_frame_problem(const Img2Img::Impl& e, const Image& src, const Image* dst) {
+    const int s = e.cfg.scaling;
+    if (src.depth != 8 || (dst && dst->depth != 8)) return "sharded rendering takes 8-bit frames.";
+    if (!src.data || src.rows <= 0 || src.cols <= 0 || src.step < (size_t)src.cols * 3) return "Input image is empty or has an invalid step.";
+    if (dst && (!dst->data || dst->rows != src.rows * s || dst->cols != src.cols * s || dst->step < (size_t)dst->cols * 3))
+        return "Output image has invalid size: expected " + std::to_string(src.cols * s) + "x" + std::to_string(src.rows * s) + ".";
+    return "";
+}
+
 bool Img2Img::renderSharded(Img2Img* const* engines, int count, const Image& src, Image& dst) {
     if (!engines || count <= 0 || !engines[0]) return false;
     Img2Img* const first = engines[0];
@@ -1161,94 +1257,31 @@ bool Img2Img::renderSharded(Img2Img* const* engines, int count, const Image& src
         const RenderConfig& cfg = impl->cfg;
         const Plan& plan = impl->plan;
         const int rows = src.rows, cols = src.cols, s = cfg.scaling;
-        if (src.depth != 8 || dst.depth != 8) { W2X_LOG(error, "renderSharded takes 8-bit frames."); return false; }
-        if (!src.data || rows <= 0 || cols <= 0 || src.step < (size_t)cols * 3) { W2X_LOG(error, "Input image is empty or has an invalid step."); return false; }
-        if (!dst.data || dst.rows != rows * s || dst.cols != cols * s || dst.step < (size_t)dst.cols * 3) {
-            W2X_LOG(error, "Output image has invalid size: expected " + std::to_string(cols * s) + "x" + std::to_string(rows * s) + "."); return false;
-        }
+        if (const std::string why = shard_frame_problem(*impl, src, &dst); !why.empty()) { W2X_LOG(error, why); return false; }
         const TileGrid grid = calculate_tiles(cols, rows, cols * s, rows * s, plan.T, plan.T, plan.Tout, plan.Tout, s, cfg.overlapX, cfg.overlapY);
         if (grid.count <= 0) { W2X_LOG(error, "Tile grid is empty."); return false; }
         for (const Rect& r : grid.out) if (r.w <= 0 || r.h <= 0) { W2X_LOG(error, "Tile grid does not fit the output (scaling does not match the model)."); return false; }
         std::vector<ShardPlan> sp(count);
         for (int k = 0; k < count; ++k) sp[k] = shard_plan(grid, cols * s, rows * s, plan.Tout, plan.Tout, k, count);
         if (count > 1 && sp[0].tile_count == 0 && grid.count >= count) { W2X_LOG(error, "renderSharded: the blend bands are wider than the tile stride; use renderStrip."); return false; }
-        const int steps = cfg.tta ? 8 : 1;
-        const int To = plan.Tout;
-        const size_t px = (size_t)4 * plan.elt, slot_bytes = (size_t)To * To * px;
-        const bool overlapping = cfg.overlapX != 0 || cfg.overlapY != 0;
         // ---- phase 1: every engine computes its own tiles
         for (int k = 0; k < count; ++k) {
             Impl& e = *engines[k]->impl;
             if (sp[k].tile_count == 0) continue;
             DeviceGuard guard(e.device);
-            e.deep = false;
-            e.ensure(e.d_frame, e.frame_cap, (size_t)rows * cols * 3);
-            e.ensure(e.d_out, e.out_cap, (size_t)rows * s * cols * s * 3);
-            hipAssert(hipMemcpy2DAsync(e.d_frame, (size_t)cols * 3, src.data, src.step, (size_t)cols * 3, rows, hipMemcpyHostToDevice, e.stream));
-            const int B = e.plan.B, S = e.plan.B / e.plan.userB;
-            const int batchCount = (int)std::lround(std::ceil((double)(sp[k].tile_count * steps) / e.plan.userB));
-            const int stepCount = ((batchCount + S - 1) / S) * B;
-            e.h_slots.resize(stepCount);
-            for (int st = 0; st < stepCount; ++st) {
-                const int ti = st / steps, aug = st % steps;
-                TileSlot sl{0, 0, aug, 0};
-                if (ti < sp[k].tile_count) { sl.x = grid.in[sp[k].first_tile + ti].x; sl.y = grid.in[sp[k].first_tile + ti].y; sl.valid = 1; }
-                e.h_slots[st] = sl;
-            }
-            e.ensure(e.d_slots, e.slots_cap, (size_t)stepCount * sizeof(TileSlot));
-            hipAssert(hipMemcpyAsync(e.d_slots, e.h_slots.data(), (size_t)stepCount * sizeof(TileSlot), hipMemcpyHostToDevice, e.stream));
-            e.shard_halo_slots = (size_t)(sp[k].first_tile - sp[k].halo_first) * steps;
-            e.ensure(e.d_slab, e.slab_cap, (e.shard_halo_slots + (size_t)stepCount) * slot_bytes);
-            hipAssert(hipEventRecord(e.ev0, e.stream));
-            e.run_passes(rows, cols, sp[k].tile_count, e.shard_halo_slots, k == 0, 0, true);
-            if (!e.ev_shard) hipAssert(hipEventCreateWithFlags(&e.ev_shard, hipEventDisableTiming));
-            hipAssert(hipEventRecord(e.ev_shard, e.stream));
+            shard_phase1(e, src, grid, sp[k], k == 0);
         }
         // ---- phase 2: seam exchange, compose, download
+        std::vector<ShardPeer> peers(count);
+        for (int k = 0; k < count; ++k) {
+            const Impl& e = *engines[k]->impl;
+            if (sp[k].tile_count) peers[k] = ShardPeer{e.d_slab, e.shard_halo_slots, e.device, e.ev_shard, sp[k].first_tile, sp[k].tile_count};
+        }
         for (int k = 0; k < count; ++k) {
             Impl& e = *engines[k]->impl;
             if (sp[k].tile_count == 0) continue;
             DeviceGuard guard(e.device);
-            int waited = -1;
-            for (int g = sp[k].halo_first; g < sp[k].first_tile && overlapping; ++g) {
-                int q = k - 1;
-                while (q >= 0 && !(sp[q].tile_count > 0 && g >= sp[q].first_tile && g < sp[q].first_tile + sp[q].tile_count)) --q;
-                if (q < 0) throw std::runtime_error("shard plan: tile " + std::to_string(g) + " has no owner");
-                Impl& o = *engines[q]->impl;
-                if (q != waited) { hipAssert(hipStreamWaitEvent(e.stream, o.ev_shard, 0)); waited = q; }   // (parts are visited in descending order of q per run of g: at most a few waits)
-                const bool same = o.device == e.device;
-                bool peer2d = same;
-                if (!same) {      // strided band copies between devices need peer access; without it whole slots travel by hipMemcpyPeerAsync
-                    int can = 0;
-                    if (hipDeviceCanAccessPeer(&can, e.device, o.device) == hipSuccess && can) {
-                        const hipError_t pe = hipDeviceEnablePeerAccess(o.device, 0);
-                        peer2d = pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled;
-                    }
-                    (void)hipGetLastError();
-                }
-                for (int a = 0; a < steps; ++a) {
-                    const uint8_t* from = (const uint8_t*)o.d_slab + (o.shard_halo_slots + (size_t)(g - sp[q].first_tile) * steps + a) * slot_bytes;
-                    uint8_t* to = (uint8_t*)e.d_slab + ((size_t)(g - sp[k].halo_first) * steps + a) * slot_bytes;
-                    if (!peer2d) { hipAssert(hipMemcpyPeerAsync(to, e.device, from, o.device, slot_bytes, e.stream)); continue; }
-                    int bx = std::min(To, grid.outOvX), by = std::min(To, grid.outOvY);
-                    if (steps > 1) bx = by = std::max(bx, by);                     // a rotation turns a column band into a row band of the same width
-                    const size_t pitch = (size_t)To * px;
-                    auto cols_band = [&](int x0) { if (bx > 0) hipAssert(hipMemcpy2DAsync(to + (size_t)x0 * px, pitch, from + (size_t)x0 * px, pitch, (size_t)bx * px, To, hipMemcpyDeviceToDevice, e.stream)); };
-                    auto rows_band = [&](int y0) { if (by > 0) hipAssert(hipMemcpyAsync(to + (size_t)y0 * pitch, from + (size_t)y0 * pitch, (size_t)by * pitch, hipMemcpyDeviceToDevice, e.stream)); };
-                    cols_band(To - bx); rows_band(To - by);                        // what the cells to the right of / below the tile read
-                    if (steps > 1) { cols_band(0); rows_band(0); }                // an augmented tile is read through its inverse dihedral map
-                }
-            }
-            for (int r = 0; r < sp[k].nrect; ++r) {
-                const Rect& rc = sp[k].rect[r];
-                e.compose_rect(rows, cols, grid, rc.x, rc.x + rc.w, rc.y, rc.y + rc.h, sp[k].halo_first);
-            }
-            hipAssert(hipEventRecord(e.ev1, e.stream));
-            for (int r = 0; r < sp[k].nrect; ++r) {
-                const Rect& rc = sp[k].rect[r];
-                hipAssert(hipMemcpy2DAsync(dst.data + (size_t)rc.y * dst.step + (size_t)rc.x * 3, dst.step, e.d_out + ((size_t)rc.y * dst.cols + rc.x) * 3, (size_t)dst.cols * 3,
-                                           (size_t)rc.w * 3, rc.h, hipMemcpyDeviceToHost, e.stream));
-            }
+            shard_phase2(e, k, sp, peers, grid, rows, cols, dst);
         }
         for (int k = 0; k < count; ++k) {
             Impl& e = *engines[k]->impl;
@@ -1264,6 +1297,78 @@ bool Img2Img::renderSharded(Img2Img* const* engines, int count, const Image& src
         return false;
     }
 }
+
+// The same two phases for ONE PROCESS PER GPU (the launch contract of bench.py / torch.distributed.run): rank r calls shardCompute(src, r, N), publishes
+// its slab (shardSlab: a device pointer the caller exports with w2x_ipc_export and its peers open with w2x_ipc_open), and after every rank has done so
+// (a host-side barrier - the handle exchange itself) shardFinish(dst, r, N, slabs) with the opened pointers of the parts in front of it.  No collective on
+// the data path: the seam bands are device-to-device copies out of the neighbours' slabs.
+bool Img2Img::shardCompute(const Image& src, int part, int parts) try {
+    if (!impl->loaded) { W2X_LOG(error, "Render called before a successful load."); return false; }
+    if (parts <= 0 || part < 0 || part >= parts) { W2X_LOG(error, "Invalid part index."); return false; }
+    DeviceGuard guard(impl->device);
+    if (const std::string why = shard_frame_problem(*impl, src, nullptr); !why.empty()) { W2X_LOG(error, why); return false; }
+    const Plan& plan = impl->plan;
+    const int rows = src.rows, cols = src.cols, s = impl->cfg.scaling;
+    const TileGrid grid = calculate_tiles(cols, rows, cols * s, rows * s, plan.T, plan.T, plan.Tout, plan.Tout, s, impl->cfg.overlapX, impl->cfg.overlapY);
+    if (grid.count <= 0) { W2X_LOG(error, "Tile grid is empty."); return false; }
+    const ShardPlan sp = shard_plan(grid, cols * s, rows * s, plan.Tout, plan.Tout, part, parts);
+    impl->shard_rows = rows; impl->shard_cols = cols;
+    if (sp.tile_count == 0) { if (parts > 1 && part == 0 && grid.count >= parts) { W2X_LOG(error, "the blend bands are wider than the tile stride; use renderStrip."); return false; } return true; }
+    shard_phase1(*impl, src, grid, sp, true);
+    hipAssert(hipStreamSynchronize(impl->stream));           // the slab is complete when this returns: what the peers copy from after the barrier
+    return true;
+} catch (const std::exception& e) {
+    W2X_LOG(error, "Render failed unexpectedly: " + std::string(e.what()) + ".");
+    return false;
+}
+
+const void* Img2Img::shardSlab(size_t* bytes) const { if (bytes) *bytes = impl->slab_cap; return impl->d_slab; }
+
+bool Img2Img::shardFinish(Image& dst, int part, int parts, const void* const* slabs, const int* devices) try {
+    if (!impl->loaded || impl->shard_rows <= 0) { W2X_LOG(error, "shardFinish without a shardCompute."); return false; }
+    if (parts <= 0 || part < 0 || part >= parts || !slabs) { W2X_LOG(error, "Invalid part index."); return false; }
+    DeviceGuard guard(impl->device);
+    const Plan& plan = impl->plan;
+    const int rows = impl->shard_rows, cols = impl->shard_cols, s = impl->cfg.scaling, steps = impl->cfg.tta ? 8 : 1;
+    Image probe; probe.data = (uint8_t*)1; probe.rows = rows; probe.cols = cols; probe.step = (size_t)cols * 3;
+    if (const std::string why = shard_frame_problem(*impl, probe, &dst); !why.empty()) { W2X_LOG(error, why); return false; }
+    const TileGrid grid = calculate_tiles(cols, rows, cols * s, rows * s, plan.T, plan.T, plan.Tout, plan.Tout, s, impl->cfg.overlapX, impl->cfg.overlapY);
+    std::vector<ShardPlan> sp(parts);
+    std::vector<ShardPeer> peers(parts);
+    for (int k = 0; k < parts; ++k) {
+        sp[k] = shard_plan(grid, cols * s, rows * s, plan.Tout, plan.Tout, k, parts);
+        if (sp[k].tile_count) peers[k] = ShardPeer{k == part ? impl->d_slab : slabs[k], (size_t)(sp[k].first_tile - sp[k].halo_first) * steps, k == part ? impl->device : devices ? physical_device(devices[k]) : -1,
+                                                   nullptr, sp[k].first_tile, sp[k].tile_count};
+    }
+    if (sp[part].tile_count == 0) return true;
+    shard_phase2(*impl, part, sp, peers, grid, rows, cols, dst);
+    hipAssert(hipStreamSynchronize(impl->stream));
+    hipAssert(hipEventElapsedTime(&impl->last_ms, impl->ev0, impl->ev1));
+    return true;
+} catch (const std::exception& e) {
+    if (impl->stream) (void)hipStreamSynchronize(impl->stream);
+    W2X_LOG(error, "Render failed unexpectedly: " + std::string(e.what()) + ".");
+    return false;
+}
+
+// device memory of another process: export / open / close (hipIpc*); the opened pointer is valid in this process on the current device
+bool ipc_export(const void* device_ptr, uint8_t out[64]) {
+    static_assert(sizeof(hipIpcMemHandle_t) <= 64, "handle size");
+    hipIpcMemHandle_t h;
+    if (!device_ptr || hipIpcGetMemHandle(&h, const_cast<void*>(device_ptr)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    memset(out, 0, 64); memcpy(out, &h, sizeof(h));
+    return true;
+}
+void* ipc_open(const uint8_t handle[64], int deviceId) {
+    const int dev = physical_device(deviceId);
+    if (!device_ordinal_problem(deviceId, dev).empty()) return nullptr;
+    DeviceGuard guard(dev);
+    hipIpcMemHandle_t h; memcpy(&h, handle, sizeof(h));
+    void* p = nullptr;
+    if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void ipc_close(void* p) { if (p && hipIpcCloseMemHandle(p) != hipSuccess) (void)hipGetLastError(); }
 
 // A sequence of equally sized frames (a video, main.cpp:263-269) with the PCIe copies taken off the critical path: frame i+1 is
 // uploaded and frame i-1 downloaded on two copy streams while frame i runs on the compute stream (two device frame / output

@@ -112,6 +112,12 @@ def lib():
     L.w2x_unpin_host.argtypes = [vp, vp]; L.w2x_unpin_host.restype = None
     L.w2x_strip_plan.argtypes = [C.c_int] * 7 + [C.c_double, C.c_double, C.c_int, C.c_int, vp]; L.w2x_strip_plan.restype = C.c_int
     L.w2x_render_sharded.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t]; L.w2x_render_sharded.restype = C.c_int
+    L.w2x_shard_compute.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int]; L.w2x_shard_compute.restype = C.c_int
+    L.w2x_shard_slab.argtypes = [vp, vp]; L.w2x_shard_slab.restype = vp
+    L.w2x_shard_finish.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, vp, vp]; L.w2x_shard_finish.restype = C.c_int
+    L.w2x_ipc_export.argtypes = [vp, vp]; L.w2x_ipc_export.restype = C.c_int
+    L.w2x_ipc_open.argtypes = [vp, C.c_int]; L.w2x_ipc_open.restype = vp
+    L.w2x_ipc_close.argtypes = [vp]; L.w2x_ipc_close.restype = None
     L.w2x_shard_plan.argtypes = [C.c_int] * 7 + [C.c_double, C.c_double, C.c_int, C.c_int, vp]; L.w2x_shard_plan.restype = C.c_int
     L.w2x_infer.argtypes = [vp, vp, vp]; L.w2x_infer.restype = C.c_int
     L.w2x_output_tile_size.argtypes = [vp]; L.w2x_output_tile_size.restype = C.c_int
@@ -137,7 +143,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "w2x_create", "w2x_destroy", "w2x_set_message_callback", "w2x_set_progress_callback", "w2x_build", "w2x_load",
     "w2x_render", "w2x_render16", "w2x_infer", "w2x_output_tile_size", "w2x_plan_flops", "w2x_pass_tiles", "w2x_last_render_ms", "w2x_bench_resident", "w2x_profile_frame", "w2x_op_times",
-    "w2x_render_strip", "w2x_strip_plan", "w2x_render_sharded", "w2x_shard_plan", "w2x_render_sequence", "w2x_alloc_host", "w2x_free_host", "w2x_pin_host", "w2x_unpin_host", "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_describe_plan_precision", "w2x_write_engine_file", "w2x_validate_engine_file", "w2x_device_pci_bus_id", "w2x_sha256_hex", "w2x_version"]
+    "w2x_render_strip", "w2x_strip_plan", "w2x_render_sharded", "w2x_shard_plan", "w2x_shard_compute", "w2x_shard_slab", "w2x_shard_finish", "w2x_ipc_export", "w2x_ipc_open", "w2x_ipc_close", "w2x_render_sequence", "w2x_alloc_host", "w2x_free_host", "w2x_pin_host", "w2x_unpin_host", "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_describe_plan_precision", "w2x_write_engine_file", "w2x_validate_engine_file", "w2x_device_pci_bus_id", "w2x_sha256_hex", "w2x_version"]
 
 
 class Img2Img:
@@ -231,6 +237,28 @@ class Img2Img:
             raise ValueError("dst must be a packed uint8 array of the scaled size")
         return bool(self._L.w2x_render_strip(self._h, src.ctypes.data, src.shape[0], src.shape[1], src.strides[0],
                                              dst.ctypes.data, dst.strides[0], int(part), int(parts)))
+
+    # ---- one frame over several PROCESSES (one engine each): w2x_shard_compute / w2x_shard_slab / w2x_shard_finish + the IPC helpers below
+    def shard_compute(self, src: np.ndarray, part: int, parts: int) -> bool:
+        if src.dtype != np.uint8 or src.ndim != 3 or src.shape[2] != 3 or src.strides[2] != 1 or src.strides[1] != 3:
+            raise ValueError("src must be a uint8 [rows, cols, 3] BGR array with packed pixels")
+        return bool(self._L.w2x_shard_compute(self._h, src.ctypes.data, src.shape[0], src.shape[1], src.strides[0], int(part), int(parts)))
+
+    def shard_slab_handle(self):
+        """(device pointer, 64-byte IPC handle) of this engine's tile slab (changes only when a larger frame makes the slab grow)"""
+        ptr = self._L.w2x_shard_slab(self._h, None)
+        buf = (C.c_uint8 * 64)()
+        if not ptr or not self._L.w2x_ipc_export(ptr, buf):
+            raise W2xError("could not export the tile slab (hipIpcGetMemHandle)")
+        return int(ptr), bytes(buf)
+
+    def shard_finish(self, dst: np.ndarray, part: int, parts: int, slabs, devices=None) -> bool:
+        """slabs[q]: device pointer (int) of part q's slab in THIS process (w2x ipc_open of its handle; 0 for parts that are not needed)"""
+        if dst.dtype != np.uint8 or dst.ndim != 3 or dst.shape[2] != 3 or dst.strides[2] != 1 or dst.strides[1] != 3:
+            raise ValueError("dst must be a packed uint8 [rows, cols, 3] array of the scaled size")
+        arr = (C.c_void_p * parts)(*[C.c_void_p(int(p) or None) for p in slabs])
+        dev = (C.c_int * parts)(*[int(d) for d in devices]) if devices is not None else None
+        return bool(self._L.w2x_shard_finish(self._h, dst.ctypes.data, dst.shape[0], dst.shape[1], dst.strides[0], int(part), int(parts), arr, dev))
 
     def alloc_host(self, shape) -> np.ndarray:
         """A uint8 array over page-locked memory owned by the engine (w2x_alloc_host): frame buffers whose PCIe copies
@@ -360,6 +388,17 @@ def device_pci_bus_id(device: int):
     """PCI bus id of HIP device `device` of this process (W2X_DEVICE_MAP applied), or None: w2x_device_pci_bus_id.  Initialises the HIP runtime."""
     buf = C.create_string_buffer(64)
     return buf.value.decode() if lib().w2x_device_pci_bus_id(int(device), buf, 64) else None
+
+
+def ipc_open(handle: bytes, device: int) -> int:
+    """open another process's 64-byte device-memory handle on logical device `device` -> device pointer (0: failed)"""
+    buf = (C.c_uint8 * 64)(*handle)
+    return int(lib().w2x_ipc_open(buf, int(device)) or 0)
+
+
+def ipc_close(ptr: int) -> None:
+    if ptr:
+        lib().w2x_ipc_close(C.c_void_p(ptr))
 
 
 def shard_plan(in_w, in_h, out_w, out_h, tile_in, tile_out, scaling, overlap, part, parts):
