@@ -438,12 +438,14 @@ def main():
     prof = eng.profile_frame()
     desc = pkg.describe_plan(path, eng.pass_tiles, TILE).splitlines()[2:]
     op_ms = eng.op_times()
-    # an op the engine folded into the previous launch (the image head riding on the last C = 96 MLP, engine.cpp fuse_head) has no launch of its own:
-    # its time is inside the previous op's
+    # an op the engine folded into a neighbour's launch has no launch of its own and reports 0 ms: the image head riding on the last C = 96 MLP
+    # (engine.cpp fuse_head; its time is inside the previous op's) and the stem computed by the patch convolution behind it (fuse_stem; inside the next op's)
     folded = [i for i, (line, t) in enumerate(zip(desc, op_ms)) if t == 0.0 and i > 0 and " gemm " in f" {line} " and " mlp " in f" {desc[i - 1]} "]
+    folded_fwd = [i for i, (line, t) in enumerate(zip(desc, op_ms)) if t == 0.0 and i + 1 < len(desc) and " gemm " in f" {line} " and " gemm " in f" {desc[i + 1]} " and i not in folded]
     if a.op_times and rank == 0:
         for i, (line, t) in enumerate(zip(desc, op_ms)):
-            note = "  (no launch of its own: folded into the previous op's launch, whose time includes it)" if i in folded else ""
+            note = "  (no launch of its own: folded into the previous op's launch, whose time includes it)" if i in folded else \
+                   "  (no launch of its own: computed inside the next op's launch, whose time includes it)" if i in folded_fwd else ""
             print(f"{t:8.3f} ms  {line[:150]}{note}", file=sys.stderr)
     if rank == 0:
         import re
@@ -499,8 +501,13 @@ def main():
                 "other_roof": {"unit": "TFLOP/s" if hbm_bound else "GB/s", "achieved": round(tflops if hbm_bound else gbs, 2),
                                "frac": round((tflops / MFMA_F16_PEAK_TFLOPS) if hbm_bound else (gbs / HBM_PEAK_GBS), 5)},
                 "kernels_ms_per_frame": {symbols.get(k, k[0] if not isinstance(k[1], str) else k[0] + " " + k[1]): round(v[0], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])}}
+        notes = []
         if folded:
-            roof["kernels_note"] = "mlp96q_kernel's figure includes the image head (Linear 96 -> 64, Clip, DepthToSpace), which the engine folds into the last C = 96 MLP launch; that plan op has no launch and reports 0 ms"
+            notes.append("mlp96q_kernel's figure includes the image head (Linear 96 -> 64, Clip, DepthToSpace), which the engine folds into the last C = 96 MLP launch; that plan op has no launch and reports 0 ms")
+        if folded_fwd:
+            notes.append("the stem convolution (3x3, 4 -> 48) is computed inside the patch convolution's launch (conv48_kernel<true>) and is counted with it; that plan op has no launch and reports 0 ms")
+        if notes:
+            roof["kernels_note"] = "; ".join(notes)
         tr = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/profile_round.sh)
         if os.path.exists(tr) and CONFIG_NAME == "configs[2]":
             try:

@@ -566,6 +566,32 @@ def test_image_head_folded_into_the_last_mlp_is_bit_identical(pkg, onnx_model, m
     assert np.array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("tile,batch,shape,tta", [(64, 2, (150, 170), False), (64, 3, (101, 119), True), (256, 4, (300, 420), False)])
+def test_stem_folded_into_the_patch_convolution_is_bit_identical(pkg, onnx_model, monkeypatch, tile, batch, shape, tta):
+    """swin_unet's first two ops - the stem (3x3, 4-halves-per-pixel tile -> 48 channels) and the patch convolution behind it - run as ONE launch
+    (engine.cpp fuse_stem, k_conv48.hip conv48_kernel<true>): every workgroup computes the halo tile it needs from the input tile with the stem
+    kernel's own instruction sequence, and the 48-channel map between the two is neither stored nor read.  W2X_NO_FUSE_STEM=1 keeps the two
+    launches.  Same products in the same order: infer() and render() return the same bytes, through captured graphs and two tile groups (the
+    input tile must outlive the stem by one op in the arena); the odd batch leaves a group with one tile."""
+    path = onnx_model("swin_unet/art", 4, batch, tile, noise=1)
+    frame = smooth_frame(shape[0], shape[1], 14)
+    x = np.random.default_rng(37).random((batch, 3, tile, tile), dtype=np.float32)
+    outs = []
+    for nofuse in (True, False):
+        if nofuse: monkeypatch.setenv("W2X_NO_FUSE_STEM", "1")
+        else: monkeypatch.delenv("W2X_NO_FUSE_STEM")
+        eng = make_engine(pkg, path, batch, tile, 4, tta=tta)
+        folded = any("stem folded" in m for _, m in eng.messages)
+        assert folded == (not nofuse), [m for _, m in eng.messages if "folded" in m]
+        ys = [eng.infer(x) for _ in range(2)]
+        rs = [eng.render(frame) for _ in range(3)]
+        assert np.array_equal(ys[0], ys[1]) and np.array_equal(rs[0], rs[1]) and np.array_equal(rs[0], rs[2])
+        outs.append((ys[0], rs[0]))
+        eng.close()
+    assert np.array_equal(outs[0][0], outs[1][0]), np.abs(outs[0][0] - outs[1][0]).max()
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("name,kw,tile", [
     ("window 8 (64 tokens)", dict(variant={"ws": 8}), 80),
     ("4 / 8 heads of 24 / 48", dict(variant={"heads": 4}), 64),

@@ -26,4 +26,5 @@ desc = pkg.describe_plan(path, eng.pass_tiles, tile, prec).splitlines()[2:]
 times = list(eng.op_times())
 for i, (line, t) in enumerate(zip(desc, times)):
     folded = t == 0.0 and i > 0 and " gemm " in f" {line} " and " mlp " in f" {desc[i - 1]} "      # the image head riding on the last MLP launch (engine.cpp fuse_head)
-    print(f"{t:8.3f} ms  {line[:170]}" + ("  (folded into the previous op's launch)" if folded else ""))
+    fwd = not folded and t == 0.0 and i + 1 < len(desc) and " gemm " in f" {line} " and " gemm " in f" {desc[i + 1]} "   # the stem computed by the patch convolution's launch (fuse_stem)
+    print(f"{t:8.3f} ms  {line[:170]}" + ("  (folded into the previous op's launch)" if folded else "  (computed inside the next op's launch)" if fwd else ""))

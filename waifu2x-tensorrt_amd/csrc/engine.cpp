@@ -234,6 +234,7 @@ struct Img2Img::Impl {
     std::vector<int> pool_tensors;
     int final_op = -1;
     std::vector<int> tensor_last;      // last op that touches each tensor (upload_plan)
+    std::vector<char> fuse_stem;       // op i is the stem convolution whose 48-channel map only feeds the patch convolution that follows: op i + 1's launch computes it in its halo stage (k_conv48.hip), op i is skipped
     std::vector<char> fuse_head;       // op i is a C = 96 MLP whose rows only feed the image head that follows: one launch (k_mlp96q.hip), op i + 1 is skipped
 
     // frame-level buffers (grown on demand, reused across frames like the reference's input/output GpuMats, img2img.h:37-38)
@@ -367,7 +368,6 @@ struct Img2Img::Impl {
             }
             first[plan.in_tensor] = -1;                       // written by the gather kernel before op 0
             last[plan.out_tensor] = nops;                     // read after the last op (infer) / replaced by the frame slab
-            tensor_last = last;
             // An image head that rides on the MLP launch in front of it (fuse_head, decided below) writes its output WHILE that MLP still reads its input:
             // the output must be alive from the MLP on, or it would be given the memory of the MLP's input, which dies at the MLP in the un-fused order.
             fuse_head.assign(nops, 0);
@@ -380,6 +380,19 @@ struct Img2Img::Impl {
                         first[b.g.out.t] = std::min(first[b.g.out.t], i);
                     }
                 }
+            // The stem folded into the patch convolution behind it (fuse_stem, confirmed below with the prepared parameters): that launch reads the stem's INPUT,
+            // which must therefore outlive the stem by one op (its memory would otherwise go to the convolution's output).
+            fuse_stem.assign(nops, 0);
+            if (plan.elt == 2)
+                for (int i = 0; i + 1 < nops; ++i) {
+                    const Op& a = plan.ops[i]; const Op& b = plan.ops[i + 1];
+                    if (a.kind == OP_GEMM && b.kind == OP_GEMM && a.g.a.t >= 0 && plan.tensors[a.g.a.t].C == 4 && a.g.N == 48 && b.g.K == 9 * 48 && b.g.a.t == a.g.out.t && first[a.g.out.t] == i && last[a.g.out.t] == i + 1 &&
+                        a.g.out.t != plan.out_tensor && a.g.stats_out < 0 && a.g.pool_out < 0) {
+                        fuse_stem[i] = 1;
+                        last[a.g.a.t] = std::max(last[a.g.a.t], i + 1);
+                    }
+                }
+            tensor_last = last;
             struct Block { size_t off, size; };
             std::vector<Block> free_list;
             std::vector<size_t> off(nt, 0);
@@ -517,6 +530,10 @@ struct Img2Img::Impl {
                 if (!(g.wt_frag && g.out.Cs == 4 && g.a.y0 == 0 && g.a.x0 == 0 && g.a.Ws == g.aW && (long)g.a.Hs * g.a.Ws == g.Mrows && g.Mrows % 32 == 0 && g.aW >= 32 && pixgemm_supported(g) &&
                       (!g.has_clip || (f16_to_f32(f32_to_f16(g.clip_lo)) == g.clip_lo && f16_to_f32(f32_to_f16(g.clip_hi)) == g.clip_hi)))) fuse_head[i] = 0;   // (k_mlp96q.hip: a 32-row tile inside one image, at most two token rows; clip bounds that fp16 holds exactly)
             }
+        // The stem (3x3, 4 -> 48 channels) in front of the patch convolution (3x3, 48 -> 96): its output has no other reader, so the convolution computes the halo tile
+        // it needs from the input tile and the 48-channel map is neither stored nor read (k_conv48.hip conv48_kernel<true>; W2X_NO_FUSE_STEM=1 keeps the two launches).
+        for (size_t i = 0; i + 1 < plan.ops.size(); ++i)
+            if (fuse_stem[i] && !conv48_stem_supported(gemm[i + 1], gemm[i])) fuse_stem[i] = 0;
         hipAssert(hipStreamSynchronize(stream));
     }
 
@@ -541,6 +558,7 @@ struct Img2Img::Impl {
         auto shift = [&](const void* ptr, int) -> void* { return group_ptr(ptr, grp); };
         const int b0 = grp < 0 ? 0 : 1;   // (non-zero: re-address the prepared parameters)
         bool skip_next = false;           // the op was folded into the previous launch (fuse_head)
+        GemmParams stem_p; bool stem_held = false; double stem_flops = 0;   // the op is folded into the NEXT launch (fuse_stem): its re-addressed parameters wait here
         for (size_t i = 0; i < plan.ops.size(); ++i) try {
             const Op& op = plan.ops[i];
             cur_op = (int)i;
@@ -558,6 +576,14 @@ struct Img2Img::Impl {
                         p.a_scale = (const float*)shift(p.a_scale, g.se_scale); p.res_scale = (const float*)shift(p.res_scale, g.res_scale);
                     }
                     if ((int)i == final_op && out_override) p.out.p = out_override;
+                    if (fuse_stem[i] && !check_general) { stem_p = p; stem_held = true; stem_flops = op.flops; break; }    // computed by the next op's launch
+                    if (stem_held) {
+                        stem_held = false;
+                        stamp_begin(0, op.flops + stem_flops);
+                        hipAssert(launch_conv48_stem(p, stem_p, s));
+                        stamp_end();
+                        break;
+                    }
                     stamp_begin(0, op.flops);
                     if (op.g.pool_out >= 0) pool_blocks[op.g.pool_out] = plan.elt == 2 && conv3_supported(p) ? conv3_tiles(p) : 0;   // partial sums per image written by this launch (0: plan default)
                     hipAssert(plan.elt == 4 ? launch_gemm_f32(p, s) : pixgemm_supported(p) ? launch_pixgemm(p, s) : conv3_supported(p) ? launch_conv3(p, s) : conv3h_supported(p) ? launch_conv3h(p, s) : conv48_supported(p) ? launch_conv48(p, s) : stem_supported(p) ? launch_stem(p, s) : launch_gemm(p, s));
@@ -978,6 +1004,7 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
     impl->cfg = config;
     W2X_LOG(info, "Loaded \"" + enginePath + "\": " + std::to_string(plan.ops.size()) + " ops, " + std::to_string(plan.B) + " tiles per pass, activation arena " +
                       std::to_string(impl->arena_bytes >> 20) + " MiB" +
+                      (std::count(impl->fuse_stem.begin(), impl->fuse_stem.end(), (char)1) ? ", stem folded into the patch convolution's launch" : "") +
                       (std::count(impl->fuse_head.begin(), impl->fuse_head.end(), (char)1) ? ", image head folded into the last MLP launch." : "."));
     // :262-269 blend ramps
     impl->ovx = (int)std::lround(plan.T * config.scaling * config.overlapX);

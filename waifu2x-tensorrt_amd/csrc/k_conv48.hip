@@ -32,7 +32,15 @@ constexpr int SMEM48 = HALO + 2 * WBUF;
 constexpr int PPP = CIN / 8;                                    // 16-byte pieces per halo pixel
 static_assert(4 * OT <= HALO && NF % 4 == 0 && KSTEPS % SK == 0, "layout");
 
-__global__ __launch_bounds__(256, 2) void conv48_kernel(const GemmParams p, int Ho, int Wo, int tiles_x, int tiles_y) {
+// STEM (round 4): the launch also computes its own input.  swin_unet's patch stage is stem (3x3, the 4-halves-per-pixel tile -> 48 channels, k_stem.hip) followed by this
+// convolution, and the 48-channel map between them (0.28 GB per pass at config 3) is written by one launch and read by the next and by nothing else.  With ps = the
+// stem's parameters the halo tile is not fetched but COMPUTED: the 6 x 66 halo pixels are 25 groups of 16, the four waves take them round-robin, each group is
+// stem_kernel's three 16x16x16 k-steps on operands read straight from the input tile (L2-resident: 24 MB per pass), bias as the initial accumulator, LeakyReLU, fp16 -
+// the same instructions on the same operands as stem_kernel, so the halo tile holds the bytes that kernel would have stored (bit-identical frames by test) - and goes to
+// LDS in 8-byte pieces (a lane ends with 12 consecutive channels of one pixel).  The stem's products are recomputed for the halo (x 1.55), 17 % on top of this launch's
+// matrix work; the stem launch (0.07 ms), its 0.28 GB of stores and this launch's 0.28 GB of halo loads go.
+template <bool STEM>
+__global__ __launch_bounds__(256, 2) void conv48_kernel(const GemmParams p, int Ho, int Wo, int tiles_x, int tiles_y, const GemmParams ps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* Hl = (_Float16*)smem;                                   // [HR][HC][LDP]
     _Float16* WB = (_Float16*)(smem + HALO);                          // [2][NF][64][8]
@@ -52,10 +60,66 @@ __global__ __launch_bounds__(256, 2) void conv48_kernel(const GemmParams p, int 
 #pragma unroll
     for (int i = 0; i < NFW; ++i) stg[i] = *(const half8*)frag_src(0, wv * NFW + i);
 
+    const int hrows = min(HR, Ho + 2 - oy0), hcols = min(HC, Wo + 2 - ox0);
+    if (STEM) {
+        // ---- halo tile computed from the network's input tile (see the kernel's header): stem_kernel<3>'s arithmetic per group of 16 halo pixels
+        constexpr int SNT = 3, NPIX = HR * HC, NGRP = (NPIX + 15) / 16, GPW = (NGRP + 3) / 4;
+        const int Hs_o = ps.Mrows / ps.aW, Ws_o = ps.aW;                    // extent of the stem's output = this convolution's input map
+        const _Float16* __restrict__ Wt = (const _Float16*)ps.wt;
+        const half4 zero4h = {};
+        half4 wf[SNT][3];
+        float4v sbias[SNT];
+#pragma unroll
+        for (int nt = 0; nt < SNT; ++nt) {
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3) {
+                const int tap = 4 * t3 + g;
+                wf[nt][t3] = tap < 9 ? *(const half4*)(Wt + (size_t)(4 * SNT * (fr >> 2) + 4 * nt + (fr & 3)) * ps.Kw + tap * 4) : zero4h;
+            }
+            sbias[nt] = *(const float4v*)(ps.bias + 4 * SNT * g + 4 * nt);  // accumulator row 4g + j of n-tile nt = channel 12 g + 4 nt + j
+        }
+        int toff[3];
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3) {
+            const int tap = 4 * t3 + g < 9 ? 4 * t3 + g : 8;
+            toff[t3] = ((tap / 3) * ps.a.Ws + tap % 3) * 4;
+        }
+        const _Float16* __restrict__ In = (const _Float16*)ps.a.p;
+        half4 xf[GPW][3];
+#pragma unroll
+        for (int k = 0; k < GPW; ++k) {                                     // every operand of the wave's groups is requested before the first product
+            const int pi = min((wv + 4 * k) * 16 + fr, NPIX - 1), hr = pi / HC, hc = pi - hr * HC;
+            const int Y = min(p.a.y0 + oy0 + hr, Hs_o - 1), X = min(p.a.x0 + ox0 + hc, Ws_o - 1);   // (halo pixels beyond the map feed outputs nobody stores)
+            const _Float16* src = In + ((size_t)(b * ps.a.Hs + ps.a.y0 + Y) * ps.a.Ws + ps.a.x0 + X) * 4;
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3) {
+                const half4 v = *(const half4*)(src + toff[t3]);
+                xf[k][t3] = 4 * t3 + g < 9 ? v : zero4h;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < GPW; ++k) {
+            const int gi = wv + 4 * k, pi = gi * 16 + fr;
+            if (gi >= NGRP) break;
+#pragma unroll
+            for (int nt = 0; nt < SNT; ++nt) {
+                float4v a4 = sbias[nt];
+#pragma unroll
+                for (int t3 = 0; t3 < 3; ++t3) a4 = __builtin_amdgcn_mfma_f32_16x16x16f16(wf[nt][t3], xf[k][t3], a4, 0, 0, 0);
+                half4 hq;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = a4[j];
+                    if (ps.act == 1) v = v > 0.f ? v : v * ps.alpha;
+                    hq[j] = (_Float16)v;
+                }
+                if (pi < NPIX) *(half4*)(Hl + pi * LDP + 4 * SNT * g + 4 * nt) = hq;
+            }
+        }
+    } else {
     // ---- halo tile, all 48 channels (valid convolution: input extent = output extent + 2; pixels beyond it are zeros).  Every piece of the
     // tile is requested before the first one is stored (round 2's loop fetched, waited and stored piece by piece: ten memory round trips in a
     // row per workgroup - most of its life); pieces outside the map go through the buffer resource's bounds check (offset 0xFFFFFFFF reads zeros).
-    const int hrows = min(HR, Ho + 2 - oy0), hcols = min(HC, Wo + 2 - ox0);
     {
         constexpr int NPIECE = HR * HC * PPP, NIT = (NPIECE + 255) / 256;
         const size_t map_bytes = (size_t)p.B * p.a.Hs * p.a.Ws * CIN * 2;          // conv48_supported() keeps this below 4 GB
@@ -73,6 +137,7 @@ __global__ __launch_bounds__(256, 2) void conv48_kernel(const GemmParams p, int 
             const int i = k * 256 + tid, pix = i / PPP, c8 = i - pix * PPP;
             if (i < NPIECE) *(half8*)(Hl + pix * LDP + c8 * 8) = hv[k];
         }
+    }
     }
 #pragma unroll
     for (int i = 0; i < NFW; ++i) *(half8*)(WB + (size_t)(wv * NFW + i) * 512 + lane * 8) = stg[i];
@@ -163,10 +228,26 @@ bool conv48_supported(const GemmParams& p) {
 
 hipError_t launch_conv48(const GemmParams& p, hipStream_t s) {
     static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
-    if (hipError_t e = ensure_dynamic_lds((const void*)conv48_kernel, SMEM48, lds_ok); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)conv48_kernel<false>, SMEM48, lds_ok); e != hipSuccess) return e;
     const int Ho = p.Mrows / p.aW, Wo = p.aW;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
-    hipLaunchKernelGGL(conv48_kernel, dim3((unsigned)(p.B * tiles_x * tiles_y)), dim3(256), SMEM48, s, p, Ho, Wo, tiles_x, tiles_y);
+    hipLaunchKernelGGL(conv48_kernel<false>, dim3((unsigned)(p.B * tiles_x * tiles_y)), dim3(256), SMEM48, s, p, Ho, Wo, tiles_x, tiles_y, GemmParams{});
+    return hipGetLastError();
+}
+
+// the stem (ps: a launch stem_supported() takes, 48 output channels) folded into the patch convolution that is the only reader of its output (p.a = a view of ps.out)
+bool conv48_stem_supported(const GemmParams& p, const GemmParams& ps) {
+    if (getenv("W2X_NO_FUSE_STEM") || !conv48_supported(p) || !stem_supported(ps) || ps.N != CIN || ps.out.Cs != CIN || p.a.p != ps.out.p || ps.out.y0 || ps.out.x0) return false;   // (W2X_NO_FUSE_STEM: A/B switch, read when an engine loads)
+    const int Hs_o = ps.Mrows / ps.aW, Ws_o = ps.aW, Ho = p.Mrows / p.aW, Wo = p.aW;
+    return p.a.Hs == ps.out.Hs && p.a.Ws == ps.out.Ws && p.a.y0 + Ho + 2 <= Hs_o && p.a.x0 + Wo + 2 <= Ws_o && p.B == ps.B;
+}
+
+hipError_t launch_conv48_stem(const GemmParams& p, const GemmParams& ps, hipStream_t s) {
+    static unsigned lds_ok = 0;
+    if (hipError_t e = ensure_dynamic_lds((const void*)conv48_kernel<true>, SMEM48, lds_ok); e != hipSuccess) return e;
+    const int Ho = p.Mrows / p.aW, Wo = p.aW;
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
+    hipLaunchKernelGGL(conv48_kernel<true>, dim3((unsigned)(p.B * tiles_x * tiles_y)), dim3(256), SMEM48, s, p, Ho, Wo, tiles_x, tiles_y, ps);
     return hipGetLastError();
 }
 
