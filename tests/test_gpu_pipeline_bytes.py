@@ -68,6 +68,29 @@ def test_other_graph_families_and_scales_byte_exact(pkg, onnx_model, model, scal
     eng.close()
 
 
+@pytest.mark.parametrize("tta,batch", [(False, 3), (True, 4)])
+def test_render_call_in_pipelined_parts_returns_the_one_part_bytes(pkg, onnx_model, monkeypatch, tta, batch):
+    """render() runs a frame of >= 16 tiles as up to four PARTS (engine.cpp renderPart: contiguous tile ranges cut at whole reference batches, each
+    part's canvas cells composed and sent to the host while the next part computes; W2X_RENDER_PARTS, read at load).  Every part count must return
+    the bytes of the one-part frame - which is the oracle's - for 8- and 16-bit frames, with TTA (a tile = 8 slots: the cut is a whole batch for
+    any tile) and with a batch that does not divide the tile count."""
+    path = onnx_model("swin_unet/art", 4, batch, 64)
+    frame = noisy_frame(262, 300, 77)
+    deep = (frame.astype(np.uint16) * 257) ^ np.random.default_rng(5).integers(0, 256, frame.shape, dtype=np.uint16)
+    outs = {}
+    for parts in ("1", "2", "3", "4"):
+        monkeypatch.setenv("W2X_RENDER_PARTS", parts)
+        eng = make_engine(pkg, path, batch, 64, 4, tta=tta)
+        outs[parts] = (eng.render(frame), eng.render(deep), eng.render(frame))
+        if parts == "1":
+            assert_same_bytes("one part against the oracle", outs[parts][0], oracle_with_engine_net(eng, frame, batch=batch, tile=64, scale=4, ov=0.0625, tta=tta))
+        eng.close()
+        assert outs[parts][1].dtype == np.uint16
+        assert_same_bytes(f"{parts} parts, second call", outs[parts][2], outs[parts][0])
+        assert_same_bytes(f"{parts} parts", outs[parts][0], outs["1"][0])
+        assert_same_bytes(f"{parts} parts, 16-bit", outs[parts][1], outs["1"][1])
+
+
 @pytest.mark.parametrize("tta", [False, True])
 def test_strips_are_byte_exact_against_the_oracle(pkg, onnx_model, tta):
     """the frame rendered as 2 and 3 tile-column strips (w2x_render_strip), reassembled, against the oracle's whole frame."""

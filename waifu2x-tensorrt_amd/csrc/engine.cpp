@@ -215,8 +215,9 @@ struct Img2Img::Impl {
     // W2X_ROCTX=1 (read at load): roctxRangePushA / roctxRangePop around the launches of every plan op, resolved from libroctx64.so at run time (no link dependency)
     int (*roctx_push)(const char*) = nullptr; int (*roctx_pop)() = nullptr;
     hipEvent_t ev_shard = nullptr;       // renderSharded(): this engine's tiles are in its slab
-    hipEvent_t ev_part[2] = {nullptr, nullptr};
-    int pipeline_parts = 2;              // W2X_RENDER_PARTS (read at load): 1 = render() runs a frame as one part
+    static constexpr int kMaxRenderParts = 4;
+    hipEvent_t ev_part[kMaxRenderParts] = {nullptr, nullptr, nullptr, nullptr};
+    int pipeline_parts = 3;              // W2X_RENDER_PARTS (read at load): parts a render() call runs a frame in (1 = one part; at most kMaxRenderParts)
     size_t shard_halo_slots = 0;         // renderSharded(): slab slots in front of this engine's own tiles (the bands copied from the preceding parts)
     int shard_rows = 0, shard_cols = 0;  // shardCompute(): the frame shardFinish() completes
     hipStream_t gstream[3] = {nullptr, nullptr, nullptr};   // further tile groups of a pass (run_frame)
@@ -275,8 +276,18 @@ struct Img2Img::Impl {
     // onto the compute streams' queues (host-to-host 7.6 -> 9.8 ms per frame, profiles/r4_kernels/render_parts_ab.txt, first run).
     void ensure_copy_streams() {
         if (s_up) return;
-        hipAssert(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking));
-        hipAssert(hipStreamCreateWithFlags(&s_dn, hipStreamNonBlocking));
+        // W2X_COPY_STREAM_PRIO = high | low | normal (default, plain streams).  A stream of another priority level takes its hardware queue from that level's own
+        // pool, which no compute stream - the engine's or a replayed graph's internal ones - ever shares.
+        static const int prio_mode = [] { const char* e = getenv("W2X_COPY_STREAM_PRIO"); return !e ? 0 : !strcmp(e, "high") ? 1 : !strcmp(e, "low") ? 2 : 0; }();
+        int least = 0, greatest = 0;
+        if (prio_mode) hipAssert(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        if (prio_mode && least != greatest) {
+            hipAssert(hipStreamCreateWithPriority(&s_up, hipStreamNonBlocking, prio_mode == 1 ? greatest : least));
+            hipAssert(hipStreamCreateWithPriority(&s_dn, hipStreamNonBlocking, prio_mode == 1 ? greatest : least));
+        } else {
+            hipAssert(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking));
+            hipAssert(hipStreamCreateWithFlags(&s_dn, hipStreamNonBlocking));
+        }
         for (int b = 0; b < 2; ++b) { hipAssert(hipEventCreateWithFlags(&ev_up[b], hipEventDisableTiming)); hipAssert(hipEventCreateWithFlags(&ev_comp[b], hipEventDisableTiming)); hipAssert(hipEventCreateWithFlags(&ev_dn[b], hipEventDisableTiming)); }
     }
 
@@ -291,11 +302,18 @@ struct Img2Img::Impl {
     // A pass is captured the second time it is met (the first run stays eager so that one-time attribute calls are out of the
     // way) and replayed from then on.  The key holds everything the captured launches bake in.
     using GraphKey = std::tuple<const void*, const void*, const void*, const void*, int, int, int, int>;   // frame, slots, slab out, arena, rows, cols, live, 16-bit samples
-    std::map<GraphKey, hipGraphExec_t> graphs;
+    // A pass that runs as NG tile groups is NG graphs, one per group, each a straight line of launches replayed on that group's OWN stream (fork / join
+    // events between the streams are issued around the replays): a single captured graph with NG branches runs its side branches on streams the runtime
+    // creates at instantiation, which land on whichever hardware queue has the fewest users at that moment - sometimes the copy streams' queue, where the
+    // next download or upload then waits behind a whole pass (render() in three parts 10.1 ms, in two or four 9.0 / 8.6, same work).
+    // W2X_GRAPH_FORKED=1 keeps the one forked graph per pass.
+    struct PassGraphs { hipGraphExec_t g[4] = {nullptr, nullptr, nullptr, nullptr}; int n = 0; };
+    std::map<GraphKey, PassGraphs> graphs;
     std::map<GraphKey, int> graph_seen;
     long graph_replays = 0, eager_passes = 0;
+    bool graph_per_group = true;
     void drop_graphs() {
-        for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+        for (auto& kv : graphs) for (int k = 0; k < kv.second.n; ++k) if (kv.second.g[k]) (void)hipGraphExecDestroy(kv.second.g[k]);
         graphs.clear(); graph_seen.clear();
     }
 
@@ -730,81 +748,103 @@ struct Img2Img::Impl {
             const auto t0 = std::chrono::steady_clock::now();
             const int live = std::max(0, std::min(B, tile_count * steps - bi * B));
             void* const slab_out = (uint8_t*)d_slab + (slab_slot0 + (size_t)bi * B) * slot_bytes;
-            auto run_pass = [&] {
-                GatherParams gp;
-                gp.frame = d_frame; gp.rows = rows; gp.cols = cols; gp.step = (size_t)cols * 3 * (deep ? 2 : 1); gp.deep = deep ? 1 : 0;
-                gp.out = tensors[plan.in_tensor]; gp.slots = d_slots + slots_off + (size_t)bi * B; gp.B = B; gp.T = T; gp.fp32 = plan.elt == 4;
-                const int NG = groups;
-                struct NgReset { int& r; ~NgReset() { r = 1; } } ng_reset{ng_now};   // also when a launch throws mid-pass
-                ng_now = NG;
-                const bool split = NG > 1 && !profiling && !check_general && live >= 4 * NG && B % NG == 0 && (size_t)NG * arena_part() <= arena_bytes + 1024;
-                if (!split) {
-                    ng_now = 1;
-                    stamp_begin(3, 0);
-                    hipAssert(launch_gather(gp, stream));
-                    stamp_end();
-                    run_network(slab_out, live);
-                    return;
-                }
+            GatherParams gp0;
+            gp0.frame = d_frame; gp0.rows = rows; gp0.cols = cols; gp0.step = (size_t)cols * 3 * (deep ? 2 : 1); gp0.deep = deep ? 1 : 0;
+            gp0.out = tensors[plan.in_tensor]; gp0.slots = d_slots + slots_off + (size_t)bi * B; gp0.B = B; gp0.T = T; gp0.fp32 = plan.elt == 4;
+            const int NG = groups;
+            struct NgReset { int& r; ~NgReset() { r = 1; } } ng_reset{ng_now};   // also when a launch throws mid-pass
+            ng_now = NG;                                                          // (arena_part() is the part of an NG-group pass)
+            const bool split = NG > 1 && !profiling && !check_general && live >= 4 * NG && B % NG == 0 && (size_t)NG * arena_part() <= arena_bytes + 1024;
+            ng_now = 1;
+            // NG tile groups side by side: tiles never exchange data, so the groups run the same launches on their own streams in
+            // their own parts of the arena.  Each kernel then has 1/NG of the workgroups, but a kernel's ramp and tail (and the
+            // gaps between launches) fill with the other groups' work.  Bit-identical by construction.
+            int first[5] = {0, 0, 0, 0, 0};
+            for (int grp = 0; grp < NG; ++grp) first[grp + 1] = first[grp] + live / NG + (grp < live % NG ? 1 : 0);
+            static const int stagger_env = [] { const char* e = getenv("W2X_STAGGER_OP"); return e ? atoi(e) : -1; }();
+            stagger_op = split && NG == 2 && stagger_env >= 0 && stagger_env < (int)plan.ops.size() ? stagger_env : -1;
+            if (split) {
                 if (!ev_fork) hipAssert(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
                 for (int k = 0; k + 1 < NG; ++k) if (!gstream[k]) {
                     hipAssert(hipStreamCreateWithFlags(&gstream[k], hipStreamNonBlocking));
                     hipAssert(hipEventCreateWithFlags(&ev_join[k], hipEventDisableTiming));
                 }
-                // NG tile groups side by side: tiles never exchange data, so the groups run the same launches on their own streams in
-                // their own parts of the arena.  Each kernel then has 1/NG of the workgroups, but a kernel's ramp and tail (and the
-                // gaps between launches) fill with the other groups' work.  Bit-identical by construction.
-                int first[5] = {0, 0, 0, 0, 0};
-                for (int grp = 0; grp < NG; ++grp) first[grp + 1] = first[grp] + live / NG + (grp < live % NG ? 1 : 0);
-                for (int grp = 0; grp < NG; ++grp) {      // each group's tiles at the start of its part of the arena
-                    gp.out = group_ptr(tensors[plan.in_tensor], grp); gp.slots = d_slots + slots_off + (size_t)bi * B + (size_t)first[grp]; gp.B = first[grp + 1] - first[grp];
-                    hipAssert(launch_gather(gp, stream));
-                }
-                hipAssert(hipEventRecord(ev_fork, stream));
-                for (int grp = 1; grp < NG; ++grp) hipAssert(hipStreamWaitEvent(gstream[grp - 1], ev_fork, 0));
-                static const int stagger_env = [] { const char* e = getenv("W2X_STAGGER_OP"); return e ? atoi(e) : -1; }();
-                stagger_op = NG == 2 && stagger_env >= 0 && stagger_env < (int)plan.ops.size() ? stagger_env : -1;
                 if (stagger_op >= 0 && !ev_stagger) hipAssert(hipEventCreateWithFlags(&ev_stagger, hipEventDisableTiming));
+            }
+            auto group_stream = [&](int grp) { return grp ? gstream[grp - 1] : stream; };
+            auto gather_group = [&](int grp, hipStream_t gs) {       // the group's tiles at the start of its part of the arena
+                GatherParams gp = gp0;
+                gp.out = group_ptr(tensors[plan.in_tensor], grp); gp.slots = gp0.slots + (size_t)first[grp]; gp.B = first[grp + 1] - first[grp];
+                hipAssert(launch_gather(gp, gs));
+            };
+            auto network_group = [&](int grp, hipStream_t gs) { run_network((uint8_t*)slab_out + (size_t)first[grp] * slot_bytes, first[grp + 1] - first[grp], grp, gs); };
+            auto fork = [&] { hipAssert(hipEventRecord(ev_fork, stream)); for (int grp = 1; grp < NG; ++grp) hipAssert(hipStreamWaitEvent(gstream[grp - 1], ev_fork, 0)); };
+            auto join = [&] { for (int grp = 1; grp < NG; ++grp) { hipAssert(hipEventRecord(ev_join[grp - 1], gstream[grp - 1])); hipAssert(hipStreamWaitEvent(stream, ev_join[grp - 1], 0)); } };
+            // the whole pass as launches issued from `stream` (the groups forked off it by events: capturable as ONE graph with NG branches)
+            auto run_pass = [&] {
+                if (!split) {
+                    stamp_begin(3, 0);
+                    hipAssert(launch_gather(gp0, stream));
+                    stamp_end();
+                    run_network(slab_out, live);
+                    return;
+                }
+                ng_now = NG;
+                for (int grp = 0; grp < NG; ++grp) gather_group(grp, stream);
+                fork();
                 for (int grp = 0; grp < NG; ++grp) {
                     if (grp == 1 && stagger_op >= 0) hipAssert(hipStreamWaitEvent(gstream[0], ev_stagger, 0));
-                    run_network((uint8_t*)slab_out + (size_t)first[grp] * slot_bytes, first[grp + 1] - first[grp], grp, grp ? gstream[grp - 1] : stream);
+                    network_group(grp, group_stream(grp));
                 }
-                for (int grp = 1; grp < NG; ++grp) {
-                    hipAssert(hipEventRecord(ev_join[grp - 1], gstream[grp - 1]));
-                    hipAssert(hipStreamWaitEvent(stream, ev_join[grp - 1], 0));
-                }
+                join();
                 ng_now = 1;
             };
-            if (!graphable) run_pass();
+            // one group of a split pass, gather included, as launches on ONE stream (capturable as a straight-line graph)
+            auto run_group = [&](int grp) { ng_now = NG; gather_group(grp, group_stream(grp)); network_group(grp, group_stream(grp)); ng_now = 1; };
+            const bool per_group = split && graph_per_group && stagger_op < 0;
+            auto run_eager = [&] { if (per_group) { fork(); for (int grp = 0; grp < NG; ++grp) run_group(grp); join(); } else run_pass(); };
+            if (!graphable) run_eager();
             else {
                 const GraphKey key{d_frame, d_slots + slots_off + (size_t)bi * B, slab_out, arena_base, rows, cols, live, deep ? 1 : 0};
+                auto replay = [&](const PassGraphs& pg) {
+                    if (pg.n == 1) { hipAssert(hipGraphLaunch(pg.g[0], stream)); return; }
+                    fork();
+                    for (int grp = 0; grp < pg.n; ++grp) hipAssert(hipGraphLaunch(pg.g[grp], group_stream(grp)));
+                    join();
+                };
                 auto it = graphs.find(key);
-                if (it != graphs.end()) { hipAssert(hipGraphLaunch(it->second, stream)); ++graph_replays; }
-                else if (graph_seen.size() >= 4096 && !graph_seen.count(key)) { graph_seen.clear(); run_pass(); ++eager_passes; }   // sizes that keep changing: bounded bookkeeping
-                else if (graph_seen[key]++ == 0) { run_pass(); ++eager_passes; }
+                if (it != graphs.end()) { replay(it->second); ++graph_replays; }
+                else if (graph_seen.size() >= 4096 && !graph_seen.count(key)) { graph_seen.clear(); run_eager(); ++eager_passes; }   // sizes that keep changing: bounded bookkeeping
+                else if (graph_seen[key]++ == 0) { run_eager(); ++eager_passes; }
                 else {
                     if (graphs.size() >= 1024) drop_graphs();      // frames of ever-changing sizes: start over rather than grow without bound
                     // Capture -> instantiate -> launch.  Nothing runs while a stream captures, so whatever fails on the way (begin,
                     // a capture invalidated by a runtime call inside a launcher, end, instantiate) the pass is still to be done:
                     // graphs are switched off for good (otherwise every later frame would retry and fail again) and it runs on plain launches.
-                    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
-                    hipError_t ge = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal);
-                    std::string why = ge == hipSuccess ? "" : std::string("begin capture: ") + hipGetErrorString(ge);
-                    if (ge == hipSuccess) {
-                        try { run_pass(); } catch (const std::exception& e) { why = std::string("capture: ") + e.what(); }
-                        ge = hipStreamEndCapture(stream, &graph);
+                    PassGraphs pg;
+                    std::string why;
+                    const int ncap = per_group ? NG : 1;
+                    for (int c = 0; c < ncap && why.empty(); ++c) {
+                        hipStream_t cs = per_group ? group_stream(c) : stream;
+                        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+                        hipError_t ge = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+                        if (ge != hipSuccess) { why = std::string("begin capture: ") + hipGetErrorString(ge); break; }
+                        try { if (per_group) run_group(c); else run_pass(); } catch (const std::exception& e) { why = std::string("capture: ") + e.what(); }
+                        ge = hipStreamEndCapture(cs, &graph);
                         if (why.empty() && ge != hipSuccess) why = std::string("end capture: ") + hipGetErrorString(ge);
                         if (why.empty()) { ge = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0); if (ge != hipSuccess) why = std::string("instantiation: ") + hipGetErrorString(ge); }
                         if (graph) (void)hipGraphDestroy(graph);
+                        if (why.empty()) pg.g[pg.n++] = exec;
                     }
                     if (!why.empty()) {
                         (void)hipGetLastError();
+                        for (int c = 0; c < pg.n; ++c) (void)hipGraphExecDestroy(pg.g[c]);
                         use_graphs = false;
                         log(Severity::warn, "hipGraph " + why + " - passes stay on plain launches");
-                        run_pass(); ++eager_passes;          // a real launch error surfaces here, outside the capture
+                        run_eager(); ++eager_passes;          // a real launch error surfaces here, outside the capture
                     } else {
-                        graphs[key] = exec;
-                        hipAssert(hipGraphLaunch(exec, stream)); ++graph_replays;
+                        graphs[key] = pg;
+                        replay(pg); ++graph_replays;
                     }
                 }
             }
@@ -952,7 +992,8 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
     impl->poison = getenv("W2X_POISON") != nullptr;
     impl->check_general = getenv("W2X_PIXGEMM_CHECK") != nullptr;
     impl->use_graphs = getenv("W2X_NO_GRAPH") == nullptr;
-    if (const char* e = getenv("W2X_RENDER_PARTS")) impl->pipeline_parts = atoi(e) >= 2 ? 2 : 1;
+    impl->graph_per_group = getenv("W2X_GRAPH_FORKED") == nullptr;
+    if (const char* e = getenv("W2X_RENDER_PARTS")) impl->pipeline_parts = std::min(Impl::kMaxRenderParts, std::max(1, atoi(e)));
     if (getenv("W2X_ROCTX") && !impl->roctx_push) {
         if (void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL)) {
             impl->roctx_push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
@@ -994,6 +1035,18 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
     hipAssert(hipEventCreate(&impl->ev0));
     hipAssert(hipEventCreate(&impl->ev1));
     impl->groups = getenv("W2X_NO_SPLIT") ? 1 : getenv("W2X_GROUPS") ? std::min(4, std::max(1, atoi(getenv("W2X_GROUPS")))) : 2;   // (the extra streams are created by the first pass that splits)
+    // Every stream the engine will use is created HERE, before anything touches the null stream (upload_plan()'s synchronous copies do): the runtime hands its
+    // hardware queues (four by default) to streams in creation order and lets later streams share, so created now the compute stream, the two copy streams and the
+    // second tile group's stream have a queue each and the null stream shares one.  Created lazily, in whatever order the first calls needed them, the second
+    // group's kernels shared a queue with a copy stream on some orders: renderSequence() 7.69 (this order) / 7.85 (lazy) / 10.0 ms per frame (group stream
+    // first), profiles/r4_kernels/stream_order.txt.  W2X_STREAM_ORDER = a string of 'c' (copy streams) and 'g' (group stream) overrides the order; "-" = lazy.
+    {
+        const char* order = getenv("W2X_STREAM_ORDER");
+        for (const char* c = order ? order : "cg"; *c; ++c) {
+            if (*c == 'g' && impl->groups > 1 && !impl->gstream[0]) { hipAssert(hipStreamCreateWithFlags(&impl->gstream[0], hipStreamNonBlocking)); hipAssert(hipEventCreateWithFlags(&impl->ev_join[0], hipEventDisableTiming)); }
+            if (*c == 'c') impl->ensure_copy_streams();
+        }
+    }
     try {
         impl->upload_plan();                                                      // :225-248
     } catch (const std::exception& e) {
@@ -1058,26 +1111,45 @@ bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, cons
     if (sp.tile_count == 0) return true;                       // more devices than tile columns: this one has no share
     // :246-267 step schedule: slot = step index, tile = step / stepsPerTile, aug = step % stepsPerTile, zero pad slots at the end
     const int steps = cfg.tta ? 8 : 1, B = plan.B, S = plan.B / plan.userB;
-    // A whole frame (render()) runs as TWO parts one after the other: the first part's tiles, its canvas cells composed and handed to the
-    // download stream, then the second part's while those cells travel to the host - the synchronous contract of img2img_render.cpp:226-344
-    // with most of the 100 MB download of a 4K frame off the critical path (10.0 -> 9.x ms per call at config 3).  The parts are those of
-    // shard_plan() (contiguous tile ranges, canvas cells of their tiles; the second part reads the first one's tiles from the same slab), cut
-    // at a multiple of the batch size so that batches, their order and the progress schedule (:246-250, 336-338) are the reference's.
-    int cut = 0;                                               // tiles in the first part (0: one part)
+    // A whole frame (render()) runs as a few PARTS one after the other: a part's tiles, its canvas cells composed and handed to the download
+    // stream, then the next part's while those cells travel to the host - the synchronous contract of img2img_render.cpp:226-344 with most of
+    // the 100 MB download of a 4K frame off the critical path: only the last part's cells travel after the last kernel (config 3: 9.9 ms per
+    // call as one part, 8.4 as three, profiles/r4_kernels/render_parts_*.txt).  The parts are those of shard_plan() (contiguous tile ranges, canvas cells of their
+    // tiles; a part reads the tiles in front of its range from the same slab), cut at multiples of the batch size so that batches, their order
+    // and the progress schedule (:246-250, 336-338) are the reference's.
+    constexpr int kMaxParts = Impl::kMaxRenderParts;
+    int npart = 1;
+    int first_of[kMaxParts + 1] = {0, sp.tile_count, 0, 0, 0};   // part k = tiles [first_of[k], first_of[k + 1]) of the strip
     if (parts == 1 && impl->pipeline_parts > 1 && sp.tile_count >= 16 && grid.outOvX < plan.Tout - grid.outOvX && grid.outOvY < plan.Tout - grid.outOvY) {
-        for (int t = sp.tile_count / 2; t >= sp.tile_count / 4 && !cut; --t) if ((t * steps) % plan.userB == 0) cut = t;
+        int q = 1; while ((q * steps) % plan.userB) ++q;        // part boundaries: whole reference batches
+        const int want = std::min({impl->pipeline_parts, kMaxParts, sp.tile_count / 8});
+        // the LAST part is the small one - its cells are the only ones that travel after the last kernel (a fifth of the tiles, at least 8: smaller passes no longer
+        // fill the device) - and the tiles in front of it split evenly: config 3's 45 tiles run as 16 + 20 + 9 (8.4 ms per call; as 15 + 15 + 15: 8.8, 12 + 12 + 12 + 9: 8.45)
+        int n = 0;
+        const int body = want >= 2 ? (sp.tile_count - std::max(8, sp.tile_count / 5)) / q * q : 0;
+        for (int k = 1; k < want; ++k) {
+            const int t = k + 1 == want ? body : (int)((long)k * body / (want - 1)) / q * q;
+            if (t > first_of[n] && t < sp.tile_count) first_of[++n] = t;
+        }
+        if (const char* e = getenv("W2X_RENDER_CUTS")) {        // experiments (tools/ab/render_parts.py): explicit part boundaries "t1,t2,.." (ascending; whole batches are NOT enforced)
+            n = 0;
+            for (const char* c = e; *c && n + 1 < kMaxParts;) { const int t = atoi(c); if (t > first_of[n] && t < sp.tile_count) first_of[++n] = t; while (*c && *c != ',') ++c; if (*c) ++c; }
+        }
+        first_of[++n] = sp.tile_count;
+        npart = n;
     }
-    const int npart = cut ? 2 : 1;
-    const int tiles_of[2] = {cut ? cut : sp.tile_count, cut ? sp.tile_count - cut : 0};
-    size_t slots_off[2] = {0, 0}; int batches_of[2] = {0, 0}; size_t stepTotal = 0;
+    int tiles_of[kMaxParts] = {}, batches_of[kMaxParts] = {}, batches_before[kMaxParts] = {};
+    size_t slots_off[kMaxParts] = {}; size_t stepTotal = 0; int batch_total = 0;
     for (int k = 0; k < npart; ++k) {
+        tiles_of[k] = first_of[k + 1] - first_of[k];
         batches_of[k] = (int)std::lround(std::ceil((double)(tiles_of[k] * steps) / plan.userB));
+        batches_before[k] = batch_total; batch_total += batches_of[k];
         slots_off[k] = stepTotal;
         stepTotal += (size_t)((batches_of[k] + S - 1) / S) * B;   // reference batches rounded up to whole network passes
     }
     impl->h_slots.resize(stepTotal);
     for (int k = 0; k < npart; ++k) {
-        const int t0 = k ? cut : 0;
+        const int t0 = first_of[k];
         const size_t n = (k + 1 < npart ? slots_off[k + 1] : stepTotal) - slots_off[k];
         for (size_t st = 0; st < n; ++st) {
             const int ti = (int)(st / steps), aug = (int)(st % steps);
@@ -1089,7 +1161,7 @@ bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, cons
     impl->ensure(impl->d_slots, impl->slots_cap, stepTotal * sizeof(TileSlot));
     hipAssert(hipMemcpyAsync(impl->d_slots, impl->h_slots.data(), stepTotal * sizeof(TileSlot), hipMemcpyHostToDevice, stream));
     // the slab holds the frame's tiles in tile order: the last part's passes end at most a pass beyond them
-    impl->ensure(impl->d_slab, impl->slab_cap, ((size_t)(cut * steps) + (stepTotal - slots_off[npart - 1])) * plan.Tout * plan.Tout * 4 * plan.elt);
+    impl->ensure(impl->d_slab, impl->slab_cap, ((size_t)first_of[npart - 1] * steps + (stepTotal - slots_off[npart - 1])) * plan.Tout * plan.Tout * 4 * plan.elt);
 
     hipAssert(hipEventRecord(impl->ev0, stream));
     if (npart == 1) {
@@ -1100,11 +1172,11 @@ bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, cons
         hipAssert(hipStreamSynchronize(stream));
     } else {
         impl->ensure_copy_streams();
-        for (int k = 0; k < 2; ++k) if (!impl->ev_part[k]) hipAssert(hipEventCreateWithFlags(&impl->ev_part[k], hipEventDisableTiming));
-        ShardPlan part_plan[2];
-        for (int k = 0; k < 2; ++k) {
-            // the cells of tiles [0, cut) and [cut, count): shard_plan()'s rectangles for an uneven two-way split
-            ShardPlan q; q.first_tile = k ? cut : 0; q.tile_count = tiles_of[k];
+        for (int k = 0; k < npart; ++k) if (!impl->ev_part[k]) hipAssert(hipEventCreateWithFlags(&impl->ev_part[k], hipEventDisableTiming));
+        ShardPlan part_plan[kMaxParts];
+        for (int k = 0; k < npart; ++k) {
+            // the cells of the part's tiles: shard_plan()'s rectangles for these (batch-aligned) boundaries
+            ShardPlan q; q.first_tile = first_of[k]; q.tile_count = tiles_of[k];
             const int sx = plan.Tout - grid.outOvX, sy = plan.Tout - grid.outOvY;
             auto x_of = [&](int i) { return i >= grid.nx ? cols * s : i * sx; };
             auto y_of = [&](int j) { return j >= grid.ny ? rows * s : j * sy; };
@@ -1115,28 +1187,31 @@ bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, cons
             else { int full0 = c0; if (r0) { add(c0, c0 + 1, r0, grid.ny); full0 = c0 + 1; } add(full0, c1, 0, grid.ny); if (r1) add(c1, c1 + 1, 0, r1); }
             part_plan[k] = q;
         }
-        for (int k = 0; k < 2; ++k) {
-            impl->run_passes(rows, cols, tiles_of[k], (size_t)(k ? cut : 0) * steps, true, slots_off[k], k == 0, k ? batches_of[0] : 0, batches_of[0] + batches_of[1]);
-            for (int r = 0; r < part_plan[k].nrect; ++r) {
-                const Rect& rc = part_plan[k].rect[r];
-                impl->compose_rect(rows, cols, grid, rc.x, rc.x + rc.w, rc.y, rc.y + rc.h, 0);
-            }
-            hipAssert(hipEventRecord(impl->ev_part[k], stream));
-        }
-        hipAssert(hipEventRecord(impl->ev1, stream));
-        // the downloads, in order, on a copy stream: part 0's cells travel while part 1 computes.  Which of the two copy streams: the one created
-        // FIRST (renderSequence()'s upload stream, idle here) - the runtime spreads streams over its hardware queues in creation order, and from
-        // pageable memory the download only ran beside the kernels on that one (9.1 against 9.9 ms per call, profiles/r4_kernels/render_parts_ab*.txt)
         static const bool dn_on_second = getenv("W2X_RENDER_DN_STREAM") != nullptr;
+        static const bool dn_interleaved = getenv("W2X_RENDER_DN_INTERLEAVE") != nullptr;
         hipStream_t dn = dn_on_second ? impl->s_dn : impl->s_up;
-        for (int k = 0; k < 2; ++k) {
+        auto download_part = [&](int k) {
             hipAssert(hipStreamWaitEvent(dn, impl->ev_part[k], 0));
             for (int r = 0; r < part_plan[k].nrect; ++r) {
                 const Rect& rc = part_plan[k].rect[r];
                 hipAssert(hipMemcpy2DAsync(dst.data + (size_t)rc.y * dst.step + (size_t)rc.x * 3 * bps, dst.step, impl->d_out + ((size_t)rc.y * dst.cols + rc.x) * 3 * bps, (size_t)dst.cols * 3 * bps,
                                            (size_t)rc.w * 3 * bps, rc.h, hipMemcpyDeviceToHost, dn));
             }
+        };
+        for (int k = 0; k < npart; ++k) {
+            impl->run_passes(rows, cols, tiles_of[k], (size_t)first_of[k] * steps, true, slots_off[k], k == 0, batches_before[k], batch_total);
+            for (int r = 0; r < part_plan[k].nrect; ++r) {
+                const Rect& rc = part_plan[k].rect[r];
+                impl->compose_rect(rows, cols, grid, rc.x, rc.x + rc.w, rc.y, rc.y + rc.h, 0);
+            }
+            hipAssert(hipEventRecord(impl->ev_part[k], stream));
+            if (k + 1 == npart) hipAssert(hipEventRecord(impl->ev1, stream));
+            if (dn_interleaved) download_part(k);
         }
+        // the downloads, in order, on a copy stream: a part's cells travel while the next part computes.  Which of the two copy streams: the one created
+        // FIRST (renderSequence()'s upload stream, idle here) - the runtime spreads streams over its hardware queues in creation order, and from
+        // pageable memory the download only ran beside the kernels on that one (9.1 against 9.9 ms per call, profiles/r4_kernels/render_parts_ab*.txt)
+        if (!dn_interleaved) for (int k = 0; k < npart; ++k) download_part(k);
         hipAssert(hipStreamSynchronize(dn));
         hipAssert(hipStreamSynchronize(stream));
     }
