@@ -1043,7 +1043,8 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
     {
         const char* order = getenv("W2X_STREAM_ORDER");
         for (const char* c = order ? order : "cg"; *c; ++c) {
-            if (*c == 'g' && impl->groups > 1 && !impl->gstream[0]) { hipAssert(hipStreamCreateWithFlags(&impl->gstream[0], hipStreamNonBlocking)); hipAssert(hipEventCreateWithFlags(&impl->ev_join[0], hipEventDisableTiming)); }
+            if (*c == 'g')       // the next group stream not yet created
+                for (int k = 0; k + 1 < impl->groups; ++k) if (!impl->gstream[k]) { hipAssert(hipStreamCreateWithFlags(&impl->gstream[k], hipStreamNonBlocking)); hipAssert(hipEventCreateWithFlags(&impl->ev_join[k], hipEventDisableTiming)); break; }
             if (*c == 'c') impl->ensure_copy_streams();
         }
     }
