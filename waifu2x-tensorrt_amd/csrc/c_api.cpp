@@ -111,7 +111,7 @@ void* w2x_ipc_open(const uint8_t* handle64, int device) { return handle64 ? w2x:
 void w2x_ipc_close(void* p) { w2x::ipc_close(p); }
 
 int w2x_render_sequence(w2x_engine* e, const uint8_t* const* srcs, int rows, int cols, size_t src_step, uint8_t* const* dsts, size_t dst_step, int count) {
-    if (!e || count < 0) return 0;
+    if (!e || count < 0 || (count > 0 && (!srcs || !dsts))) return 0;
     const int sc = e->engine.scaling();
     std::vector<w2x::Image> s(count), d(count);
     for (int i = 0; i < count; ++i) {

@@ -1287,21 +1287,24 @@ static void shard_phase2(Img2Img::Impl& e, int k, const std::vector<ShardPlan>& 
     const size_t px = (size_t)4 * e.plan.elt, slot_bytes = (size_t)To * To * px;
     const bool overlapping = e.cfg.overlapX != 0 || e.cfg.overlapY != 0;
     int waited = -1;
+    bool peer2d = true;                                                    // (of the owner last waited for)
     for (int g = sp[k].halo_first; g < sp[k].first_tile && overlapping; ++g) {
         int q = k - 1;
         while (q >= 0 && !(sp[q].tile_count > 0 && g >= sp[q].first_tile && g < sp[q].first_tile + sp[q].tile_count)) --q;
         if (q < 0 || !peers[q].slab) throw std::runtime_error("shard plan: tile " + std::to_string(g) + " has no owner");
         const ShardPeer& o = peers[q];
-        if (q != waited) { if (o.ev) hipAssert(hipStreamWaitEvent(e.stream, o.ev, 0)); waited = q; }
-        const bool same = o.device == e.device;
-        bool peer2d = same;
-        if (!same) {      // strided band copies between devices need peer access; without it whole slots travel by hipMemcpyPeerAsync
-            int can = 0;
-            if (o.device >= 0 && hipDeviceCanAccessPeer(&can, e.device, o.device) == hipSuccess && can) {
-                const hipError_t pe = hipDeviceEnablePeerAccess(o.device, 0);
-                peer2d = pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled;
+        if (q != waited) {                                                 // once per owner: its event, and how its bands can travel
+            if (o.ev) hipAssert(hipStreamWaitEvent(e.stream, o.ev, 0));
+            waited = q;
+            peer2d = o.device == e.device;
+            if (!peer2d) {      // strided band copies between devices need peer access; without it whole slots travel by hipMemcpyPeerAsync
+                int can = 0;
+                if (o.device >= 0 && hipDeviceCanAccessPeer(&can, e.device, o.device) == hipSuccess && can) {
+                    const hipError_t pe = hipDeviceEnablePeerAccess(o.device, 0);
+                    peer2d = pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled;
+                }
+                (void)hipGetLastError();
             }
-            (void)hipGetLastError();
         }
         for (int a = 0; a < steps; ++a) {
             const uint8_t* from = (const uint8_t*)o.slab + (o.halo_slots + (size_t)(g - sp[q].first_tile) * steps + a) * slot_bytes;
