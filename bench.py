@@ -43,6 +43,8 @@ CONFIGS = {
     3: dict(name="configs[2]", model="swin_unet/art", scale=4, noise=3, batch=4, tile=256, w=1920, h=1080, tta=False),
     4: dict(name="configs[3]", model="swin_unet/photo", scale=4, noise=3, batch=8, tile=400, w=1920, h=1080, tta=True),
     5: dict(name="configs[4]", model="swin_unet/art_scan", scale=4, noise=3, batch=16, tile=640, w=3840, h=2160, tta=False),
+    # not a BASELINE configuration: the size the multi-process tests run this script at (tests/test_gpu_pipeline_bytes.py), 48 tiles of 64
+    0: dict(name="test size (not a BASELINE config)", model="swin_unet/art", scale=4, noise=3, batch=2, tile=64, w=380, h=290, tta=False),
 }
 CONFIG_NAME = "configs[2]"
 MFMA_F16_PEAK_TFLOPS = 2500.0        # dense, /opt/skills/guides/MI355X_MICROARCH.md
@@ -316,7 +318,7 @@ def main():
                          "shards: one frame in N tile ranges with every tile computed once, one process per GPU, the seam bands copied out of the neighbours' slabs through IPC handles "
                          "(strong scaling); shards1p: the same with one process driving N engines")
     ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=3,
-                    help="BASELINE.json configuration (1-based; 3 = configs[2], the one the metric is quoted on); the others emit the same JSON record for their workload")
+                    help="BASELINE.json configuration (1-based; 3 = configs[2], the one the metric is quoted on); the others emit the same JSON record for their workload; 0 = a test-sized frame")
     ap.add_argument("--cpu-baseline", action="store_true", help="time the CPU oracle for --config other than 3 as well (minutes for the 400 / 640 tiles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frame", choices=["synthetic", "flat", "noise"], default="synthetic",
@@ -359,6 +361,9 @@ def main():
 
     dist = None
     if world > 1:
+        # a rank uses torch for the ONNX export and gloo only (the CPU baseline runs at N = 1): a small fixed team - the default, one thread per CPU of the
+        # NUMA node, spends a minute spinning in that export when ranks share a node's CPUs (two ranks on one GPU: 95 s -> see tests/test_gpu_pipeline_bytes.py)
+        torch.set_num_threads(8)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")              # CPU tensors only: PyTorch's HIP runtime is never initialised beside /opt/rocm's

@@ -99,6 +99,12 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) acc[r][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[slot][nt], xa[mt], acc[r][mt][nt], 0, 0, 0);
     };
+#ifdef W2X_CONV3_STAGGER   // experiment (tools/ab/lib_variants.sh "k_conv3.hip:-DW2X_CONV3_STAGGER=n"): the workgroups of the launch's first generation that land on the second wave
+    if (blockIdx.x < 2u * 256u) {      // slot of their SIMD sleep n x 8128 cycles first, so that the two workgroups of a CU run out of phase (one fetching / storing while the other multiplies)
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID bits 3:0 = wave slot on the SIMD
+        if (slot & 1) for (int i = 0; i < W2X_CONV3_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     wload(0, 0, 0, 0);
     wload(1, 0, 1, 0);
 
