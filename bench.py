@@ -138,8 +138,32 @@ def cpu_baseline(work: str, tile_out: int) -> dict:
             one_tile(k)
         samples.append((time.perf_counter() - t0) / len(mine) * n)
     frame_s = sorted(samples)[1]
+    # the second restatement of the network: C++ loops under OpenMP (oracle/cnet/onnx_net.cpp, SURVEY 8d's "C++/OpenMP fp32 CPU oracle"), same tiles, same
+    # pre / post work; its loops are rows of convolutions and matrix products, which keep scaling where the operator-at-a-time executor does not
+    cpp = None
+    try:
+        from oracle import cnet
+        cex = cnet.Executor(path)
+        ex_torch, ctried = ex, {}
+        for th in sorted({min(32, usable), min(64, usable), min(128, usable)}):
+            cex.threads = th
+            ex = cex
+            one_tile(0)
+            t0 = time.perf_counter(); one_tile(n // 2); ctried[th] = time.perf_counter() - t0
+        cth = min(ctried, key=ctried.get)
+        cex.threads = cth
+        csamples = []
+        for k in picks[:3]:
+            t0 = time.perf_counter(); one_tile(k); csamples.append((time.perf_counter() - t0) * n)
+        ex = ex_torch
+        cframe = sorted(csamples)[1]
+        cpp = {"value": round(OUT_MPIX / cframe, 4), "unit": "MPix/s", "cores": cth, "seconds_per_tile_by_threads": {str(k): round(v, 3) for k, v in ctried.items()},
+               "sample": f"oracle/cnet (C++ loops, OpenMP) + numpy pipeline, 3 tiles T={TILE} on {cth} threads, median extrapolated to {n} tiles/frame ({cframe:.0f} s/frame)"}
+        cex.close()
+    except Exception as e:                                       # the figure is an extra: the torch-operator leg above is the baseline on record
+        cpp = {"error": str(e)[:200]}
     return {"value": round(OUT_MPIX / frame_s, 4), "unit": "MPix/s", "cores": threads, "host_cores": host, "usable_cores": usable, "kind": "port",
-            "samples_mpix_per_s": [round(OUT_MPIX / v, 4) for v in samples],
+            "samples_mpix_per_s": [round(OUT_MPIX / v, 4) for v in samples], "cpp_loops": cpp,
             "seconds_per_tile_by_threads": {str(k): round(v, 3) for k, v in tried.items()},
             "sample": f"oracle (torch-CPU fp32 ONNX executor + numpy pipeline), 3 samples of {len(picks) // 3} tiles T={TILE} each on {threads} threads "
                       f"(host shows {host} CPUs, {usable} usable; one tile took " + ", ".join(f"{v:.2f} s on {k}" for k, v in tried.items()) + f" threads; 81.4 s on all 256 threads of such a box, profiles/r4_final/bench_cpu_all_cores_probe.json), "

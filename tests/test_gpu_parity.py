@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 
 import synth_models as sm
-from oracle import onnx_exec, pipeline
+from oracle import cnet, onnx_exec, pipeline
 from parity_util import (BLOCK_MEAN_TOL, ULP16, assert_as_accurate_as_ideal_fp16, check_config_fixture, frame_report, network_report, psnr,  # noqa: F401
                          smooth_frame)
 
@@ -66,6 +66,8 @@ def test_network_matches_oracle(pkg, onnx_model, model, scale, batch, tile, smal
     ref32 = onnx_exec.Executor(path).run(x)
     ref16 = oracle16(path)(x)
     assert not np.isnan(y).any()
+    # the fp32 reference both bounds below are measured against is the reading of TWO independent executors (torch operators / C++ loops: tests/test_oracle_cnet.py)
+    assert float(np.abs(cnet.Executor(path).run(x) - ref32).max()) < 2e-5
     r = network_report(f"network[{model} s{scale} B{batch} T{tile} {'small' if small else 'full'}]", y, ref16, ref32)
     assert r["max_ulp16"] <= (NET_MAX_ULP16_UNFUSED if small else NET_MAX_ULP16) and r["mean_abs"] <= NET_MEAN_ABS, r
     # and against fp32 arithmetic itself: a loss of accuracy that the fp16-boundary oracle happens to share would still fail here
