@@ -64,7 +64,7 @@ def kernel_source_sha(symbol: str):
     recorded in profiles/pmc_traffic.json; it is only quoted while the kernel it was measured on is the kernel that runs now."""
     import hashlib
     files = {"swin_attn96_kernel": "k_swinattn96.hip", "swin_attn192_kernel": "k_swinattn192.hip", "swin_attn192u_kernel": "k_swinattn192u.hip", "mlp96q_kernel": "k_mlp96q.hip",
-             "mlp2q_kernel": "k_mlp2.hip", "mlp2_kernel": "k_mlp2.hip", "conv48_kernel": "k_conv48.hip", "compose_kernel": "k_prepost.hip", "gather_kernel": "k_prepost.hip",
+             "mlp2q_kernel": "k_mlp2.hip", "mlp2_kernel": "k_mlp2.hip", "conv48_kernel": "k_conv48.hip", "conv48p_kernel": "k_conv48p.hip", "compose_kernel": "k_prepost.hip", "gather_kernel": "k_prepost.hip",
              "pixgemm_kernel": "k_pixgemm.hip", "merge_kernel": "k_pixgemm.hip", "toimage_kernel": "k_pixgemm.hip", "conv3_kernel": "k_conv3.hip", "conv3h_kernel": "k_conv3h.hip",
              "stem_kernel": "k_stem.hip", "gemm_kernel": "k_gemm.hip"}
     f = files.get(symbol.split("<")[0])

@@ -568,13 +568,16 @@ def test_image_head_folded_into_the_last_mlp_is_bit_identical(pkg, onnx_model, m
     assert np.array_equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("tile,batch,shape,tta", [(64, 2, (150, 170), False), (64, 3, (101, 119), True), (256, 4, (300, 420), False)])
-def test_stem_folded_into_the_patch_convolution_is_bit_identical(pkg, onnx_model, monkeypatch, tile, batch, shape, tta):
+@pytest.mark.parametrize("tile,batch,shape,tta,persistent", [(64, 2, (150, 170), False, False), (64, 3, (101, 119), True, False), (256, 4, (300, 420), False, False),
+                                                             (64, 3, (150, 170), False, True)])
+def test_stem_folded_into_the_patch_convolution_is_bit_identical(pkg, onnx_model, monkeypatch, tile, batch, shape, tta, persistent):
     """swin_unet's first two ops - the stem (3x3, 4-halves-per-pixel tile -> 48 channels) and the patch convolution behind it - run as ONE launch
     (engine.cpp fuse_stem, k_conv48.hip conv48_kernel<true>): every workgroup computes the halo tile it needs from the input tile with the stem
     kernel's own instruction sequence, and the 48-channel map between the two is neither stored nor read.  W2X_NO_FUSE_STEM=1 keeps the two
     launches.  Same products in the same order: infer() and render() return the same bytes, through captured graphs and two tile groups (the
-    input tile must outlive the stem by one op in the arena); the odd batch leaves a group with one tile."""
+    input tile must outlive the stem by one op in the arena); the odd batch leaves a group with one tile.  `persistent`: the same pair as the
+    weight-resident persistent kernel (k_conv48p.hip, W2X_CONV48_PERSIST=1 - measured slower and off by default, kept as a record): same bytes."""
+    if persistent: monkeypatch.setenv("W2X_CONV48_PERSIST", "1")
     path = onnx_model("swin_unet/art", 4, batch, tile, noise=1)
     frame = smooth_frame(shape[0], shape[1], 14)
     x = np.random.default_rng(37).random((batch, 3, tile, tile), dtype=np.float32)

@@ -243,6 +243,7 @@ bool conv48_stem_supported(const GemmParams& p, const GemmParams& ps) {
 }
 
 hipError_t launch_conv48_stem(const GemmParams& p, const GemmParams& ps, hipStream_t s) {
+    if (conv48p_enabled()) return launch_conv48p(p, ps, s);     // W2X_CONV48_PERSIST=1: the weight-resident persistent kernel (k_conv48p.hip; measured slower, kept as a record)
     static unsigned lds_ok = 0;
     if (hipError_t e = ensure_dynamic_lds((const void*)conv48_kernel<true>, SMEM48, lds_ok); e != hipSuccess) return e;
     const int Ho = p.Mrows / p.aW, Wo = p.aW;
