@@ -325,6 +325,39 @@ def test_strips_reassemble_the_frame_bit_exactly(pkg, onnx_model, model, scale, 
     eng.close()
 
 
+@pytest.mark.parametrize("shape,tta", [((200, 260), False), ((420, 560), False), ((101, 119), True)])
+def test_rolling_sequence_of_frames_matches_render(pkg, onnx_model, monkeypatch, shape, tta):
+    """renderSequence / benchResident on frames whose passes run as two tile groups ROLL (engine.cpp run_rolling_frame): no join at the end of a frame - the
+    first stream goes on with the next frame's first group while the second stream composes the frame behind its own group, the tile slab alternating
+    between two buffers.  Seven different frames (the fourth sighting of each buffer pair replays captured graphs), one pass per frame, two passes per
+    frame (108 tiles of 64) and TTA (8 slots per tile): every frame is the bytes of render(), with output buffers reused as a ring, and W2X_NO_ROLLING=1
+    gives the same; the engine is left usable and a resident replay leaves the last frame's output in place."""
+    path = onnx_model("swin_unet/art", 4, 2, 64)
+    frames = [smooth_frame(shape[0], shape[1], 60 + k) for k in range(7)]
+    outs = {}
+    for rolling in (True, False):
+        if rolling: monkeypatch.delenv("W2X_NO_ROLLING", raising=False)
+        else: monkeypatch.setenv("W2X_NO_ROLLING", "1")
+        eng = make_engine(pkg, path, 2, 64, 4, tta=tta)
+        want = [eng.render(f) for f in frames]
+        host = [eng.alloc_host(f.shape) for f in frames]
+        for h, f in zip(host, frames):
+            h[...] = f
+        got = eng.render_sequence(host, pinned=True)
+        for k, (a, b) in enumerate(zip(got, want)):
+            assert np.array_equal(a, b), f"frame {k}, rolling={rolling}"
+        ring = [eng.alloc_host(want[0].shape) for _ in range(3)]
+        for rep in range(2):                                                        # the second time every pass is a replayed graph
+            eng.render_sequence(host, outs=[ring[k % 3] for k in range(7)])
+            assert np.array_equal(ring[6 % 3], want[6]) and np.array_equal(ring[5 % 3], want[5]) and np.array_equal(ring[4 % 3], want[4])
+        assert np.array_equal(eng.render(frames[2]), want[2])
+        assert eng.bench_resident(5) > 0 and eng.bench_resident(4) > 0          # resident replays of the last frame roll too (odd and even counts)
+        assert np.array_equal(eng.render(frames[3]), want[3])
+        outs[rolling] = want
+        eng.close()
+    assert all(np.array_equal(a, b) for a, b in zip(outs[True], outs[False]))
+
+
 @pytest.mark.parametrize("pinned,small", [(False, True), (True, True), (True, False)])
 def test_frame_sequence_with_overlapped_copies_matches_render(pkg, onnx_model, pinned, small):
     """renderSequence: upload / compute / download of consecutive frames overlap on three streams (two device buffers, events);

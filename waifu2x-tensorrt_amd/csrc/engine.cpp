@@ -243,6 +243,10 @@ struct Img2Img::Impl {
     uint8_t* d_frame = nullptr; size_t frame_cap = 0;
     uint8_t* d_out = nullptr; size_t out_cap = 0;
     void* d_slab = nullptr; size_t slab_cap = 0;
+    void* d_slab2 = nullptr; size_t slab2_cap = 0;      // second tile slab of a rolling sequence (run_rolling_frame)
+    hipEvent_t ev_g0[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr};   // rolling sequence: first group's passes of a frame issued / its compose done
+    bool rolling = false;                               // inside run_rolling_frame: split passes do not join their streams
+    bool rolling_ok = true;                             // W2X_NO_ROLLING switches the frame-to-frame pipeline of benchResident / renderSequence off
     TileSlot* d_slots = nullptr; size_t slots_cap = 0;
     float *d_rampx = nullptr, *d_rampy = nullptr;
     int ovx = 0, ovy = 0;
@@ -341,13 +345,15 @@ struct Img2Img::Impl {
         if (s_up) { (void)hipStreamDestroy(s_up); s_up = nullptr; }
         if (s_dn) { (void)hipStreamDestroy(s_dn); s_dn = nullptr; }
         frame2_cap = out2_cap = 0;
-        for (void** p : {(void**)&d_frame, (void**)&d_out, (void**)&d_frame2, (void**)&d_out2, &d_slab, (void**)&d_slots, (void**)&d_rampx, (void**)&d_rampy, (void**)&d_blob_in, (void**)&d_blob_out})
+        for (void** p : {(void**)&d_frame, (void**)&d_out, (void**)&d_frame2, (void**)&d_out2, &d_slab, &d_slab2, (void**)&d_slots, (void**)&d_rampx, (void**)&d_rampy, (void**)&d_blob_in, (void**)&d_blob_out})
             if (*p) { (void)hipFree(*p); *p = nullptr; }
         frame_cap = out_cap = slab_cap = slots_cap = 0;
         if (ev0) { (void)hipEventDestroy(ev0); ev0 = nullptr; }
         if (ev1) { (void)hipEventDestroy(ev1); ev1 = nullptr; }
         if (ev_shard) { (void)hipEventDestroy(ev_shard); ev_shard = nullptr; }
         for (hipEvent_t& e : ev_part) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        for (hipEvent_t& e : ev_g0) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        for (hipEvent_t& e : ev_cmp) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
         if (ev_stagger) { (void)hipEventDestroy(ev_stagger); ev_stagger = nullptr; }
         for (hipEvent_t& e : ev_join) if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -726,8 +732,44 @@ struct Img2Img::Impl {
     // device part of one frame: gather -> network per batch -> compose.  Frame must already be in d_frame.
     void run_frame(int rows, int cols, const TileGrid& grid, bool report, const StripPlan& sp) {
         run_passes(rows, cols, sp.tile_count, 0, report, 0, true);
+        static const bool skip_compose = getenv("W2X_EXP_SKIP_COMPOSE") != nullptr;     // timing experiment (wrong output): what hiding the compose launch could buy
+        if (skip_compose) return;
         compose_rect(rows, cols, grid, sp.x0, sp.x1, 0, 0, sp.first_tile);
     }
+
+    // One frame of a ROLLING sequence (benchResident, renderSequence): frames of one size, one after the other, whose passes all run as two tile groups.
+    // A lone frame ends with a join (the first stream waits for the second group), then the compose launch runs alone, then the next frame forks again:
+    // a tenth of a millisecond of compose plus the last tiles of the longer group with half the device idle, per frame.  Here nothing joins: the first
+    // stream carries its group from pass to pass and from frame to frame; the second stream carries the other group and, behind it, the frame's compose
+    // launch (which waits for the first stream's last pass of the frame by event) - so frame f is composed while frame f + 1's first group is already
+    // running.  What that takes: a second tile slab (frame f + 1's tiles must not land on the tiles compose(f) is reading; `which` alternates), and
+    // events instead of stream order where a buffer comes round again (ev_cmp).  Same launches on the same data: the frames are the bytes of render().
+    // Returns false when the frame cannot roll (a pass that does not split, profiling, one group): the caller then runs run_frame().
+    bool can_roll(int tile_count) const {
+        const int steps = cfg.tta ? 8 : 1, B = plan.B;
+        const int last_live = tile_count * steps - (tile_count * steps - 1) / B * B;                    // live slots of the frame's last pass
+        return rolling_ok && groups == 2 && graph_per_group && use_graphs && !profiling && !check_general && !poison && gstream[0] && last_live >= 8 && B % 2 == 0 &&
+               !getenv("W2X_STAGGER_OP");
+    }
+    void run_rolling_frame(int rows, int cols, const TileGrid& grid, const StripPlan& sp, int which, hipEvent_t out_free) {
+        for (int k = 0; k < 2; ++k) {
+            if (!ev_g0[k]) hipAssert(hipEventCreateWithFlags(&ev_g0[k], hipEventDisableTiming));
+            if (!ev_cmp[k]) hipAssert(hipEventCreateWithFlags(&ev_cmp[k], hipEventDisableTiming));
+        }
+        struct Swap { Impl* e; void* slab; size_t cap; bool on; ~Swap() { if (on) { std::swap(e->d_slab, e->d_slab2); std::swap(e->slab_cap, e->slab2_cap); } e->rolling = false; } } sw{this, d_slab, slab_cap, which == 1};
+        if (which == 1) { std::swap(d_slab, d_slab2); std::swap(slab_cap, slab2_cap); }
+        rolling = true;
+        hipAssert(hipStreamWaitEvent(stream, ev_cmp[which], 0));          // the compose launch that last read this slab (two frames ago) is done (a never-recorded event does not wait)
+        run_passes(rows, cols, sp.tile_count, 0, false, 0, true);
+        hipAssert(hipEventRecord(ev_g0[which], stream));
+        hipStream_t s2 = gstream[0];
+        hipAssert(hipStreamWaitEvent(s2, ev_g0[which], 0));
+        if (out_free) hipAssert(hipStreamWaitEvent(s2, out_free, 0));     // the frame that last left through this output buffer has been downloaded
+        compose_rect(rows, cols, grid, sp.x0, sp.x1, 0, 0, sp.first_tile, s2);
+        hipAssert(hipEventRecord(ev_cmp[which], s2));
+    }
+    // after the last frame of a rolling sequence: the first stream waits for the second, so that whatever follows on it sees the sequence done
+    void end_rolling() { hipAssert(hipEventRecord(ev_join[0], gstream[0])); hipAssert(hipStreamWaitEvent(stream, ev_join[0], 0)); }
 
     // the network passes of `tile_count` tiles (slots d_slots[slots_off ..]); their outputs go to slab slots slab_slot0, slab_slot0 + 1, ...
     // fresh: the first passes of a frame (W2X_POISON wipes the arena and the slab here, not between the parts of a pipelined frame)
@@ -801,21 +843,24 @@ struct Img2Img::Impl {
             };
             // one group of a split pass, gather included, as launches on ONE stream (capturable as a straight-line graph)
             auto run_group = [&](int grp) { ng_now = NG; gather_group(grp, group_stream(grp)); network_group(grp, group_stream(grp)); ng_now = 1; };
-            const bool per_group = split && graph_per_group && stagger_op < 0;
-            auto run_eager = [&] { if (per_group) { fork(); for (int grp = 0; grp < NG; ++grp) run_group(grp); join(); } else run_pass(); };
+            auto per_group_ok = [&](bool sp) { return sp && graph_per_group && stagger_op < 0; };
+            const bool per_group = per_group_ok(split);
+            // (a rolling sequence leaves the groups un-joined: each stream carries its group from pass to pass and from frame to frame, run_rolling_frame)
+            const bool no_join = rolling && per_group_ok(split);
+            auto run_eager = [&] { if (per_group) { fork(); for (int grp = 0; grp < NG; ++grp) run_group(grp); if (!no_join) join(); } else { if (rolling && gstream[0]) { join(); } run_pass(); } };
             if (!graphable) run_eager();
             else {
                 const GraphKey key{d_frame, d_slots + slots_off + (size_t)bi * B, slab_out, arena_base, rows, cols, live, deep ? 1 : 0};
                 auto replay = [&](const PassGraphs& pg) {
-                    if (pg.n == 1) { hipAssert(hipGraphLaunch(pg.g[0], stream)); return; }
+                    if (pg.n == 1) { if (rolling && gstream[0]) join(); hipAssert(hipGraphLaunch(pg.g[0], stream)); return; }   // (a whole-arena pass inside a rolling sequence: the other stream's group first)
                     fork();
                     for (int grp = 0; grp < pg.n; ++grp) hipAssert(hipGraphLaunch(pg.g[grp], group_stream(grp)));
-                    join();
+                    if (!no_join) join();
                 };
                 auto it = graphs.find(key);
                 if (it != graphs.end()) { replay(it->second); ++graph_replays; }
                 else if (graph_seen.size() >= 4096 && !graph_seen.count(key)) { graph_seen.clear(); run_eager(); ++eager_passes; }   // sizes that keep changing: bounded bookkeeping
-                else if (graph_seen[key]++ == 0) { run_eager(); ++eager_passes; }
+                else if (graph_seen[key]++ == 0 && !(rolling && !graphs.empty())) { run_eager(); ++eager_passes; }   // (a rolling frame on the second slab repeats launches that have run: captured at first sight)
                 else {
                     if (graphs.size() >= 1024) drop_graphs();      // frames of ever-changing sizes: start over rather than grow without bound
                     // Capture -> instantiate -> launch.  Nothing runs while a stream captures, so whatever fails on the way (begin,
@@ -860,7 +905,7 @@ struct Img2Img::Impl {
 
     // compose: output columns [x0, x1) (x1 = 0: to the right edge) and rows [y0, y1) (y1 = 0: to the bottom) from the slab, whose slot 0 holds
     // global tile `first_tile`
-    void compose_rect(int rows, int cols, const TileGrid& grid, int x0, int x1, int y0, int y1, long first_tile) {
+    void compose_rect(int rows, int cols, const TileGrid& grid, int x0, int x1, int y0, int y1, long first_tile, hipStream_t on = nullptr) {
         const int To = plan.Tout;
         ComposeParams cp;
         cp.tiles = d_slab; cp.fp32 = plan.elt == 4; cp.dst = d_out; cp.dst_step = (size_t)cols * cfg.scaling * 3 * (deep ? 2 : 1); cp.deep = deep ? 1 : 0;
@@ -871,7 +916,7 @@ struct Img2Img::Impl {
         cp.ramp_x = d_rampx; cp.ramp_y = d_rampy; cp.tta = cfg.tta ? 1 : 0; cp.tta_bug_compat = cfg.ttaBugCompat ? 1 : 0;
         cp.x0 = x0; cp.x1 = x1; cp.y0 = y0; cp.y1 = y1; cp.first_tile = first_tile;
         stamp_begin(4, 0);
-        hipAssert(launch_compose(cp, stream));
+        hipAssert(launch_compose(cp, on ? on : stream));
         stamp_end();
     }
 };
@@ -993,6 +1038,7 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
     impl->check_general = getenv("W2X_PIXGEMM_CHECK") != nullptr;
     impl->use_graphs = getenv("W2X_NO_GRAPH") == nullptr;
     impl->graph_per_group = getenv("W2X_GRAPH_FORKED") == nullptr;
+    impl->rolling_ok = getenv("W2X_NO_ROLLING") == nullptr;
     if (const char* e = getenv("W2X_RENDER_PARTS")) impl->pipeline_parts = std::min(Impl::kMaxRenderParts, std::max(1, atoi(e)));
     if (getenv("W2X_ROCTX") && !impl->roctx_push) {
         if (void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL)) {
@@ -1199,14 +1245,28 @@ bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, cons
                                            (size_t)rc.w * 3 * bps, rc.h, hipMemcpyDeviceToHost, dn));
             }
         };
+        // the parts ROLL like the frames of a sequence (run_rolling_frame) when all their passes split: no join at the end of a part - the second group's stream
+        // composes the part's cells behind its own tiles while the first stream starts the next part's (one slab: the parts' tiles lie side by side in it)
+        bool roll = true;
+        for (int k = 0; k < npart; ++k) roll = roll && impl->can_roll(tiles_of[k]);
+        struct Unroll { Impl* e; ~Unroll() { e->rolling = false; } } unroll{impl.get()};
+        if (roll) for (int k = 0; k < 2; ++k) if (!impl->ev_g0[k]) hipAssert(hipEventCreateWithFlags(&impl->ev_g0[k], hipEventDisableTiming));
         for (int k = 0; k < npart; ++k) {
+            impl->rolling = roll;
             impl->run_passes(rows, cols, tiles_of[k], (size_t)first_of[k] * steps, true, slots_off[k], k == 0, batches_before[k], batch_total);
+            impl->rolling = false;
+            hipStream_t cs = stream;
+            if (roll) {
+                cs = impl->gstream[0];
+                hipAssert(hipEventRecord(impl->ev_g0[k & 1], stream));
+                hipAssert(hipStreamWaitEvent(cs, impl->ev_g0[k & 1], 0));
+            }
             for (int r = 0; r < part_plan[k].nrect; ++r) {
                 const Rect& rc = part_plan[k].rect[r];
-                impl->compose_rect(rows, cols, grid, rc.x, rc.x + rc.w, rc.y, rc.y + rc.h, 0);
+                impl->compose_rect(rows, cols, grid, rc.x, rc.x + rc.w, rc.y, rc.y + rc.h, 0, cs);
             }
-            hipAssert(hipEventRecord(impl->ev_part[k], stream));
-            if (k + 1 == npart) hipAssert(hipEventRecord(impl->ev1, stream));
+            hipAssert(hipEventRecord(impl->ev_part[k], cs));
+            if (k + 1 == npart) { if (roll) impl->end_rolling(); hipAssert(hipEventRecord(impl->ev1, stream)); }
             if (dn_interleaved) download_part(k);
         }
         // the downloads, in order, on a copy stream: a part's cells travel while the next part computes.  Which of the two copy streams: the one created
@@ -1521,6 +1581,10 @@ bool Img2Img::renderSequence(const Image* srcs, Image* dsts, int count) try {
     uint8_t* const frames[2] = {impl->d_frame, impl->d_frame2};
     uint8_t* const outs[2] = {impl->d_out, impl->d_out2};
     struct Restore { Impl* im; uint8_t* f; uint8_t* o; ~Restore() { im->d_frame = f; im->d_out = o; } } restore{impl.get(), frames[0], outs[0]};   // also on exceptions
+    // frame f is composed on the second group's stream while frame f + 1's first group already runs (run_rolling_frame) when every pass of a frame splits
+    const bool roll = count > 1 && impl->can_roll(sp.tile_count);
+    if (roll) impl->ensure(impl->d_slab2, impl->slab2_cap, impl->slab_cap);
+    hipAssert(hipStreamSynchronize(stream));
     hipAssert(hipEventRecord(impl->ev0, stream));
     for (int i = 0; i < count; ++i) {
         const int b = i & 1;
@@ -1528,14 +1592,20 @@ bool Img2Img::renderSequence(const Image* srcs, Image* dsts, int count) try {
         hipAssert(hipMemcpy2DAsync(frames[b], (size_t)cols * 3, srcs[i].data, srcs[i].step, (size_t)cols * 3, rows, hipMemcpyHostToDevice, impl->s_up));
         hipAssert(hipEventRecord(impl->ev_up[b], impl->s_up));
         hipAssert(hipStreamWaitEvent(stream, impl->ev_up[b], 0));
-        if (i >= 2) hipAssert(hipStreamWaitEvent(stream, impl->ev_dn[b], 0));             // frame i-2 has left this output buffer
         impl->d_frame = frames[b]; impl->d_out = outs[b];
-        impl->run_frame(rows, cols, grid, false, sp);
-        hipAssert(hipEventRecord(impl->ev_comp[b], stream));
+        if (roll) {
+            impl->run_rolling_frame(rows, cols, grid, sp, b, i >= 2 ? impl->ev_dn[b] : nullptr);
+            hipAssert(hipEventRecord(impl->ev_comp[b], impl->gstream[0]));              // (behind the compose launch: both groups have gathered, the output is whole)
+        } else {
+            if (i >= 2) hipAssert(hipStreamWaitEvent(stream, impl->ev_dn[b], 0));         // frame i-2 has left this output buffer
+            impl->run_frame(rows, cols, grid, false, sp);
+            hipAssert(hipEventRecord(impl->ev_comp[b], stream));
+        }
         hipAssert(hipStreamWaitEvent(impl->s_dn, impl->ev_comp[b], 0));
         hipAssert(hipMemcpy2DAsync(dsts[i].data, dsts[i].step, outs[b], (size_t)cols * s * 3, (size_t)cols * s * 3, rows * s, hipMemcpyDeviceToHost, impl->s_dn));
         hipAssert(hipEventRecord(impl->ev_dn[b], impl->s_dn));
     }
+    if (roll) impl->end_rolling();
     hipAssert(hipEventRecord(impl->ev1, stream));
     hipAssert(hipStreamSynchronize(impl->s_dn));
     hipAssert(hipStreamSynchronize(stream));
@@ -1630,8 +1700,15 @@ float Img2Img::benchResident(int iters) try {
     if (!impl->loaded || impl->last_rows == 0 || iters <= 0) return -1.f;
     DeviceGuard guard(impl->device);
     hipStream_t stream = impl->stream;
+    // frames of one size back to back: a rolling sequence where every pass splits (run_rolling_frame), else frame after frame
+    const bool roll = iters > 1 && impl->can_roll(impl->last_strip.tile_count);
+    if (roll) impl->ensure(impl->d_slab2, impl->slab2_cap, impl->slab_cap);
     hipAssert(hipEventRecord(impl->ev0, stream));
-    for (int i = 0; i < iters; ++i) impl->run_frame(impl->last_rows, impl->last_cols, impl->last_grid, false, impl->last_strip);
+    for (int i = 0; i < iters; ++i) {
+        if (roll) impl->run_rolling_frame(impl->last_rows, impl->last_cols, impl->last_grid, impl->last_strip, i & 1, nullptr);
+        else impl->run_frame(impl->last_rows, impl->last_cols, impl->last_grid, false, impl->last_strip);
+    }
+    if (roll) impl->end_rolling();
     hipAssert(hipEventRecord(impl->ev1, stream));
     hipAssert(hipStreamSynchronize(stream));
     float ms = 0.f;
