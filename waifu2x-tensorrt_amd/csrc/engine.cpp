@@ -1293,6 +1293,8 @@ bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, cons
         hipAssert(hipMemcpy(impl->d_slots, impl->h_slots.data(), stepCount * sizeof(TileSlot), hipMemcpyHostToDevice));
         impl->ensure(impl->d_slab, impl->slab_cap, stepCount * plan.Tout * plan.Tout * 4 * plan.elt);
     }
+    // the second slab of a rolling sequence now (an allocation drops the captured passes: better here, on the frame size's first sight, than inside benchResident / renderSequence)
+    if (parts == 1 && impl->slab2_cap < impl->slab_cap && impl->can_roll(sp.tile_count)) impl->ensure(impl->d_slab2, impl->slab2_cap, impl->slab_cap);
     return true;
 } catch (const std::exception& e) {
     W2X_LOG_AS(who, error, "Render failed unexpectedly: " + std::string(e.what()) + ".");
