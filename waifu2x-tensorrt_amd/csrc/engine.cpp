@@ -1149,7 +1149,7 @@ bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, cons
     impl->ensure(impl->d_frame, impl->frame_cap, (size_t)rows * cols * 3 * bps);
     impl->ensure(impl->d_out, impl->out_cap, (size_t)rows * s * cols * s * 3 * bps);
     impl->deep = bps == 2;
-    hipAssert(hipMemcpy2DAsync(impl->d_frame, (size_t)cols * 3 * bps, src.data, src.step, (size_t)cols * 3 * bps, rows, hipMemcpyHostToDevice, stream));
+    // img2img_render.cpp:226 upload: below, once the parts are known (a frame that runs in parts uploads the first part's columns first)
     // :232-240
     TileGrid grid = calculate_tiles(cols, rows, cols * s, rows * s, plan.T, plan.T, plan.Tout, plan.Tout, s, cfg.overlapX, cfg.overlapY);
     if (grid.count <= 0) { W2X_LOG_AS(who, error, "Tile grid is empty."); return false; }
@@ -1194,6 +1194,15 @@ bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, cons
         slots_off[k] = stepTotal;
         stepTotal += (size_t)((batches_of[k] + S - 1) / S) * B;   // reference batches rounded up to whole network passes
     }
+    // :226 upload.  In parts: the frame columns the first part's tiles read go first, on the compute stream; the rest follows on the upload stream while that
+    // part computes (tiles are ordered by column, :43-44, so a part reads a column range; the second part waits for the event)
+    int x_split = cols;
+    if (npart > 1) {
+        int xm = 0;
+        for (int t = 0; t < first_of[1]; ++t) xm = std::max(xm, grid.in[sp.first_tile + t].x + plan.T);
+        if (xm > 0 && xm < cols - 64) x_split = xm;
+    }
+    hipAssert(hipMemcpy2DAsync(impl->d_frame, (size_t)cols * 3 * bps, src.data, src.step, (size_t)x_split * 3 * bps, rows, hipMemcpyHostToDevice, stream));
     impl->h_slots.resize(stepTotal);
     for (int k = 0; k < npart; ++k) {
         const int t0 = first_of[k];
@@ -1252,9 +1261,15 @@ bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, cons
         struct Unroll { Impl* e; ~Unroll() { e->rolling = false; } } unroll{impl.get()};
         if (roll) for (int k = 0; k < 2; ++k) if (!impl->ev_g0[k]) hipAssert(hipEventCreateWithFlags(&impl->ev_g0[k], hipEventDisableTiming));
         for (int k = 0; k < npart; ++k) {
+            if (k == 1 && x_split < cols) hipAssert(hipStreamWaitEvent(stream, impl->ev_up[0], 0));      // the rest of the frame has arrived
             impl->rolling = roll;
             impl->run_passes(rows, cols, tiles_of[k], (size_t)first_of[k] * steps, true, slots_off[k], k == 0, batches_before[k], batch_total);
             impl->rolling = false;
+            if (k == 0 && x_split < cols) {      // issued behind the first part's launches: from pageable memory the call returns when the copy is done
+                hipAssert(hipMemcpy2DAsync(impl->d_frame + (size_t)x_split * 3 * bps, (size_t)cols * 3 * bps, src.data + (size_t)x_split * 3 * bps, src.step, (size_t)(cols - x_split) * 3 * bps, rows,
+                                           hipMemcpyHostToDevice, impl->s_dn));
+                hipAssert(hipEventRecord(impl->ev_up[0], impl->s_dn));
+            }
             hipStream_t cs = stream;
             if (roll) {
                 cs = impl->gstream[0];
