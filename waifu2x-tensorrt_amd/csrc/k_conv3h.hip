@@ -37,7 +37,7 @@ struct Conv3hCfg {
 // (k_conv3.hip has the derivation)
 __device__ __forceinline__ int halo_slot(int x, int pc) { return x * 64 + ((pc + 2 * ((x >> 2) & 3)) & 3) * 16; }
 
-template <int PIX>
+template <int PIX, bool TWO>
 __global__ __launch_bounds__(256, 4) void conv3h_kernel(const GemmParams p, int Ho, int Wo, int tiles_x, int tiles_y) {
     using C = Conv3hCfg;
     constexpr int HR = C::HR, HC = C::HC;
@@ -64,15 +64,15 @@ __global__ __launch_bounds__(256, 4) void conv3h_kernel(const GemmParams p, int 
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) xoff[kx] = halo_slot(kx + fr, g);
     const unsigned char* xrow = smem + wv * C::ROWB;
-#pragma unroll 1
-    for (int kc = 0; kc < nchunk; ++kc) {
-        half8 h[C::NI];
+    auto fetch = [&](int kc, half8 (&h)[C::NI]) {
 #pragma unroll
         for (int i = 0; i < C::NI; ++i) {
             const int idx = tid + i * 256, pix = idx >> 2, c8 = idx & 3, hr = pix / HC, hc = pix - hr * HC;
             h[i] = (half8){};
             if (idx < C::NP && hr < hrows && hc < hcols) h[i] = *(const half8*)(Ag + ((size_t)hr * p.a.Ws + hc) * Cin + kc * 32 + c8 * 8);
         }
+    };
+    auto chunk = [&](int kc, const half8 (&h)[C::NI]) {
         // weights of this chunk: fragment (tap) of lane (fr, g) = W[fr][tap][32 kc + 8g .. + 7], rows >= N read as zero
         half8 wf[9];
 #pragma unroll
@@ -92,6 +92,22 @@ __global__ __launch_bounds__(256, 4) void conv3h_kernel(const GemmParams p, int 
             for (int mt = 0; mt < 4; ++mt) xa[mt] = *(const half8*)(xrow + ky * C::ROWB + xoff[kx] + mt * 1024);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t], xa[mt], acc[mt], 0, 0, 0);
+        }
+    };
+    if (TWO) {
+        // Both 32-channel chunks of a 64-channel map are requested before anything waits (late round 4): the second chunk's halo tile travels under the first
+        // chunk's LDS stores, barriers and products instead of being asked for after them - one exposed fetch per workgroup instead of two; 28 more registers.
+        half8 h0[C::NI], h1[C::NI];
+        fetch(0, h0);
+        fetch(1, h1);
+        chunk(0, h0);
+        chunk(1, h1);
+    } else {
+#pragma unroll 1
+        for (int kc = 0; kc < nchunk; ++kc) {
+            half8 h[C::NI];
+            fetch(kc, h);
+            chunk(kc, h);
         }
     }
 
@@ -118,14 +134,19 @@ __global__ __launch_bounds__(256, 4) void conv3h_kernel(const GemmParams p, int 
     }
 }
 
-template <int PIX>
-hipError_t launch_c3h(const GemmParams& p, int Ho, int Wo, hipStream_t s) {
+template <int PIX, bool TWO>
+hipError_t launch_c3h2(const GemmParams& p, int Ho, int Wo, hipStream_t s) {
     using C = Conv3hCfg;
     static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
-    if (hipError_t e = ensure_dynamic_lds((const void*)conv3h_kernel<PIX>, C::SMEM, lds_ok); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)conv3h_kernel<PIX, TWO>, C::SMEM, lds_ok); e != hipSuccess) return e;
     const int tiles_x = (Wo + C::TW - 1) / C::TW, tiles_y = (Ho + C::TH - 1) / C::TH;
-    hipLaunchKernelGGL((conv3h_kernel<PIX>), dim3((unsigned)(p.B * tiles_x * tiles_y)), dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y);
+    hipLaunchKernelGGL((conv3h_kernel<PIX, TWO>), dim3((unsigned)(p.B * tiles_x * tiles_y)), dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y);
     return hipGetLastError();
+}
+template <int PIX>
+hipError_t launch_c3h(const GemmParams& p, int Ho, int Wo, hipStream_t s) {
+    static const bool one_at_a_time = getenv("W2X_CONV3H_SERIAL") != nullptr;   // A/B switch: the chunks fetched one after the other (until late round 4)
+    return p.a.Cs == 64 && !one_at_a_time ? launch_c3h2<PIX, true>(p, Ho, Wo, s) : launch_c3h2<PIX, false>(p, Ho, Wo, s);
 }
 
 }  // namespace
