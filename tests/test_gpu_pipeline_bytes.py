@@ -91,6 +91,35 @@ def test_render_call_in_pipelined_parts_returns_the_one_part_bytes(pkg, onnx_mod
         assert_same_bytes(f"{parts} parts, 16-bit", outs[parts][1], outs["1"][1])
 
 
+@pytest.mark.parametrize("tta,batch", [(False, 3), (True, 4)])
+def test_render_pipelines_agree_on_random_frame_sizes(pkg, onnx_model, monkeypatch, tta, batch):
+    """The machinery around a render() call - parts with a small last one, the upload split at the first part's columns, parts rolling into each other,
+    one graph per tile group - against the plain path (one part, joins, W2X_RENDER_PARTS=1 W2X_NO_ROLLING=1) on seeded random frame sizes from one tile
+    row to 130 tiles, 8- and 16-bit, each rendered twice (eager, then replayed) and followed by a resident replay: same bytes every time.  With TTA a
+    tile is eight slots, so a part boundary may fall on any tile."""
+    path = onnx_model("swin_unet/art", 4, batch, 64)
+    rng = np.random.default_rng(2024 + batch)
+    shapes = [(int(rng.integers(40, 520)), int(rng.integers(40, 640))) for _ in range(5 if tta else 10)] + [(48, 600), (600, 48), (199, 263)]
+    frames = [noisy_frame(r, c, 100 + k) for k, (r, c) in enumerate(shapes)]
+    deep = [(f.astype(np.uint16) * 257) ^ 0x5A for f in frames[:4]]
+    outs = {}
+    for plain in (True, False):
+        if plain: monkeypatch.setenv("W2X_RENDER_PARTS", "1"); monkeypatch.setenv("W2X_NO_ROLLING", "1")
+        else: monkeypatch.delenv("W2X_RENDER_PARTS"); monkeypatch.delenv("W2X_NO_ROLLING")
+        eng = make_engine(pkg, path, batch, 64, 4, tta=tta)
+        got = []
+        for f in frames + deep:
+            a = eng.render(f); b = eng.render(f)
+            assert np.array_equal(a, b)
+            assert eng.bench_resident(3) > 0
+            assert np.array_equal(eng.render(f), a)
+            got.append(a)
+        outs[plain] = got
+        eng.close()
+    for k, (a, b) in enumerate(zip(outs[True], outs[False])):
+        assert_same_bytes(f"frame {k} {(frames + deep)[k].shape} {(frames + deep)[k].dtype}", b, a)
+
+
 @pytest.mark.parametrize("tta", [False, True])
 def test_strips_are_byte_exact_against_the_oracle(pkg, onnx_model, tta):
     """the frame rendered as 2 and 3 tile-column strips (w2x_render_strip), reassembled, against the oracle's whole frame."""
