@@ -9,10 +9,17 @@ A step = one pass of the hot path (gather -> network on every tile batch -> blen
 1920x1080 frame that is already resident in HBM; frames are independent, so ranks shard frames with no data-path
 collective (weak scaling: every rank renders K frames).  Rank 0 prints ONE JSON line.
 
-`value` is the resident figure (inputs in HBM when the timed region starts).  The same K frames are then rendered by every
-rank through the reference's whole render() contract - host frame in, host frame out (img2img_render.cpp:226,344; caller
-loop main.cpp:263-269) - as a renderSequence over page-locked buffers with the copies on side streams; that PCIe-inclusive
-figure is reported next to it as config.full_path_* (max over ranks, same barriers), never as `value`.
+`value` is the resident figure (inputs in HBM when the timed region starts: the measurement contract of this build).  The same K
+frames are then rendered by every rank through the reference's whole render() contract - host frame in, host frame out
+(img2img_render.cpp:226,344; caller loop main.cpp:263-269) - as a renderSequence over page-locked buffers with the copies on
+side streams; that PCIe-inclusive figure is the top-level `host_to_host` object of the same line (max over ranks, same barriers,
+per-rank spread), never `value`.  At N > 1 it is the number that can fail to scale (N x 100 MB per frame into host memory);
+the resident one touches no shared resource.
+
+Every line says where it ran: `placement` holds, per rank, the PCI bus id of the GPU the rank's HIP runtime rendered on, the
+number of DISTINCT GPUs behind the ranks and W2X_DEVICE_MAP.  `n_gpus` is that distinct count: ranks sharing a card (a
+rehearsal) give `n_gpus` < `n_ranks` and a metric that starts with "REHEARSAL".  --host-rehearsal runs the whole rank protocol
+(spawn / rendezvous / barriers / reductions / the one JSON line) with the engine calls replaced by sleeps: no GPU, no value.
 
 Ranks never touch torch.cuda: libw2x.so links /opt/rocm's HIP runtime and PyTorch bundles its own, so the timing barrier
 and the max-reduction run over gloo on CPU tensors (there is no data-path collective to put on RCCL).  With --gpus N > 1
@@ -63,8 +70,8 @@ def kernel_source_sha(symbol: str):
     """sha256 (12 hex digits) of the source file + build recipe that produce a kernel symbol: roofline.traffic comes from rocprofv3 --pmc passes
     recorded in profiles/pmc_traffic.json; it is only quoted while the kernel it was measured on is the kernel that runs now."""
     import hashlib
-    files = {"swin_attn96_kernel": "k_swinattn96.hip", "swin_attn192_kernel": "k_swinattn192.hip", "swin_attn192u_kernel": "k_swinattn192u.hip", "mlp96q_kernel": "k_mlp96q.hip",
-             "mlp2q_kernel": "k_mlp2.hip", "mlp2_kernel": "k_mlp2.hip", "conv48_kernel": "k_conv48.hip", "conv48p_kernel": "k_conv48p.hip", "compose_kernel": "k_prepost.hip", "gather_kernel": "k_prepost.hip",
+    files = {"swin_attn96_kernel": "k_swinattn96.hip", "swin_attn192u_kernel": "k_swinattn192u.hip", "mlp96q_kernel": "k_mlp96q.hip",
+             "mlp2q_kernel": "k_mlp2.hip", "mlp2_kernel": "k_mlp2.hip", "conv48_kernel": "k_conv48.hip", "compose_kernel": "k_prepost.hip", "gather_kernel": "k_prepost.hip",
              "pixgemm_kernel": "k_pixgemm.hip", "merge_kernel": "k_pixgemm.hip", "toimage_kernel": "k_pixgemm.hip", "conv3_kernel": "k_conv3.hip", "conv3h_kernel": "k_conv3h.hip",
              "stem_kernel": "k_stem.hip", "gemm_kernel": "k_gemm.hip"}
     f = files.get(symbol.split("<")[0])
@@ -144,21 +151,15 @@ def cpu_baseline(work: str, tile_out: int) -> dict:
     try:
         from oracle import cnet
         cex = cnet.Executor(path)
-        ex_torch, ctried = ex, {}
-        for th in sorted({min(32, usable), min(64, usable), min(128, usable)}):
-            cex.threads = th
-            ex = cex
-            one_tile(0)
-            t0 = time.perf_counter(); one_tile(n // 2); ctried[th] = time.perf_counter() - t0
-        cth = min(ctried, key=ctried.get)
+        ex_torch = ex
+        cth = min(32, usable)                 # (its thread sweep is on record: 1.73 s per tile on 32 threads, 3.1 on 64, 7.2 on 128 - profiles/r4_final/bench.json)
         cex.threads = cth
-        csamples = []
-        for k in picks[:3]:
-            t0 = time.perf_counter(); one_tile(k); csamples.append((time.perf_counter() - t0) * n)
+        ex = cex
+        one_tile(0)
+        t0 = time.perf_counter(); one_tile(n // 2); cframe = (time.perf_counter() - t0) * n
         ex = ex_torch
-        cframe = sorted(csamples)[1]
-        cpp = {"value": round(OUT_MPIX / cframe, 4), "unit": "MPix/s", "cores": cth, "seconds_per_tile_by_threads": {str(k): round(v, 3) for k, v in ctried.items()},
-               "sample": f"oracle/cnet (C++ loops, OpenMP) + numpy pipeline, 3 tiles T={TILE} on {cth} threads, median extrapolated to {n} tiles/frame ({cframe:.0f} s/frame)"}
+        cpp = {"value": round(OUT_MPIX / cframe, 4), "unit": "MPix/s", "cores": cth,
+               "sample": f"oracle/cnet (C++ loops, OpenMP) + numpy pipeline, 1 tile T={TILE} on {cth} threads after one warm-up tile, extrapolated to {n} tiles/frame ({cframe:.0f} s/frame); a second oracle, not the baseline"}
         cex.close()
     except Exception as e:                                       # the figure is an extra: the torch-operator leg above is the baseline on record
         cpp = {"error": str(e)[:200]}
@@ -168,6 +169,46 @@ def cpu_baseline(work: str, tile_out: int) -> dict:
             "sample": f"oracle (torch-CPU fp32 ONNX executor + numpy pipeline), 3 samples of {len(picks) // 3} tiles T={TILE} each on {threads} threads "
                       f"(host shows {host} CPUs, {usable} usable; one tile took " + ", ".join(f"{v:.2f} s on {k}" for k, v in tried.items()) + f" threads; 81.4 s on all 256 threads of such a box, profiles/r4_final/bench_cpu_all_cores_probe.json), "
                       f"median extrapolated to {n} tiles/frame ({frame_s:.0f} s/frame)"}
+
+
+def rank_record(rank: int, local_rank: int, pci_bus_id, pinned) -> dict:
+    """What one rank reports about where it runs (shard.certify turns the ranks' records into the line's `placement`)."""
+    import socket
+    return {"rank": rank, "local_rank": local_rank, "host": socket.gethostname(), "pid": os.getpid(), "pci_bus_id": pci_bus_id, "cpus": len(pinned) or None}
+
+
+def rehearsal_prefix(placement: dict) -> str:
+    """'' for a run with one GPU per rank; otherwise the words that keep the line from reading like an N-GPU result."""
+    if placement["one_gpu_per_rank"]:
+        return ""
+    return f"REHEARSAL ({placement['n_ranks']} ranks on {placement['distinct_gpus']} GPU{'' if placement['distinct_gpus'] == 1 else 's'}): "
+
+
+def host_rehearsal(a, dist, rank: int, world: int, json_out, placement: dict) -> int:
+    """--host-rehearsal: the protocol of the frames mode - barrier, K timed steps, barrier, max over ranks, per-rank spread, rank 0 prints the line - with a
+    sleep where a rank would render.  Nothing is measured; the line carries value = null."""
+    import shard
+    shard.barrier(dist)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        time.sleep(0.002 * (1 + rank % 3))
+    shard.barrier(dist)
+    wall = time.perf_counter() - t0
+    wall_max = shard.max_over_ranks(wall, dist)
+    walls = shard.gather_objects(wall, dist)
+    frames = shard.gather_objects(shard.frames_for_rank(a.steps * world, rank, world), dist)
+    if rank == 0:
+        line = {"metric": rehearsal_prefix(placement) + "host rehearsal of the rank protocol: no GPU work, nothing measured", "value": None, "unit": "MPix/s",
+                "n_gpus": placement["distinct_gpus"], "n_ranks": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(wall_max * 1e3 / a.steps, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": None, "data": "none",
+                "config": {"workload": "none (sleeps)", "mode": a.mode, "frames_rendered": sorted(f for fs in frames for f in fs),
+                           "per_rank_ms_per_step": shard.spread([w * 1e3 / a.steps for w in walls])},
+                "placement": placement}
+        print(json.dumps(line), file=json_out, flush=True)
+    json_out.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
 
 
 def bench_shards_one_process(a) -> int:
@@ -212,21 +253,23 @@ def bench_shards_one_process(a) -> int:
     n = pkg.calculate_tiles(FRAME_W, FRAME_H, FRAME_W * SCALE, FRAME_H * SCALE, TILE, engs[0].output_tile_size, SCALE, (BLEND, BLEND))[0]
     parts = [pkg.shard_plan(FRAME_W, FRAME_H, FRAME_W * SCALE, FRAME_H * SCALE, TILE, engs[0].output_tile_size, SCALE, (BLEND, BLEND), p, a.gpus) for p in range(a.gpus)]
     fps = a.steps / wall
-    line = {"metric": f"upscaled MPix/s, one {FRAME_W}x{FRAME_H} frame over N engines ({MODEL} fp16)", "value": round(fps * OUT_MPIX, 2), "unit": "MPix/s", "n_gpus": a.gpus,
+    import socket
+    placement = shard.certify([rank_record(d, d, pkg.device_pci_bus_id(d), set()) for d in range(a.gpus)], os.environ.get("W2X_DEVICE_MAP"))      # (one record per ENGINE here)
+    line = {"metric": rehearsal_prefix(placement) + f"upscaled MPix/s, one {FRAME_W}x{FRAME_H} frame over N engines ({MODEL} fp16)", "value": round(fps * OUT_MPIX, 2), "unit": "MPix/s",
+            "n_gpus": placement["distinct_gpus"], "n_ranks": 1, "n_engines": a.gpus, "placement": placement,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(wall * 1e3 / a.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{CONFIG_NAME}: {MODEL} scale{SCALE} noise{NOISE} batch{BATCH} tile{TILE} fp16{' +TTA' if TTA else ''}, {FRAME_W}x{FRAME_H} frame, blend={BLEND} ({n} tiles); host frame in -> host frame out",
                        "mode": "shards1p", "parallelism": f"one frame in {a.gpus} contiguous tile ranges (renderSharded), every tile computed once, seam bands copied device to device, no collectives; one process drives all engines",
                        "tiles_per_engine": [c for _, c, _, _ in parts], "speedup_bound": round(n / max(c for _, c, _, _ in parts), 2),
-                       "one_engine_render_ms": round(wall1 * 1e3 / a.steps, 3), "speedup_measured": round(wall1 / wall, 3),
-                       "device_map": os.environ.get("W2X_DEVICE_MAP")}}
+                       "one_engine_render_ms": round(wall1 * 1e3 / a.steps, 3), "speedup_measured": round(wall1 / wall, 3)}}
     print(json.dumps(line), flush=True)
     for e in engs:
         e.close()
     return 0
 
 
-def bench_shards_ranks(a, pkg, eng, dist, rank, local_rank, world, json_out, pinned) -> int:
+def bench_shards_ranks(a, pkg, eng, dist, rank, local_rank, world, json_out, pinned, placement) -> int:
     """--mode shards: ONE frame over N ranks, one process per GPU, every tile computed once.  Per step: rank r computes its contiguous range of the tile
     order into its slab (w2x_shard_compute), the ranks exchange the IPC handles of their slabs (a gloo all_gather of 64 bytes each - also the barrier that says
     every slab is complete), rank r opens the slabs of the parts in front of it, copies their seam bands device to device, composes its canvas cells and
@@ -235,7 +278,17 @@ def bench_shards_ranks(a, pkg, eng, dist, rank, local_rank, world, json_out, pin
     import shard
     frame = synthetic_frame(0)
     oh, ow = FRAME_H * SCALE, FRAME_W * SCALE
-    shm = f"/dev/shm/w2x_shards_{os.environ.get('MASTER_PORT', '0')}.u8"      # the frame all ranks write their cells into (one launch = one port)
+    # the frame all ranks write their cells into: named after rank 0's process, so that two launches at once never share (or unlink) one file
+    shm = f"/dev/shm/w2x_shards_{placement['ranks'][0]['pid']}_{os.environ.get('MASTER_PORT', '0')}.u8"
+    # where rank q's slab lives AS THIS PROCESS SEES IT: the local ordinal whose PCI address is rank q's GPU, -1 when that card is not a device of this
+    # process (per-rank *_VISIBLE_DEVICES isolation): the seam bands then travel as whole slots by hipMemcpyDefault instead of peer copies
+    mine = {}
+    for d in range(64):
+        bus = pkg.device_pci_bus_id(d)
+        if bus is None:
+            break
+        mine.setdefault(bus, d)
+    peer_device = [mine.get(r.get("pci_bus_id"), -1) for r in placement["ranks"]]
     if rank == 0:
         with open(shm, "wb") as f:
             f.truncate(oh * ow * 3)
@@ -259,8 +312,7 @@ def bench_shards_ranks(a, pkg, eng, dist, rank, local_rank, world, json_out, pin
                 if not opened[handles[q]]:
                     raise SystemExit(f"rank {rank}: hipIpcOpenMemHandle of rank {q}'s slab failed")
             slabs[q] = opened[handles[q]]
-        # every logical device of a W2X_DEVICE_MAP rehearsal is the same card; on a real node rank q's slab lives on device q
-        if not eng.shard_finish(out, rank, world, slabs, devices=list(range(world))):
+        if not eng.shard_finish(out, rank, world, slabs, devices=peer_device):
             raise SystemExit("shard_finish failed: " + eng.last_error())
         shard.barrier(dist)
 
@@ -282,14 +334,15 @@ def bench_shards_ranks(a, pkg, eng, dist, rank, local_rank, world, json_out, pin
         n = pkg.calculate_tiles(FRAME_W, FRAME_H, ow, oh, TILE, eng.output_tile_size, SCALE, (BLEND, BLEND))[0]
         parts = [pkg.shard_plan(FRAME_W, FRAME_H, ow, oh, TILE, eng.output_tile_size, SCALE, (BLEND, BLEND), p, world) for p in range(world)]
         fps = a.steps / wall
-        line = {"metric": f"upscaled MPix/s, one {FRAME_W}x{FRAME_H} frame over N ranks ({MODEL} fp16)", "value": round(fps * OUT_MPIX, 2), "unit": "MPix/s", "n_gpus": world,
+        line = {"metric": rehearsal_prefix(placement) + f"upscaled MPix/s, one {FRAME_W}x{FRAME_H} frame over N ranks ({MODEL} fp16)", "value": round(fps * OUT_MPIX, 2), "unit": "MPix/s",
+                "n_gpus": placement["distinct_gpus"], "n_ranks": world, "placement": placement,
                 "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(wall * 1e3 / a.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                 "dtype": "f16", "data": "synthetic",
                 "config": {"workload": f"{CONFIG_NAME}: {MODEL} scale{SCALE} noise{NOISE} batch{BATCH} tile{TILE} fp16{' +TTA' if TTA else ''}, {FRAME_W}x{FRAME_H} frame, blend={BLEND} ({n} tiles); host frame in -> host frame out (a /dev/shm mapping shared by the ranks)",
                            "mode": "shards", "parallelism": f"one frame in {world} contiguous tile ranges, one process per GPU, every tile computed once; seam bands copied device to device out of the neighbours' slabs (hipIpc handles exchanged over gloo), no data-path collective",
                            "tiles_per_rank": [c for _, c, _, _ in parts], "speedup_bound": round(n / max(c for _, c, _, _ in parts), 2),
                            "one_rank_render_ms": round(wall1 * 1e3 / a.steps, 3), "speedup_measured": round(wall1 / wall, 3), "bytes_equal_render": same,
-                           "rank0_cpus": len(pinned) or None, "device_map": os.environ.get("W2X_DEVICE_MAP")}}
+                           "rank0_cpus": len(pinned) or None, "peer_device_ordinals_seen_by_rank0": peer_device}}
         print(json.dumps(line), file=json_out, flush=True)
         if not same:
             print("[w2x] the sharded frame differs from render()", file=sys.stderr)
@@ -317,7 +370,7 @@ def spawn_ranks(a) -> int:
     import subprocess
     import shard
     have = len(shard.gpu_nodes())                    # KFD topology in sysfs: this parent makes no HIP / torch.cuda call at all
-    if have < a.gpus and not os.environ.get("W2X_DEVICE_MAP"):
+    if have < a.gpus and not os.environ.get("W2X_DEVICE_MAP") and not a.host_rehearsal:
         raise SystemExit(f"--gpus {a.gpus} but this node shows {have} GPU(s); refusing to report n_gpus != requested")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
@@ -349,6 +402,9 @@ def main():
                     help="diagnostic: frame content (flat = one grey level, noise = uniform random bytes); `value` is quoted on synthetic")
     ap.add_argument("--op-times", action="store_true", help="print HIP-event time per plan op (one frame) to stderr")
     ap.add_argument("--work", default=os.environ.get("W2X_BENCH_WORK", "/tmp/w2x_bench"))
+    ap.add_argument("--host-rehearsal", action="store_true",
+                    help="the rank protocol only (spawn or launcher environment, gloo rendezvous, barriers, max-reduction, placement records, the one JSON line) with every engine "
+                         "call replaced by a sleep: runs without a GPU, prints value = null and n_gpus = 0.  What tests/test_shard_gloo.py runs at 2 and 8 ranks")
     a = ap.parse_args()
     select_config(a.config)
 
@@ -375,11 +431,13 @@ def main():
     dmap = os.environ.get("W2X_DEVICE_MAP")
     phys = int(dmap.split(",")[local_rank]) if dmap and local_rank < len(dmap.split(",")) else local_rank
     import torch
-    import __graft_entry__ as g
-    import synth_models as sm
-    pkg = g.package()
+    pkg = None
+    if not a.host_rehearsal:
+        import __graft_entry__ as g
+        import synth_models as sm
+        pkg = g.package()
     pinned = set()
-    if world > 1 or os.environ.get("W2X_PIN_NUMA"):
+    if pkg and (world > 1 or os.environ.get("W2X_PIN_NUMA")):
         # the CPUs of THIS rank's GPU by its PCI address as the HIP runtime reports it (no assumption about ordinal orders); nothing is allocated yet
         pinned = shard.pin_to_gpu_numa(phys, pci_bus_id=pkg.device_pci_bus_id(local_rank))
 
@@ -391,6 +449,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")              # CPU tensors only: PyTorch's HIP runtime is never initialised beside /opt/rocm's
+
+    # where every rank runs: gathered once, printed with the line (shard.certify)
+    placement = shard.certify(shard.gather_objects(rank_record(rank, local_rank, pkg.device_pci_bus_id(local_rank) if pkg else None, pinned), dist), dmap)
+    if a.host_rehearsal:
+        raise SystemExit(host_rehearsal(a, dist, rank, world, json_out, placement))
 
     work = os.path.join(a.work, f"rank{rank}")
     path = sm.model_path(work, MODEL, SCALE, NOISE)
@@ -408,7 +471,7 @@ def main():
             print("[w2x] " + m, file=sys.stderr)
 
     if a.mode == "shards":
-        raise SystemExit(bench_shards_ranks(a, pkg, eng, dist, rank, local_rank, world, json_out, pinned))
+        raise SystemExit(bench_shards_ranks(a, pkg, eng, dist, rank, local_rank, world, json_out, pinned, placement))
     strips = a.mode == "strips"
     my_frames = [0] if strips else shard.frames_for_rank(a.steps * world, rank, world)   # frame f -> rank f mod N; each rank renders K frames
     frame = synthetic_frame(my_frames[0])
@@ -440,10 +503,11 @@ def main():
     if ms <= 0:
         raise SystemExit("bench failed: " + eng.last_error())
     wall_max = shard.max_over_ranks(wall, dist)
+    walls = shard.gather_objects(wall, dist)
 
     # ---- the same K frames through the whole render() contract (host buffer in, host buffer out), copies overlapped on side
     # streams (renderSequence over page-locked buffers, a ring of 3 output frames); every rank, same barriers, max over ranks
-    full_wall_max = None
+    full_wall_max, full_wall = None, None
     if not strips:
         try:
             pf = eng.alloc_host(frame.shape); pf[...] = frame                    # page-locked frame buffers owned by the engine
@@ -453,7 +517,8 @@ def main():
             t0 = time.perf_counter()
             eng.render_sequence([pf] * a.steps, outs=[ring[k % 3] for k in range(a.steps)])
             sync_all()
-            full_wall_max = shard.max_over_ranks(time.perf_counter() - t0, dist)
+            full_wall = time.perf_counter() - t0
+            full_wall_max = shard.max_over_ranks(full_wall, dist)
             if not np.array_equal(ring[(a.steps - 1) % 3], out):
                 raise RuntimeError("renderSequence and render disagree")
             for hb in [pf] + ring:
@@ -463,6 +528,7 @@ def main():
                 raise
             print(f"[w2x] full-path measurement skipped: {e}", file=sys.stderr)
         render_once()                        # restore the single-frame state profile_frame() works on
+    full_walls = shard.gather_objects(full_wall, dist)
 
     prof = eng.profile_frame()
     desc = pkg.describe_plan(path, eng.pass_tiles, TILE).splitlines()[2:]
@@ -487,7 +553,7 @@ def main():
         live = n_tiles / eng.pass_tiles          # the zero-pad slots of the last batch are not computed (plan FLOPs are per pass of pass_tiles)
         # dominant kernel of the frame: plan ops grouped by the kernel that serves them, by summed HIP-event time
         # (measured on the compute stream by w2x_profile_frame / w2x_op_times)
-        symbols = {("swinattn", 96): "swin_attn96_kernel", ("swinattn", 192): "swin_attn192_kernel" if os.environ.get("W2X_A192_TWO_PER_CU") else "swin_attn192u_kernel",
+        symbols = {("swinattn", 96): "swin_attn96_kernel", ("swinattn", 192): "swin_attn192u_kernel",
                    ("mlp", 96): "mlp96q_kernel", ("mlp", 192): "mlp2q_kernel<192,4>"}
         groups = {}
         for line, t in zip(desc, op_ms):
@@ -524,7 +590,7 @@ def main():
                                             "gemm_kernel / pixgemm kernels") if dom[0] == "gemm" else dom[0]),
                 "plan_ops": dom[1] if isinstance(dom[1], str) else None,
                 "launches_per_frame": dom_n, "avg_launch_us": round(dom_ms * 1e3 / dom_n, 2),
-                "launch_note": "HIP events around each launch with every pass in one piece on one stream (the engine's profiling pass, = W2X_NO_SPLIT=1: a launch covers all live tiles); the timed region of `value` runs each pass as two tile groups on two streams",
+                "launch_note": "HIP events around each launch with every pass in one piece on one stream (the engine's profiling pass, = W2X_GROUPS=1: a launch covers all live tiles); the timed region of `value` runs each pass as two tile groups on two streams",
                 "algorithmic_gflop_per_launch": round(dom_flop / dom_n / 1e9, 3),
                 "algorithmic_mbyte_per_launch": round(dom_bytes / dom_n / 1e6, 3),
                 "other_roof": {"unit": "TFLOP/s" if hbm_bound else "GB/s", "achieved": round(tflops if hbm_bound else gbs, 2),
@@ -549,8 +615,8 @@ def main():
             except Exception:
                 pass
         line = {
-            "metric": "upscaled MPix/s, 1080p->4K swin_unet/art fp16" if CONFIG_NAME == "configs[2]" else f"upscaled MPix/s, {FRAME_W}x{FRAME_H} x{SCALE} {MODEL} fp16{' +TTA' if TTA else ''}",
-            "value": round(fps * OUT_MPIX, 2), "unit": "MPix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "metric": rehearsal_prefix(placement) + ("upscaled MPix/s, 1080p->4K swin_unet/art fp16" if CONFIG_NAME == "configs[2]" else f"upscaled MPix/s, {FRAME_W}x{FRAME_H} x{SCALE} {MODEL} fp16{' +TTA' if TTA else ''}"),
+            "value": round(fps * OUT_MPIX, 2), "unit": "MPix/s", "n_gpus": placement["distinct_gpus"], "n_ranks": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(wall_max * 1e3 / a.steps, 3), "higher_is_better": True, "scaling": "strong" if strips else "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic" if a.frame == "synthetic" else "synthetic (" + a.frame + " frame: diagnostic)",
             "config": {"workload": f"{CONFIG_NAME}: {MODEL} scale{SCALE} noise{NOISE} batch{BATCH} tile{TILE} fp16{' +TTA' if TTA else ''}, {FRAME_W}x{FRAME_H} frame, blend={BLEND} "
@@ -558,16 +624,26 @@ def main():
                        "frames_per_s": round(fps, 3), "device_ms_per_frame": round(ms, 3), "frames_per_rank": a.steps,
                        "parallelism": (f"one frame in {world} tile-column strips (renderStrip), no collectives" if strips else f"frame-sharded x{world}, no collectives") + "; timing barrier over gloo",
                        "mode": a.mode, "rank0_cpus": len(pinned) or None,
+                       "per_rank_resident_ms_per_step": shard.spread([w * 1e3 / a.steps for w in walls]),
                        "render_call_ms_pageable": round(pcie_ms_one, 2),
                        "full_path_ms_per_frame": None if full_wall_max is None else round(full_wall_max * 1e3 / a.steps, 3),
                        "full_path_frames_per_s": None if full_wall_max is None else round(a.steps * world / full_wall_max, 3),
                        "full_path_mpix_per_s": None if full_wall_max is None else round(a.steps * world / full_wall_max * OUT_MPIX, 2),
                        "full_path_note": "host frame in -> host frame out for all K frames on every rank (renderSequence over engine-allocated page-locked buffers, H2D/D2H on side streams); max over ranks",
                        "tiles_per_network_pass": eng.pass_tiles,
-                       "tile_groups_per_pass": 1 if os.environ.get("W2X_NO_SPLIT") else int(os.environ.get("W2X_GROUPS", "2")),
+                       "tile_groups_per_pass": int(os.environ.get("W2X_GROUPS", "2")),
                        "algorithmic_tflop_per_frame": round(eng.plan_flops * live / 1e12, 4),
                        "families_ms_per_frame": {k: round(v[0], 3) for k, v in prof.items() if k != "frame_ms"}},
             "roofline": roof,
+            "placement": placement,
+            # the path the reference's render() is (img2img_render.cpp:226,344): host frame in -> host frame out, PCIe included.  Not `value` (docstring).
+            "host_to_host": None if full_wall_max is None else {
+                "ms_per_frame": round(full_wall_max * 1e3 / a.steps, 3), "frames_per_s": round(a.steps * world / full_wall_max, 3),
+                "mpix_per_s": round(a.steps * world / full_wall_max * OUT_MPIX, 2), "unit": "MPix/s",
+                "per_rank_ms_per_frame": shard.spread([None if w is None else w * 1e3 / a.steps for w in full_walls]),
+                "vs_resident": round(wall_max / full_wall_max, 4),
+                "one_synchronous_render_call_ms": round(pcie_ms_one, 2),
+                "how": "all K frames of every rank through renderSequence over engine-allocated page-locked buffers, H2D / D2H on side streams; same barriers, max over ranks"},
         }
         if not a.no_cpu_baseline and world == 1 and (a.config == 3 or a.cpu_baseline):
             line["cpu_baseline"] = cpu_baseline(a.work, eng.output_tile_size)

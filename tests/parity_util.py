@@ -46,7 +46,10 @@ def network_report(name, y, ref16, ref32=None):
     ulp_ref = np.where(top, np.exp2(np.floor(np.log2(np.maximum(np.abs(ref16), 2.0 ** -14))) - 10), np.inf)
     rec = {"test": name, "kind": "network", "max_abs": float(d.max()), "mean_abs": float(d.mean()),
            "max_ulp16": float(d.max() / ULP16), "p999_ulp16": float(np.quantile(d, 0.999) / ULP16),
-           "max_ulp_of_ref_top_binade": float((d / ulp_ref).max()) if top.any() else 0.0}
+           "max_ulp_of_ref_top_binade": float((d / ulp_ref).max()) if top.any() else 0.0,
+           # how far from north_star's "within 1 ULP fp16 per pixel" the outputs are, as fractions of the outputs (the distance itself cannot be
+           # measured against TensorRT here; these are against the oracle's model of an fp16 engine, and below against fp32)
+           "frac_within_1_ulp16": float((d <= ULP16 * (1 + 1e-9)).mean()), "frac_within_2_ulp16": float((d <= 2 * ULP16 * (1 + 1e-9)).mean())}
     if ref32 is not None:
         e32 = y.astype(np.float64) - ref32.astype(np.float64)
         o32 = ref16.astype(np.float64) - ref32.astype(np.float64)
@@ -58,6 +61,8 @@ def network_report(name, y, ref16, ref32=None):
         rec.update({"max_ulp16_vs_fp32_oracle": float(d32.max() / ULP16), "mean_abs_vs_fp32_oracle": float(d32.mean()),
                     "p999_ulp16_vs_fp32_oracle": float(np.quantile(d32, 0.999) / ULP16),
                     "rms_ulp16_vs_fp32_oracle": float(np.sqrt(np.mean(e32 ** 2)) / ULP16),
+                    "frac_within_1_ulp16_vs_fp32_oracle": float((d32 <= ULP16).mean()), "frac_within_2_ulp16_vs_fp32_oracle": float((d32 <= 2 * ULP16).mean()),
+                    "fp16_oracle_frac_within_1_ulp16_of_fp32_oracle": float((o <= ULP16).mean()),
                     "fp16_oracle_vs_fp32_oracle_max_ulp16": float(o.max() / ULP16),
                     "fp16_oracle_vs_fp32_oracle_p999_ulp16": float(np.quantile(o, 0.999) / ULP16),
                     "fp16_oracle_vs_fp32_oracle_rms_ulp16": float(np.sqrt(np.mean(o32 ** 2)) / ULP16),

@@ -30,7 +30,7 @@ pytestmark = pytest.mark.gpu
 #    (parity.jsonl `straddle_at_worst`: e.g. [-1.6, +1.4] at the one element that measures 3.00 on swin_unet/art T112) and quantised in whole / half ULPs.  Its bound is
 #    therefore the sum of the two, not a statement about the engine: 3.5 (measured 1.0-3.0).  Round 3 asserted 3.0 on a measured 3.00.
 NET_MAX_ULP16 = 3.5
-NET_MAX_ULP16_UNFUSED = 3.5   # the un-fused operator path (48-channel graphs, W2X_NO_FUSE_ATTN): measured 2.0-3.0
+NET_MAX_ULP16_UNFUSED = 3.5   # the un-fused operator path (48-channel graphs, debug switch no_fuse_attn): measured 2.0-3.0
 NET_MAX_ULP16_VS_FP32 = 3.0   # measured <= 2.52 (T = 256: the maximum over 2.7 M outputs)
 NET_MEAN_ABS = 2.2e-4    # measured <= 1.7e-4
 FRAME_MAX_LSB = 1        # u8; measured 1 on every case
@@ -160,13 +160,12 @@ def test_opset13_graph_with_decomposed_layernorm_runs_on_the_fused_kernels(pkg, 
 def test_unfused_attention_core_on_full_width_graphs(pkg, onnx_model, monkeypatch):
     """Graphs whose transformer shapes the fused kernels do not cover keep the QKV / proj linears on the general MFMA GEMM and run
     the attention core on k_attn.hip: attn_mfma_kernel (head sizes 8 / 16 / 32 on v_mfma_f32_16x16x16_f16; the 48-channel test
-    graphs use head size 8 everywhere in this file) or, under W2X_ATTN_VALU, the lane-per-query kernel it replaced.  Here the
-    full-width graph is forced down that path (W2X_NO_FUSE_ATTN at build time): head sizes 16 and 32, shifted windows, all
+    graphs use head size 8 everywhere in this file) or, under the debug switch attn_valu, the lane-per-query kernel it replaced.  Here the
+    full-width graph is forced down that path (debug switch no_fuse_attn at build time, csrc/switches.h): head sizes 16 and 32, shifted windows, all
     mask classes, against the same oracle and bounds as the fused kernels."""
     path = onnx_model("swin_unet/art", 4, 1, 64, noise=1)
-    monkeypatch.setenv("W2X_NO_FUSE_ATTN", "1")
-    eng = make_engine(pkg, path, 1, 64, 4)
-    monkeypatch.delenv("W2X_NO_FUSE_ATTN")
+    with pkg.debug_switches(no_fuse_attn=1):
+        eng = make_engine(pkg, path, 1, 64, 4)
     rng = np.random.default_rng(11)
     x = rng.random((1, 3, 64, 64), dtype=np.float32).astype(np.float16).astype(np.float32)
     y = eng.infer(x)
@@ -358,6 +357,29 @@ def test_rolling_sequence_of_frames_matches_render(pkg, onnx_model, monkeypatch,
     assert all(np.array_equal(a, b) for a, b in zip(outs[True], outs[False]))
 
 
+def test_an_engine_loaded_again_rolls_and_replays_like_a_fresh_one(pkg, onnx_model):
+    """load() on an engine that is already loaded releases everything the first load owned (img2img_load.cpp:149-154 resets engine and context the same way).
+    Round 4's release() freed the second tile slab of a rolling sequence but kept its capacity, so after a re-load the rolling frames (render_sequence,
+    bench_resident) swapped a null slab in: a device fault.  Here: load, render, roll, load again (other batch size: another plan), render, roll, replay -
+    every frame is the bytes of a fresh engine's, and bench_resident() before any render() of the new load has no frame to replay."""
+    path = onnx_model("swin_unet/art", 4, 2, 64)
+    frames = [smooth_frame(200, 260, 90 + k) for k in range(4)]
+    fresh = make_engine(pkg, path, 2, 64, 4)
+    want = [fresh.render(f) for f in frames]
+    fresh.close()
+    eng = make_engine(pkg, path, 2, 64, 4)
+    assert all(np.array_equal(a, b) for a, b in zip(eng.render_sequence(frames), want))
+    assert eng.bench_resident(3) > 0
+    for again in range(2):
+        assert eng.load(path, pkg.RenderConfig(batchSize=2, height=64, width=64, scaling=4)), eng.last_error()
+        assert eng.bench_resident(2) < 0                                       # nothing rendered since this load
+        assert all(np.array_equal(a, b) for a, b in zip(eng.render_sequence(frames), want)), again
+        assert np.array_equal(eng.render(frames[1]), want[1])
+        assert eng.bench_resident(4) > 0 and eng.bench_resident(3) > 0
+        assert np.array_equal(eng.render(frames[2]), want[2])
+    eng.close()
+
+
 @pytest.mark.parametrize("pinned,small", [(False, True), (True, True), (True, False)])
 def test_frame_sequence_with_overlapped_copies_matches_render(pkg, onnx_model, pinned, small):
     """renderSequence: upload / compute / download of consecutive frames overlap on three streams (two device buffers, events);
@@ -477,18 +499,18 @@ def test_engines_on_their_own_host_threads(pkg, onnx_model, monkeypatch):
 ])
 def test_shape_specialised_kernels_agree_with_the_general_kernel(pkg, onnx_model, monkeypatch, model, scale, tile, kernels):
     """Every launch that a shape-specialised kernel takes (k_stem / k_conv3 / k_conv3h / k_conv48 / k_pixgemm) is repeated on
-    gemm_kernel, the implicit-GEMM kernel that covers all of them (W2X_PIXGEMM_CHECK, engine.cpp): the two outputs may differ by
+    gemm_kernel, the implicit-GEMM kernel that covers all of them (W2X_CHECK_GENERAL, engine.cpp): the two outputs may differ by
     the rounding of one fp16 value (different summation order; k_conv3h rounds once where gemm_kernel rounds before and after the
     skip add; the streaming projections round before their skip add, gemm_kernel after) - 2^-7 for activations in [8, 16), 2^-6 for the
     few in [16, 32) - and never by more."""
     path = onnx_model(model, scale, 2, tile, noise=1)
-    monkeypatch.setenv("W2X_PIXGEMM_CHECK", "1")
+    monkeypatch.setenv("W2X_CHECK_GENERAL", "1")
     eng = pkg.Img2Img()
     lines = []
     eng.setMessageCallback(lambda sev, m: lines.append(m) if "pixgemm check" in m else None)
     assert eng.build(path, pkg.BuildConfig.fixed(2, tile)), eng.last_error()
     assert eng.load(path, pkg.RenderConfig(batchSize=2, height=tile, width=tile, scaling=scale)), eng.last_error()
-    monkeypatch.delenv("W2X_PIXGEMM_CHECK")
+    monkeypatch.delenv("W2X_CHECK_GENERAL")
     eng.infer(np.random.default_rng(5).random((2, 3, tile, tile), dtype=np.float32))
     eng.close()
     import re
@@ -543,16 +565,15 @@ def test_fp32_engine_matches_the_fp32_oracle(pkg, onnx_model, model, scale, batc
 def test_folded_squeeze_excite_gates_equal_the_in_place_pass(pkg, onnx_model, monkeypatch):
     """cunet's squeeze-excite gates are folded into their consumers (the 1x1 / 2x2 (transposed) convolutions scale their operand
     on load, the skip add scales its residual: lower.cpp pending_gate) with the rounding of the separate in-place pass they
-    replace (W2X_NO_SE_FOLD=1 keeps that pass): the network outputs and the frames are bit-identical."""
+    replace (the debug switch no_se_fold keeps that pass): the network outputs and the frames are bit-identical."""
     path = onnx_model("cunet/art", 2, 2, 96, noise=1)
     x = np.random.default_rng(9).random((2, 3, 96, 96), dtype=np.float32)
     frame = smooth_frame(150, 170, 4)
     outs = []
     for nofold in (True, False):
-        if nofold: monkeypatch.setenv("W2X_NO_SE_FOLD", "1")
-        else: monkeypatch.delenv("W2X_NO_SE_FOLD")
-        assert (" scale t" in pkg.describe_plan(path, 2, 96)) == nofold
-        eng = make_engine(pkg, path, 2, 96, 2)
+        with pkg.debug_switches(no_se_fold=int(nofold)):
+            assert (" scale t" in pkg.describe_plan(path, 2, 96)) == nofold
+            eng = make_engine(pkg, path, 2, 96, 2)
         outs.append((eng.infer(x), eng.render(frame)))
         eng.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
@@ -561,14 +582,14 @@ def test_folded_squeeze_excite_gates_equal_the_in_place_pass(pkg, onnx_model, mo
 @pytest.mark.parametrize("model,scale,tile,tta", [("cunet/art", 2, 64, False), ("swin_unet/art", 4, 64, True)])
 def test_two_tile_groups_on_two_streams_are_bit_identical_to_one(pkg, onnx_model, monkeypatch, model, scale, tile, tta):
     """A pass is cut into two tile groups that run side by side on two streams, each in its own half of the activation arena
-    (engine.cpp run_frame); W2X_NO_SPLIT=1 keeps the pass in one piece.  Tiles never exchange data: same bytes, also through the
+    (engine.cpp run_frame); W2X_GROUPS=1 keeps the pass in one piece.  Tiles never exchange data: same bytes, also through the
     captured graphs (three renders per engine) and for an odd number of live tiles."""
     path = onnx_model(model, scale, 2, tile, noise=1)
     frame = smooth_frame(150, 170, 8)
     outs = []
     for nosplit in (True, False):
-        if nosplit: monkeypatch.setenv("W2X_NO_SPLIT", "1")
-        else: monkeypatch.delenv("W2X_NO_SPLIT")
+        if nosplit: monkeypatch.setenv("W2X_GROUPS", "1")
+        else: monkeypatch.delenv("W2X_GROUPS")
         eng = make_engine(pkg, path, 2, tile, scale, tta=tta)
         rs = [eng.render(frame) for _ in range(3)]
         assert np.array_equal(rs[0], rs[1]) and np.array_equal(rs[0], rs[2])
@@ -580,7 +601,7 @@ def test_two_tile_groups_on_two_streams_are_bit_identical_to_one(pkg, onnx_model
 @pytest.mark.parametrize("tile,batch,shape,tta", [(64, 2, (150, 170), False), (64, 2, (101, 119), True), (256, 4, (300, 420), False)])
 def test_image_head_folded_into_the_last_mlp_is_bit_identical(pkg, onnx_model, monkeypatch, tile, batch, shape, tta):
     """The plan's last MLP and the image head behind it (Linear 96 -> 4x4 sub-pixels x 4 channels, Clip, DepthToSpace) run as ONE launch
-    (engine.cpp fuse_head, k_mlp96q.hip): the 96-channel map between them is neither stored nor read back.  W2X_NO_FUSE_HEAD=1 keeps the
+    (engine.cpp fuse_head, k_mlp96q.hip): the 96-channel map between them is neither stored nor read back.  The debug switch no_fuse_head keeps the
     two launches.  Same sums in the same order, so infer() - whose output tensor lives in the activation arena, where the head's output
     must not be given the memory of the MLP's input - and render() - which writes into the frame slab - return the same bytes, also
     through captured graphs and two tile groups; the tile-256 engine makes every wave of the persistent MLP kernel walk several tiles."""
@@ -589,9 +610,8 @@ def test_image_head_folded_into_the_last_mlp_is_bit_identical(pkg, onnx_model, m
     x = np.random.default_rng(31).random((batch, 3, tile, tile), dtype=np.float32)
     outs = []
     for nofuse in (True, False):
-        if nofuse: monkeypatch.setenv("W2X_NO_FUSE_HEAD", "1")
-        else: monkeypatch.delenv("W2X_NO_FUSE_HEAD")
-        eng = make_engine(pkg, path, batch, tile, 4, tta=tta)
+        with pkg.debug_switches(no_fuse_head=int(nofuse)):
+            eng = make_engine(pkg, path, batch, tile, 4, tta=tta)
         ys = [eng.infer(x) for _ in range(2)]
         rs = [eng.render(frame) for _ in range(3)]
         assert np.array_equal(ys[0], ys[1]) and np.array_equal(rs[0], rs[1]) and np.array_equal(rs[0], rs[2])
@@ -601,24 +621,20 @@ def test_image_head_folded_into_the_last_mlp_is_bit_identical(pkg, onnx_model, m
     assert np.array_equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("tile,batch,shape,tta,persistent", [(64, 2, (150, 170), False, False), (64, 3, (101, 119), True, False), (256, 4, (300, 420), False, False),
-                                                             (64, 3, (150, 170), False, True)])
-def test_stem_folded_into_the_patch_convolution_is_bit_identical(pkg, onnx_model, monkeypatch, tile, batch, shape, tta, persistent):
+@pytest.mark.parametrize("tile,batch,shape,tta", [(64, 2, (150, 170), False), (64, 3, (101, 119), True), (256, 4, (300, 420), False)])
+def test_stem_folded_into_the_patch_convolution_is_bit_identical(pkg, onnx_model, monkeypatch, tile, batch, shape, tta):
     """swin_unet's first two ops - the stem (3x3, 4-halves-per-pixel tile -> 48 channels) and the patch convolution behind it - run as ONE launch
     (engine.cpp fuse_stem, k_conv48.hip conv48_kernel<true>): every workgroup computes the halo tile it needs from the input tile with the stem
-    kernel's own instruction sequence, and the 48-channel map between the two is neither stored nor read.  W2X_NO_FUSE_STEM=1 keeps the two
+    kernel's own instruction sequence, and the 48-channel map between the two is neither stored nor read.  The debug switch no_fuse_stem keeps the two
     launches.  Same products in the same order: infer() and render() return the same bytes, through captured graphs and two tile groups (the
-    input tile must outlive the stem by one op in the arena); the odd batch leaves a group with one tile.  `persistent`: the same pair as the
-    weight-resident persistent kernel (k_conv48p.hip, W2X_CONV48_PERSIST=1 - measured slower and off by default, kept as a record): same bytes."""
-    if persistent: monkeypatch.setenv("W2X_CONV48_PERSIST", "1")
+    input tile must outlive the stem by one op in the arena); the odd batch leaves a group with one tile."""
     path = onnx_model("swin_unet/art", 4, batch, tile, noise=1)
     frame = smooth_frame(shape[0], shape[1], 14)
     x = np.random.default_rng(37).random((batch, 3, tile, tile), dtype=np.float32)
     outs = []
     for nofuse in (True, False):
-        if nofuse: monkeypatch.setenv("W2X_NO_FUSE_STEM", "1")
-        else: monkeypatch.delenv("W2X_NO_FUSE_STEM")
-        eng = make_engine(pkg, path, batch, tile, 4, tta=tta)
+        with pkg.debug_switches(no_fuse_stem=int(nofuse)):
+            eng = make_engine(pkg, path, batch, tile, 4, tta=tta)
         folded = any("stem folded" in m for _, m in eng.messages)
         assert folded == (not nofuse), [m for _, m in eng.messages if "folded" in m]
         ys = [eng.infer(x) for _ in range(2)]

@@ -219,14 +219,16 @@ def test_tf32_requests_lower_to_an_fp32_plan_of_unfused_ops(pkg, onnx_model, mod
 
 def test_cunet_gates_are_folded_into_their_consumers(pkg, onnx_model, monkeypatch):
     """No in-place scaling pass is left in a cunet plan: each squeeze-excite gate rides on the operand load of the (transposed)
-    convolution that consumes the map and on the skip add that reads it; W2X_NO_SE_FOLD=1 and fp32 plans keep the pass."""
+    convolution that consumes the map and on the skip add that reads it; the debug switch no_se_fold and fp32 plans keep the pass."""
     path = onnx_model("cunet/art", 2, 2, 64, noise=1)
     d = pkg.describe_plan(path, 2, 64)
     assert " scale t" not in d and d.count(" a*gate") == 4 and d.count(" res*gate") == 1
     assert pkg.describe_plan(path, 2, 64, pkg.Precision.TF32).count(" scale t") == 4
-    monkeypatch.setenv("W2X_NO_SE_FOLD", "1")
-    d = pkg.describe_plan(path, 2, 64)
+    with pkg.debug_switches(no_se_fold=1):
+        d = pkg.describe_plan(path, 2, 64)
     assert d.count(" scale t") == 4 and "gate" not in d
+    with pytest.raises(pkg.W2xError):
+        pkg.debug_switches(no_such_switch=1).__enter__()
 
 
 @pytest.mark.parametrize("W,H,T,s,Tout,ov", [(1920, 1080, 256, 4, 960, 0.0625), (1920, 1080, 256, 2, 440, 0.0625), (3840, 2160, 640, 4, 2496, 0.0625),

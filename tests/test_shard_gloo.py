@@ -3,6 +3,7 @@ barrier + max-over-ranks timing reduction; no data-path collective is involved."
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -99,6 +100,54 @@ def test_bench_refuses_a_rank_count_that_differs_from_gpus():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "W2X_DEVICE_MAP")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "refusing to report n_gpus" in (r.stderr + r.stdout)
+
+
+def _one_json_line(stdout: str) -> dict:
+    import json
+    lines = [l for l in stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                                       # rank 0's stdout carries exactly one line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world,launcher", [(2, "self"), (8, "self"), (2, "torchrun"), (8, "torchrun")])
+def test_bench_rank_protocol_at_two_and_eight_ranks_without_a_gpu(world, launcher):
+    """bench.py --host-rehearsal: everything a multi-rank run does EXCEPT the engine calls - ranks spawned by the script itself or started by
+    `python -m torch.distributed.run` exactly as the driver starts them (one process per GPU, rendezvous on 127.0.0.1), gloo process group, placement records
+    gathered from every rank, barrier / K steps / barrier, MAX over ranks, per-rank spread, frame f -> rank f mod N, and rank 0 printing ONE JSON line on
+    stdout.  The first real 8-GPU launch is then not also the first 8-process run of the script.  The line cannot be mistaken for a result: value is null,
+    n_gpus counts distinct GPUs (none here) and the metric starts with REHEARSAL."""
+    import subprocess, sys
+    steps = 3
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", str(steps), "--warmup", "1", "--host-rehearsal"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "W2X_DEVICE_MAP")}
+    env["OMP_NUM_THREADS"] = "1"
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + args
+    else:
+        cmd = [sys.executable] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _one_json_line(r.stdout)
+    assert d["value"] is None and d["n_gpus"] == 0 and d["n_ranks"] == world and d["metric"].startswith(f"REHEARSAL ({world} ranks on 0 GPUs)")
+    assert d["steps"] == steps and d["warmup"] == 1 and d["scaling"] == "weak"
+    p = d["placement"]
+    assert [rec["rank"] for rec in p["ranks"]] == list(range(world)) and [rec["local_rank"] for rec in p["ranks"]] == list(range(world))
+    assert len({rec["pid"] for rec in p["ranks"]}) == world and p["distinct_gpus"] == 0 and not p["one_gpu_per_rank"]
+    assert d["config"]["frames_rendered"] == list(range(steps * world))      # every frame of the weak-scaled job exactly once
+    spread = d["config"]["per_rank_ms_per_step"]
+    assert spread["min"] <= spread["mean"] <= spread["max"] and d["ms_per_step"] >= spread["max"] - 1e-3     # the line's time is the MAX over ranks
+
+
+def test_placement_certificate_counts_distinct_gpus():
+    """shard.certify: ranks that share a card (a W2X_DEVICE_MAP rehearsal) or sit on different hosts are told apart by (host, PCI bus id)."""
+    rec = lambda r, host, bus: {"rank": r, "local_rank": r, "host": host, "pid": 100 + r, "pci_bus_id": bus, "cpus": None}
+    real = shard.certify([rec(r, "node0", f"0000:{r:02x}:00.0") for r in range(8)])
+    assert real["distinct_gpus"] == 8 and real["one_gpu_per_rank"] and real["n_ranks"] == 8 and real["device_map"] is None
+    shared = shard.certify([rec(r, "node0", "0000:05:00.0") for r in range(4)], "0,0,0,0")
+    assert shared["distinct_gpus"] == 1 and not shared["one_gpu_per_rank"] and shared["device_map"] == "0,0,0,0"
+    two_hosts = shard.certify([rec(0, "a", "0000:05:00.0"), rec(1, "b", "0000:05:00.0")])
+    assert two_hosts["distinct_gpus"] == 2 and two_hosts["one_gpu_per_rank"]
+    assert shard.spread([1.0, None, 3.0]) == {"min": 1.0, "max": 3.0, "mean": 2.0} and shard.spread([None]) is None
 
 
 def _fake_sysfs(root, gpus):

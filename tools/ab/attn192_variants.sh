@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds tools/ab/attn192_variants from variants of csrc/k_swinattn192.hip:  tools/ab/attn192_variants.sh "<flags v0>" "<flags v1>" ... ["STAMPS <flags>"]
+# Builds tools/ab/attn192_variants from variants of tools/ab/k_swinattn192_r3.hip (round 3, two workgroups per CU) or csrc/k_swinattn192u.hip via SRC=:  tools/ab/attn192_variants.sh "<flags v0>" "<flags v1>" ... ["STAMPS <flags>"]
 # A last argument that starts with STAMPS builds that variant with the per-phase s_memtime stamps and prints the phase table.
 # A baseline from an earlier revision: git show 38f61ee:waifu2x-tensorrt_amd/csrc/<kernel>.hip > tools/ab/<kernel>_r2.hip, then "SRC=$PWD/tools/ab/<kernel>_r2.hip".
 set -eu
@@ -8,7 +8,7 @@ CXX="/opt/rocm/bin/hipcc -std=c++17 -O3 --offload-arch=gfx950 -I $ROOT/waifu2x-t
 TMP=$(mktemp -d)
 i=0; objs=""; hflags=""
 for arg in "$@"; do
-  src=$ROOT/waifu2x-tensorrt_amd/csrc/k_swinattn192.hip; fl="$arg"
+  src=$ROOT/waifu2x-tensorrt_amd/tools/ab/k_swinattn192_r3.hip (round 3, two workgroups per CU) or csrc/k_swinattn192u.hip via SRC=; fl="$arg"
   case "$arg" in SRC=*) src=${arg%% *}; src=${src#SRC=}; fl=${arg#SRC=$src}; ;; esac
   case "$fl" in STAMPS*) fl="${fl#STAMPS} -DW2X_A192_STAMPS"; hflags="-DW2X_A192_STAMPS";; esac
   $CXX $fl -Dlaunch_swin_attn192=launch_swin_attn96_v$i -Dlaunch_swin_attn192w=launch_swin_attn96_v$i -c "$src" -o $TMP/v$i.o      # (the wide-workgroup file names its launcher ...192w)

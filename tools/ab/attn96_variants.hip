@@ -164,12 +164,13 @@ int main(int argc, char** argv) {
             printf("TIMING %d x %d x %d tokens, ms per launch (mean of %d rounds / min):", B, H, W, rounds - 1);
             for (int v = 0; v < NVAR; ++v) printf("  v%d %.4f / %.4f", v, sum[v] / (rounds - 1), best[v]);
             printf("\n");
-            // run-to-run determinism of the last variant
-            p.y = yv[NVAR - 1]; CK(variants[NVAR - 1](p, 0)); CK(hipDeviceSynchronize());
+            // run-to-run determinism of every variant (the timed launches above were the second .. n-th runs on the same buffers)
             std::vector<uint16_t> again(npix * C);
-            CK(hipMemcpy(again.data(), yv[NVAR - 1], npix * C * 2, hipMemcpyDeviceToHost));
-            long nd = 0; for (long i = 0; i < npix * C; ++i) nd += again[i] != hv[NVAR - 1][i];
-            printf("last variant run twice: %ld elements differ\n", nd);
+            for (int v = 0; v < NVAR; ++v) {
+                CK(hipMemcpy(again.data(), yv[v], npix * C * 2, hipMemcpyDeviceToHost));
+                long nd = 0; for (long i = 0; i < npix * C; ++i) nd += again[i] != hv[v][i];
+                printf("v%d run again: %ld elements differ from its first run\n", v, nd);
+            }
 #ifdef W2X_A192_STAMPS
             {   // the LAST variant is the stamped build: wave cycles per phase, averaged over the waves
                 unsigned long long st[8];

@@ -2,7 +2,7 @@
 // (LayerNormalization, roll + window partition, QKV MatMul+Add, per-head scale / QK^T / rel-pos bias (+ shift mask) / Softmax /
 //  .V, head merge, proj MatMul+Add, window reverse + reverse roll, residual Add of the ONNX graph: one launch.)
 //
-// A workgroup = 4 waves = 2 windows (72 token rows), four workgroups per CU (one wave of each per SIMD: workgroups whose wave
+// A workgroup = 4 waves = 2 windows (72 token rows), three workgroups per CU (one wave of each per SIMD: workgroups whose wave
 // count is not a multiple of four load the SIMDs unevenly - a 6-wave variant measured that in round 2: git history, tools/ab/k_swinattn96_g4.hip).  The 12 (window, head)
 // units of a workgroup go 3 to a wave so that two of them share a head:
 //     wave v:  unit 0 = (window 0, head v),  unit 1 = (window 1, head v),  unit 2 = (window v & 1, head 4 + (v >> 1)).
@@ -29,30 +29,25 @@
 #include <algorithm>
 
 // Build switches (tools/ab/attn96_variants.sh times them against each other):
-//   W2X_A96_PV32  O^T = V^T P^T over the 32 keys of the two full key tiles as ONE v_mfma_f32_16x16x32_f16 (the accumulator tiles of
-//                 S^T and v pair up into its operands with the k order permuted identically on both sides) + one 16x16x16 for the
-//                 left-over keys, instead of three 16x16x16 - which cost the matrix pipe as much as a 16x16x32 each
-//                 (tools/issue_model.hip): 9 matrix instructions less per wave; 2 = the softmax denominators too (16 less).
-//                 The two shapes NEVER share an accumulator: a 16x16x16 whose SrcC is the vDst of the 16x16x32 right in front of it
-//                 gets no wait states from hipcc (it treats the pair like two instructions of one opcode, which the hardware forwards),
-//                 and the second product then reads a half-written accumulator - outputs off by up to 0.8 and different from run to run
-//                 in three of the four builds that had such a pair (profiles/r5_kernels/a96_mixed_chain.txt; tools/isa_mfma_chain.py
-//                 finds the pairs in the ISA, tests/test_isa_hazards.py keeps them out of the library).  Each shape accumulates into
-//                 its own registers and the two sums meet in the epilogue's fused multiply-adds.
+//   W2X_A96_PV32  O^T = V^T P^T and the softmax denominators over the 32 keys of the two full key tiles as ONE v_mfma_f32_16x16x32_f16
+//                 (the accumulator tiles of S^T and v pair up into its operands with the k order permuted identically on both sides) +
+//                 one 16x16x16 for the left-over keys, instead of three 16x16x16 - which cost the matrix pipe as much as a 16x16x32
+//                 each (tools/issue_model.hip): 16 matrix instructions less per wave.
 //   W2X_A96_BUF   weight fragments, bias tables and the rel-pos bias through buffer loads (lane offset in a VGPR once, everything else
 //                 in the scalar offset) instead of flat loads with 64-bit per-lane addresses.
 #ifndef W2X_A96_PV32
-#define W2X_A96_PV32 1     // round 5, with BQ_LDS = 1 and XRES_EARLY = 1 (126 registers, no spill): 0.510 -> 0.496 ms per launch in the harness (profiles/r5_kernels/a96_pv32_split.txt);
-#endif                     // 2 measured the same (0.498); at __launch_bounds__(256, 3) - 148 registers, three waves per SIMD - 0.533
+#define W2X_A96_PV32 0     // measured (tools/ab/attn96_variants.sh, profiles/r3_*/attn96_variants.txt): at 128 registers the wider operands spill
+#endif                     // (4-7 registers to scratch) and the launch is 2-5 % SLOWER; kept as a switch for a build with registers to spare
 #ifndef W2X_A96_BUF
 #define W2X_A96_BUF 1
 #endif
 #ifndef W2X_A96_BQ_LDS
-#define W2X_A96_BQ_LDS 1       // 1: the q / k / v bias vectors are copied to LDS when the workgroup starts and read from there (tools/ab/k_swinattn192_r3.hip gains 3 % from it).
-#endif                         // (round 3, without PV32: 0.516 against 0.502 ms, three spilled registers; with PV32 the allocation fits and the bias loads leave the vector-memory queue)
+#define W2X_A96_BQ_LDS 0       // 1: the q / k / v bias vectors are copied to LDS when the workgroup starts and read from there (k_swinattn192.hip gains 3 % from it).
+                               // Measured here: 0.516 against 0.502 ms - at 128 registers the LDS addresses cost three spilled registers and four waves per SIMD already cover the loads
+#endif
 #ifndef W2X_A96_XRES_EARLY
-#define W2X_A96_XRES_EARLY 1   // where the residual rows are requested: 0 in front of the projection (round 2), 1 after the last unit's q / k / v products,
-#endif                         // 2 after its score products.  Round 3 (no PV32): 0.524 / 0.534 (two spills) / 0.518 ms; round 5 with PV32 + BQ_LDS: 1 = 0.496, 2 = 0.502
+#define W2X_A96_XRES_EARLY 2   // where the residual rows are requested: 0 in front of the projection (round 2), 1 after the last unit's q / k / v products
+#endif                         // (two registers spill), 2 after its score products.  Measured per launch: 0.524 / 0.534 / 0.518 ms (round 2: 0.550)
 
 namespace w2x {
 namespace {
@@ -176,54 +171,34 @@ __device__ __forceinline__ void probs(const float4v s0, const float4v s1, float 
 }
 __device__ __forceinline__ half4 lo4(const half8 v) { return (half4){v[0], v[1], v[2], v[3]}; }
 __device__ __forceinline__ half4 hi4(const half8 v) { return (half4){v[4], v[5], v[6], v[7]}; }
-// product over the 36 keys: operands (a01 | a2) x (p01 | p2), added to `acc`.  W2X_A96_PV32: .a = the 32 keys of the full tiles (16x16x32), .b = the
-// left-over keys (16x16x16) - one accumulator per instruction shape (header); otherwise everything is in .a
-struct KeysAcc { float4v a, b; };
-__device__ __forceinline__ KeysAcc keys_product(const half8 a01, const half4 a2, const half8 p01, const half4 p2, const KeysAcc acc) {
-    KeysAcc o;
+// product over the 36 keys: operands (a01 | a2) x (p01 | p2)
+__device__ __forceinline__ float4v keys_product(const half8 a01, const half4 a2, const half8 p01, const half4 p2) {
+    const float4v zero4 = {0.f, 0.f, 0.f, 0.f};
 #if W2X_A96_PV32
-    o.a = __builtin_amdgcn_mfma_f32_16x16x32_f16(a01, p01, acc.a, 0, 0, 0);
-    o.b = __builtin_amdgcn_mfma_f32_16x16x16f16(a2, p2, acc.b, 0, 0, 0);
+    float4v o = __builtin_amdgcn_mfma_f32_16x16x32_f16(a01, p01, zero4, 0, 0, 0);
 #else
-    o.a = __builtin_amdgcn_mfma_f32_16x16x16f16(lo4(a01), lo4(p01), acc.a, 0, 0, 0);
-    o.a = __builtin_amdgcn_mfma_f32_16x16x16f16(hi4(a01), hi4(p01), o.a, 0, 0, 0);
-    o.a = __builtin_amdgcn_mfma_f32_16x16x16f16(a2, p2, o.a, 0, 0, 0);
-    o.b = acc.b;
+    float4v o = __builtin_amdgcn_mfma_f32_16x16x16f16(lo4(a01), lo4(p01), zero4, 0, 0, 0);
+    o = __builtin_amdgcn_mfma_f32_16x16x16f16(hi4(a01), hi4(p01), o, 0, 0, 0);
 #endif
-    return o;
-}
-// (o.a [+ o.b]) * inv + bv as the four fp16 values a lane stores
-__device__ __forceinline__ half4 scaled_output(const KeysAcc o, float inv, const float4v bv) {
-    const float2v i2 = {inv, inv};
-    float2v o0 = __builtin_elementwise_fma((float2v){o.a[0], o.a[1]}, i2, (float2v){bv[0], bv[1]});
-    float2v o1 = __builtin_elementwise_fma((float2v){o.a[2], o.a[3]}, i2, (float2v){bv[2], bv[3]});
-#if W2X_A96_PV32
-    o0 = __builtin_elementwise_fma((float2v){o.b[0], o.b[1]}, i2, o0);
-    o1 = __builtin_elementwise_fma((float2v){o.b[2], o.b[3]}, i2, o1);
-#endif
-    return (half4){(_Float16)o0[0], (_Float16)o0[1], (_Float16)o1[0], (_Float16)o1[1]};
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a2, p2, o, 0, 0, 0);
 }
 // column sums of P (the softmax denominators) off the matrix pipe: a ones matrix in place of V^T.  W2X_A96_PV32 == 2 spends four
 // registers on a ones operand for the 16x16x32 form, otherwise three 16x16x16 products share a two-register one
-__device__ __forceinline__ float keys_sum(const half8 p01, const half4 p2) {
+__device__ __forceinline__ float4v keys_sum(const half8 p01, const half4 p2) {
     const float4v zero4 = {0.f, 0.f, 0.f, 0.f};
 #if W2X_A96_PV32 == 2
     const half8 ones8 = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
-    const float4v l32 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, p01, zero4, 0, 0, 0);      // (two shapes, two accumulators: header)
-    const float4v l16 = __builtin_amdgcn_mfma_f32_16x16x16f16(lo4(ones8), p2, zero4, 0, 0, 0);
-    return l32[0] + l16[0];
+    float4v l = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, p01, zero4, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(lo4(ones8), p2, l, 0, 0, 0);
 #else
     const half4 ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
     float4v l = __builtin_amdgcn_mfma_f32_16x16x16f16(ones, lo4(p01), zero4, 0, 0, 0);
     l = __builtin_amdgcn_mfma_f32_16x16x16f16(ones, hi4(p01), l, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_16x16x16f16(ones, p2, l, 0, 0, 0)[0];
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(ones, p2, l, 0, 0, 0);
 #endif
 }
 
-#ifndef W2X_A96_WPS
-#define W2X_A96_WPS 4          // waves per SIMD the register allocation is held to (= workgroups per CU).  3 (up to 168 registers) measured 4.5 - 10 % slower in every
-#endif                         // combination of the switches above (profiles/r5_kernels/a96_*.txt): the kernel lives on its fourth wave per SIMD
-__global__ __launch_bounds__(NTHR, W2X_A96_WPS) void swin_attn96_kernel(const SwinAttnParams p) {
+__global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* Xs = (_Float16*)smem;              // [RPX][LDX] normalised x slabs; later the output tile [RP][LDX] (token order)
     _Float16* Os = Xs + XS;                      // [RP][LDX]  attention output, all heads, token order
@@ -337,7 +312,7 @@ __global__ __launch_bounds__(NTHR, W2X_A96_WPS) void swin_attn96_kernel(const Sw
     }
     __syncthreads();
 
-#ifdef W2X_A96_PRIO     // s_setprio by phase (tools/ab/k_swinattn192_r3.hip): 1 = head loop at priority 1, row phases at 0; 2 = rising with progress
+#ifdef W2X_A96_PRIO     // s_setprio by phase (k_swinattn192.hip): 1 = head loop at priority 1, row phases at 0; 2 = rising with progress
     __builtin_amdgcn_s_setprio(1);
 #endif
     const float qscale = p.scale * 1.44269504088896341f;   // log2(e) folded into q: softmax uses exp2
@@ -479,23 +454,33 @@ __global__ __launch_bounds__(NTHR, W2X_A96_WPS) void swin_attn96_kernel(const Sw
         // (fp16) probabilities of query fr in every row of its column - the lane that scales the column already holds it.
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
-            const KeysAcc o = keys_product(vk01[u], vk2[u], pf01[qi], pf2[qi], KeysAcc{zero4, zero4});
-            const float inv = __builtin_amdgcn_rcpf(keys_sum(pf01[qi], pf2[qi]));
-            *(half4*)(Os + (w * NTOK + qi * 16 + fr) * LDX + h * HD + g * 4) = scaled_output(o, inv, bv);
+            const float4v o = keys_product(vk01[u], vk2[u], pf01[qi], pf2[qi]);
+            const float4v l = keys_sum(pf01[qi], pf2[qi]);
+            const float inv = __builtin_amdgcn_rcpf(l[0]);
+            const float2v i2 = {inv, inv};
+            const float2v o0 = __builtin_elementwise_fma((float2v){o[0], o[1]}, i2, (float2v){bv[0], bv[1]});
+            const float2v o1 = __builtin_elementwise_fma((float2v){o[2], o[3]}, i2, (float2v){bv[2], bv[3]});
+            *(half4*)(Os + (w * NTOK + qi * 16 + fr) * LDX + h * HD + g * 4) = (half4){(_Float16)o0[0], (_Float16)o0[1], (_Float16)o1[0], (_Float16)o1[1]};
         }
     }
 #undef W2X_LOAD_W
 #undef W2X_WFRAG
 #undef W2X_BQKV
-    // ---- left-over queries: O^T against every unit's V; a column only carries probabilities into the product with its own unit, so the three
-    // products accumulate into one output tile
+    // ---- left-over queries: O^T against every unit's V, each column keeps the product with its own unit
     {
-        const float inv = __builtin_amdgcn_rcpf(keys_sum(pl01, pl2));
-        KeysAcc o = {zero4, zero4};
+        const float4v l = keys_sum(pl01, pl2);
+        float4v o = zero4;
 #pragma unroll
-        for (int u = 0; u < NU; ++u) o = keys_product(vk01[u], vk2[u], ul == u ? pl01 : zero8, ul == u ? pl2 : zeroh4, o);
+        for (int u = 0; u < NU; ++u) {
+            const float4v ou = keys_product(vk01[u], vk2[u], pl01, pl2);
+            o = ul == u ? ou : o;
+        }
         const float4v bv = *(const float4v*)(p.bqkv + 2 * C + hl_ * HD + g * 4);   // (hl_ differs per lane)
-        if (ul < NU) *(half4*)(Os + (wl_ * NTOK + 32 + ql) * LDX + hl_ * HD + g * 4) = scaled_output(o, inv, bv);
+        const float inv = __builtin_amdgcn_rcpf(l[0]);
+        const float2v i2 = {inv, inv};
+        const float2v o0 = __builtin_elementwise_fma((float2v){o[0], o[1]}, i2, (float2v){bv[0], bv[1]});
+        const float2v o1 = __builtin_elementwise_fma((float2v){o[2], o[3]}, i2, (float2v){bv[2], bv[3]});
+        if (ul < NU) *(half4*)(Os + (wl_ * NTOK + 32 + ql) * LDX + hl_ * HD + g * 4) = (half4){(_Float16)o0[0], (_Float16)o0[1], (_Float16)o1[0], (_Float16)o1[1]};
     }
 #if defined(W2X_A96_PRIO) && W2X_A96_PRIO == 1
     __builtin_amdgcn_s_setprio(0);

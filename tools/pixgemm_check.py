@@ -1,6 +1,6 @@
-"""Diagnostic: run a graph with W2X_PIXGEMM_CHECK=1 so every launch taken by the streaming kernels is compared with gemm_kernel."""
+"""Diagnostic: run a graph with W2X_CHECK_GENERAL=1 so every launch taken by the streaming kernels is compared with gemm_kernel."""
 import os, sys
-os.environ["W2X_PIXGEMM_CHECK"] = "1"
+os.environ["W2X_CHECK_GENERAL"] = "1"
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))

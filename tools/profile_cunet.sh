@@ -11,7 +11,7 @@ cd "$ROOT"
 CMD="python3 tools/op_times.py cunet/art 2 1 4 256 1080 1920"
 $CMD > "$OUT/op_times.txt" 2>&1
 # per-kernel evidence with every pass in one piece on one stream, as in profile_round.sh
-export W2X_NO_SPLIT=1
+export W2X_GROUPS=1
 export W2X_RENDER_PARTS=1     # render() as one part: every launch of the traced run covers all live tiles (the two-part render() of round 4 would add half-size launches to the averages)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o w2x -- $CMD > "$OUT/trace.log" 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o w2x -- $CMD > "$OUT/pmc_fetch.log" 2>&1

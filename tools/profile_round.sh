@@ -11,10 +11,10 @@ export TMPDIR=/tmp
 cd "$ROOT"
 python3 bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --op-times > "$OUT/op_times.txt" 2>&1
-# Per-kernel evidence is collected with every pass in one piece on one stream (W2X_NO_SPLIT=1): a launch is then the 45-tile launch
+# Per-kernel evidence is collected with every pass in one piece on one stream (W2X_GROUPS=1): a launch is then the 45-tile launch
 # that bench.py's roofline block prices (its HIP-event durations come from the engine's profiling mode, which does not split either);
 # the timed region of bench.json above runs each pass as two tile groups on two streams, whose half-size launches overlap.
-export W2X_NO_SPLIT=1
+export W2X_GROUPS=1
 export W2X_RENDER_PARTS=1     # render() as one part: every launch of the traced run covers all live tiles (the two-part render() of round 4 would add half-size launches to the averages)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o w2x -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/trace.log" 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o w2x -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1

@@ -26,6 +26,30 @@ def barrier(dist=None):
         dist.barrier()
 
 
+def gather_objects(obj, dist=None) -> list:
+    """Every rank's `obj`, in rank order, on every rank (a list of one when not distributed).  Host-side bookkeeping only."""
+    if dist is None or not dist.is_initialized():
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def certify(records: list, device_map=None) -> dict:
+    """What a bench line says about WHERE its ranks ran, from the records the ranks gathered (rank, local_rank, host, pci_bus_id as the HIP runtime of
+    that rank reports it, pid): the number of distinct GPUs behind the ranks and whether that is one per rank.  A run whose ranks share a card
+    (W2X_DEVICE_MAP rehearsals) or touch no card at all (--host-rehearsal) cannot then print a line that reads like an N-GPU result."""
+    gpus = sorted({(r.get("host"), r["pci_bus_id"]) for r in records if r.get("pci_bus_id")})
+    return {"ranks": records, "n_ranks": len(records), "distinct_gpus": len(gpus), "one_gpu_per_rank": len(gpus) == len(records),
+            "device_map": device_map or None}
+
+
+def spread(values: list) -> dict:
+    """min / max / mean of the per-rank values of one quantity (None entries left out)."""
+    v = [float(x) for x in values if x is not None]
+    return {"min": round(min(v), 4), "max": round(max(v), 4), "mean": round(sum(v) / len(v), 4)} if v else None
+
+
 # ---- node topology without touching the GPU (the launcher parent of bench.py must stay GPU-free: it spawns the ranks)
 def gpu_nodes(sysfs: str = "/sys") -> list[dict]:
     """GPUs of this node from the KFD topology (/sys/class/kfd/kfd/topology/nodes/*/properties: a node with simd_count > 0 is a

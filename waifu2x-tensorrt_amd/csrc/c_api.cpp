@@ -220,4 +220,6 @@ void w2x_sha256_hex(const void* data, size_t len, char* out) {
 
 const char* w2x_version(void) { return "w2x-hip 0.1 (gfx950)"; }
 
+int w2x_debug_set(const char* name, int value) { return w2x::set_switch(name, value) ? 1 : 0; }
+
 }  // extern "C"

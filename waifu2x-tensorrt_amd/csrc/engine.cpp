@@ -23,6 +23,7 @@
 #include "lower.h"
 #include "plan.h"
 #include "sha256.h"
+#include "switches.h"
 #include "tiles.h"
 
 #define W2X_LOG(sev, message) impl->log(sev, message, __FUNCTION__, __LINE__)
@@ -168,13 +169,13 @@ constexpr const char* kEngineExt = ".w2x";
 // Lowering of a model for one input shape, shared by build() (which writes the result to disk) and by load() when the render
 // configuration lies inside an engine's [min, max] range but is not the shape that engine was specialised for.
 // Super-batching: tiles are independent, so one network pass may carry several reference batches (S x batchSize tiles); results
-// are bit-identical, launches per frame drop S-fold and the low-resolution stages fill all 256 CUs.  W2X_SUPERBATCH overrides;
+// are bit-identical, launches per frame drop S-fold and the low-resolution stages fill all 256 CUs.  W2X_SUPERBATCH (switches.h) overrides;
 // the default targets the pixel count of 48 tiles of 256x256 per pass (one 1080p frame at config 3), capped at 64 tiles.  Small
 // tiles gain the most: at tile 64 / batch 1 a pass of one tile is ~40 launches of a few microseconds of work each (a 1080p frame:
 // 1100 passes, 650 ms, hipGraph replay or not); 64 tiles per pass make it 18 passes.
 Plan lower_for_shape(const std::string& onnxModelPath, int batch, int channels, int height, int width, bool fp32) {
     int S = 1;
-    if (const char* env = getenv("W2X_SUPERBATCH")) S = std::max(1, atoi(env));
+    if (switches().superbatch > 0) S = switches().superbatch;
     else {
         const double want = 48.0 * 256 * 256 / ((double)batch * height * width);
         S = std::max(1, (int)std::lround(want));
@@ -204,9 +205,9 @@ struct Img2Img::Impl {
 
     bool loaded = false;
     int device = -1;                   // physical HIP ordinal this engine lives on (set by load)
-    // switches read from the environment once per load(), never on the launch path
+    // copies of the operational switches (switches.h), taken once per load(), never read from the environment on the launch path
     bool poison = false;               // W2X_POISON: stale activations become fp16 NaNs before every frame (tests)
-    bool check_general = false;        // W2X_PIXGEMM_CHECK: every shape-specialised launch is compared with the general kernel
+    bool check_general = false;        // W2X_CHECK_GENERAL: every shape-specialised launch is compared with the general kernel
     bool use_graphs = true;            // W2X_NO_GRAPH switches the hipGraph replay of network passes off
     Plan plan;
     RenderConfig cfg;
@@ -222,9 +223,6 @@ struct Img2Img::Impl {
     int shard_rows = 0, shard_cols = 0;  // shardCompute(): the frame shardFinish() completes
     hipStream_t gstream[3] = {nullptr, nullptr, nullptr};   // further tile groups of a pass (run_frame)
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-    // Experiment (W2X_STAGGER_OP=k, two groups): the second group starts when the first has finished op k, so that the two streams run
-    // different kernels side by side instead of the same one.  Off by default (-1): DESIGN.md section 3 has the measurement.
-    hipEvent_t ev_stagger = nullptr; int stagger_op = -1;
     int groups = 2;                      // W2X_GROUPS (1..4; W2X_NO_SPLIT = 1): tile groups a pass is cut into
     std::vector<void*> tensors, blobs;   // tensors point into one arena
     std::vector<void*> frag_blobs;       // per blob id: fragment-major copy of a weight matrix (or null)
@@ -280,22 +278,30 @@ struct Img2Img::Impl {
     // onto the compute streams' queues (host-to-host 7.6 -> 9.8 ms per frame, profiles/r4_kernels/render_parts_ab.txt, first run).
     void ensure_copy_streams() {
         if (s_up) return;
-        // W2X_COPY_STREAM_PRIO = high | low | normal (default, plain streams).  A stream of another priority level takes its hardware queue from that level's own
-        // pool, which no compute stream - the engine's or a replayed graph's internal ones - ever shares.
-        static const int prio_mode = [] { const char* e = getenv("W2X_COPY_STREAM_PRIO"); return !e ? 0 : !strcmp(e, "high") ? 1 : !strcmp(e, "low") ? 2 : 0; }();
-        int least = 0, greatest = 0;
-        if (prio_mode) hipAssert(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        if (prio_mode && least != greatest) {
-            hipAssert(hipStreamCreateWithPriority(&s_up, hipStreamNonBlocking, prio_mode == 1 ? greatest : least));
-            hipAssert(hipStreamCreateWithPriority(&s_dn, hipStreamNonBlocking, prio_mode == 1 ? greatest : least));
-        } else {
-            hipAssert(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking));
-            hipAssert(hipStreamCreateWithFlags(&s_dn, hipStreamNonBlocking));
-        }
+        hipAssert(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking));
+        hipAssert(hipStreamCreateWithFlags(&s_dn, hipStreamNonBlocking));
         for (int b = 0; b < 2; ++b) { hipAssert(hipEventCreateWithFlags(&ev_up[b], hipEventDisableTiming)); hipAssert(hipEventCreateWithFlags(&ev_comp[b], hipEventDisableTiming)); hipAssert(hipEventCreateWithFlags(&ev_dn[b], hipEventDisableTiming)); }
     }
 
-    // last frame (for benchResident)
+    // last frame (for benchResident / profileFrame, which replay it as ONE part)
+    bool one_part_stale = false;          // the last render() ran in parts: d_slots holds the parts' slot tables
+    void one_part_slots() {
+        if (!one_part_stale) return;
+        const int steps = cfg.tta ? 8 : 1, B = plan.B, S = plan.B / plan.userB;
+        const int batchCount = (int)std::lround(std::ceil((double)(last_strip.tile_count * steps) / plan.userB));
+        const size_t stepCount = (size_t)((batchCount + S - 1) / S) * B;
+        h_slots.resize(stepCount);
+        for (size_t st = 0; st < stepCount; ++st) {
+            const int ti = (int)(st / steps), aug = (int)(st % steps);
+            TileSlot sl{0, 0, aug, 0};
+            if (ti < last_strip.tile_count) { sl.x = last_grid.in[last_strip.first_tile + ti].x; sl.y = last_grid.in[last_strip.first_tile + ti].y; sl.valid = 1; }
+            h_slots[st] = sl;
+        }
+        ensure(d_slots, slots_cap, stepCount * sizeof(TileSlot));
+        hipAssert(hipMemcpy(d_slots, h_slots.data(), stepCount * sizeof(TileSlot), hipMemcpyHostToDevice));
+        ensure(d_slab, slab_cap, stepCount * plan.Tout * plan.Tout * 4 * plan.elt);      // (already that large: renderPart sizes the slab for both layouts)
+        one_part_stale = false;
+    }
     int last_rows = 0, last_cols = 0, last_batches = 0;
     TileGrid last_grid;
     StripPlan last_strip;
@@ -310,12 +316,10 @@ struct Img2Img::Impl {
     // events between the streams are issued around the replays): a single captured graph with NG branches runs its side branches on streams the runtime
     // creates at instantiation, which land on whichever hardware queue has the fewest users at that moment - sometimes the copy streams' queue, where the
     // next download or upload then waits behind a whole pass (render() in three parts 10.1 ms, in two or four 9.0 / 8.6, same work).
-    // W2X_GRAPH_FORKED=1 keeps the one forked graph per pass.
     struct PassGraphs { hipGraphExec_t g[4] = {nullptr, nullptr, nullptr, nullptr}; int n = 0; };
     std::map<GraphKey, PassGraphs> graphs;
     std::map<GraphKey, int> graph_seen;
     long graph_replays = 0, eager_passes = 0;
-    bool graph_per_group = true;
     void drop_graphs() {
         for (auto& kv : graphs) for (int k = 0; k < kv.second.n; ++k) if (kv.second.g[k]) (void)hipGraphExecDestroy(kv.second.g[k]);
         graphs.clear(); graph_seen.clear();
@@ -347,7 +351,9 @@ struct Img2Img::Impl {
         frame2_cap = out2_cap = 0;
         for (void** p : {(void**)&d_frame, (void**)&d_out, (void**)&d_frame2, (void**)&d_out2, &d_slab, &d_slab2, (void**)&d_slots, (void**)&d_rampx, (void**)&d_rampy, (void**)&d_blob_in, (void**)&d_blob_out})
             if (*p) { (void)hipFree(*p); *p = nullptr; }
-        frame_cap = out_cap = slab_cap = slots_cap = 0;
+        frame_cap = out_cap = slab_cap = slab2_cap = slots_cap = 0;
+        shard_rows = shard_cols = 0; shard_halo_slots = 0; rolling = false; one_part_stale = false;
+        last_rows = last_cols = last_batches = 0;      // (benchResident / profileFrame replay the last frame of THIS load)
         if (ev0) { (void)hipEventDestroy(ev0); ev0 = nullptr; }
         if (ev1) { (void)hipEventDestroy(ev1); ev1 = nullptr; }
         if (ev_shard) { (void)hipEventDestroy(ev_shard); ev_shard = nullptr; }
@@ -355,7 +361,6 @@ struct Img2Img::Impl {
         for (hipEvent_t& e : ev_g0) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         for (hipEvent_t& e : ev_cmp) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
-        if (ev_stagger) { (void)hipEventDestroy(ev_stagger); ev_stagger = nullptr; }
         for (hipEvent_t& e : ev_join) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         for (hipStream_t& st : gstream) if (st) { (void)hipStreamDestroy(st); st = nullptr; }
         if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
@@ -395,7 +400,7 @@ struct Img2Img::Impl {
             // An image head that rides on the MLP launch in front of it (fuse_head, decided below) writes its output WHILE that MLP still reads its input:
             // the output must be alive from the MLP on, or it would be given the memory of the MLP's input, which dies at the MLP in the un-fused order.
             fuse_head.assign(nops, 0);
-            if (plan.elt == 2 && !getenv("W2X_NO_FUSE_HEAD"))
+            if (plan.elt == 2 && !switches().no_fuse_head)
                 for (int i = 0; i + 1 < nops; ++i) {
                     const Op& a = plan.ops[i]; const Op& b = plan.ops[i + 1];
                     if (a.kind == OP_MLP && b.kind == OP_GEMM && a.m.C == 96 && a.m.stats_out < 0 && b.g.a.t == a.m.y && last[a.m.y] == i + 1 && b.g.amode == A_ROWS && b.g.K == 96 && b.g.N == 64 &&
@@ -422,8 +427,7 @@ struct Img2Img::Impl {
             std::vector<size_t> off(nt, 0);
             size_t arena = 0;
             // 256 bytes x 12: offsets stay 256-byte aligned when the arena is cut into 2, 3 or 4 group parts (run_network).
-            // W2X_ARENA_ALIGN (a multiple of 3072) is a placement experiment: tools/ab/arena_placement.sh
-            static const size_t unit = [] { const char* e = getenv("W2X_ARENA_ALIGN"); const size_t v = e ? strtoull(e, nullptr, 10) : 0; return v >= 3072 && v % 3072 == 0 ? v : (size_t)3072; }();
+            constexpr size_t unit = 3072;
             auto align = [](size_t v) { return (v + unit - 1) / unit * unit; };
             auto alloc = [&](size_t bytes) -> size_t {
                 bytes = align(bytes);
@@ -448,8 +452,6 @@ struct Img2Img::Impl {
             }
             // (tensors no op touches - the q / k / v, score and hidden maps inside the fused attention and MLP ops - get no memory: at config 3 they
             //  were 19 of the arena's 20.7 GiB until round 3)
-            if (getenv("W2X_DUMP_ARENA"))
-                for (int t = 0; t < nt; ++t) if (last[t] >= 0) fprintf(stderr, "[arena] t%d ops %d..%d offset %zu (%.1f MiB) bytes %zu\n", t, first[t], last[t], off[t], off[t] / 1048576.0, (size_t)plan.tensors[t].bytes());
             hipAssert(hipMalloc(&arena_base, arena + 1024));   // slack: vector reads past a table's last row; the group parts rounded up to 256 bytes
             hipAssert(hipMemsetAsync(arena_base, 0, arena + 1024, stream));
             arena_bytes = arena;
@@ -547,7 +549,7 @@ struct Img2Img::Impl {
         }
         if (final_op < 0) throw std::runtime_error("plan: the output tensor is not produced by a fused op");
         // The image head (Linear 96 -> 4x4 sub-pixels x 4 channels, Clip) behind the last MLP: its input rows have no other reader, so the MLP launch
-        // runs the head on every tile it produces and neither stores nor re-reads the 96-channel map (W2X_NO_FUSE_HEAD=1 keeps the two launches).
+        // runs the head on every tile it produces and neither stores nor re-reads the 96-channel map (switches.h no_fuse_head keeps the two launches).
         for (size_t i = 0; i + 1 < plan.ops.size(); ++i)       // the candidates of the arena pass above, now with the prepared launch parameters
             if (fuse_head[i]) {
                 const GemmParams& g = gemm[i + 1];
@@ -555,7 +557,7 @@ struct Img2Img::Impl {
                       (!g.has_clip || (f16_to_f32(f32_to_f16(g.clip_lo)) == g.clip_lo && f16_to_f32(f32_to_f16(g.clip_hi)) == g.clip_hi)))) fuse_head[i] = 0;   // (k_mlp96q.hip: a 32-row tile inside one image, at most two token rows; clip bounds that fp16 holds exactly)
             }
         // The stem (3x3, 4 -> 48 channels) in front of the patch convolution (3x3, 48 -> 96): its output has no other reader, so the convolution computes the halo tile
-        // it needs from the input tile and the 48-channel map is neither stored nor read (k_conv48.hip conv48_kernel<true>; W2X_NO_FUSE_STEM=1 keeps the two launches).
+        // it needs from the input tile and the 48-channel map is neither stored nor read (k_conv48.hip conv48_kernel<true>; switches.h no_fuse_stem keeps the two launches).
         for (size_t i = 0; i + 1 < plan.ops.size(); ++i)
             if (fuse_stem[i] && !conv48_stem_supported(gemm[i + 1], gemm[i])) fuse_stem[i] = 0;
         hipAssert(hipStreamSynchronize(stream));
@@ -626,17 +628,6 @@ struct Img2Img::Impl {
                         hipAssert(hipStreamSynchronize(stream));
                         hipAssert(hipMemcpy(b.data(), tmp, n * 2, hipMemcpyDeviceToHost));
                         hipAssert(hipFree(tmp));
-                        if (getenv("W2X_PIXGEMM_PROBE")) {   // host evaluation of out[b=0][0][0][0]: sub-pixel (0,0) of input pixel (0,0)
-                            std::vector<uint16_t> xr(p.K), wr(p.K); float bias0 = 0.f; uint16_t r0 = 0;
-                            hipAssert(hipMemcpy(xr.data(), (const uint16_t*)p.a.p + (size_t)(p.a.y0 * p.a.Ws + p.a.x0) * p.a.Cs, p.K * 2, hipMemcpyDeviceToHost));
-                            hipAssert(hipMemcpy(wr.data(), p.wt, p.K * 2, hipMemcpyDeviceToHost));
-                            hipAssert(hipMemcpy(&bias0, p.bias, 4, hipMemcpyDeviceToHost));
-                            if (p.res.p) hipAssert(hipMemcpy(&r0, (const uint16_t*)p.res.p + (size_t)(p.res.y0 * p.res.Ws + p.res.x0) * p.res.Cs, 2, hipMemcpyDeviceToHost));
-                            double dot = 0; for (int k = 0; k < p.K; ++k) dot += (double)f16_to_f32(xr[k]) * f16_to_f32(wr[k]);
-                            const double lin = dot + bias0, lk = lin > 0 ? lin : lin * p.alpha;
-                            log(Severity::warn, "probe op " + std::to_string(i) + ": lin=" + std::to_string(lin) + " leaky=" + std::to_string(lk) + " res=" + std::to_string(f16_to_f32(r0)) + " -> leaky+res=" + std::to_string(lk + f16_to_f32(r0)) +
-                                " streaming=" + std::to_string(f16_to_f32(a[0])) + " general=" + std::to_string(f16_to_f32(b[0])) + " x0=" + std::to_string(f16_to_f32(xr[0])) + " w0=" + std::to_string(f16_to_f32(wr[0])) + " bias0=" + std::to_string(bias0));
-                        }
                         double md = 0; size_t at = 0, bad = 0;
                         for (size_t k = 0; k < n; ++k) { const double d = std::fabs(f16_to_f32(a[k]) - f16_to_f32(b[k])); if (d > 0.01) ++bad; if (d > md) { md = d; at = k; } }
                         log(Severity::warn, "pixgemm check op " + std::to_string(i) + " [" + op.name + "]: max|d|=" + std::to_string(md) + " at pixel " + std::to_string(at / od.C) +
@@ -713,7 +704,6 @@ struct Img2Img::Impl {
                 }
                 default: throw std::runtime_error("plan: unknown op kind");
             }
-            if (grp == 0 && (int)i == stagger_op && ev_stagger) hipAssert(hipEventRecord(ev_stagger, s));   // W2X_STAGGER_OP: the next group starts here
         } catch (const std::exception& e) {     // name the op: "invalid argument" alone says nothing about a 60-op plan
             throw std::runtime_error("op " + std::to_string(i) + " [" + plan.ops[i].name + "]: " + e.what());
         }
@@ -732,8 +722,6 @@ struct Img2Img::Impl {
     // device part of one frame: gather -> network per batch -> compose.  Frame must already be in d_frame.
     void run_frame(int rows, int cols, const TileGrid& grid, bool report, const StripPlan& sp) {
         run_passes(rows, cols, sp.tile_count, 0, report, 0, true);
-        static const bool skip_compose = getenv("W2X_EXP_SKIP_COMPOSE") != nullptr;     // timing experiment (wrong output): what hiding the compose launch could buy
-        if (skip_compose) return;
         compose_rect(rows, cols, grid, sp.x0, sp.x1, 0, 0, sp.first_tile);
     }
 
@@ -748,8 +736,7 @@ struct Img2Img::Impl {
     bool can_roll(int tile_count) const {
         const int steps = cfg.tta ? 8 : 1, B = plan.B;
         const int last_live = tile_count * steps - (tile_count * steps - 1) / B * B;                    // live slots of the frame's last pass
-        return rolling_ok && groups == 2 && graph_per_group && use_graphs && !profiling && !check_general && !poison && gstream[0] && last_live >= 8 && B % 2 == 0 &&
-               !getenv("W2X_STAGGER_OP");
+        return rolling_ok && groups == 2 && use_graphs && !profiling && !check_general && !poison && gstream[0] && last_live >= 8 && B % 2 == 0;
     }
     void run_rolling_frame(int rows, int cols, const TileGrid& grid, const StripPlan& sp, int which, hipEvent_t out_free) {
         for (int k = 0; k < 2; ++k) {
@@ -803,15 +790,12 @@ struct Img2Img::Impl {
             // gaps between launches) fill with the other groups' work.  Bit-identical by construction.
             int first[5] = {0, 0, 0, 0, 0};
             for (int grp = 0; grp < NG; ++grp) first[grp + 1] = first[grp] + live / NG + (grp < live % NG ? 1 : 0);
-            static const int stagger_env = [] { const char* e = getenv("W2X_STAGGER_OP"); return e ? atoi(e) : -1; }();
-            stagger_op = split && NG == 2 && stagger_env >= 0 && stagger_env < (int)plan.ops.size() ? stagger_env : -1;
             if (split) {
                 if (!ev_fork) hipAssert(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
                 for (int k = 0; k + 1 < NG; ++k) if (!gstream[k]) {
                     hipAssert(hipStreamCreateWithFlags(&gstream[k], hipStreamNonBlocking));
                     hipAssert(hipEventCreateWithFlags(&ev_join[k], hipEventDisableTiming));
                 }
-                if (stagger_op >= 0 && !ev_stagger) hipAssert(hipEventCreateWithFlags(&ev_stagger, hipEventDisableTiming));
             }
             auto group_stream = [&](int grp) { return grp ? gstream[grp - 1] : stream; };
             auto gather_group = [&](int grp, hipStream_t gs) {       // the group's tiles at the start of its part of the arena
@@ -834,19 +818,15 @@ struct Img2Img::Impl {
                 ng_now = NG;
                 for (int grp = 0; grp < NG; ++grp) gather_group(grp, stream);
                 fork();
-                for (int grp = 0; grp < NG; ++grp) {
-                    if (grp == 1 && stagger_op >= 0) hipAssert(hipStreamWaitEvent(gstream[0], ev_stagger, 0));
-                    network_group(grp, group_stream(grp));
-                }
+                for (int grp = 0; grp < NG; ++grp) network_group(grp, group_stream(grp));
                 join();
                 ng_now = 1;
             };
             // one group of a split pass, gather included, as launches on ONE stream (capturable as a straight-line graph)
             auto run_group = [&](int grp) { ng_now = NG; gather_group(grp, group_stream(grp)); network_group(grp, group_stream(grp)); ng_now = 1; };
-            auto per_group_ok = [&](bool sp) { return sp && graph_per_group && stagger_op < 0; };
-            const bool per_group = per_group_ok(split);
+            const bool per_group = split;
             // (a rolling sequence leaves the groups un-joined: each stream carries its group from pass to pass and from frame to frame, run_rolling_frame)
-            const bool no_join = rolling && per_group_ok(split);
+            const bool no_join = rolling && split;
             auto run_eager = [&] { if (per_group) { fork(); for (int grp = 0; grp < NG; ++grp) run_group(grp); if (!no_join) join(); } else { if (rolling && gstream[0]) { join(); } run_pass(); } };
             if (!graphable) run_eager();
             else {
@@ -943,6 +923,7 @@ bool Img2Img::build(const std::string& onnxModelPath, const BuildConfig& config)
     }
     // :123-135 - precision: FP16 = the fused fp16 kernels; gfx950 has no TF32 matrix instruction, a TF32 request gets the fp32
     // engine (fp32 storage, v_mfma_f32_16x16x4_f32 products, fp32 accumulation - a superset of TF32's precision; k_f32.hip)
+    switches_from_env();                                   // (W2X_SUPERBATCH is read by the lowering: switches.h)
     const bool fp32 = config.precision == Precision::TF32;
     if (fp32) W2X_LOG(info, "Precision TF32: this platform has no TF32 matrix instructions, the engine computes in fp32.");
     // :81-88 parse ; :102-116 one profile: the plan on disk is specialised for the opt shape (channels come from the model);
@@ -1034,13 +1015,15 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
 
     impl->release();   // :149-154, :209-222
     impl->device = dev;
-    impl->poison = getenv("W2X_POISON") != nullptr;
-    impl->check_general = getenv("W2X_PIXGEMM_CHECK") != nullptr;
-    impl->use_graphs = getenv("W2X_NO_GRAPH") == nullptr;
-    impl->graph_per_group = getenv("W2X_GRAPH_FORKED") == nullptr;
-    impl->rolling_ok = getenv("W2X_NO_ROLLING") == nullptr;
-    if (const char* e = getenv("W2X_RENDER_PARTS")) impl->pipeline_parts = std::min(Impl::kMaxRenderParts, std::max(1, atoi(e)));
-    if (getenv("W2X_ROCTX") && !impl->roctx_push) {
+    switches_from_env();                                   // every switch of the library: switches.h
+    const Switches& sw = switches();
+    impl->poison = sw.poison;
+    impl->check_general = sw.check_general;
+    impl->use_graphs = !sw.no_graph;
+    impl->rolling_ok = !sw.no_rolling;
+    impl->pipeline_parts = std::min(Impl::kMaxRenderParts, std::max(1, sw.render_parts));
+    if (const std::string nd = switches_nondefault(); !nd.empty()) W2X_LOG(warn, "Switches off their defaults: " + nd + ".");
+    if (sw.roctx && !impl->roctx_push) {
         if (void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL)) {
             impl->roctx_push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
             impl->roctx_pop = (int (*)())dlsym(h, "roctxRangePop");
@@ -1080,20 +1063,14 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
     hipAssert(hipStreamCreateWithFlags(&impl->stream, hipStreamNonBlocking));   // :206
     hipAssert(hipEventCreate(&impl->ev0));
     hipAssert(hipEventCreate(&impl->ev1));
-    impl->groups = getenv("W2X_NO_SPLIT") ? 1 : getenv("W2X_GROUPS") ? std::min(4, std::max(1, atoi(getenv("W2X_GROUPS")))) : 2;   // (the extra streams are created by the first pass that splits)
+    impl->groups = sw.groups;
     // Every stream the engine will use is created HERE, before anything touches the null stream (upload_plan()'s synchronous copies do): the runtime hands its
     // hardware queues (four by default) to streams in creation order and lets later streams share, so created now the compute stream, the two copy streams and the
     // second tile group's stream have a queue each and the null stream shares one.  Created lazily, in whatever order the first calls needed them, the second
     // group's kernels shared a queue with a copy stream on some orders: renderSequence() 7.69 (this order) / 7.85 (lazy) / 10.0 ms per frame (group stream
-    // first), profiles/r4_kernels/stream_order.txt.  W2X_STREAM_ORDER = a string of 'c' (copy streams) and 'g' (group stream) overrides the order; "-" = lazy.
-    {
-        const char* order = getenv("W2X_STREAM_ORDER");
-        for (const char* c = order ? order : "cg"; *c; ++c) {
-            if (*c == 'g')       // the next group stream not yet created
-                for (int k = 0; k + 1 < impl->groups; ++k) if (!impl->gstream[k]) { hipAssert(hipStreamCreateWithFlags(&impl->gstream[k], hipStreamNonBlocking)); hipAssert(hipEventCreateWithFlags(&impl->ev_join[k], hipEventDisableTiming)); break; }
-            if (*c == 'c') impl->ensure_copy_streams();
-        }
-    }
+    // first), profiles/r4_kernels/stream_order.txt.  Further group streams (W2X_GROUPS > 2) are created by the first pass that splits.
+    impl->ensure_copy_streams();
+    if (impl->groups > 1) { hipAssert(hipStreamCreateWithFlags(&impl->gstream[0], hipStreamNonBlocking)); hipAssert(hipEventCreateWithFlags(&impl->ev_join[0], hipEventDisableTiming)); }
     try {
         impl->upload_plan();                                                      // :225-248
     } catch (const std::exception& e) {
@@ -1178,10 +1155,6 @@ bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, cons
             const int t = k + 1 == want ? body : (int)((long)k * body / (want - 1)) / q * q;
             if (t > first_of[n] && t < sp.tile_count) first_of[++n] = t;
         }
-        if (const char* e = getenv("W2X_RENDER_CUTS")) {        // experiments (tools/ab/render_parts.py): explicit part boundaries "t1,t2,.." (ascending; whole batches are NOT enforced)
-            n = 0;
-            for (const char* c = e; *c && n + 1 < kMaxParts;) { const int t = atoi(c); if (t > first_of[n] && t < sp.tile_count) first_of[++n] = t; while (*c && *c != ',') ++c; if (*c) ++c; }
-        }
         first_of[++n] = sp.tile_count;
         npart = n;
     }
@@ -1216,8 +1189,10 @@ bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, cons
     }
     impl->ensure(impl->d_slots, impl->slots_cap, stepTotal * sizeof(TileSlot));
     hipAssert(hipMemcpyAsync(impl->d_slots, impl->h_slots.data(), stepTotal * sizeof(TileSlot), hipMemcpyHostToDevice, stream));
-    // the slab holds the frame's tiles in tile order: the last part's passes end at most a pass beyond them
-    impl->ensure(impl->d_slab, impl->slab_cap, ((size_t)first_of[npart - 1] * steps + (stepTotal - slots_off[npart - 1])) * plan.Tout * plan.Tout * 4 * plan.elt);
+    // the slab holds the frame's tiles in tile order: the last part's passes end at most a pass beyond them (and the frame as ONE part - what
+    // benchResident / profileFrame replay - ends at most a pass beyond its tiles: sized for both now, an allocation later would drop the captured passes)
+    const size_t one_part_steps = (size_t)(((int)std::lround(std::ceil((double)(sp.tile_count * steps) / plan.userB)) + S - 1) / S) * B;
+    impl->ensure(impl->d_slab, impl->slab_cap, std::max((size_t)first_of[npart - 1] * steps + (stepTotal - slots_off[npart - 1]), one_part_steps) * plan.Tout * plan.Tout * 4 * plan.elt);
 
     hipAssert(hipEventRecord(impl->ev0, stream));
     if (npart == 1) {
@@ -1243,9 +1218,7 @@ bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, cons
             else { int full0 = c0; if (r0) { add(c0, c0 + 1, r0, grid.ny); full0 = c0 + 1; } add(full0, c1, 0, grid.ny); if (r1) add(c1, c1 + 1, 0, r1); }
             part_plan[k] = q;
         }
-        static const bool dn_on_second = getenv("W2X_RENDER_DN_STREAM") != nullptr;
-        static const bool dn_interleaved = getenv("W2X_RENDER_DN_INTERLEAVE") != nullptr;
-        hipStream_t dn = dn_on_second ? impl->s_dn : impl->s_up;
+        hipStream_t dn = impl->s_up;      // (which of the two copy streams: below)
         auto download_part = [&](int k) {
             hipAssert(hipStreamWaitEvent(dn, impl->ev_part[k], 0));
             for (int r = 0; r < part_plan[k].nrect; ++r) {
@@ -1282,36 +1255,25 @@ bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, cons
             }
             hipAssert(hipEventRecord(impl->ev_part[k], cs));
             if (k + 1 == npart) { if (roll) impl->end_rolling(); hipAssert(hipEventRecord(impl->ev1, stream)); }
-            if (dn_interleaved) download_part(k);
         }
         // the downloads, in order, on a copy stream: a part's cells travel while the next part computes.  Which of the two copy streams: the one created
         // FIRST (renderSequence()'s upload stream, idle here) - the runtime spreads streams over its hardware queues in creation order, and from
         // pageable memory the download only ran beside the kernels on that one (9.1 against 9.9 ms per call, profiles/r4_kernels/render_parts_ab*.txt)
-        if (!dn_interleaved) for (int k = 0; k < npart; ++k) download_part(k);
+        for (int k = 0; k < npart; ++k) download_part(k);
         hipAssert(hipStreamSynchronize(dn));
         hipAssert(hipStreamSynchronize(stream));
     }
     hipAssert(hipEventElapsedTime(&impl->last_ms, impl->ev0, impl->ev1));
     impl->last_rows = rows; impl->last_cols = cols; impl->last_grid = grid; impl->last_strip = sp;
-    // (benchResident / profileFrame replay the frame as ONE part: the slots of a one-part frame)
-    if (npart > 1) {
-        const int batchCount = (int)std::lround(std::ceil((double)(sp.tile_count * steps) / plan.userB));
-        const size_t stepCount = (size_t)((batchCount + S - 1) / S) * B;
-        impl->h_slots.resize(stepCount);
-        for (size_t st = 0; st < stepCount; ++st) {
-            const int ti = (int)(st / steps), aug = (int)(st % steps);
-            TileSlot sl{0, 0, aug, 0};
-            if (ti < sp.tile_count) { sl.x = grid.in[sp.first_tile + ti].x; sl.y = grid.in[sp.first_tile + ti].y; sl.valid = 1; }
-            impl->h_slots[st] = sl;
-        }
-        impl->ensure(impl->d_slots, impl->slots_cap, stepCount * sizeof(TileSlot));
-        hipAssert(hipMemcpy(impl->d_slots, impl->h_slots.data(), stepCount * sizeof(TileSlot), hipMemcpyHostToDevice));
-        impl->ensure(impl->d_slab, impl->slab_cap, stepCount * plan.Tout * plan.Tout * 4 * plan.elt);
-    }
+    impl->one_part_stale = npart > 1;     // (benchResident / profileFrame replay the frame as ONE part and rebuild the slot table when they are called: one_part_slots)
     // the second slab of a rolling sequence now (an allocation drops the captured passes: better here, on the frame size's first sight, than inside benchResident / renderSequence)
     if (parts == 1 && impl->slab2_cap < impl->slab_cap && impl->can_roll(sp.tile_count)) impl->ensure(impl->d_slab2, impl->slab2_cap, impl->slab_cap);
     return true;
 } catch (const std::exception& e) {
+    // a frame in parts copies to and from the caller's buffers on the side streams and may have left the second group's stream un-joined: let everything
+    // drain before the caller gets its buffers back (errors here are ignored, the first one is what gets reported)
+    impl->rolling = false;
+    for (hipStream_t st : {impl->s_up, impl->s_dn, impl->gstream[0], impl->stream}) if (st && hipStreamSynchronize(st) != hipSuccess) (void)hipGetLastError();
     W2X_LOG_AS(who, error, "Render failed unexpectedly: " + std::string(e.what()) + ".");
     return false;
 }
@@ -1446,7 +1408,11 @@ bool Img2Img::renderSharded(Img2Img* const* engines, int count, const Image& src
         for (const Rect& r : grid.out) if (r.w <= 0 || r.h <= 0) { W2X_LOG(error, "Tile grid does not fit the output (scaling does not match the model)."); return false; }
         std::vector<ShardPlan> sp(count);
         for (int k = 0; k < count; ++k) sp[k] = shard_plan(grid, cols * s, rows * s, plan.Tout, plan.Tout, k, count);
-        if (count > 1 && sp[0].tile_count == 0 && grid.count >= count) { W2X_LOG(error, "renderSharded: the blend bands are wider than the tile stride; use renderStrip."); return false; }
+        {   // every tile must have an owner: shard_plan() hands out nothing when the blend bands are as wide as the tile stride
+            int owned = 0;
+            for (int k = 0; k < count; ++k) owned += sp[k].tile_count;
+            if (owned != grid.count) { W2X_LOG(error, "renderSharded: the blend bands are wider than the tile stride; use render or renderStrip."); return false; }
+        }
         // ---- phase 1: every engine computes its own tiles
         for (int k = 0; k < count; ++k) {
             Impl& e = *engines[k]->impl;
@@ -1496,7 +1462,12 @@ bool Img2Img::shardCompute(const Image& src, int part, int parts) try {
     if (grid.count <= 0) { W2X_LOG(error, "Tile grid is empty."); return false; }
     const ShardPlan sp = shard_plan(grid, cols * s, rows * s, plan.Tout, plan.Tout, part, parts);
     impl->shard_rows = rows; impl->shard_cols = cols;
-    if (sp.tile_count == 0) { if (parts > 1 && part == 0 && grid.count >= parts) { W2X_LOG(error, "the blend bands are wider than the tile stride; use renderStrip."); return false; } return true; }
+    {   // every tile must have an owner (shard_plan() hands out nothing when the blend bands are as wide as the tile stride)
+        int owned = 0;
+        for (int k = 0; k < parts; ++k) owned += shard_plan(grid, cols * s, rows * s, plan.Tout, plan.Tout, k, parts).tile_count;
+        if (owned != grid.count) { W2X_LOG(error, "the blend bands are wider than the tile stride; use render or renderStrip."); return false; }
+    }
+    if (sp.tile_count == 0) return true;                       // more parts than tiles: this one has no share
     shard_phase1(*impl, src, grid, sp, true);
     hipAssert(hipStreamSynchronize(impl->stream));           // the slab is complete when this returns: what the peers copy from after the barrier
     return true;
@@ -1717,6 +1688,7 @@ float Img2Img::benchResident(int iters) try {
     if (!impl->loaded || impl->last_rows == 0 || iters <= 0) return -1.f;
     DeviceGuard guard(impl->device);
     hipStream_t stream = impl->stream;
+    impl->one_part_slots();
     // frames of one size back to back: a rolling sequence where every pass splits (run_rolling_frame), else frame after frame
     const bool roll = iters > 1 && impl->can_roll(impl->last_strip.tile_count);
     if (roll) impl->ensure(impl->d_slab2, impl->slab2_cap, impl->slab_cap);
@@ -1743,6 +1715,7 @@ bool Img2Img::profileFrame(double* out, int cap) try {
     if (!impl->loaded || impl->last_rows == 0 || cap < 31) return false;
     DeviceGuard guard(impl->device);
     for (int i = 0; i < 31; ++i) out[i] = 0;
+    impl->one_part_slots();
     impl->profiling = true; impl->stamps.clear();
     impl->run_frame(impl->last_rows, impl->last_cols, impl->last_grid, false, impl->last_strip);
     impl->profiling = false;

@@ -507,6 +507,7 @@ FoldedGraph fold_graph(const Model& m, const std::vector<int64_t>& input_shape) 
     if (!g.vals.count(g.output)) throw std::runtime_error("graph: output tensor is never produced");
     if (g.vals[g.output].shape.size() != 4)
         throw std::runtime_error("model has invalid IO tensor shape: expected 4 dims, got " + std::to_string(g.vals[g.output].shape.size()));
+    simplify_graph(g);
     return g;
 }
 

@@ -1,5 +1,5 @@
 // Host-side re-ordering of fp16 weight matrices into MFMA-fragment order for the kernels that read weights straight
-// from L2 (k_swinattn96.hip, k_swinattn192.hip, k_mlp2.hip): a wave's fragment load becomes one contiguous KiB instead
+// from L2 (k_swinattn96.hip, k_swinattn192u.hip, k_mlp2.hip): a wave's fragment load becomes one contiguous KiB instead
 // of 16 half cache lines.
 #pragma once
 #include <cstddef>

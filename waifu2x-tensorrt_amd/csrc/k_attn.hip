@@ -1,6 +1,6 @@
 // Window multi-head self-attention on window-ordered rows (Swin W-MSA / SW-MSA core) for graphs whose shapes the fused
-// kernels (k_swinattn96.hip / k_swinattn192.hip) do not cover.  Two kernels: attn_mfma_kernel (below, the default) on the matrix
-// pipe, and the original lane-per-query VALU kernel (W2X_ATTN_VALU=1), kept as its reference.
+// kernels (k_swinattn96.hip / k_swinattn192u.hip) do not cover.  Two kernels: attn_mfma_kernel (below, the default) on the matrix
+// pipe, and the original lane-per-query VALU kernel (switches().attn_valu), kept as its reference.
 //   out[w][q][h*hd+d] = sum_k softmax_k( scale * q.k + bias[mask(w)][h][q][k] ) v[k][d]
 // One wave per (window, head); lane q owns query row q (ntok = ws*ws <= 64 tokens): scores, softmax and the
 // weighted sum all stay in that lane's registers, K/V rows are broadcast from LDS.  fp32 math on fp16 inputs.
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
 }  // namespace
 
 hipError_t launch_attn(const AttnParams& p, hipStream_t s) {
-    static const bool valu = getenv("W2X_ATTN_VALU") != nullptr;   // A/B switch, read once per process: the lane-per-query VALU kernel above
+    const bool valu = switches().attn_valu;   // reference path (switches.h): the lane-per-query VALU kernel above
     long total = (long)p.B * p.nwin * p.heads;
     dim3 grid((unsigned)((total + 3) / 4));
 #define W2X_ATTN_CASE(HD_, NTOK_)                                                                                      \

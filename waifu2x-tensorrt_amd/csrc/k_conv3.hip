@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
     // The 2 - 4 output blocks of a pixel tile share its halo.  Workgroups are handed to the eight XCDs round-robin (workgroup q -> XCD q % 8), each XCD
     // with its own L2: as consecutive workgroups the blocks of a tile land on different XCDs and each fetches the halo into its own L2.  XCD-grouped
     // order (round 4): the r-th workgroup of an XCD (r = q / 8) is block r % nblk of tile (r / nblk) * 8 + xcd, so the blocks of a tile are consecutive
-    // workgroups of ONE XCD and the halo goes through one L2.  (W2X_CONV3_XCD=0 keeps the plain order.)
+    // workgroups of ONE XCD and the halo goes through one L2.
     int nb, tidx;
     const int tpi = tiles_x * tiles_y;
     if (xcd_order) {
@@ -211,8 +211,7 @@ int conv3_tiles(const GemmParams& p) {   // workgroups (pooling partials) per im
 }
 
 bool conv3_supported(const GemmParams& p) {
-    static const bool off = getenv("W2X_NO_CONV3") != nullptr;   // A/B switch
-    if (off || p.a_scale || p.res_scale || !p.wt_perm || p.amode != 2 || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.omode != 0 || p.ln || (p.act != 0 && p.act != 1) ||
+    if (switches().no_conv3 || p.a_scale || p.res_scale || !p.wt_perm || p.amode != 2 || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.omode != 0 || p.ln || (p.act != 0 && p.act != 1) ||
         p.has_clip || p.stats_out || p.res.p || p.res2.p) return false;
     if (p.act == 1 && !(p.alpha >= 0.f && p.alpha <= 1.f)) return false;   // LeakyReLU as max(v, v * alpha)
     const int Cin = p.a.Cs;
@@ -232,8 +231,7 @@ hipError_t launch_conv3(const GemmParams& p, hipStream_t s) {
     if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<false>, C::SMEM, lds_ok); e != hipSuccess) return e;
     if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<true>, C::SMEM, lds_ok_pool); e != hipSuccess) return e;
     const int tiles_x = (Wo + C::TW - 1) / C::TW, tiles_y = (Ho + C::TH - 1) / C::TH, nblk = p.N / 64;
-    static const bool xcd_off = [] { const char* e = getenv("W2X_CONV3_XCD"); return e && e[0] == '0'; }();   // A/B switch, read once
-    const int xcd_order = nblk > 1 && !xcd_off ? 1 : 0;
+    const int xcd_order = nblk > 1 ? 1 : 0;
     const int ntiles = p.B * tiles_x * tiles_y;
     const dim3 grid((unsigned)((xcd_order ? (ntiles + 7) / 8 * 8 : ntiles) * nblk));
     if (p.pool_out) hipLaunchKernelGGL(conv3_kernel<true>, grid, dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, nblk, xcd_order);

@@ -145,15 +145,13 @@ hipError_t launch_c3h2(const GemmParams& p, int Ho, int Wo, hipStream_t s) {
 }
 template <int PIX>
 hipError_t launch_c3h(const GemmParams& p, int Ho, int Wo, hipStream_t s) {
-    static const bool one_at_a_time = getenv("W2X_CONV3H_SERIAL") != nullptr;   // A/B switch: the chunks fetched one after the other (until late round 4)
-    return p.a.Cs == 64 && !one_at_a_time ? launch_c3h2<PIX, true>(p, Ho, Wo, s) : launch_c3h2<PIX, false>(p, Ho, Wo, s);
+    return p.a.Cs == 64 ? launch_c3h2<PIX, true>(p, Ho, Wo, s) : launch_c3h2<PIX, false>(p, Ho, Wo, s);
 }
 
 }  // namespace
 
 bool conv3h_supported(const GemmParams& p) {
-    static const bool off = getenv("W2X_NO_CONV3H") != nullptr;   // A/B switch
-    if (off || p.a_scale || p.res_scale || p.amode != 2 || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.ln || (p.act != 0 && p.act != 1) || p.stats_out || p.pool_out || p.res2.p) return false;
+    if (switches().no_conv3h || p.a_scale || p.res_scale || p.amode != 2 || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.ln || (p.act != 0 && p.act != 1) || p.stats_out || p.pool_out || p.res2.p) return false;
     const int Cin = p.a.Cs;
     if (Cin % 32 || Cin > 256 || p.K != 9 * Cin || p.Kw != p.K || p.out.Cs != 4 || p.aW <= 0 || p.Mrows % p.aW || p.B <= 0) return false;
     const int Ho = p.Mrows / p.aW, Wo = p.aW;

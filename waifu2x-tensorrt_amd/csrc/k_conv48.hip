@@ -216,8 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv48_kernel(const GemmParams p, int 
 }  // namespace
 
 bool conv48_supported(const GemmParams& p) {
-    static const bool off = getenv("W2X_NO_CONV48") != nullptr;   // A/B switch (read once per process)
-    if (off || p.a_scale || !p.wt_frag || p.amode != 2 || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.omode != 0 || p.ln || (p.act != 0 && p.act != 1) ||
+    if (switches().no_conv48 || p.a_scale || !p.wt_frag || p.amode != 2 || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.omode != 0 || p.ln || (p.act != 0 && p.act != 1) ||
         p.has_clip || p.stats_out || p.pool_out || p.res.p || p.res2.p) return false;
     if (p.act == 1 && !(p.alpha >= 0.f && p.alpha <= 1.f)) return false;
     if (p.a.Cs != CIN || p.N != N || p.K != 9 * CIN || p.out.Cs != N || p.aW <= 0 || p.Mrows % p.aW) return false;
@@ -237,13 +236,12 @@ hipError_t launch_conv48(const GemmParams& p, hipStream_t s) {
 
 // the stem (ps: a launch stem_supported() takes, 48 output channels) folded into the patch convolution that is the only reader of its output (p.a = a view of ps.out)
 bool conv48_stem_supported(const GemmParams& p, const GemmParams& ps) {
-    if (getenv("W2X_NO_FUSE_STEM") || !conv48_supported(p) || !stem_supported(ps) || ps.N != CIN || ps.out.Cs != CIN || p.a.p != ps.out.p || ps.out.y0 || ps.out.x0) return false;   // (W2X_NO_FUSE_STEM: A/B switch, read when an engine loads)
+    if (switches().no_fuse_stem || !conv48_supported(p) || !stem_supported(ps) || ps.N != CIN || ps.out.Cs != CIN || p.a.p != ps.out.p || ps.out.y0 || ps.out.x0) return false;
     const int Hs_o = ps.Mrows / ps.aW, Ws_o = ps.aW, Ho = p.Mrows / p.aW, Wo = p.aW;
     return p.a.Hs == ps.out.Hs && p.a.Ws == ps.out.Ws && p.a.y0 + Ho + 2 <= Hs_o && p.a.x0 + Wo + 2 <= Ws_o && p.B == ps.B;
 }
 
 hipError_t launch_conv48_stem(const GemmParams& p, const GemmParams& ps, hipStream_t s) {
-    if (conv48p_enabled()) return launch_conv48p(p, ps, s);     // W2X_CONV48_PERSIST=1: the weight-resident persistent kernel (k_conv48p.hip; measured slower, kept as a record)
     static unsigned lds_ok = 0;
     if (hipError_t e = ensure_dynamic_lds((const void*)conv48_kernel<true>, SMEM48, lds_ok); e != hipSuccess) return e;
     const int Ho = p.Mrows / p.aW, Wo = p.aW;

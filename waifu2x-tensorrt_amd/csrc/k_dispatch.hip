@@ -9,16 +9,13 @@ namespace w2x {
 
 hipError_t launch_mlp2(const MlpParams& p, hipStream_t s);                // k_mlp2.hip
 hipError_t launch_swin_attn96(const SwinAttnParams& p, hipStream_t s);    // k_swinattn96.hip
-hipError_t launch_swin_attn192(const SwinAttnParams& p, hipStream_t s);   // k_swinattn192.hip: two workgroups per CU, a head's weights shared by both windows
-hipError_t launch_swin_attn192u(const SwinAttnParams& p, hipStream_t s);  // k_swinattn192u.hip: three workgroups per CU, one (window, head) unit at a time (round 4)
+hipError_t launch_swin_attn192u(const SwinAttnParams& p, hipStream_t s);  // k_swinattn192u.hip: three workgroups per CU, one (window, head) unit at a time (round 4; round 3's
+                                                                          // two-per-CU kernel, 0.3 % slower at frame level in 4 of 4 alternating pairs, lives on as tools/ab/k_swinattn192_r3.hip)
 
 hipError_t launch_swin_attn(const SwinAttnParams& p, hipStream_t s) {
     if (!p.wqkv_frag || !p.wproj_frag) return hipErrorInvalidValue;       // the kernels read fragment-major weights only
     if (p.C == 96 && p.hd == 16) return launch_swin_attn96(p, s);
-    if (p.C == 192 && p.hd == 32) {
-        static const bool two_per_cu = getenv("W2X_A192_TWO_PER_CU") != nullptr;      // A/B switch, read once: the round-3 kernel
-        return two_per_cu ? launch_swin_attn192(p, s) : launch_swin_attn192u(p, s);
-    }
+    if (p.C == 192 && p.hd == 32) return launch_swin_attn192u(p, s);
     return hipErrorInvalidValue;
 }
 

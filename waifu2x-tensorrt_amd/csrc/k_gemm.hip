@@ -341,8 +341,7 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     else bn = p.N % 192 == 0 ? 192 : p.N % 96 == 0 ? 96 : p.N % 128 == 0 ? 128 : p.N % 64 == 0 ? 64 : p.N % 48 == 0 ? 48 : p.N % 32 == 0 ? 32 : 0;
     // pixel-shuffle projections onto 96-channel pixels are memory-bound: 96-wide tiles (150 VGPRs, 3 workgroups per CU) keep
     // more rows in flight than the 192-wide ones (244 VGPRs, 2 per CU): 0.69 -> 0.61 ms on config 3's last up-projection
-    static const bool wide = getenv("W2X_GEMM_WIDE") != nullptr;       // A/B switch
-    if (!wide && bn == 192 && !p.stats_out && p.omode == 2 && 96 % p.out.Cs == 0) bn = 96;
+    if (bn == 192 && !p.stats_out && p.omode == 2 && 96 % p.out.Cs == 0) bn = 96;
     if (p.stats_out && p.omode != 2 && bn < p.N) return hipErrorInvalidValue;
     switch (bn) {
         case 192: return k96 ? launch_cfg<96, 2, 2, 4, 6, 8, 8>(p, s) : launch_cfg<64, 2, 2, 4, 6, 8, 8>(p, s);

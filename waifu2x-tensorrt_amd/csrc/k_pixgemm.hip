@@ -638,7 +638,7 @@ hipError_t launch_merge(const GemmParams& p, hipStream_t s) {
 
 // true if this launch can take the streaming kernel (everything else stays on gemm_kernel)
 bool pixgemm_supported(const GemmParams& p) {
-    static const bool off = getenv("W2X_NO_PIXGEMM") != nullptr;   // A/B switch
+    const bool off = switches().no_pixgemm;   // reference path (switches.h)
     if ((p.a_scale || p.res_scale) && p.a.Cs != 64 && p.a.Cs != 128) return false;   // gated operands: compiled into cunet's shapes only (PixCfg / MergeCfg GATES)
     if (!off && p.wt_frag && p.amode == 2 && p.kh == 2 && p.kw == 2 && p.stride == 2 && p.omode == 0 && !p.ln && (p.act == 0 || p.act == 1) && !p.has_clip &&
         !p.stats_out && !p.pool_out && !p.res.p && !p.res2.p && p.out.Cs == p.N && p.Kw == p.K && p.K == 4 * p.a.Cs && (long)p.out.Hs * p.out.Ws == p.Mrows && p.out.Ws == p.aW &&

@@ -1,6 +1,6 @@
 // First convolution of a network for gfx950: 3x3, stride 1, valid, on the 3-channel tile stored as 4 halves per pixel
 // (r, g, b, 0), to 32 / 48 / 64 channels with bias and LeakyReLU.  Same result as gemm_kernel (k_gemm.hip), which remains
-// the reference for it (W2X_NO_STEM / W2X_PIXGEMM_CHECK in engine.cpp).
+// the reference for it (switches.h: no_stem / W2X_CHECK_GENERAL).
 //
 // The launch is a pure output stream (config 3: 0.3 GB written for 8 GFLOP); the general kernel gathers its A operand
 // element by element for the 4-channel input and reaches 1.5 TB/s.  Here a pixel IS an operand register pair:
@@ -92,8 +92,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const GemmParams p, int Ho, i
 }  // namespace
 
 bool stem_supported(const GemmParams& p) {
-    static const bool off = getenv("W2X_NO_STEM") != nullptr;   // A/B switch
-    if (off || p.a_scale || p.res_scale || p.amode != 2 || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.omode != 0 || p.ln || (p.act != 0 && p.act != 1) || p.has_clip ||
+    if (switches().no_stem || p.a_scale || p.res_scale || p.amode != 2 || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.omode != 0 || p.ln || (p.act != 0 && p.act != 1) || p.has_clip ||
         p.stats_out || p.pool_out || p.res.p || p.res2.p) return false;
     if (p.a.Cs != 4 || p.K != 36 || p.Kw < 36 || p.Kw % 4 || (p.N != 32 && p.N != 48 && p.N != 64) || p.out.Cs != p.N || p.aW <= 0 || p.Mrows % p.aW) return false;
     const int Ho = p.Mrows / p.aW, Wo = p.aW;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "support.h"
+#include "switches.h"
 #include <cstdint>
 
 namespace w2x {
@@ -99,7 +100,7 @@ struct SwinAttnParams {          // y = x + proj(W-MSA(LN(x))) on token maps [B]
     float eps = 1e-5f;
     float* stats_out = nullptr; float eps_out = 1e-5f;
     // the same two matrices in MFMA-fragment order (engine.cpp frag_major): [16-row tile][32-column k-step][lane][8], so a
-    // wave's fragment load is one contiguous KiB.  Required by k_swinattn96.hip / k_swinattn192.hip.
+    // wave's fragment load is one contiguous KiB.  Required by k_swinattn96.hip / k_swinattn192u.hip.
     const void* wqkv_frag = nullptr; const void* wproj_frag = nullptr;
 };
 
@@ -156,8 +157,6 @@ bool conv48_supported(const GemmParams& p);                     // k_conv48.hip:
 hipError_t launch_conv48(const GemmParams& p, hipStream_t s);
 bool conv48_stem_supported(const GemmParams& p, const GemmParams& ps);   // k_conv48.hip: the stem launch ps folded into the patch convolution p that alone reads its output
 hipError_t launch_conv48_stem(const GemmParams& p, const GemmParams& ps, hipStream_t s);
-bool conv48p_enabled();                                                                    // k_conv48p.hip: the same pair as one persistent, weight-resident kernel (W2X_CONV48_PERSIST=1 switches it on: measured slower)
-hipError_t launch_conv48p(const GemmParams& p, const GemmParams& ps, hipStream_t s);
 int conv3_tiles(const GemmParams& p);                           // workgroups (= pooling partials) per image of launch_conv3
 hipError_t launch_attn(const AttnParams& p, hipStream_t s);
 // k_f32.hip: the fp32 engine's kernels (Plan::elt == 4): general GEMM / convolution and the window attention core on fp32 rows

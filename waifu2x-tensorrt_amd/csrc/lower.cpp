@@ -9,6 +9,7 @@
 
 #include "common.h"
 #include "support.h"
+#include "switches.h"
 
 namespace w2x {
 namespace {
@@ -689,7 +690,7 @@ struct Lowerer {
         // in-place pass first (apply_gate).  Saves a read + write of the map per squeeze-excite block.
         gate_names[x.v.t] = mul->name.empty() ? "se_scale" : mul->name;
         pending_gate[x.v.t] = s.scale;
-        if (plan.elt != 2 || getenv("W2X_NO_SE_FOLD")) apply_gate(x.v.t);
+        if (plan.elt != 2 || switches().no_se_fold) apply_gate(x.v.t);
         for (auto* z : {n, c1, r, c2, sg, mul}) done.insert(z);
         vals[mul->out[0]] = x;
         return true;
@@ -965,7 +966,7 @@ struct Lowerer {
         const TensorDesc& td = plan.tensors[y.v.t];
         if (y.v.y0 || y.v.x0 || y.v.H != td.H || y.v.W != td.W) throw std::runtime_error("graph output is a cropped view");
         plan.out_tensor = y.v.t; plan.Tout = (int)os[2]; plan.Cout = 3;
-        if (!getenv("W2X_NO_FUSE") && plan.elt == 2) { if (!getenv("W2X_NO_FUSE_ATTN")) fuse_attn(); fuse_mlp(); }   // the fused kernels are fp16 kernels
+        if (!switches().no_fuse && plan.elt == 2) { if (!switches().no_fuse_attn) fuse_attn(); fuse_mlp(); }   // the fused kernels are fp16 kernels
         for (auto& op : plan.ops) plan.flops += op.flops;
         bool has_attn = false; for (auto& op : plan.ops) has_attn |= op.kind == OP_ATTN;
         plan.model_kind = has_attn ? "swin_unet" : "cunet";

@@ -136,6 +136,7 @@ def lib():
     L.w2x_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_size_t]; L.w2x_device_pci_bus_id.restype = C.c_int
     L.w2x_sha256_hex.argtypes = [vp, C.c_size_t, C.c_char_p]
     L.w2x_version.restype = C.c_char_p
+    L.w2x_debug_set.argtypes = [C.c_char_p, C.c_int]; L.w2x_debug_set.restype = C.c_int
     _lib = L
     return L
 
@@ -143,7 +144,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "w2x_create", "w2x_destroy", "w2x_set_message_callback", "w2x_set_progress_callback", "w2x_build", "w2x_load",
     "w2x_render", "w2x_render16", "w2x_infer", "w2x_output_tile_size", "w2x_plan_flops", "w2x_pass_tiles", "w2x_last_render_ms", "w2x_bench_resident", "w2x_profile_frame", "w2x_op_times",
-    "w2x_render_strip", "w2x_strip_plan", "w2x_render_sharded", "w2x_shard_plan", "w2x_shard_compute", "w2x_shard_slab", "w2x_shard_finish", "w2x_ipc_export", "w2x_ipc_open", "w2x_ipc_close", "w2x_render_sequence", "w2x_alloc_host", "w2x_free_host", "w2x_pin_host", "w2x_unpin_host", "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_describe_plan_precision", "w2x_write_engine_file", "w2x_validate_engine_file", "w2x_device_pci_bus_id", "w2x_sha256_hex", "w2x_version"]
+    "w2x_render_strip", "w2x_strip_plan", "w2x_render_sharded", "w2x_shard_plan", "w2x_shard_compute", "w2x_shard_slab", "w2x_shard_finish", "w2x_ipc_export", "w2x_ipc_open", "w2x_ipc_close", "w2x_render_sequence", "w2x_alloc_host", "w2x_free_host", "w2x_pin_host", "w2x_unpin_host", "w2x_calculate_tiles", "w2x_tile_weights", "w2x_describe_plan", "w2x_describe_plan_precision", "w2x_write_engine_file", "w2x_validate_engine_file", "w2x_device_pci_bus_id", "w2x_sha256_hex", "w2x_version", "w2x_debug_set"]
 
 
 class Img2Img:
@@ -382,6 +383,25 @@ def render_sharded(engines, src: np.ndarray, dst: np.ndarray = None) -> np.ndarr
     if not lib().w2x_render_sharded(handles, len(engines), src.ctypes.data, src.shape[0], src.shape[1], src.strides[0], dst.ctypes.data, dst.strides[0]):
         raise W2xError(engines[0].last_error() or "sharded render failed")
     return dst
+
+
+class debug_switches:
+    """Test hook (w2x_debug_set, csrc/switches.h): the reference paths the A/B tests compare the shipped plans and kernels with -
+    `with debug_switches(no_fuse_attn=1): eng.build(...)`.  Process-wide; every switch goes back to 0 on exit."""
+
+    def __init__(self, **switches):
+        self.switches = switches
+
+    def __enter__(self):
+        for k, v in self.switches.items():
+            if not lib().w2x_debug_set(k.encode(), int(v)):
+                raise W2xError(f"no such switch: {k}")
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.switches:
+            lib().w2x_debug_set(k.encode(), 0)
+        return False
 
 
 def device_pci_bus_id(device: int):
