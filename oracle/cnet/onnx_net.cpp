@@ -445,7 +445,7 @@ TP run_node(const Node& n, const std::vector<TP>& a, double& flops) {
         if (const Attr* v = attr(n, "value_floats")) { TP t = make(F32, {(i64)v->floats.size()}); t->f = v->floats; return t; }
         fail("Constant: no value");
     }
-    if (op == "Identity") return in(0);
+    if (op == "Identity" || op == "Dropout") return in(0);      // (Dropout at inference is the identity)
     if (op == "Conv") return conv2d(*in(0), *in(1), opt(2), conv_args(n), flops);
     if (op == "ConvTranspose") return conv_transpose2d(*in(0), *in(1), opt(2), conv_args(n), flops);
     if (op == "LeakyRelu") { const float al = attr_f(n, "alpha", 0.01f); return unary_f(in(0), [al](float x) { return x >= 0.f ? x : x * al; }); }

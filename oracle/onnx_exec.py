@@ -318,7 +318,7 @@ class Executor:
                 return F.pixel_shuffle(a[0], r)
             t = a[0].reshape(b, r, r, c // (r * r), h, w).permute(0, 3, 4, 1, 5, 2)
             return t.reshape(b, c // (r * r), h * r, w * r)
-        if op == "Identity":
+        if op in ("Identity", "Dropout"):      # (Dropout at inference is the identity)
             return a[0]
         raise NotImplementedError(f"oracle: ONNX op {op}")
 

@@ -380,6 +380,30 @@ def test_an_engine_loaded_again_rolls_and_replays_like_a_fresh_one(pkg, onnx_mod
     eng.close()
 
 
+@pytest.mark.parametrize("model,scale", [("swin_unet/art", 4), ("cunet/art", 2)])
+def test_rewritten_graphs_render_the_bytes_of_the_original(pkg, onnx_model, tmp_path, model, scale):
+    """Five re-spellings per family of the graph the exporter wrote (tools/onnx_rewrite.py: Gemm sandwiches, Identity / Cast / Transpose pairs, Constant nodes,
+    0 / -1 Reshape targets, permuted node order ...; the CPU side is tests/test_loader_rewrites.py) built, loaded and rendered like any model file:
+    the frames are the original's, byte for byte."""
+    import onnx_rewrite as rw
+    from oracle import onnx_reader
+    path = onnx_model(model, scale, 2, 64, noise=1)
+    frame = smooth_frame(150, 170, 21)
+    eng = make_engine(pkg, path, 2, 64, scale)
+    want = eng.render(frame)
+    eng.close()
+    g, shapes = onnx_reader.load(path), rw.runtime_shapes(path, 2, 64)
+    for seed in range(5):
+        v = rw.rewrite(g, shapes, 1000 + seed, kinds=rw.EXACT, count=5)
+        vdir = tmp_path / f"v{seed}"; vdir.mkdir()
+        vpath = str(vdir / os.path.basename(path))
+        rw.dump(v, vpath, packed=bool(seed & 1))
+        eng = make_engine(pkg, vpath, 2, 64, scale)
+        got = eng.render(frame)
+        eng.close()
+        assert np.array_equal(got, want), (seed, v.applied)
+
+
 @pytest.mark.parametrize("pinned,small", [(False, True), (True, True), (True, False)])
 def test_frame_sequence_with_overlapped_copies_matches_render(pkg, onnx_model, pinned, small):
     """renderSequence: upload / compute / download of consecutive frames overlap on three streams (two device buffers, events);

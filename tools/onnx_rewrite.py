@@ -1,0 +1,461 @@
+"""Test infrastructure: an ONNX writer and a set of semantics-preserving graph rewrites.
+
+The reference hands whatever ONNX file it is given to TensorRT's parser (src/tensorrt/img2img_build.cpp:81-88); the files its
+users have are nunif exports this repository cannot see (README.md:11-15, no network).  What CAN be done offline: take the graphs
+tools/synth_models.py exports and re-spell them the ways exporters, opsets and optimiser passes spell the same computation - and
+require the loader (csrc/fold.cpp, simplify.cpp, lower.cpp) to produce the plan of the original for every spelling
+(tests/test_loader_rewrites.py).
+
+    g = oracle.onnx_reader.load(path); shapes = runtime_shapes(path)
+    v = rewrite(g, shapes, seed)          # a deep copy with 2-5 rewrites applied at random sites; v.applied lists them
+    dump(v, out_path)
+
+Rewrites (each keeps the function the graph computes, bit for bit in fp32 arithmetic, except `fp16_init`, which stores weights
+rounded to fp16 - the precision an fp16 engine gives them anyway):
+    gemm            MatMul(x, W) + Add(b)  ->  Reshape([-1, K]) -> Gemm(transB at random) -> Reshape(lead.., N)   (shape via Shape/Slice/Concat or a constant)
+    identity        Identity on an edge
+    dropout         Dropout (inference: identity) on an edge
+    cast            Cast(to=FLOAT) on a float edge
+    transpose2      Transpose(p) -> Transpose(p^-1) on an edge
+    squeeze         Unsqueeze(axis) -> Squeeze(axis) on an edge  (Flatten -> Reshape back for 4-D edges)
+    const_node      an initializer becomes a Constant node
+    fp16_init       a float initializer is stored as FLOAT16 and widened by a Cast node
+    reshape_0_m1    a Reshape target is re-spelled with 0 (copy the input dimension) and / or -1 (infer)
+    bias_unsqueeze  a bias vector [N] is stored as [N] and reaches its Add through Unsqueeze to [1, 1, N] (or stored [1, N] and squeezed)
+    ln_axis         LayerNormalization axis -1 <-> rank - 1
+    permute         the node list in another topological order
+    commute         the operands of an Add / Mul swapped
+    dead            a node nothing reads (a Shape or a Relu of some runtime tensor)
+"""
+from __future__ import annotations
+
+import copy
+import os
+import struct
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import onnx_reader  # noqa: E402
+from oracle.onnx_reader import Graph, Node  # noqa: E402
+
+# ------------------------------------------------------------------------------------------------ protobuf writer
+
+
+def _varint(v: int) -> bytes:
+    v &= (1 << 64) - 1
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _key(fn: int, wt: int) -> bytes:
+    return _varint((fn << 3) | wt)
+
+
+def _ld(fn: int, payload: bytes) -> bytes:
+    return _key(fn, 2) + _varint(len(payload)) + payload
+
+
+def _vi(fn: int, v: int) -> bytes:
+    return _key(fn, 0) + _varint(v)
+
+
+_NP2ONNX = {np.dtype(np.float32): 1, np.dtype(np.uint8): 2, np.dtype(np.int8): 3, np.dtype(np.int32): 6, np.dtype(np.int64): 7,
+            np.dtype(np.bool_): 9, np.dtype(np.float16): 10, np.dtype(np.float64): 11}
+
+
+def _tensor(name: str, a: np.ndarray, packed_dims: bool) -> bytes:
+    a = np.asarray(a)
+    out = b""
+    if packed_dims and a.ndim:
+        out += _ld(1, b"".join(_varint(d) for d in a.shape))          # the official writer packs repeated scalars ...
+    else:
+        out += b"".join(_vi(1, d) for d in a.shape)                   # ... torch's legacy exporter writes one tagged varint each
+    out += _vi(2, _NP2ONNX[a.dtype])
+    if name:
+        out += _ld(8, name.encode())
+    out += _ld(9, np.ascontiguousarray(a).astype(a.dtype.newbyteorder("<")).tobytes())
+    return out
+
+
+def _attr(name: str, v, packed: bool) -> bytes:
+    out = _ld(1, name.encode())
+    if isinstance(v, np.ndarray):
+        out += _ld(5, _tensor("", v, packed)) + _vi(20, 4)
+    elif isinstance(v, bool):
+        out += _vi(3, int(v)) + _vi(20, 2)
+    elif isinstance(v, (int, np.integer)):
+        out += _vi(3, int(v)) + _vi(20, 2)
+    elif isinstance(v, float):
+        out += _key(2, 5) + struct.pack("<f", v) + _vi(20, 1)
+    elif isinstance(v, str):
+        out += _ld(4, v.encode()) + _vi(20, 3)
+    elif isinstance(v, (list, tuple)) and all(isinstance(e, float) for e in v) and v:
+        out += (_ld(7, b"".join(struct.pack("<f", e) for e in v)) if packed else b"".join(_key(7, 5) + struct.pack("<f", e) for e in v)) + _vi(20, 6)
+    elif isinstance(v, (list, tuple)) and all(isinstance(e, str) for e in v) and v:
+        out += b"".join(_ld(9, e.encode()) for e in v) + _vi(20, 8)
+    elif isinstance(v, (list, tuple)):
+        out += (_ld(8, b"".join(_varint(int(e)) for e in v)) if packed and v else b"".join(_vi(8, int(e)) for e in v)) + _vi(20, 7)
+    else:
+        raise TypeError(f"attribute {name}: {type(v)}")
+    return out
+
+
+def _value_info(vi) -> bytes:
+    dims = b""
+    for d in vi.shape:
+        dims += _ld(1, _ld(2, d.encode()) if isinstance(d, str) else _vi(1, int(d)))
+    tensor_type = _vi(1, vi.elem_type) + _ld(2, dims)
+    return _ld(1, vi.name.encode()) + _ld(2, _ld(1, tensor_type))
+
+
+def dump(g: Graph, path: str, packed: bool = False, producer: str = "w2x-rewrite", ir_version: int = 8) -> None:
+    """Write `g` as an ONNX ModelProto.  packed: repeated integers / floats as one length-delimited blob (what the `onnx` package writes) instead of one
+    tagged scalar per element (what torch's legacy exporter writes) - the reader must take both."""
+    parts = []
+    for n in g.nodes:
+        nb = b"".join(_ld(1, i.encode()) for i in n.inputs) + b"".join(_ld(2, o.encode()) for o in n.outputs)
+        if n.name:
+            nb += _ld(3, n.name.encode())
+        nb += _ld(4, n.op.encode())
+        for k, v in n.attrs.items():
+            nb += _ld(5, _attr(k, v, packed))
+        parts.append(_ld(1, nb))
+    parts.append(_ld(2, b"main_graph"))
+    for name, a in g.initializers.items():
+        parts.append(_ld(5, _tensor(name, a, packed)))
+    for vi in g.inputs:
+        parts.append(_ld(11, _value_info(vi)))
+    for vi in g.outputs:
+        parts.append(_ld(12, _value_info(vi)))
+    graph = b"".join(parts)
+    model = _vi(1, ir_version) + _ld(2, producer.encode()) + _ld(7, graph) + _ld(8, _ld(1, b"") + _vi(2, g.opset))
+    with open(path, "wb") as f:
+        f.write(model)
+
+
+# ------------------------------------------------------------------------------------------------ shapes of the runtime tensors
+
+
+def runtime_shapes(path: str, batch: int, tile: int) -> dict:
+    """name -> shape of every float tensor that depends on the graph input's DATA (Shape / Size outputs and what is computed from them are constants at a
+    static input shape), from one run of the oracle's executor on a zero tile."""
+    from oracle import onnx_exec
+    ex = onnx_exec.Executor(path)
+    g = ex.g
+    runtime = {g.inputs[0].name}
+    for n in g.nodes:
+        if n.op not in ("Shape", "Size") and any(i in runtime for i in n.inputs if i):
+            runtime.update(o for o in n.outputs if o)
+    vals = ex.run(np.zeros((batch, 3, tile, tile), np.float32), keep=tuple(runtime))
+    shapes = {k: tuple(int(d) for d in v.shape) for k, v in vals.items() if k in runtime and v.dtype.kind == "f"}      # float tensors only (not the Shape -> ... integer chains)
+    shapes[g.inputs[0].name] = (batch, 3, tile, tile)
+    return shapes
+
+
+# ------------------------------------------------------------------------------------------------ rewrites
+
+
+class Variant(Graph):
+    applied: list
+
+
+def _fresh(g, stem: str) -> str:
+    g._n = getattr(g, "_n", 0) + 1
+    return f"/rw/{stem}_{g._n}"
+
+
+def _runtime_edges(g, shapes):
+    """(consumer node index, input slot, tensor name) of every runtime float tensor read by a node."""
+    out = []
+    for k, n in enumerate(g.nodes):
+        for s, i in enumerate(n.inputs):
+            if i in shapes:
+                out.append((k, s, i))
+    return out
+
+
+def _insert_on_edge(g, shapes, rng, make_nodes, min_rank=1, want_rank=None):
+    """Put the nodes make_nodes(src, dst, shape) returns between a random producer and ONE of its consumers."""
+    edges = [e for e in _runtime_edges(g, shapes) if len(shapes[e[2]]) >= min_rank and (want_rank is None or len(shapes[e[2]]) == want_rank)]
+    if not edges:
+        return False
+    k, s, name = edges[rng.integers(len(edges))]
+    dst = _fresh(g, "e")
+    new = make_nodes(name, dst, shapes[name])
+    for n in new:
+        for o in n.outputs:
+            shapes.setdefault(o, shapes[name])        # (intermediate shapes are only needed for rank decisions of later rewrites: approximate is fine)
+    shapes[dst] = shapes[name]
+    g.nodes[k].inputs[s] = dst
+    g.nodes[k:k] = new
+    return True
+
+
+def rw_identity(g, shapes, rng):
+    return _insert_on_edge(g, shapes, rng, lambda a, b, sh: [Node("Identity", [a], [b], {}, _fresh(g, "Identity"))])
+
+
+def rw_dropout(g, shapes, rng):
+    return _insert_on_edge(g, shapes, rng, lambda a, b, sh: [Node("Dropout", [a], [b], {}, _fresh(g, "Dropout"))])
+
+
+def rw_cast(g, shapes, rng):
+    return _insert_on_edge(g, shapes, rng, lambda a, b, sh: [Node("Cast", [a], [b], {"to": 1}, _fresh(g, "Cast"))])
+
+
+def rw_transpose2(g, shapes, rng):
+    def mk(a, b, sh):
+        r = len(sh)
+        p = [int(v) for v in rng.permutation(r)]
+        inv = [p.index(k) for k in range(r)]
+        mid = _fresh(g, "t")
+        shapes[mid] = tuple(sh[k] for k in p)
+        return [Node("Transpose", [a], [mid], {"perm": p}, _fresh(g, "Transpose")), Node("Transpose", [mid], [b], {"perm": inv}, _fresh(g, "Transpose"))]
+    return _insert_on_edge(g, shapes, rng, mk, min_rank=2)
+
+
+def rw_squeeze(g, shapes, rng):
+    def mk(a, b, sh):
+        mid = _fresh(g, "u")
+        if len(sh) == 4 and rng.integers(2):
+            shp = _fresh(g, "shape")
+            g.initializers[shp] = np.asarray(sh, np.int64)
+            shapes[mid] = (sh[0], int(np.prod(sh[1:])))
+            return [Node("Flatten", [a], [mid], {"axis": 1}, _fresh(g, "Flatten")), Node("Reshape", [mid, shp], [b], {}, _fresh(g, "Reshape"))]
+        ax = int(rng.integers(len(sh) + 1))
+        shapes[mid] = tuple(sh[:ax]) + (1,) + tuple(sh[ax:])
+        if g.opset >= 13:
+            axn = _fresh(g, "axes")
+            g.initializers[axn] = np.asarray([ax], np.int64)
+            return [Node("Unsqueeze", [a, axn], [mid], {}, _fresh(g, "Unsqueeze")), Node("Squeeze", [mid, axn], [b], {}, _fresh(g, "Squeeze"))]
+        return [Node("Unsqueeze", [a], [mid], {"axes": [ax]}, _fresh(g, "Unsqueeze")), Node("Squeeze", [mid], [b], {"axes": [ax]}, _fresh(g, "Squeeze"))]
+    return _insert_on_edge(g, shapes, rng, mk)
+
+
+def _consumers(g, name):
+    return [(k, n) for k, n in enumerate(g.nodes) if name in n.inputs]
+
+
+def rw_gemm(g, shapes, rng):
+    """MatMul(x, W[K, N]) + Add(b[N]) -> 2-D sandwich around a Gemm."""
+    sites = []
+    for k, n in enumerate(g.nodes):
+        if n.op == "MatMul" and n.inputs[0] in shapes and n.inputs[1] in g.initializers and g.initializers[n.inputs[1]].ndim == 2 and len(shapes[n.inputs[0]]) >= 3:
+            us = _consumers(g, n.outputs[0])
+            if len(us) == 1 and us[0][1].op == "Add":
+                other = [i for i in us[0][1].inputs if i != n.outputs[0]]
+                if len(other) == 1 and other[0] in g.initializers and g.initializers[other[0]].ndim == 1:
+                    sites.append((k, us[0][0], other[0]))
+    if not sites:
+        return False
+    k, ka, bias = sites[rng.integers(len(sites))]
+    mm, add = g.nodes[k], g.nodes[ka]
+    x, w = mm.inputs
+    K, N = g.initializers[w].shape
+    sh = shapes[x]
+    two = _fresh(g, "shape2d"); g.initializers[two] = np.asarray([-1, K], np.int64)
+    x2, y2 = _fresh(g, "x2d"), _fresh(g, "y2d")
+    shapes[x2] = (int(np.prod(sh[:-1])), K); shapes[y2] = (shapes[x2][0], N)
+    new = [Node("Reshape", [x, two], [x2], {}, _fresh(g, "Reshape"))]
+    attrs = {"alpha": 1.0, "beta": 1.0}
+    wname = w
+    if rng.integers(2):      # torch.nn.Linear exports its weight as [N, K] with transB = 1
+        wname = _fresh(g, "wT"); g.initializers[wname] = np.ascontiguousarray(g.initializers[w].T)
+        attrs["transB"] = 1
+    new.append(Node("Gemm", [x2, wname, bias], [y2], attrs, mm.name))           # the product keeps the MatMul's name
+    if rng.integers(2):      # output shape as a constant ...
+        tgt = _fresh(g, "shapeNd"); g.initializers[tgt] = np.asarray(list(sh[:-1]) + [N], np.int64)
+    else:                    # ... or computed from the input's shape, as a tracing exporter writes it
+        s0, lead, tgt = _fresh(g, "shape"), _fresh(g, "lead"), _fresh(g, "shapeNd")
+        st, en, ax, nn = _fresh(g, "c"), _fresh(g, "c"), _fresh(g, "c"), _fresh(g, "c")
+        g.initializers[st] = np.asarray([0], np.int64); g.initializers[en] = np.asarray([-1], np.int64)
+        g.initializers[ax] = np.asarray([0], np.int64); g.initializers[nn] = np.asarray([N], np.int64)
+        new += [Node("Shape", [x], [s0], {}, _fresh(g, "Shape")), Node("Slice", [s0, st, en, ax], [lead], {}, _fresh(g, "Slice")),
+                Node("Concat", [lead, nn], [tgt], {"axis": 0}, _fresh(g, "Concat"))]
+    new.append(Node("Reshape", [y2, tgt], [add.outputs[0]], {}, _fresh(g, "Reshape")))
+    for idx in sorted((k, ka), reverse=True):
+        del g.nodes[idx]
+    g.nodes[k:k] = new
+    if not _consumers(g, w) and w in g.initializers and wname != w:
+        del g.initializers[w]
+    return True
+
+
+def rw_const_node(g, shapes, rng):
+    names = [n for n in g.initializers if not n.startswith("/rw/")]
+    if not names:
+        return False
+    name = names[rng.integers(len(names))]
+    first = min((k for k, n in enumerate(g.nodes) if name in n.inputs), default=None)
+    if first is None:
+        return False
+    a = g.initializers.pop(name)
+    g.nodes.insert(first, Node("Constant", [], [name], {"value": a}, _fresh(g, "Constant")))
+    return True
+
+
+def rw_fp16_init(g, shapes, rng):
+    """A weight of a Conv / MatMul stored in fp16 and widened by a Cast (how a half-precision checkpoint exports)."""
+    names = sorted({n.inputs[1] for n in g.nodes if n.op in ("Conv", "ConvTranspose", "MatMul") and len(n.inputs) > 1 and n.inputs[1] in g.initializers
+                    and g.initializers[n.inputs[1]].dtype == np.float32})
+    if not names:
+        return False
+    name = names[rng.integers(len(names))]
+    first = min(k for k, n in enumerate(g.nodes) if name in n.inputs)
+    half = _fresh(g, "half")
+    g.initializers[half] = g.initializers.pop(name).astype(np.float16)
+    g.nodes.insert(first, Node("Cast", [half], [name], {"to": 1}, _fresh(g, "Cast")))
+    return True
+
+
+def rw_reshape_0_m1(g, shapes, rng):
+    # (a target computed by a Shape / Gather / Concat chain - what a tracing exporter writes - becomes a constant: the output shape is known)
+    sites = [(k, n) for k, n in enumerate(g.nodes) if n.op == "Reshape" and n.inputs[0] in shapes and n.outputs[0] in shapes and not n.attrs.get("allowzero")]
+    if not sites:
+        return False
+    k, n = sites[rng.integers(len(sites))]
+    src = shapes[n.inputs[0]]
+    full = list(shapes[n.outputs[0]])
+    new = list(full)
+    zero_ok = [i for i, v in enumerate(full) if i < len(src) and src[i] == v]
+    for i in zero_ok:
+        if rng.integers(2):
+            new[i] = 0
+    cand = [i for i, v in enumerate(new) if v != 0]
+    if cand and rng.integers(2):
+        new[cand[rng.integers(len(cand))]] = -1
+    name = _fresh(g, "target")
+    g.initializers[name] = np.asarray(new, np.int64)
+    n.inputs[1] = name
+    return True
+
+
+def rw_bias_unsqueeze(g, shapes, rng):
+    sites = []
+    for k, n in enumerate(g.nodes):
+        if n.op == "Add":
+            for s, i in enumerate(n.inputs):
+                if i in g.initializers and g.initializers[i].ndim == 1 and n.inputs[1 - s] in shapes and len(shapes[n.inputs[1 - s]]) >= 3 and not i.startswith("/rw/"):
+                    sites.append((k, s, i))
+    if not sites:
+        return False
+    k, s, name = sites[rng.integers(len(sites))]
+    a = g.initializers[name]
+    out = _fresh(g, "bias")
+    if rng.integers(2):        # [N] -> Unsqueeze -> [1, 1, N]
+        axes = [0, 1]
+        if g.opset >= 13:
+            axn = _fresh(g, "axes"); g.initializers[axn] = np.asarray(axes, np.int64)
+            node = Node("Unsqueeze", [name, axn], [out], {}, _fresh(g, "Unsqueeze"))
+        else:
+            node = Node("Unsqueeze", [name], [out], {"axes": axes}, _fresh(g, "Unsqueeze"))
+    else:                      # stored [1, N], squeezed back to [N]
+        stored = _fresh(g, "bias2d"); g.initializers[stored] = a.reshape(1, -1)
+        if g.opset >= 13:
+            axn = _fresh(g, "axes"); g.initializers[axn] = np.asarray([0], np.int64)
+            node = Node("Squeeze", [stored, axn], [out], {}, _fresh(g, "Squeeze"))
+        else:
+            node = Node("Squeeze", [stored], [out], {"axes": [0]}, _fresh(g, "Squeeze"))
+    g.nodes[k].inputs[s] = out
+    g.nodes.insert(k, node)
+    return True
+
+
+def rw_ln_axis(g, shapes, rng):
+    sites = [n for n in g.nodes if n.op == "LayerNormalization" and n.inputs[0] in shapes]
+    if not sites:
+        return False
+    n = sites[rng.integers(len(sites))]
+    r = len(shapes[n.inputs[0]])
+    ax = n.attrs.get("axis", -1)
+    n.attrs["axis"] = r - 1 if ax < 0 else -1
+    return True
+
+
+def rw_permute(g, shapes, rng):
+    """Another topological order of the node list (Kahn's algorithm with a random choice among the ready nodes)."""
+    produced_by = {}
+    for k, n in enumerate(g.nodes):
+        for o in n.outputs:
+            if o:
+                produced_by[o] = k
+    deps = [sorted({produced_by[i] for i in n.inputs if i in produced_by}) for n in g.nodes]
+    users = [[] for _ in g.nodes]
+    for k, d in enumerate(deps):
+        for p in d:
+            users[p].append(k)
+    left = [len(d) for d in deps]
+    ready = [k for k, c in enumerate(left) if c == 0]
+    order = []
+    while ready:
+        k = ready.pop(int(rng.integers(len(ready))))
+        order.append(k)
+        for u in users[k]:
+            left[u] -= 1
+            if left[u] == 0:
+                ready.append(u)
+    assert len(order) == len(g.nodes)
+    g.nodes = [g.nodes[k] for k in order]
+    return True
+
+
+def rw_commute(g, shapes, rng):
+    sites = [n for n in g.nodes if n.op in ("Add", "Mul") and len(n.inputs) == 2 and (n.inputs[0] in shapes or n.inputs[1] in shapes)]
+    if not sites:
+        return False
+    n = sites[rng.integers(len(sites))]
+    n.inputs.reverse()
+    return True
+
+
+def rw_dead(g, shapes, rng):
+    names = sorted(shapes)
+    src = names[rng.integers(len(names))]
+    k = max((i for i, n in enumerate(g.nodes) if src in n.outputs), default=-1)
+    g.nodes.insert(k + 1, Node("Shape" if rng.integers(2) else "Relu", [src], [_fresh(g, "dead")], {}, _fresh(g, "Dead")))
+    return True
+
+
+REWRITES = {"gemm": rw_gemm, "identity": rw_identity, "dropout": rw_dropout, "cast": rw_cast, "transpose2": rw_transpose2, "squeeze": rw_squeeze,
+            "const_node": rw_const_node, "fp16_init": rw_fp16_init, "reshape_0_m1": rw_reshape_0_m1, "bias_unsqueeze": rw_bias_unsqueeze,
+            "ln_axis": rw_ln_axis, "permute": rw_permute, "commute": rw_commute, "dead": rw_dead}
+EXACT = [k for k in REWRITES if k != "fp16_init"]          # rewrites under which the engine file must not change by a byte
+
+
+def rewrite(g: Graph, shapes: dict, seed: int, kinds=None, count=None):
+    """A deep copy of g with `count` (default 2-5) rewrites drawn from `kinds` (default: all) applied at random sites.  .applied lists what took."""
+    rng = np.random.default_rng(seed)
+    v = copy.copy(g)                                   # nodes are copied, weight arrays shared (no rewrite writes into an array)
+    v.nodes = [Node(n.op, list(n.inputs), list(n.outputs), dict(n.attrs), n.name) for n in g.nodes]
+    v.initializers = dict(g.initializers)
+    v.inputs, v.outputs = list(g.inputs), list(g.outputs)
+    shapes = dict(shapes)
+    kinds = list(kinds or REWRITES)
+    v.applied = []
+    for _ in range(count or int(rng.integers(2, 6))):
+        kind = kinds[rng.integers(len(kinds))]
+        if kind == "permute" and "permute" in v.applied:
+            continue
+        if REWRITES[kind](v, shapes, rng):
+            v.applied.append(kind)
+    return v
+
+
+if __name__ == "__main__":      # tools/onnx_rewrite.py in.onnx out.onnx batch tile seed [kind ...]
+    src, dst, batch, tile, seed = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    gg = onnx_reader.load(src)
+    vv = rewrite(gg, runtime_shapes(src, batch, tile), seed, sys.argv[6:] or None)
+    dump(vv, dst, packed=bool(seed & 1))
+    print(f"{dst}: {', '.join(vv.applied)}")

@@ -968,7 +968,7 @@ struct Lowerer {
         plan.out_tensor = y.v.t; plan.Tout = (int)os[2]; plan.Cout = 3;
         if (!switches().no_fuse && plan.elt == 2) { if (!switches().no_fuse_attn) fuse_attn(); fuse_mlp(); }   // the fused kernels are fp16 kernels
         for (auto& op : plan.ops) plan.flops += op.flops;
-        bool has_attn = false; for (auto& op : plan.ops) has_attn |= op.kind == OP_ATTN;
+        bool has_attn = false; for (auto& op : plan.ops) has_attn |= op.kind == OP_ATTN || op.kind == OP_SWINATTN;
         plan.model_kind = has_attn ? "swin_unet" : "cunet";
         return plan;
     }

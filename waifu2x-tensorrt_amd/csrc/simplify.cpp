@@ -83,14 +83,18 @@ struct Simplifier {
         return n;
     }
 
-    // one rewrite; true if the graph changed
-    bool step() {
+    // one rewrite; true if the graph changed.  products_only: the Gemm and 2-D sandwich rules alone - they run to their fixed point first, so that the
+    // Reshape-of-a-Reshape rule does not merge a sandwich's Reshapes into their neighbours (a window partition's last Reshape in front, the q / k / v
+    // split behind) before the sandwich is recognised
+    bool step(bool products_only) {
         index();
         for (size_t idx = 0; idx < nodes.size(); ++idx) {
             Node* n = nodes[idx];
             const std::string& op = n->op;
             if (n->in.empty() || n->in[0].empty() || g.is_const(n->in[0])) continue;
             const std::string x = n->in[0];
+            if (products_only && op != "Gemm" && op != "Reshape") continue;
+            if (products_only && op == "Reshape") { if (sandwich(n, x)) return true; continue; }
             // ---- no-ops
             bool noop = op == "Identity" || op == "Dropout";
             if (op == "Cast") noop = float_dtype(g.val(x).dtype) && float_dtype((int)n->ai("to", DT_F32));
@@ -163,29 +167,31 @@ struct Simplifier {
                 }
                 return true;
             }
-            // ---- the 2-D sandwich around a product of rows: Reshape([M, K]) -> MatMul(const [K, N]) -> [Add(const)] -> Reshape(lead.., N)
-            if (op == "Reshape" && shape(n->out[0]).size() == 2 && shape(x).size() > 2 && shape(x).back() == shape(n->out[0])[1]) {
-                Node* mm = only_consumer(n->out[0]);
-                if (mm && mm->op == "MatMul" && mm->in[0] == n->out[0] && g.is_const(mm->in[1]) && g.cst(mm->in[1]).rank() == 2) {
-                    Node* last = mm;
-                    Node* add = only_consumer(mm->out[0]);
-                    if (add && add->op == "Add" && ((add->in[0] == mm->out[0] && g.is_const(add->in[1])) || (add->in[1] == mm->out[0] && g.is_const(add->in[0])))) last = add; else add = nullptr;
-                    Node* r2 = only_consumer(last->out[0]);
-                    Shape want(shape(x).begin(), shape(x).end() - 1);
-                    want.push_back(g.cst(mm->in[1]).shape[1]);
-                    if (r2 && r2->op == "Reshape" && shape(r2->out[0]) == want) {
-                        mm->in[0] = x;
-                        g.vals[mm->out[0]].shape = want;
-                        if (add) g.vals[add->out[0]].shape = want;
-                        index();
-                        alias(r2->out[0], last->out[0]);
-                        erase(r2); erase(n);
-                        return true;
-                    }
-                }
-            }
         }
         return false;
+    }
+
+    // The 2-D sandwich around a product of rows: n = Reshape(x -> [M, K]) (x of higher rank, last dimension kept) -> MatMul(const [K, N]) -> [Add(const)]
+    // -> Reshape(s) only.  The product runs on the rows where they are: its result gets x's leading dimensions, the Reshape(s) behind it re-shape the
+    // same elements in the same order (one that restores [lead.., N] is then a no-op and goes in the second phase).
+    bool sandwich(Node* n, const std::string& x) {
+        if (!(shape(n->out[0]).size() == 2 && shape(x).size() > 2 && shape(x).back() == shape(n->out[0])[1])) return false;
+        Node* mm = only_consumer(n->out[0]);
+        if (!(mm && mm->op == "MatMul" && mm->in[0] == n->out[0] && g.is_const(mm->in[1]) && g.cst(mm->in[1]).rank() == 2)) return false;
+        Node* last = mm;
+        Node* add = only_consumer(mm->out[0]);
+        if (add && add->op == "Add" && ((add->in[0] == mm->out[0] && g.is_const(add->in[1])) || (add->in[1] == mm->out[0] && g.is_const(add->in[0])))) last = add; else add = nullptr;
+        if (last->out[0] == g.output) return false;
+        auto us = consumers.find(last->out[0]);
+        if (us == consumers.end() || us->second.empty()) return false;
+        for (Node* u : us->second) if (u->op != "Reshape" || u->in[0] != last->out[0]) return false;
+        Shape want(shape(x).begin(), shape(x).end() - 1);
+        want.push_back(g.cst(mm->in[1]).shape[1]);
+        mm->in[0] = x;
+        g.vals[mm->out[0]].shape = want;
+        if (add) g.vals[add->out[0]].shape = want;
+        erase(n);
+        return true;
     }
 
     void canonical_order() {
@@ -213,8 +219,15 @@ struct Simplifier {
 void simplify_graph(FoldedGraph& g) {
     Simplifier s(g);
     for (const Node* n : g.nodes) { g.owned.push_back(*n); s.nodes.push_back(&g.owned.back()); }
-    for (int guard = 0; s.step(); ++guard)
-        if (guard > 1000000) throw std::runtime_error("graph: simplification does not terminate");
+    int guard = 0;
+    for (bool changed = true; changed;) {          // (a sandwich may only show once a no-op inside it is gone: both phases until neither finds anything)
+        changed = false;
+        for (int phase = 0; phase < 2; ++phase)
+            while (s.step(phase == 0)) {
+                changed = true;
+                if (++guard > 1000000) throw std::runtime_error("graph: simplification does not terminate");
+            }
+    }
     s.canonical_order();
     g.nodes.assign(s.nodes.begin(), s.nodes.end());
     g.consumers.clear(); g.producer.clear();
