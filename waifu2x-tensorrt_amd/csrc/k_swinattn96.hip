@@ -234,7 +234,7 @@ __global__ __launch_bounds__(NTHR, W2X_A96_WPS) void swin_attn96_kernel(const Sw
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, g = lane >> 4;
 
-    const int iw0 = blockIdx.x * G, itotal = p.B * p.nwin;
+    const int wl0 = blockIdx.x * G;              // the workgroup's windows: wl0 and wl0 + 1 of image blockIdx.y (a pair never straddles two images: no division by the window count)
     const int HW = p.nwin * NTOK;
     const unsigned xbytes = (unsigned)p.B * (unsigned)HW * (C * 2);
     const __amdgpu_buffer_rsrc_t X = make_rsrc(p.x, xbytes), Y = make_rsrc(p.y, xbytes);
@@ -282,18 +282,19 @@ __global__ __launch_bounds__(NTHR, W2X_A96_WPS) void swin_attn96_kernel(const Sw
             srow = (w * SLAB + 33 + (kk / 3) * 4 + (kk % 3)) * LDX * 2;
         } else if (tid < R) {
             const int w = tid >= NTOK ? 1 : 0, t = tid - w * NTOK;
-            const int iw = iw0 + w;
+            const int wl = wl0 + w;
             srow = (w * SLAB + slab_row(t)) * LDX * 2;
-            if (iw < itotal) {
-                const int wb = iw / p.nwin, wl = iw - wb * p.nwin;
+            if (wl < p.nwin) {
                 if (p.ry >= 0) {
+                    // window -> (wy, wx) through a reciprocal instead of an integer division (two of which were a third of this block's instructions):
+                    // (wl + 0.5) / nwx is at least 0.5 / nwx away from an integer, far more than the rounding of the product for any token map a pass holds
                     const int nwx = p.W / 6;
-                    const int wy = wl / nwx, wx = wl - wy * nwx;
-                    const int ty = t / 6, tx = t - ty * 6;
+                    const int wy = (int)(((float)wl + 0.5f) * __builtin_amdgcn_rcpf((float)nwx)), wx = wl - wy * nwx;
+                    const int ty = (t * 43) >> 8, tx = t - ty * 6;           // t / 6 for t < 36
                     int y = wy * 6 + ty + p.ry, x = wx * 6 + tx + p.rx;
                     y -= y >= p.H ? p.H : 0; x -= x >= p.W ? p.W : 0;
-                    pix = wb * HW + y * p.W + x;
-                } else pix = wb * HW + p.table[wl * NTOK + t];
+                    pix = (int)blockIdx.y * HW + y * p.W + x;
+                } else pix = (int)blockIdx.y * HW + p.table[wl * NTOK + t];
                 if (t == 0) Cls[w] = p.maskid[wl];
             } else if (t == 0) Cls[w] = 0;
         }
@@ -586,8 +587,7 @@ hipError_t launch_swin_attn96(const SwinAttnParams& p, hipStream_t s) {
         q.x = (const char*)p.x + (size_t)b0 * img_bytes;
         q.y = (char*)p.y + (size_t)b0 * img_bytes;
         if (p.stats_out) q.stats_out = p.stats_out + (size_t)b0 * p.nwin * NTOK * 2;
-        const long total_win = (long)q.B * q.nwin;
-        hipLaunchKernelGGL(swin_attn96_kernel, dim3((unsigned)((total_win + G - 1) / G)), dim3(NTHR), SMEM96, s, q);
+        hipLaunchKernelGGL(swin_attn96_kernel, dim3((unsigned)((q.nwin + G - 1) / G), (unsigned)q.B), dim3(NTHR), SMEM96, s, q);      // x: window pairs of an image, y: images
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     }
     return hipSuccess;
