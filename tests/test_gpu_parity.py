@@ -34,6 +34,19 @@ NET_MAX_ULP16_UNFUSED = 3.5   # the un-fused operator path (48-channel graphs, d
 NET_MAX_ULP16_VS_FP32 = 3.0   # measured <= 2.52 (T = 256: the maximum over 2.7 M outputs)
 NET_MEAN_ABS = 2.2e-4    # measured <= 1.7e-4
 FRAME_MAX_LSB = 1        # u8; measured 1 on every case
+# north_star's "within 1 ULP fp16 per pixel", as tested quantities (round 5): the FRACTION of the network's outputs within 1 and 2 ULP16 of the fp16-boundary oracle and
+# of the fp32 oracle at the shipping tile sizes (T = 256 live, T = 400 against the committed oracle windows).  Floors sit just under the measurements
+# (profiles/r5_final/parity.jsonl; README.md has the table): a loss of accuracy that stays under the max-bounds above still fails here.
+NET_FRAC_FLOORS = {   # tile: (within 1 ULP16 of the fp16 oracle, within 2, within 1 ULP16 of fp32, within 2)
+    256: (0.992, 0.9999, 0.975, 0.9999),     # measured 0.9941 / 0.999998 / 0.9779 / 0.999993 (the fp16-boundary oracle itself: 0.9761 of its outputs within 1 ULP16 of fp32)
+    400: (0.992, 0.9999, 0.975, 0.9999),     # measured 0.9940 / 0.999999 / 0.9776 / 0.999994
+}
+
+
+def assert_ulp_fractions(r, tile):
+    f1, f2, g1, g2 = NET_FRAC_FLOORS[tile]
+    assert r["frac_within_1_ulp16"] >= f1 and r["frac_within_2_ulp16"] >= f2, r
+    assert r["frac_within_1_ulp16_vs_fp32_oracle"] >= g1 and r["frac_within_2_ulp16_vs_fp32_oracle"] >= g2, r
 
 
 def oracle16(path):
@@ -74,6 +87,8 @@ def test_network_matches_oracle(pkg, onnx_model, model, scale, batch, tile, smal
     assert r["max_ulp16_vs_fp32_oracle"] <= NET_MAX_ULP16_VS_FP32 and r["mean_abs_vs_fp32_oracle"] <= NET_MEAN_ABS, r
     # ... and relative to an ideal fp16 engine: no further from fp32 than the fp16-boundary oracle is
     assert_as_accurate_as_ideal_fp16(r)
+    if tile in NET_FRAC_FLOORS and model.startswith("swin"):
+        assert_ulp_fractions(r, tile)
     # batch items are independent: same tile in slot 0 and slot B-1 gives the same bytes
     if batch > 1:
         x2 = np.repeat(x[:1], batch, axis=0)
@@ -97,6 +112,7 @@ def test_network_at_shipping_tile_sizes_against_fixture(pkg, onnx_model):
     r = network_report(f"network[{model} s{scale} B1 T{tile} full, committed oracle windows]", got, z["ref16"].astype(np.float32), z["ref32"])
     assert r["max_ulp16"] <= NET_MAX_ULP16 and r["mean_abs"] <= NET_MEAN_ABS and r["max_ulp16_vs_fp32_oracle"] <= NET_MAX_ULP16_VS_FP32, r
     assert_as_accurate_as_ideal_fp16(r)
+    assert_ulp_fractions(r, tile)
     # whole-output checksum: the per-channel sums of all 3 x 1536^2 values against the fp32 oracle's (mean error per element, in ULP16)
     drift = np.abs(y.astype(np.float64).sum(axis=(1, 2)) - z["sum32"]) / y[0].size / ULP16
     print("PARITY " + str({"test": "network T400 whole-output mean drift per channel (ULP16)", "drift": drift.tolist()}), flush=True)

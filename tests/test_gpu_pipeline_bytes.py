@@ -263,5 +263,10 @@ def test_one_frame_over_two_processes_through_ipc_handles(pkg, tmp_path):
                            capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr[-3000:]
         line = json.loads(r.stdout.strip().splitlines()[-1])
-        assert line["n_gpus"] == n and line["config"]["mode"] == "shards" and line["config"]["bytes_equal_render"] is True
+        assert line["config"]["mode"] == "shards" and line["config"]["bytes_equal_render"] is True
+        # the line certifies where it ran: two ranks, ONE distinct GPU (the ranks share the box's card) - a rehearsal, and it says so
+        p = line["placement"]
+        assert line["n_ranks"] == n and line["n_gpus"] == 1 and p["distinct_gpus"] == 1 and not p["one_gpu_per_rank"] and line["metric"].startswith(f"REHEARSAL ({n} ranks on 1 GPU)")
+        assert len({rec["pid"] for rec in p["ranks"]}) == n and len({rec["pci_bus_id"] for rec in p["ranks"]}) == 1 and p["device_map"] == env["W2X_DEVICE_MAP"]
+        assert line["config"]["peer_device_ordinals_seen_by_rank0"] == [0] * n
         assert sum(line["config"]["tiles_per_rank"]) == 63 and min(line["config"]["tiles_per_rank"]) > 0

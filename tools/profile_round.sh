@@ -22,8 +22,8 @@ rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write" -o w2x -- pyt
 rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA -d "$OUT/pmc_sq" -o w2x -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_sq.log" 2>&1
 rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE -d "$OUT/pmc_mfma" -o w2x -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_mfma.log" 2>&1
 for d in pmc_fetch pmc_write pmc_sq pmc_mfma; do python3 tools/pmc_summary.py "$OUT/$d" > "$OUT/$d.summary.txt" 2>&1; done
-python3 tools/mfma_util.py "$OUT/pmc_mfma" > "$OUT/mfma_util.txt" 2>&1
 find "$OUT" -name "*_kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
+python3 tools/mfma_util.py "$OUT/pmc_mfma" "$OUT/kernel_stats.csv" > "$OUT/mfma_util.txt" 2>&1
 python3 tools/pmc_traffic.py "$OUT" "$OUT/pmc_traffic.json" "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --steps 2 --warmup 1, profiles/$TAG" > "$OUT/pmc_traffic.txt" 2>&1
 # keep the merge-back small: raw traces are not needed once summarised
 find "$OUT" -name "*kernel_trace.csv" -size +8M -delete
