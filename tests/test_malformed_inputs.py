@@ -134,6 +134,7 @@ def _iv(field, v): return _vint(field << 3 | 0) + _vint(v)
 def _tensor(name, dtype, dims, raw): return b"".join(_iv(1, d) for d in dims) + _iv(2, dtype) + _ld(8, name.encode()) + _ld(9, raw)
 def _attr_t(name, tensor): return _ld(1, name.encode()) + _ld(5, tensor) + _iv(20, 4)
 def _attr_i(name, v): return _ld(1, name.encode()) + _iv(3, v) + _iv(20, 2)
+def _attr_ints(name, vals): return _ld(1, name.encode()) + b"".join(_iv(8, v) for v in vals) + _iv(20, 7)
 def _node(op, ins, outs, attrs=(), name=""): return b"".join(_ld(1, i.encode()) for i in ins) + b"".join(_ld(2, o.encode()) for o in outs) + _ld(3, (name or op).encode()) + _ld(4, op.encode()) + b"".join(_ld(5, a) for a in attrs)
 def _vinfo(name, dims): return _ld(1, name.encode()) + _ld(2, _ld(1, _iv(1, 1) + _ld(2, b"".join(_ld(1, _iv(1, d)) for d in dims))))
 def _i64s(vals): return np.array(vals, "<i8").tobytes()
@@ -169,6 +170,23 @@ def test_well_formed_but_hostile_onnx_graphs(tmp_path):
         "reshape_to_huge": _model([_node("Reshape", ["x", "s"], ["y"])], [_tensor("s", 7, [4], _i64s([huge, huge, huge, -1]))]),
         "conv_kernel_huge": _model([_node("Conv", ["x", "w"], ["y"], [_attr_i("group", 1)])], [_tensor("w", 1, [1 << 20, 3, 1 << 20, 3], b"")]),
         "no_nodes": _model([], out="x"),
+        # round 5: what the graph simplifier (csrc/simplify.cpp) rewrites - each in a form it must leave alone or refuse, never index out of range
+        "transpose_perm_out_of_range": _model([_node("Transpose", ["x"], ["y"], [_attr_ints("perm", [0, 7, 2, 3])])]),
+        "transpose_perm_repeats": _model([_node("Transpose", ["x"], ["t"], [_attr_ints("perm", [0, 1, 1, 3])]), _node("Transpose", ["t"], ["y"], [_attr_ints("perm", [0, 1, 2, 3])])]),
+        "transpose_perm_short": _model([_node("Transpose", ["x"], ["t"], [_attr_ints("perm", [1, 0])]), _node("Transpose", ["t"], ["y"], [_attr_ints("perm", [0, 3, 1, 2])])]),
+        "identity_input_to_output": _model([_node("Identity", ["x"], ["y"])]),
+        "gemm_transA": _model([_node("Reshape", ["x", "s"], ["x2"]), _node("Gemm", ["x2", "w"], ["y2"], [_attr_i("transA", 1)]), _node("Reshape", ["y2", "s4"], ["y"])],
+                              [_tensor("s", 7, [2], _i64s([-1, 64])), _tensor("w", 1, [192, 64], np.zeros(192 * 64, np.float32).tobytes()), _tensor("s4", 7, [4], _i64s([1, 3, 64, 64]))]),
+        "gemm_rank3_weight": _model([_node("Reshape", ["x", "s"], ["x2"]), _node("Gemm", ["x2", "w"], ["y2"]), _node("Reshape", ["y2", "s4"], ["y"])],
+                                    [_tensor("s", 7, [2], _i64s([-1, 64])), _tensor("w", 1, [2, 64, 32], np.zeros(4096, np.float32).tobytes()), _tensor("s4", 7, [4], _i64s([1, 3, 64, 64]))]),
+        "gemm_bias_wrong_length": _model([_node("Reshape", ["x", "s"], ["x2"]), _node("Gemm", ["x2", "w", "b"], ["y2"]), _node("Reshape", ["y2", "s4"], ["y"])],
+                                         [_tensor("s", 7, [2], _i64s([-1, 64])), _tensor("w", 1, [64, 64], np.zeros(4096, np.float32).tobytes()), _tensor("b", 1, [7], np.zeros(7, np.float32).tobytes()),
+                                          _tensor("s4", 7, [4], _i64s([1, 3, 64, 64]))]),
+        "reshape_chain_to_nothing": _model([_node("Reshape", ["x", "s"], ["a"]), _node("Reshape", ["a", "s4"], ["b"]), _node("Flatten", ["b"], ["c"]), _node("Reshape", ["c", "s4"], ["y"])],
+                                           [_tensor("s", 7, [2], _i64s([-1, 64])), _tensor("s4", 7, [4], _i64s([1, 3, 64, 64]))]),
+        "cast_to_int_and_back": _model([_node("Cast", ["x"], ["i"], [_attr_i("to", 7)]), _node("Cast", ["i"], ["y"], [_attr_i("to", 1)])]),
+        "squeeze_axis_out_of_range": _model([_node("Squeeze", ["x", "ax"], ["y"])], [_tensor("ax", 7, [1], _i64s([9]))]),
+        "dead_branch_only": _model([_node("Relu", ["x"], ["unused"]), _node("Identity", ["x"], ["y"])]),
     }
     res = run_corpus("onnx", write_all(tmp_path, blobs, ".onnx"), extra=(1, 64))
     assert all(rc == 2 for k, rc in res.items() if k != "no_nodes"), {k: v for k, v in res.items() if v != 2}      # (an empty graph is the identity network: a plan of zero ops)

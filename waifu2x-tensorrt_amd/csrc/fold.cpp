@@ -86,6 +86,14 @@ HTensorP make(int dtype, const Shape& shape) {
 
 double getd(const HTensor& t, int64_t k) { return t.is_float() ? (double)t.f[k] : (double)t.i[k]; }
 
+// a Transpose's perm attribute comes from the file: it must be a permutation of 0 .. rank - 1 before it indexes a shape
+void check_perm(const std::vector<int64_t>& perm, int rank) {
+    std::vector<char> seen((size_t)std::max(rank, 0), 0);
+    bool ok = (int)perm.size() == rank;
+    for (size_t k = 0; ok && k < perm.size(); ++k) { ok = perm[k] >= 0 && perm[k] < rank && !seen[(size_t)perm[k]]; if (ok) seen[(size_t)perm[k]] = 1; }
+    if (!ok) throw std::runtime_error("graph: Transpose with a perm that is not a permutation of its input's axes");
+}
+
 int64_t norm_axis(int64_t ax, int rank) { if (ax < 0) ax += rank; if (ax < 0 || ax >= std::max(rank, 1)) throw std::runtime_error("fold: axis out of range"); return ax; }
 
 HTensorP binary(const std::string& op, const HTensor& a, const HTensor& b) {
@@ -386,6 +394,7 @@ FoldedGraph fold_graph(const Model& m, const std::vector<int64_t>& input_shape) 
             if (op == "Transpose") {
                 const HTensor& a = C(0); int r = a.rank();
                 auto perm = n.aints("perm"); if (perm.empty()) for (int k = r - 1; k >= 0; --k) perm.push_back(k);
+                check_perm(perm, r);
                 Shape os(r); for (int k = 0; k < r; ++k) os[k] = a.shape[perm[k]];
                 Shape ist = strides_of(a.shape), ost = strides_of(os);
                 set_const(gather_elems(a, os, [&](int64_t flat) { int64_t s = 0; for (int k = 0; k < r; ++k) s += ((flat / ost[k]) % os[k]) * ist[perm[k]]; return s; }));
@@ -461,6 +470,7 @@ FoldedGraph fold_graph(const Model& m, const std::vector<int64_t>& input_shape) 
             set_dyn({a, prod(s0) / std::max<int64_t>(a, 1)}, dt0);
         } else if (op == "Transpose") {
             auto perm = n.aints("perm"); int r = (int)s0.size(); if (perm.empty()) for (int k = r - 1; k >= 0; --k) perm.push_back(k);
+            check_perm(perm, r);
             Shape o(r); for (int k = 0; k < r; ++k) o[k] = s0[perm[k]];
             set_dyn(o, dt0);
         } else if (op == "Unsqueeze") {
