@@ -433,6 +433,32 @@ const Attr* attr(const Node& n, const char* k) { auto it = n.at.find(k); return 
 i64 attr_i(const Node& n, const char* k, i64 dflt) { const Attr* a = attr(n, k); return a && a->has_i ? a->i : dflt; }
 float attr_f(const Node& n, const char* k, float dflt) { const Attr* a = attr(n, k); return a && a->has_f ? a->f : dflt; }
 
+// Split: the one operator here with several outputs (qkv.unbind(0) exports as Split + Squeeze) - sizes from the `split` attribute (opset < 13), the second
+// input (opset >= 13) or equal parts, one per output
+std::vector<TP> run_split(const Node& n, const std::vector<TP>& a) {
+    if (a.empty() || !a[0]) fail("Split: missing input");
+    const Tensor& x = *a[0];
+    const i64 nd = (i64)x.shape.size(), ax = norm_axis(attr_i(n, "axis", 0), nd);
+    std::vector<i64> sizes;
+    if (const Attr* s = attr(n, "split")) sizes = s->ints;
+    else if (a.size() > 1 && a[1]) sizes = ints_of(*a[1]);
+    else { const i64 k = (i64)n.out.size(); if (k <= 0 || x.shape[ax] % k) fail("Split: the axis does not divide evenly"); sizes.assign((size_t)k, x.shape[ax] / k); }
+    i64 total = 0; for (i64 s : sizes) { if (s < 0) fail("Split: negative size"); total += s; }
+    if (sizes.size() != n.out.size() || total != x.shape[ax]) fail("Split: sizes do not match the axis");
+    i64 outer = 1, inner = 1; for (i64 d = 0; d < ax; ++d) outer *= x.shape[d]; for (i64 d = ax + 1; d < nd; ++d) inner *= x.shape[d];
+    std::vector<TP> outs; i64 at = 0;
+    for (i64 s : sizes) {
+        std::vector<i64> os = x.shape; os[ax] = s;
+        TP o = make(x.dt, os);
+        for (i64 r = 0; r < outer; ++r) {
+            if (x.is_f()) memcpy(o->f.data() + r * s * inner, x.f.data() + (r * x.shape[ax] + at) * inner, (size_t)(s * inner) * 4);
+            else memcpy(o->i.data() + r * s * inner, x.i.data() + (r * x.shape[ax] + at) * inner, (size_t)(s * inner) * 8);
+        }
+        outs.push_back(o); at += s;
+    }
+    return outs;
+}
+
 TP run_node(const Node& n, const std::vector<TP>& a, double& flops) {
     const std::string& op = n.op;
     auto in = [&](size_t k) -> const TP& { if (k >= a.size() || !a[k]) fail(op + ": missing input " + std::to_string(k)); return a[k]; };
@@ -710,9 +736,14 @@ i64 run_net(Net& net, const float* x, const i64 xs[4], float* y, i64 ycap, i64 y
             a.push_back(ic->second);
         }
         TP out;
-        try { out = run_node(n, a, net.flops); } catch (const std::exception& e) { fail(std::string(e.what()) + " [node " + std::to_string(k) + " " + n.op + " " + n.name + "]"); }
+        std::vector<TP> more;      // outputs 1.. of a Split
+        try {
+            if (n.op == "Split") { more = run_split(n, a); out = more[0]; more.erase(more.begin()); }
+            else out = run_node(n, a, net.flops);
+        } catch (const std::exception& e) { fail(std::string(e.what()) + " [node " + std::to_string(k) + " " + n.op + " " + n.name + "]"); }
         if (n.out.empty()) continue;
         if (!net.folded && net.is_static[k]) net.consts[n.out[0]] = out; else env[n.out[0]] = out;
+        for (size_t j = 0; j < more.size(); ++j) { if (!net.folded && net.is_static[k]) net.consts[n.out[j + 1]] = more[j]; else env[n.out[j + 1]] = more[j]; }
         for (const std::string& s : n.in) if (!s.empty() && last[s] == k && s != net.output) env.erase(s);
     }
     net.folded = true;

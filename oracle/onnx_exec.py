@@ -255,6 +255,10 @@ class Executor:
             return y
         if op == "Concat":
             return torch.cat([t for t in a], dim=at["axis"])
+        if op == "Split":       # several outputs: qkv.unbind(0) exports as Split + Squeeze
+            ax = at.get("axis", 0)
+            sizes = at.get("split") or (a[1].tolist() if len(a) > 1 and a[1] is not None else None)
+            return list(torch.split(a[0], sizes if sizes else a[0].shape[ax] // len(n.outputs), dim=ax))
         if op == "Slice":
             starts, ends = a[1].tolist(), a[2].tolist()
             axes = a[3].tolist() if len(a) > 3 and a[3] is not None else list(range(len(starts)))

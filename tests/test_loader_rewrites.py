@@ -4,8 +4,9 @@ The reference gives ANY ONNX file to TensorRT's parser (src/tensorrt/img2img_bui
 README.md:11-15, unreachable offline).  tools/onnx_rewrite.py re-spells each exported graph the ways exporters, opsets and optimiser passes
 spell the same computation (Gemm for MatMul + Add inside a 2-D sandwich, Identity / Dropout / no-op Cast / Transpose pairs / Unsqueeze-Squeeze
 and Flatten-Reshape pairs on edges, initializers as Constant nodes, fp16-stored weights, Reshape targets with 0 and -1, biases behind
-Unsqueeze / Squeeze, LayerNormalization axis -1 <-> rank - 1, swapped Add / Mul operands, dead nodes, any topological node order, packed and
-unpacked repeated fields).  For every variant, seeded:
+Unsqueeze / Squeeze, LayerNormalization axis -1 <-> rank - 1 or decomposed into its ReduceMean chain, q / k / v through Split + Squeeze instead of three
+Gathers, the attention scale split over q and k^T the way a decomposed scaled_dot_product_attention writes it, swapped Add / Mul operands, dead nodes, any
+topological node order, packed and unpacked repeated fields).  For every variant, seeded:
 
   * the loader (csrc/fold.cpp -> simplify.cpp -> lower.cpp) must write the ENGINE FILE OF THE ORIGINAL, byte for byte (plan text for the variants
     that store weights in fp16, whose weight bytes legitimately differ) - or refuse naming a node; it must never produce another plan;
@@ -60,7 +61,7 @@ def test_every_spelling_of_a_graph_lowers_to_the_plan_of_the_original(pkg, tmp_p
         rw.dump(v, vpath, packed=bool(seed & 1))
         seen.update(set(v.applied))
         tag = f"{family} seed {seed}: {', '.join(v.applied)}"
-        if "fp16_init" in v.applied:
+        if set(v.applied) & set(rw.INEXACT):
             try:
                 assert pkg.describe_plan(vpath, batch, tile) == ref_txt, tag
             except pkg.W2xError as e:
@@ -77,7 +78,7 @@ def test_every_spelling_of_a_graph_lowers_to_the_plan_of_the_original(pkg, tmp_p
                 assert sha == ref_sha, tag + ": another plan:\n" + pkg.describe_plan(vpath, batch, tile)[:2000]
         if seed % EXEC_EVERY == 0:
             ya, yb = onnx_exec.Executor(vpath).run(x), cnet.Executor(vpath).run(x)
-            tol = 2e-3 if "fp16_init" in v.applied else 2e-5          # (weights rounded to fp16 move the output by ~1e-4)
+            tol = 2e-3 if "fp16_init" in v.applied else 2e-5          # (weights rounded to fp16 move the output by ~1e-4; sqrt(s)^2 for s by ~1e-7)
             assert float(np.abs(ya - yb).max()) < 2e-5, tag + ": the two oracle executors disagree"
             assert float(np.abs(ya - y_ref).max()) < tol, tag + ": the rewrite changed the function"
             ran += 1
@@ -86,7 +87,7 @@ def test_every_spelling_of_a_graph_lowers_to_the_plan_of_the_original(pkg, tmp_p
         assert "cannot lower node" in msg or "graph:" in msg or "fold:" in msg, (tag, msg)
     assert not refused, refused[:5]
     if N_VARIANTS >= 100:
-        want = set(rw.REWRITES) - ({"gemm", "ln_axis", "bias_unsqueeze"} if family.startswith("cunet") else set())
+        want = set(rw.REWRITES) - ({"gemm", "ln_axis", "bias_unsqueeze", "split_qkv", "ln_decompose", "sdpa_scale"} if family.startswith("cunet") else set())
         assert want <= set(seen), (sorted(want - set(seen)), dict(seen))      # every kind of rewrite took part
     print(f"{family}: {N_VARIANTS} variants, {ran} through both oracle executors; rewrites applied: {dict(sorted(seen.items()))}")
 

@@ -25,6 +25,9 @@ rounded to fp16 - the precision an fp16 engine gives them anyway):
     ln_axis         LayerNormalization axis -1 <-> rank - 1
     permute         the node list in another topological order
     commute         the operands of an Add / Mul swapped
+    split_qkv       q, k, v = qkv[0], qkv[1], qkv[2] (three Gathers)  ->  qkv.unbind(0) (one Split + three Squeezes)
+    ln_decompose    a LayerNormalization node  ->  the ReduceMean / Sub / Pow|Mul / ReduceMean / Add / Sqrt / Div / Mul / Add chain exporters write below opset 17
+    sdpa_scale      q * s  ->  (q * sqrt(s)) @ (k^T * sqrt(s)), the way a decomposed scaled_dot_product_attention scales (not bit-exact: sqrt(s)^2 != s in fp32)
     dead            a node nothing reads (a Shape or a Relu of some runtime tensor)
 """
 from __future__ import annotations
@@ -158,9 +161,12 @@ def runtime_shapes(path: str, batch: int, tile: int) -> dict:
     for n in g.nodes:
         if n.op not in ("Shape", "Size") and any(i in runtime for i in n.inputs if i):
             runtime.update(o for o in n.outputs if o)
-    vals = ex.run(np.zeros((batch, 3, tile, tile), np.float32), keep=tuple(runtime))
+    static = [o for n in g.nodes for o in n.outputs if o and o not in runtime]
+    vals = ex.run(np.zeros((batch, 3, tile, tile), np.float32), keep=tuple(runtime) + tuple(static))
     shapes = {k: tuple(int(d) for d in v.shape) for k, v in vals.items() if k in runtime and v.dtype.kind == "f"}      # float tensors only (not the Shape -> ... integer chains)
     shapes[g.inputs[0].name] = (batch, 3, tile, tile)
+    # scalars the graph computes from constants (an attention scale traced as Pow(head_dim, -0.5)): name -> value, under a key no tensor has
+    shapes["__static_scalars__"] = {k: np.asarray(vals[k]) for k in static if k in vals and np.asarray(vals[k]).size == 1}
     return shapes
 
 
@@ -181,7 +187,7 @@ def _runtime_edges(g, shapes):
     out = []
     for k, n in enumerate(g.nodes):
         for s, i in enumerate(n.inputs):
-            if i in shapes:
+            if i in shapes and not i.startswith("__"):
                 out.append((k, s, i))
     return out
 
@@ -421,17 +427,146 @@ def rw_commute(g, shapes, rng):
 
 
 def rw_dead(g, shapes, rng):
-    names = sorted(shapes)
+    names = sorted(k for k in shapes if not k.startswith("__"))
     src = names[rng.integers(len(names))]
     k = max((i for i, n in enumerate(g.nodes) if src in n.outputs), default=-1)
     g.nodes.insert(k + 1, Node("Shape" if rng.integers(2) else "Relu", [src], [_fresh(g, "dead")], {}, _fresh(g, "Dead")))
     return True
 
 
+def _const_value(g, name):
+    """The value of an initializer or of a Constant node's output (None if `name` is neither)."""
+    if name in g.initializers:
+        return g.initializers[name]
+    for n in g.nodes:
+        if n.op == "Constant" and n.outputs and n.outputs[0] == name and isinstance(n.attrs.get("value"), np.ndarray):
+            return n.attrs["value"]
+    return None
+
+
+def _qkv_sites(g):
+    """(index of the [2,0,3,1,4] Transpose, {0: gather node index, 1: .., 2: ..}) of every attention block whose q, k, v are three Gathers on axis 0."""
+    sites = []
+    for k, n in enumerate(g.nodes):
+        if n.op == "Transpose" and list(n.attrs.get("perm", [])) == [2, 0, 3, 1, 4]:
+            us = _consumers(g, n.outputs[0])
+            if len(us) == 3 and all(u.op == "Gather" and u.attrs.get("axis", 0) == 0 for _, u in us):
+                idx = {}
+                for ku, u in us:
+                    v = _const_value(g, u.inputs[1])
+                    if v is not None and v.size == 1:
+                        idx[int(v.reshape(-1)[0])] = ku
+                if sorted(idx) == [0, 1, 2]:
+                    sites.append((k, idx))
+    return sites
+
+
+def rw_split_qkv(g, shapes, rng):
+    sites = _qkv_sites(g)
+    if not sites:
+        return False
+    k, idx = sites[rng.integers(len(sites))]
+    t = g.nodes[k].outputs[0]
+    outs = [g.nodes[idx[i]].outputs[0] for i in range(3)]
+    parts = [_fresh(g, "part") for _ in range(3)]
+    new = []
+    if g.opset >= 13 and rng.integers(2):       # explicit sizes as the second input (opset >= 13) ...
+        sz = _fresh(g, "sizes"); g.initializers[sz] = np.asarray([1, 1, 1], np.int64)
+        new.append(Node("Split", [t, sz], parts, {"axis": 0}, _fresh(g, "Split")))
+    elif g.opset < 13 and rng.integers(2):      # ... or as the attribute (opset < 13) ...
+        new.append(Node("Split", [t], parts, {"axis": 0, "split": [1, 1, 1]}, _fresh(g, "Split")))
+    else:                                       # ... or equal parts, one per output
+        new.append(Node("Split", [t], parts, {"axis": 0}, _fresh(g, "Split")))
+    for pn, on in zip(parts, outs):
+        if on in shapes:
+            shapes[pn] = (1,) + tuple(shapes[on])
+        if g.opset >= 13:
+            axn = _fresh(g, "axes"); g.initializers[axn] = np.asarray([0], np.int64)
+            new.append(Node("Squeeze", [pn, axn], [on], {}, _fresh(g, "Squeeze")))
+        else:
+            new.append(Node("Squeeze", [pn], [on], {"axes": [0]}, _fresh(g, "Squeeze")))
+    first = min(idx.values())
+    for ku in sorted(idx.values(), reverse=True):
+        del g.nodes[ku]
+    g.nodes[first:first] = new
+    return True
+
+
+def rw_sdpa_scale(g, shapes, rng):
+    sites = []
+    for k, idx in _qkv_sites(g):
+        q, kk = g.nodes[idx[0]].outputs[0], g.nodes[idx[1]].outputs[0]
+        qm = [(i, n) for i, n in _consumers(g, q) if n.op == "Mul"]
+        kt = [(i, n) for i, n in _consumers(g, kk) if n.op == "Transpose" and list(n.attrs.get("perm", [])) == [0, 1, 3, 2]]
+        if len(qm) == 1 and len(kt) == 1 and len(_consumers(g, q)) == 1 and len(_consumers(g, kk)) == 1:
+            other = [i for i in qm[0][1].inputs if i != q]
+            c = _const_value(g, other[0]) if len(other) == 1 else None
+            if c is None and len(other) == 1:
+                c = shapes.get("__static_scalars__", {}).get(other[0])
+            if c is not None and c.size == 1 and c.dtype == np.float32 and float(c.reshape(-1)[0]) > 0 and not other[0].startswith("/rw/"):
+                sites.append((qm[0][0], kt[0][0], other[0], float(c.reshape(-1)[0])))
+    if not sites:
+        return False
+    iq, ikt, cname, s = sites[rng.integers(len(sites))]
+    r = _fresh(g, "sqrt_scale")
+    g.initializers[r] = np.asarray(np.sqrt(np.float32(s)), np.float32)
+    qmul, ktr = g.nodes[iq], g.nodes[ikt]
+    qmul.inputs = [r if i == cname else i for i in qmul.inputs]
+    if rng.integers(2):      # k^T * sqrt(s) behind the transpose ...
+        raw = _fresh(g, "kT")
+        out = ktr.outputs[0]
+        ktr.outputs = [raw]
+        if out in shapes:
+            shapes[raw] = shapes[out]
+        g.nodes.insert(ikt + 1, Node("Mul", [raw, r], [out], {}, _fresh(g, "Mul")))
+    else:                    # ... or k * sqrt(s) in front of it
+        src = ktr.inputs[0]
+        scaled = _fresh(g, "k_scaled")
+        if src in shapes:
+            shapes[scaled] = shapes[src]
+        ktr.inputs = [scaled]
+        g.nodes.insert(ikt, Node("Mul", [src, r], [scaled], {}, _fresh(g, "Mul")))
+    return True
+
+
+def rw_ln_decompose(g, shapes, rng):
+    sites = [(k, n) for k, n in enumerate(g.nodes) if n.op == "LayerNormalization" and n.inputs[0] in shapes and n.attrs.get("axis", -1) in (-1, len(shapes[n.inputs[0]]) - 1)
+             and len(n.outputs) == 1 and len(n.inputs) >= 2]
+    if not sites:
+        return False
+    k, n = sites[rng.integers(len(sites))]
+    x, gamma = n.inputs[0], n.inputs[1]
+    beta = n.inputs[2] if len(n.inputs) > 2 and n.inputs[2] else None
+    eps = _fresh(g, "eps"); g.initializers[eps] = np.asarray(n.attrs.get("epsilon", 1e-5), np.float32)
+    m, d, sq, var, ve, sd, nrm, sc = (_fresh(g, s) for s in ("mean", "centred", "squared", "var", "var_eps", "std", "normed", "scaled"))
+    sh = shapes[x]
+    for name in (d, sq, nrm, sc):
+        shapes[name] = sh
+    for name in (m, var, ve, sd):
+        shapes[name] = tuple(sh[:-1]) + (1,)
+    stem = n.name or "LayerNormalization"
+    new = [Node("ReduceMean", [x], [m], {"axes": [-1], "keepdims": 1}, stem + "/ReduceMean"), Node("Sub", [x, m], [d], {}, stem + "/Sub")]
+    if rng.integers(2):
+        two = _fresh(g, "two"); g.initializers[two] = np.asarray(2.0, np.float32)
+        new.append(Node("Pow", [d, two], [sq], {}, stem + "/Pow"))
+    else:
+        new.append(Node("Mul", [d, d], [sq], {}, stem + "/Mul_sq"))
+    new += [Node("ReduceMean", [sq], [var], {"axes": [-1], "keepdims": 1}, stem + "/ReduceMean_1"), Node("Add", [var, eps], [ve], {}, stem + "/Add"),
+            Node("Sqrt", [ve], [sd], {}, stem + "/Sqrt"), Node("Div", [d, sd], [nrm], {}, stem + "/Div")]
+    out = n.outputs[0]
+    new.append(Node("Mul", [nrm, gamma], [sc if beta else out], {}, stem + "/Mul"))
+    if beta:
+        new.append(Node("Add", [sc, beta], [out], {}, stem + "/Add_1"))
+    g.nodes[k:k + 1] = new
+    return True
+
+
 REWRITES = {"gemm": rw_gemm, "identity": rw_identity, "dropout": rw_dropout, "cast": rw_cast, "transpose2": rw_transpose2, "squeeze": rw_squeeze,
             "const_node": rw_const_node, "fp16_init": rw_fp16_init, "reshape_0_m1": rw_reshape_0_m1, "bias_unsqueeze": rw_bias_unsqueeze,
-            "ln_axis": rw_ln_axis, "permute": rw_permute, "commute": rw_commute, "dead": rw_dead}
-EXACT = [k for k in REWRITES if k != "fp16_init"]          # rewrites under which the engine file must not change by a byte
+            "ln_axis": rw_ln_axis, "permute": rw_permute, "commute": rw_commute, "dead": rw_dead, "split_qkv": rw_split_qkv, "ln_decompose": rw_ln_decompose,
+            "sdpa_scale": rw_sdpa_scale}
+INEXACT = ("fp16_init", "sdpa_scale")                      # weights rounded to fp16 / sqrt(s)^2 for s: the plan keeps its text, not its bytes
+EXACT = [k for k in REWRITES if k not in INEXACT]          # rewrites under which the engine file must not change by a byte
 
 
 def rewrite(g: Graph, shapes: dict, seed: int, kinds=None, count=None):

@@ -482,6 +482,14 @@ FoldedGraph fold_graph(const Model& m, const std::vector<int64_t>& input_shape) 
             if (n.has("starts")) { starts = n.aints("starts"); ends = n.aints("ends"); axes = n.aints("axes"); }
             else { starts = ints_of(C(1)); ends = ints_of(C(2)); if (has_in(3)) axes = ints_of(C(3)); if (has_in(4)) steps = ints_of(C(4)); }
             set_dyn(slice_spec(s0, starts, ends, axes, steps).oshape, dt0);
+        } else if (op == "Split") {        // several outputs (qkv.unbind(0) exports as Split + Squeeze): sizes from the attribute, the second input, or equal parts
+            int64_t ax = norm_axis(n.ai("axis", 0), (int)s0.size());
+            std::vector<int64_t> sizes = n.aints("split");
+            if (sizes.empty() && has_in(1)) sizes = ints_of(C(1));
+            if (sizes.empty()) { const int64_t k = (int64_t)n.out.size(); if (k <= 0 || s0[ax] % k) throw std::runtime_error("graph: Split \"" + n.name + "\" does not divide its axis evenly"); sizes.assign((size_t)k, s0[ax] / k); }
+            int64_t total = 0; for (int64_t v : sizes) { if (v < 0) throw std::runtime_error("graph: Split with a negative size"); total += v; }
+            if (sizes.size() != n.out.size() || total != s0[ax]) throw std::runtime_error("graph: Split \"" + n.name + "\" sizes do not match its axis");
+            for (size_t k = 0; k < sizes.size(); ++k) { Value v; v.shape = s0; v.shape[ax] = sizes[k]; v.dtype = dt0; g.vals[n.out[k]] = v; }
         } else if (op == "Concat") {
             int64_t ax = norm_axis(n.ai("axis", 0), (int)s0.size()); Shape o = s0; o[ax] = 0;
             for (auto* v : in) o[ax] += v->shape[ax];

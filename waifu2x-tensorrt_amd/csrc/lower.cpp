@@ -541,33 +541,56 @@ struct Lowerer {
         if (x.C != 3 * C) fail(r5, "qkv width mismatch");
         const Node* t5 = only_user(r5->out[0]);
         if (!t5 || t5->op != "Transpose" || perm_of(t5) != std::vector<int64_t>{2, 0, 3, 1, 4}) fail(r5, "unexpected qkv permutation");
+        // q, k, v out of the [3, B nW, heads, N, d] tensor: three Gathers on axis 0 (qkv[0], qkv[1], qkv[2]) or one Split on axis 0 whose outputs are
+        // squeezed (qkv.unbind(0): Split + Squeeze, a Reshape after simplify_graph)
         auto gs = users(t5->out[0]);
-        if (gs.size() != 3) fail(t5, "expected three q/k/v gathers");
         std::string q, k, v;
-        for (auto* gn : gs) {
-            if (gn->op != "Gather" || gn->ai("axis", 0) != 0 || !is_c(gn->in[1])) fail(gn, "unexpected qkv split");
-            int64_t idx = g.cst(gn->in[1]).i[0];
-            (idx == 0 ? q : idx == 1 ? k : v) = gn->out[0];
-            done.insert(gn);
+        if (gs.size() == 1 && gs[0]->op == "Split") {
+            const Node* sp = gs[0];
+            if (sp->ai("axis", 0) != 0 || sp->out.size() != 3) fail(sp, "unexpected qkv split");
+            std::string* dst[3] = {&q, &k, &v};
+            for (int idx = 0; idx < 3; ++idx) {
+                if (shp(sp->out[idx]) != Shape{1, s5[0], heads, Ntok, hd}) fail(sp, "unexpected qkv split sizes");
+                const Node* sq = only_user(sp->out[idx]);
+                if (!sq || sq->op != "Reshape" || shp(sq->out[0]) != Shape{s5[0], heads, Ntok, hd}) fail(sp, "expected the split outputs to be squeezed");
+                *dst[idx] = sq->out[0];
+                done.insert(sq);
+            }
+            done.insert(sp);
+        } else {
+            if (gs.size() != 3) fail(t5, "expected three q/k/v gathers");
+            for (auto* gn : gs) {
+                if (gn->op != "Gather" || gn->ai("axis", 0) != 0 || !is_c(gn->in[1])) fail(gn, "unexpected qkv split");
+                int64_t idx = g.cst(gn->in[1]).i[0];
+                (idx == 0 ? q : idx == 1 ? k : v) = gn->out[0];
+                done.insert(gn);
+            }
         }
         if (q.empty() || k.empty() || v.empty()) fail(t5, "q/k/v split incomplete");
         done.insert(r5); done.insert(t5);
         float scale = 1.f;
-        const Node* u = only_user(q);
         std::string dyn; const HTensor* c = nullptr;
-        if (u && (u->op == "Mul" || u->op == "Div") && split_binary(u, dyn, c) && c->numel() == 1) {
-            scale = u->op == "Mul" ? c->f[0] : 1.f / c->f[0]; done.insert(u); q = u->out[0];
-        }
+        // a scalar factor on q, on k (in front of or behind its transpose) or on the product: a decomposed scaled_dot_product_attention multiplies q AND k^T
+        // by sqrt(scale); all of them end up in one factor on the scores
+        auto absorb_scale = [&](std::string& name) {
+            const Node* m = only_user(name);
+            if (m && (m->op == "Mul" || m->op == "Div") && split_binary(m, dyn, c) && dyn == name && c->numel() == 1 && c->is_float()) {
+                scale *= m->op == "Mul" ? c->f[0] : 1.f / c->f[0]; done.insert(m); name = m->out[0];
+            }
+        };
+        absorb_scale(q);
+        absorb_scale(k);
         const Node* kt = only_user(k);
         if (!kt || kt->op != "Transpose" || perm_of(kt) != std::vector<int64_t>{0, 1, 3, 2}) fail(kt ? kt : t5, "expected k transpose");
         done.insert(kt);
+        std::string ktn = kt->out[0];
+        absorb_scale(ktn);
         const Node* mm1 = only_user(q);
-        if (!mm1 || mm1->op != "MatMul" || mm1->in[0] != q || mm1->in[1] != kt->out[0]) fail(mm1 ? mm1 : kt, "expected q @ k^T");
+        if (!mm1 || mm1->op != "MatMul" || mm1->in[0] != q || mm1->in[1] != ktn) fail(mm1 ? mm1 : kt, "expected q @ k^T");
         done.insert(mm1);
         std::string cur = mm1->out[0];
-        // optional scale after the product
-        u = only_user(cur);
-        if (u && (u->op == "Mul" || u->op == "Div") && split_binary(u, dyn, c) && c->numel() == 1) { scale *= u->op == "Mul" ? c->f[0] : 1.f / c->f[0]; done.insert(u); cur = u->out[0]; }
+        absorb_scale(cur);                        // optional scale after the product
+        const Node* u = nullptr;
         std::vector<float> bias((size_t)heads * Ntok * Ntok, 0.f);
         u = only_user(cur);
         if (u && u->op == "Add" && split_binary(u, dyn, c)) {
