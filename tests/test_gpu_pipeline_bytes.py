@@ -270,3 +270,28 @@ def test_one_frame_over_two_processes_through_ipc_handles(pkg, tmp_path):
         assert len({rec["pid"] for rec in p["ranks"]}) == n and len({rec["pci_bus_id"] for rec in p["ranks"]}) == 1 and p["device_map"] == env["W2X_DEVICE_MAP"]
         assert line["config"]["peer_device_ordinals_seen_by_rank0"] == [0] * n
         assert sum(line["config"]["tiles_per_rank"]) == 63 and min(line["config"]["tiles_per_rank"]) > 0
+
+
+@pytest.mark.gpu
+def test_frame_sharded_bench_line_certifies_where_it_ran(tmp_path):
+    """bench.py's headline mode (frames round-robin over ranks) with two ranks on the box's ONE GPU (W2X_DEVICE_MAP=0,0) on the test-sized frame: the line carries
+    `placement` (both ranks' pids, the one PCI bus id), n_ranks = 2 but n_gpus = 1 and a metric that starts with REHEARSAL - it cannot be read as a two-GPU
+    result - and the host-to-host figure with its per-rank spread next to the resident `value`."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, W2X_DEVICE_MAP="0,0", W2X_BENCH_WORK=str(tmp_path / "w"))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "0", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    p = d["placement"]
+    assert d["n_ranks"] == 2 and d["n_gpus"] == 1 and d["metric"].startswith("REHEARSAL (2 ranks on 1 GPU)") and d["scaling"] == "weak"
+    assert p["distinct_gpus"] == 1 and not p["one_gpu_per_rank"] and p["device_map"] == "0,0" and len({x["pid"] for x in p["ranks"]}) == 2
+    h = d["host_to_host"]
+    assert h and h["ms_per_frame"] > 0 and h["per_rank_ms_per_frame"]["min"] <= h["per_rank_ms_per_frame"]["max"] <= h["ms_per_frame"] + 1e-3
+    assert d["value"] > 0 and d["config"]["per_rank_resident_ms_per_step"]["max"] <= d["ms_per_step"] + 1e-3
+    assert d["roofline"]["bound"] in ("hbm", "mfma") and "cpu_baseline" not in d
