@@ -9,6 +9,10 @@ import synth_models as sm
 pkg = g.package()
 model, scale, noise, batch, tile, rows, cols = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
 tta = "tta" in sys.argv[8:]
+for a in sys.argv[8:]:                     # debug switches (csrc/switches.h), e.g. no_conv3=1: the reference paths for A/B runs
+    if "=" in a:
+        k, v = a.split("=")
+        assert pkg.lib().w2x_debug_set(k.encode(), int(v)), a
 prec = pkg.Precision.TF32 if "fp32" in sys.argv[8:] else pkg.Precision.FP16
 path = sm.model_path("/tmp/w2x_optimes", model, scale, noise)
 if not os.path.exists(path):
