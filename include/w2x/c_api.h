@@ -26,7 +26,7 @@ extern "C" {
 
 typedef struct w2x_engine w2x_engine;
 
-enum { W2X_PRECISION_TF32 = 0, W2X_PRECISION_FP16 = 1 };  /* config.h:7-10; CLI map main.cpp:76-84 */
+enum { W2X_PRECISION_TF32 = 0, W2X_PRECISION_FP16 = 1, W2X_PRECISION_FP32 = 2 };  /* config.h:7-10; CLI map main.cpp:76-84; FP32: an addition (include/w2x/config.h) */
 
 typedef struct w2x_build_config {   /* trt::BuildConfig, config.h:12-31 */
     int deviceId, precision;
@@ -111,7 +111,7 @@ int w2x_calculate_tiles(int in_w, int in_h, int out_w, int out_h, int tile_in, i
 int w2x_tile_weights(int which, int overlap_x, int overlap_y, int size, float* out);
 /* Lower an ONNX file at [batch,3,tile,tile] and write a textual description of the plan (ops, FLOPs) into buf. */
 int w2x_describe_plan(const char* onnx_path, int batch, int tile, char* buf, size_t cap);
-/* the same for either precision (W2X_PRECISION_FP16 / W2X_PRECISION_TF32: the plan build() would write for that BuildConfig::precision) */
+/* the same for any precision (W2X_PRECISION_FP16 / _TF32 / _FP32: the plan build() would write for that BuildConfig::precision; TF32 and FP32 share one) */
 int w2x_describe_plan_precision(const char* onnx_path, int batch, int tile, int precision, char* buf, size_t cap);
 /* Host-only halves of build() / load() for tools and tests: lower an ONNX file and write the plan (no .json side file, no
  * device); read a plan file back and run the consistency checks load() runs (img2img_load.cpp:149-154 "Failed to deserialize

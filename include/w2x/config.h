@@ -6,10 +6,14 @@
 
 namespace w2x {
 
-// Arithmetic of the network.  gfx950 has no TF32 / xf32 matrix instructions: a Precision::TF32 request builds and loads the
-// FP32 engine instead (fp32 maps and weights, v_mfma_f32_16x16x4_f32 products - a superset of TF32's precision; build() says
-// so in an info message).  An engine file serves only the precision it was built for (img2img_load.cpp:54-66).
-enum class Precision { TF32, FP16 };
+// Arithmetic of the network.  TF32 and FP16 are the reference's two values, with their values.  gfx950 has no TF32 / xf32 matrix
+// instruction, so a Precision::TF32 request gets the fp32-storage engine (fp32 maps and weights, fp32 accumulation, the un-fused
+// operator set) with TF32-CLASS products: each operand is split into two bf16 halves and a product is three v_mfma_f32_16x16x32_bf16
+// (16 significant bits per operand where TF32 keeps 11; the bf16 exponent is fp32's, so nothing can overflow that fp32 holds).
+// FP32 (not in the reference) is the same engine with exact fp32 products on v_mfma_f32_16x16x4_f32: about twice the frame time,
+// outputs within summation order of an fp32 evaluation of the graph.  An engine file serves only the precision it was built for
+// (img2img_load.cpp:54-66).
+enum class Precision { TF32, FP16, FP32 };
 
 // What build() specialises a plan for.  The reference hands TensorRT a min / opt / max optimisation profile per
 // dimension (img2img_build.cpp:102-116); its command line always sets the three equal (main.cpp:276-291).  build() checks

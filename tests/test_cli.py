@@ -40,6 +40,9 @@ def test_render_options_and_derived_names(tmp_path):
     assert c["outputs"] == [str(tmp_path / "picture.one.png")]
     r = run("--model", "swin_unet/photo", "--scale", "2", "--noise", "-1", "--batchSize", "2", "--tileSize", "400", "build", "--print-config")
     assert json.loads(r.stdout)["model_path"] == "models/swin_unet/photo/scale2x.onnx"
+    for prec in ("fp16", "tf32", "fp32", "FP32"):      # main.cpp:76-84 has fp16 and tf32 (case-insensitive); fp32 = exact products on the same engine (include/w2x/config.h)
+        r = run("--model", "cunet/art", "--scale", "2", "--noise", "0", "--batchSize", "1", "--tileSize", "64", "--precision", prec, "build", "--print-config")
+        assert r.returncode == 0 and json.loads(r.stdout)["precision"] == prec.lower(), (prec, r.stderr)
 
 
 @pytest.mark.parametrize("args,msg", [
@@ -57,6 +60,7 @@ def test_render_options_and_derived_names(tmp_path):
     (BASE + ["render", "-i", ".", "--blend", "0.3"], "--blend"),
     (BASE + ["render", "-i", ".", "--crf", "52"], "--crf"),
     (BASE + ["--precision", "int8", "build"], "--precision"),
+    (BASE + ["--precision", "bf16", "build"], "--precision"),
     (BASE + ["render", "-i", ".", "--tta", "--tta-mode", "median"], "--tta-mode"),
     (BASE + ["render", "-i", ".", "--tta-mode", "reference"], "needs --tta"),
     (BASE + ["build", "--bogus"], "not expected"),

@@ -166,8 +166,8 @@ def test_config1_as_written_fp32_b1_t64_256x256(pkg, onnx_model):
     fed with the engine's network, and the step schedule of img2img_render.cpp:246-250 through the progress callback."""
     path = onnx_model("cunet/art", 2, 1, 64, noise=0)
     eng = pkg.Img2Img()
-    assert eng.build(path, pkg.BuildConfig.fixed(1, 64, precision=pkg.Precision.TF32)), eng.last_error()
-    assert eng.load(path, pkg.RenderConfig(precision=pkg.Precision.TF32, batchSize=1, height=64, width=64, scaling=2, overlap=(0.0625, 0.0625))), eng.last_error()
+    assert eng.build(path, pkg.BuildConfig.fixed(1, 64, precision=pkg.Precision.FP32)), eng.last_error()
+    assert eng.load(path, pkg.RenderConfig(precision=pkg.Precision.FP32, batchSize=1, height=64, width=64, scaling=2, overlap=(0.0625, 0.0625))), eng.last_error()
     assert eng.output_tile_size == 56
     n, rin, rout = pkg.calculate_tiles(256, 256, 512, 512, 64, 56, 2, (0.0625, 0.0625))
     assert n == 121 and tuple(rin[0]) == (-18, -18, 64, 64) and tuple(rin[-1]) == (222, 222, 64, 64) and tuple(rout[-1]) == (480, 480, 32, 32)
@@ -192,7 +192,7 @@ def test_sixteen_bit_frames_byte_exact_and_close_to_the_oracle(pkg, onnx_model, 
     frame may differ by the fp16 network tolerance (3 ULP16 of [0.5, 1) = 96 of 65535) on the fp16 engine, by summation order on the fp32 one."""
     path = onnx_model("swin_unet/art", 4, 2, 64, noise=1)
     eng = pkg.Img2Img()
-    prec = pkg.Precision.TF32 if fp32 else pkg.Precision.FP16
+    prec = pkg.Precision.FP32 if fp32 else pkg.Precision.FP16
     assert eng.build(path, pkg.BuildConfig.fixed(2, 64, precision=prec)), eng.last_error()
     assert eng.load(path, pkg.RenderConfig(precision=prec, batchSize=2, height=64, width=64, scaling=4, overlap=(0.0625, 0.0625), tta=not fp32)), eng.last_error()
     rng = np.random.default_rng(12)

@@ -208,6 +208,7 @@ def test_tf32_requests_lower_to_an_fp32_plan_of_unfused_ops(pkg, onnx_model, mod
     path = onnx_model(model, scale, 2, 64, noise=1)
     d16, d32 = pkg.describe_plan(path, 2, 64), pkg.describe_plan(path, 2, 64, pkg.Precision.TF32)
     assert "precision=fp16" in d16.splitlines()[0] and "precision=fp32" in d32.splitlines()[0]
+    assert pkg.describe_plan(path, 2, 64, pkg.Precision.FP32) == d32      # FP32 (exact products) and TF32 (split-bf16 products) run one plan; the choice is made at launch
     assert " swinattn " not in d32 and " mlp " not in d32
     if model.startswith("swin"):
         assert " swinattn " in d16 and " attn heads=" in d32

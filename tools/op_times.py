@@ -1,5 +1,5 @@
 """HIP-event time per plan op for one resident frame of any configuration (bench.py --op-times does this for config 3 only):
-    python tools/op_times.py cunet/art 2 1 4 256 1080 1920 [tta] [fp32]"""
+    python tools/op_times.py cunet/art 2 1 4 256 1080 1920 [tta] [tf32 | fp32] [switch=value ...]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +13,7 @@ for a in sys.argv[8:]:                     # debug switches (csrc/switches.h), e
     if "=" in a:
         k, v = a.split("=")
         assert pkg.lib().w2x_debug_set(k.encode(), int(v)), a
-prec = pkg.Precision.TF32 if "fp32" in sys.argv[8:] else pkg.Precision.FP16
+prec = pkg.Precision.FP32 if "fp32" in sys.argv[8:] else pkg.Precision.TF32 if "tf32" in sys.argv[8:] else pkg.Precision.FP16
 path = sm.model_path("/tmp/w2x_optimes", model, scale, noise)
 if not os.path.exists(path):
     sm.export_onnx(sm.make_model(model, scale, seed=1234 + noise), path, 1, tile, dynamic=True)

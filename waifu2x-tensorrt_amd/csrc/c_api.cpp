@@ -39,7 +39,7 @@ void w2x_set_progress_callback(w2x_engine* e, w2x_progress_fn fn, void* user) {
 int w2x_build(w2x_engine* e, const char* onnx_path, const w2x_build_config* c) {
     if (!e || !onnx_path || !c) return 0;
     w2x::BuildConfig b;
-    b.deviceId = c->deviceId; b.precision = c->precision == W2X_PRECISION_FP16 ? w2x::Precision::FP16 : w2x::Precision::TF32;
+    b.deviceId = c->deviceId; b.precision = c->precision == W2X_PRECISION_FP16 ? w2x::Precision::FP16 : c->precision == W2X_PRECISION_FP32 ? w2x::Precision::FP32 : w2x::Precision::TF32;
     b.minBatchSize = c->minBatchSize; b.optBatchSize = c->optBatchSize; b.maxBatchSize = c->maxBatchSize;
     b.minChannels = c->minChannels; b.optChannels = c->optChannels; b.maxChannels = c->maxChannels;
     b.minWidth = c->minWidth; b.optWidth = c->optWidth; b.maxWidth = c->maxWidth;
@@ -50,7 +50,7 @@ int w2x_build(w2x_engine* e, const char* onnx_path, const w2x_build_config* c) {
 int w2x_load(w2x_engine* e, const char* onnx_path, const w2x_render_config* c) {
     if (!e || !onnx_path || !c) return 0;
     w2x::RenderConfig r;
-    r.deviceId = c->deviceId; r.precision = c->precision == W2X_PRECISION_FP16 ? w2x::Precision::FP16 : w2x::Precision::TF32;
+    r.deviceId = c->deviceId; r.precision = c->precision == W2X_PRECISION_FP16 ? w2x::Precision::FP16 : c->precision == W2X_PRECISION_FP32 ? w2x::Precision::FP32 : w2x::Precision::TF32;
     r.batchSize = c->batchSize; r.channels = c->channels; r.height = c->height; r.width = c->width; r.scaling = c->scaling;
     r.overlapX = c->overlapX; r.overlapY = c->overlapY; r.tta = c->tta != 0; r.ttaBugCompat = c->ttaBugCompat != 0;
     return e->engine.load(onnx_path, r) ? 1 : 0;

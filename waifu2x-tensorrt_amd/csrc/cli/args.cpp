@@ -54,7 +54,7 @@ std::string usage() {
            "  --batchSize INT REQUIRED    > 0\n"
            "  --tileSize INT REQUIRED     {64,128,256,400,640}\n"
            "  --device INT [0]            GPU device ID\n"
-           "  --precision TEXT [fp16]     {fp16,tf32}\n"
+           "  --precision TEXT [fp16]     {fp16,tf32,fp32}\n"
            "  --devices INT [1]           (extension) number of GPUs: video frames round-robin, one image as N tile ranges\n"
            "  --split TEXT [shards]       (extension) {shards,strips}: one image over --devices N: every tile once with the seam bands exchanged / whole tile columns\n"
            "  --deep                      (extension) 16-bit PNGs keep 16 bits per sample through the engine and in the output\n"
@@ -134,7 +134,7 @@ Options parse(int argc, const char* const* argv) {
     if (o.device < 0) throw std::runtime_error("--device: number must be non-negative");
     if (o.devices < 1) throw std::runtime_error("--devices: number must be positive");
     member<std::string>("--split", o.split, {"shards", "strips"});
-    member<std::string>("--precision", o.precision, {"fp16", "tf32"});
+    member<std::string>("--precision", o.precision, {"fp16", "tf32", "fp32"});   // fp32: an addition (include/w2x/config.h)
     if (o.command == "render") {
         if (o.inputs.empty()) throw std::runtime_error("--input is required");
         for (const auto& p : o.inputs) if (!std::filesystem::exists(p)) throw std::runtime_error("--input: Path does not exist: " + p);

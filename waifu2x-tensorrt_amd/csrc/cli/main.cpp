@@ -177,7 +177,7 @@ int main(int argc, char** argv) {
         auto on_progress = [&](int current, int total, double speed) {
             fprintf(stderr, "[info] Rendered file %zu/%zu, frame %zu/%zu, batch %d/%d @ %.2f it/s\n", fileIndex.load(), fileCount.load(), frameIndex.load(), frameCount.load(), current, total, speed);
         };
-        const Precision prec = o.precision == "tf32" ? Precision::TF32 : Precision::FP16;
+        const Precision prec = o.precision == "tf32" ? Precision::TF32 : o.precision == "fp32" ? Precision::FP32 : Precision::FP16;
 
         if (o.command == "build") {
             Img2Img engine;

@@ -93,7 +93,7 @@ bool device_pci_bus_id(int deviceId, char* buf, size_t cap) {
 }
 namespace {
 
-std::string precision_name(Precision p) { return p == Precision::FP16 ? "FP16" : "TF32"; }
+std::string precision_name(Precision p) { return p == Precision::FP16 ? "FP16" : p == Precision::FP32 ? "FP32" : "TF32"; }
 
 // img2img_build.cpp:8-27
 std::string getConfigHash(const BuildConfig& c, std::string deviceName) {
@@ -145,7 +145,8 @@ void deserializeConfig(const std::string& path, BuildConfig& c, std::string& dev
     };
     auto get_int = [&](const std::string& key) { return (int)std::strtol(j.c_str() + find_value(key), nullptr, 10); };
     deviceName = get_str("deviceName");
-    c.precision = get_str("precision") == "FP16" ? Precision::FP16 : Precision::TF32;
+    const std::string prec = get_str("precision");
+    c.precision = prec == "FP16" ? Precision::FP16 : prec == "FP32" ? Precision::FP32 : Precision::TF32;
     c.minBatchSize = get_int("minBatchSize"); c.optBatchSize = get_int("optBatchSize"); c.maxBatchSize = get_int("maxBatchSize");
     c.minChannels = get_int("minChannels"); c.optChannels = get_int("optChannels"); c.maxChannels = get_int("maxChannels");
     c.minWidth = get_int("minWidth"); c.optWidth = get_int("optWidth"); c.maxWidth = get_int("maxWidth");
@@ -612,7 +613,7 @@ struct Img2Img::Impl {
                     }
                     stamp_begin(0, op.flops);
                     if (op.g.pool_out >= 0) pool_blocks[op.g.pool_out] = plan.elt == 2 && conv3_supported(p) ? conv3_tiles(p) : 0;   // partial sums per image written by this launch (0: plan default)
-                    hipAssert(plan.elt == 4 ? launch_gemm_f32(p, s) : pixgemm_supported(p) ? launch_pixgemm(p, s) : conv3_supported(p) ? launch_conv3(p, s) : conv3h_supported(p) ? launch_conv3h(p, s) : conv48_supported(p) ? launch_conv48(p, s) : stem_supported(p) ? launch_stem(p, s) : launch_gemm(p, s));
+                    hipAssert(plan.elt == 4 ? launch_gemm_f32(p, s, cfg.precision == Precision::FP32) : pixgemm_supported(p) ? launch_pixgemm(p, s) : conv3_supported(p) ? launch_conv3(p, s) : conv3h_supported(p) ? launch_conv3h(p, s) : conv48_supported(p) ? launch_conv48(p, s) : stem_supported(p) ? launch_stem(p, s) : launch_gemm(p, s));
                     stamp_end();
                     if (check_general && plan.elt == 2 && (pixgemm_supported(p) || conv3_supported(p) || conv3h_supported(p) || conv48_supported(p) || stem_supported(p))) {   // diagnostic: the general kernel must agree
                         const TensorDesc& od = plan.tensors[op.g.out.t];
@@ -921,11 +922,12 @@ bool Img2Img::build(const std::string& onnxModelPath, const BuildConfig& config)
         W2X_LOG(error, "Failed to set hip device to device id " + std::to_string(config.deviceId) + ": " + std::string(e.what()) + ".");
         return false;
     }
-    // :123-135 - precision: FP16 = the fused fp16 kernels; gfx950 has no TF32 matrix instruction, a TF32 request gets the fp32
-    // engine (fp32 storage, v_mfma_f32_16x16x4_f32 products, fp32 accumulation - a superset of TF32's precision; k_f32.hip)
+    // :123-135 - precision: FP16 = the fused fp16 kernels; gfx950 has no TF32 matrix instruction, a TF32 request gets the fp32-storage
+    // engine (k_f32.hip: fp32 maps and accumulation, un-fused operator set) with split-bf16 products, FP32 the same engine with exact
+    // fp32 products (include/w2x/config.h)
     switches_from_env();                                   // (W2X_SUPERBATCH is read by the lowering: switches.h)
-    const bool fp32 = config.precision == Precision::TF32;
-    if (fp32) W2X_LOG(info, "Precision TF32: this platform has no TF32 matrix instructions, the engine computes in fp32.");
+    const bool fp32 = config.precision != Precision::FP16;
+    if (config.precision == Precision::TF32) W2X_LOG(info, "Precision TF32: this platform has no TF32 matrix instructions, the engine keeps fp32 maps and multiplies split-bf16 operands (16 significant bits each).");
     // :81-88 parse ; :102-116 one profile: the plan on disk is specialised for the opt shape (channels come from the model);
     // any other shape inside [min, max] is specialised by load() from the same ONNX file
     if (config.minBatchSize > config.optBatchSize || config.optBatchSize > config.maxBatchSize || config.minWidth > config.optWidth || config.optWidth > config.maxWidth ||
@@ -1044,14 +1046,14 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
         W2X_LOG(warn, "Engine \"" + enginePath + "\" is compatible with but not optimized for the render configuration; specialising the plan for batch " +
                           std::to_string(config.batchSize) + ", tile " + std::to_string(config.width) + "x" + std::to_string(config.height) + ".");
         try {
-            impl->plan = lower_for_shape(modelPath, config.batchSize, config.channels, config.height, config.width, config.precision == Precision::TF32);
+            impl->plan = lower_for_shape(modelPath, config.batchSize, config.channels, config.height, config.width, config.precision != Precision::FP16);
         } catch (const std::exception& e) {
             W2X_LOG(error, "Failed to set input tensor shape: " + std::string(e.what()) + ".");
             return false;
         }
     }
     const Plan& plan = impl->plan;
-    if ((plan.elt == 4) != (config.precision == Precision::TF32)) {   // the JSON sidecar and the engine file disagree
+    if ((plan.elt == 4) != (config.precision != Precision::FP16)) {   // the JSON sidecar and the engine file disagree
         W2X_LOG(error, "Failed to deserialize engine from buffer: precision of the plan differs from the engine's configuration.");
         return false;
     }

@@ -1,22 +1,48 @@
-// The engine's second precision for gfx950: every Conv / ConvTranspose / MatMul and the window attention core in fp32.
+// The engine's second storage type for gfx950: every Conv / ConvTranspose / MatMul and the window attention core on fp32 maps.
 // The reference offers fp16 and TF32 engines (/root/reference/src/tensorrt/config.h:7-10, img2img_build.cpp:123-135); gfx950 has
-// no TF32 / xf32 matrix instruction, so a TF32 request runs here: fp32 storage, fp32 products on v_mfma_f32_16x16x4_f32, fp32
-// accumulation - a superset of TF32's precision.  An fp32 plan (plan.h Plan::elt == 4, lower.cpp) keeps the un-fused operator
-// set (no fused transformer kernels, no shape-specialised convolutions), so two kernels cover it:
-//   gemm32_kernel : gemm_kernel (k_gemm.hip) restated for fp32 - same implicit-GEMM A operand (rows / window gather / kh x kw
+// no TF32 / xf32 matrix instruction.  An fp32 plan (plan.h Plan::elt == 4, lower.cpp) keeps fp32 maps, weights and accumulation and
+// the un-fused operator set (no fused transformer kernels, no shape-specialised convolutions), and serves two precisions
+// (include/w2x/config.h):
+//   Precision::TF32  TF32-CLASS products.  Both operands are split when they are staged into LDS, x = hi + lo with hi = bf16(x),
+//                    lo = bf16(x - hi) (16 significant bits, fp32's exponent range), and a k-step of 32 is three
+//                    v_mfma_f32_16x16x32_bf16: lo*hi + hi*lo + hi*hi (the dropped lo*lo is 2^-18 of the product).  Against the fp32 oracle
+//                    8.8e-6 at most (mean 1.4e-6) on outputs in [0, 1]; eleven-bit operands - what TF32 keeps - would give about 1e-3.
+//   Precision::FP32  exact fp32 products on v_mfma_f32_16x16x4_f32 (an addition to the reference's enum): 6.6e-7 at most, summation order.
+// Two kernels cover the plan:
+//   gemm32_kernel : gemm_kernel (k_gemm.hip) restated for fp32 maps - same implicit-GEMM A operand (rows / window gather / kh x kw
 //                   taps), same epilogue (folded LayerNorm, bias, activations, two residual adds, clip, rows / window / pixel-shuffle
 //                   stores, LayerNorm statistics and squeeze-excite partial sums of the stored rows), same 128-row workgroup tile
 //                   (kGemmBM), LDS-staged operands with register prefetch of the next k-chunk.
 //   attn32_kernel : one wave per (window, head), lane = query row, everything in that lane's registers (k_attn.hip attn_kernel
 //                   with fp32 rows).
-// This path exists for precision, not speed (about 10x the fp16 frame time); tests compare it with the fp32 oracle directly.
+// Config 3 (1080p frame, round 5): 51.7 ms with TF32, 64.7 ms with FP32 (7.4 ms on the fp16 engine).  Until round 5 both were one 70 ms
+// path; what moved it: the split products (-10 ms) and an epilogue whose piece geometry is a compile-time fact when the launch is
+// not a pixel shuffle (its index arithmetic was a third of the kernel's vector instructions: -5 ms / -8 ms).  What is left is the
+// fp32 traffic of an un-fused plan (2 - 3 TB/s per launch) and the lane-per-query attention core (10.8 ms).
 #include "kernels.h"
 #include <cmath>
+#include <type_traits>
 
 namespace w2x {
 namespace {
 
 typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// x = hi + lo + e with hi = bf16(x), lo = bf16(x - hi) (the difference is exact in fp32), |e| <= 2^-18 |x|: four values -> 4 + 4 bf16
+__device__ __forceinline__ void split4(const float4v v, uint2v& hi, uint2v& lo) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float a = v[2 * h], b = v[2 * h + 1];
+        const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector((float2v){a, b}, bf16x2));   // v_cvt_pk_bf16_f32, round to nearest even
+        const float ah = __builtin_bit_cast(float, hb << 16), bh = __builtin_bit_cast(float, hb & 0xFFFF0000u);
+        hi[h] = hb;
+        lo[h] = __builtin_bit_cast(unsigned, __builtin_convertvector((float2v){a - ah, b - bh}, bf16x2));
+    }
+}
 
 __device__ __forceinline__ float act_fn(float v, int act, float alpha) {
     switch (act) {
@@ -31,11 +57,16 @@ __device__ __forceinline__ float act_fn(float v, int act, float alpha) {
 #ifndef W2X_G32_WPC
 #define W2X_G32_WPC 3      // workgroups per CU the register budget is set for (the half-height epilogue tile leaves LDS for three)
 #endif
-template <int WAVES_M, int WAVES_N, int WM, int WN, int HALVES>
-__global__ __launch_bounds__(256, W2X_G32_WPC) void gemm32_kernel(const GemmParams p) {
-    constexpr int KB = 16;                      // k-chunk: four v_mfma_f32_16x16x4_f32 steps
+// SPLIT (the default, see the head of the file): operands staged as bf16 hi / lo planes, three v_mfma_f32_16x16x32_bf16 per k-step of 32;
+// !SPLIT: fp32 operands, v_mfma_f32_16x16x4_f32.  Gather, prefetch and epilogue are the same code.
+// PIX: pixel-shuffle stores (omode 2).  Without them the piece geometry of the epilogue is a compile-time fact (no sub-pixels, BN / 4 pieces per row) and its index
+// arithmetic folds to shifts and masks - it used to be a third of the kernel's vector instructions.
+template <int WAVES_M, int WAVES_N, int WM, int WN, int HALVES, bool SPLIT, bool PIX>
+__global__ __launch_bounds__(256, SPLIT && WM * WN > 16 ? 2 : W2X_G32_WPC) void gemm32_kernel(const GemmParams p) {   // (the 128 x 192 tile with split operands: 96 accumulators + 40 of prefetch + 40 of fragments)
+    constexpr int KB = SPLIT ? 32 : 16;         // k-chunk: one bf16 k-step / four v_mfma_f32_16x16x4_f32 steps
     constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
     constexpr int LDA = KB + 1, LDC = BN + 4;   // floats
+    constexpr int LDH = KB + 8;                 // bf16 per row of a split plane: 80 bytes, 16-byte aligned, conflict-free ds_read_b128
     constexpr int A_PIECES = BM * KB / 4, B_PIECES = BN * KB / 4;   // pieces of 4 floats
     constexpr int NA = (A_PIECES + 255) / 256, NB = (B_PIECES + 255) / 256;
     static_assert(WAVES_M * WAVES_N == 4 && BM == kGemmBM, "4 waves, kGemmBM rows");
@@ -44,7 +75,11 @@ __global__ __launch_bounds__(256, W2X_G32_WPC) void gemm32_kernel(const GemmPara
     float* As = (float*)smem;
     float* Bs = As + BM * LDA;
     float* Cs = (float*)smem;                   // aliases As / Bs after the main loop
-    constexpr int AB_BYTES = (BM + BN) * LDA * 4, C_BYTES = BM / HALVES * LDC * 4;
+    unsigned short* AsH = (unsigned short*)smem;                        // SPLIT: [BM][LDH] hi, [BM][LDH] lo, [BN][LDH] hi, [BN][LDH] lo
+    unsigned short* AsL = AsH + BM * LDH;
+    unsigned short* BsH = AsL + BM * LDH;
+    unsigned short* BsL = BsH + BN * LDH;
+    constexpr int AB_BYTES = SPLIT ? (BM + BN) * LDH * 4 : (BM + BN) * LDA * 4, C_BYTES = BM / HALVES * LDC * 4;
     constexpr int MAIN_BYTES = AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES;
     int* s_aoff = (int*)(smem + MAIN_BYTES);
     int* s_ob = s_aoff + BM;
@@ -117,8 +152,15 @@ __global__ __launch_bounds__(256, W2X_G32_WPC) void gemm32_kernel(const GemmPara
             const int idx = tid + t * 256;
             if (A_PIECES % 256 == 0 || idx < A_PIECES) {
                 const int row = idx / (KB / 4), kp = idx - row * (KB / 4);
+                if (SPLIT) {
+                    uint2v hi, lo;
+                    split4(ra[t], hi, lo);
+                    *(uint2v*)(AsH + row * LDH + kp * 4) = hi;
+                    *(uint2v*)(AsL + row * LDH + kp * 4) = lo;
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) As[row * LDA + kp * 4 + e] = ra[t][e];
+                    for (int e = 0; e < 4; ++e) As[row * LDA + kp * 4 + e] = ra[t][e];
+                }
             }
         }
 #pragma unroll
@@ -126,8 +168,15 @@ __global__ __launch_bounds__(256, W2X_G32_WPC) void gemm32_kernel(const GemmPara
             const int idx = tid + t * 256;
             if (B_PIECES % 256 == 0 || idx < B_PIECES) {
                 const int row = idx / (KB / 4), kp = idx - row * (KB / 4);
+                if (SPLIT) {
+                    uint2v hi, lo;
+                    split4(rb[t], hi, lo);
+                    *(uint2v*)(BsH + row * LDH + kp * 4) = hi;
+                    *(uint2v*)(BsL + row * LDH + kp * 4) = lo;
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Bs[row * LDA + kp * 4 + e] = rb[t][e];
+                    for (int e = 0; e < 4; ++e) Bs[row * LDA + kp * 4 + e] = rb[t][e];
+                }
             }
         }
     };
@@ -146,6 +195,25 @@ __global__ __launch_bounds__(256, W2X_G32_WPC) void gemm32_kernel(const GemmPara
         store_lds();
         __syncthreads();
         if (c + 1 < nchunks) load_regs((c + 1) * KB);
+        if (SPLIT) {   // x w ~ xh wh + xh wl + xl wh  (the dropped xl wl is 2^-18 of the product), fp32 accumulation; smallest terms first
+            bf16x8 ah[WM], al[WM];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                ah[i] = *(const bf16x8*)(AsH + ((wm * WM + i) * 16 + frow) * LDH + fk * 8);
+                al[i] = *(const bf16x8*)(AsL + ((wm * WM + i) * 16 + frow) * LDH + fk * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const bf16x8 bh = *(const bf16x8*)(BsH + ((wn * WN + j) * 16 + frow) * LDH + fk * 8);
+                const bf16x8 bl = *(const bf16x8*)(BsL + ((wn * WN + j) * 16 + frow) * LDH + fk * 8);
+#pragma unroll
+                for (int i = 0; i < WM; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+                }
+            }
+        } else
 #pragma unroll
         for (int ks = 0; ks < KB / 4; ++ks) {
             float af[WM];
@@ -169,17 +237,21 @@ __global__ __launch_bounds__(256, W2X_G32_WPC) void gemm32_kernel(const GemmPara
     float pool_sum = 0.f;                                             // column tid of the tile (BN <= 256)
     float* __restrict__ Og = (float*)p.out.p;
     const int Cso = p.out.Cs;
-    const bool pix = p.omode == 2;
+    constexpr bool pix = PIX;
     const int ppc = (pix ? Cso : BN) / 4;                  // pieces per (row, sub-pixel) in this tile
     const int subs = pix ? BN / Cso : 1;
-    int gs = 1; while (gs < ppc) gs <<= 1;
+    constexpr int GS_ROWS = BN / 4 <= 4 ? 4 : BN / 4 <= 8 ? 8 : BN / 4 <= 16 ? 16 : BN / 4 <= 32 ? 32 : 64;
+    int gs = GS_ROWS;
+    if (pix) { gs = 1; while (gs < ppc) gs <<= 1; }
     const int groups = 256 / gs;
     const int jp = tid & (gs - 1);
-#pragma unroll
-    for (int h = 0; h < HALVES; ++h) {
+    static_assert(HALVES <= 2, "rounds are spelled out below");
+    auto round = [&](auto h_c) {                                      // (a generic lambda per round instead of an unrolled loop: the accumulator indices must be compile-time)
+        constexpr int h = decltype(h_c)::value;
         __syncthreads();                                              // the operand tiles (first round) / the previous round's tile are done with
-        // phase 1: accumulators -> (LayerNorm algebra, bias, activation) -> fp32 tile in LDS
-        {
+        // phase 1: accumulators -> (LayerNorm algebra, bias, activation) -> fp32 tile in LDS; the activation is chosen once per round, not once per value
+        auto phase1 = [&](auto act_c) {
+            constexpr int ACT = decltype(act_c)::value;
             const int ccol = lane & 15, crow = (lane >> 4) * 4;
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
@@ -195,10 +267,13 @@ __global__ __launch_bounds__(256, W2X_G32_WPC) void gemm32_kernel(const GemmPara
                         float v = acc[i][j][e];
                         if (p.ln) v = s_rstd[row] * (v - s_mean[row] * cs);
                         v += bias;
-                        Cs[lrow * LDC + col] = act_fn(v, p.act, p.alpha);
+                        Cs[lrow * LDC + col] = act_fn(v, ACT < 0 ? p.act : ACT, p.alpha);
                     }
             }
-        }
+        };
+        if (p.act == 0) phase1(std::integral_constant<int, 0>{});
+        else if (p.act == 2) phase1(std::integral_constant<int, 2>{});
+        else phase1(std::integral_constant<int, -1>{});
         __syncthreads();
         // phase 2: pieces of 4 floats: residual adds, clip, store, LayerNorm statistics, SE pooling
         const int items = HROWS * subs;
@@ -262,22 +337,34 @@ __global__ __launch_bounds__(256, W2X_G32_WPC) void gemm32_kernel(const GemmPara
                 }
             }
         }
-    }
+    };
+    round(std::integral_constant<int, 0>{});
+    if constexpr (HALVES > 1) round(std::integral_constant<int, 1>{});
     if (p.pool_out && tid < BN && n0 + tid < p.N) p.pool_out[(size_t)blockIdx.x * Cso + n0 + tid] = pool_sum;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN>
-hipError_t launch_cfg32(const GemmParams& p, hipStream_t s) {
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool SPLIT>
+hipError_t launch_cfg32s(const GemmParams& p, hipStream_t s) {
     constexpr int HALVES = 2;             // the output tile goes through LDS in two half-height rounds (see the kernel's epilogue)
-    constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16, LDA = 17, LDC = BN + 4;
-    constexpr int AB = (BM + BN) * LDA * 4, CB = BM / HALVES * LDC * 4;
+    constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16, LDC = BN + 4;
+    constexpr int AB = SPLIT ? (BM + BN) * 40 * 4 : (BM + BN) * 17 * 4, CB = BM / HALVES * LDC * 4;
     constexpr int SMEM = (AB > CB ? AB : CB) + BM * 6 * 4;
-    auto kern = gemm32_kernel<WAVES_M, WAVES_N, WM, WN, HALVES>;
-    static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
-    if (hipError_t e = ensure_dynamic_lds((const void*)kern, SMEM, lds_ok); e != hipSuccess) return e;
+    static unsigned lds_ok = 0, lds_ok_pix = 0;   // per-device bits: kernels.h ensure_dynamic_lds
     const dim3 grid(p.B * ((p.Mrows + BM - 1) / BM), (p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kern, grid, dim3(256), SMEM, s, p);
+    if (p.omode == 2) {
+        auto kern = gemm32_kernel<WAVES_M, WAVES_N, WM, WN, HALVES, SPLIT, true>;
+        if (hipError_t e = ensure_dynamic_lds((const void*)kern, SMEM, lds_ok_pix); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(256), SMEM, s, p);
+    } else {
+        auto kern = gemm32_kernel<WAVES_M, WAVES_N, WM, WN, HALVES, SPLIT, false>;
+        if (hipError_t e = ensure_dynamic_lds((const void*)kern, SMEM, lds_ok); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(256), SMEM, s, p);
+    }
     return hipGetLastError();
+}
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+hipError_t launch_cfg32(const GemmParams& p, hipStream_t s, bool exact) {
+    return exact ? launch_cfg32s<WAVES_M, WAVES_N, WM, WN, false>(p, s) : launch_cfg32s<WAVES_M, WAVES_N, WM, WN, true>(p, s);
 }
 
 // ---- window attention core, fp32 rows ------------------------------------------------------------------------------------------
@@ -350,7 +437,7 @@ __global__ __launch_bounds__(256) void attn32_kernel(const AttnParams p) {
 }  // namespace
 
 // Tile selection as in launch_gemm (k_gemm.hip): the tile width follows N; pixel-shuffle outputs take whole output pixels.
-hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s) {
+hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s, bool exact) {
     if (p.a.Cs % 4 || p.out.Cs % 4 || p.Kw % 4 || p.K % 4) return hipErrorInvalidValue;   // pieces of four floats
     int bn;
     if (p.omode == 2) bn = (p.out.Cs <= 192 && 192 % p.out.Cs == 0 && p.N >= 192) ? 192 : p.out.Cs;
@@ -359,13 +446,13 @@ hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s) {
     if (p.stats_out && p.omode != 2 && bn < p.N) return hipErrorInvalidValue;
     if (p.omode == 2 && (bn % p.out.Cs)) return hipErrorInvalidValue;
     switch (bn) {
-        case 192: return launch_cfg32<2, 2, 4, 6>(p, s);
-        case 128: return launch_cfg32<2, 2, 4, 4>(p, s);
-        case 96: return launch_cfg32<4, 1, 2, 6>(p, s);
-        case 64: return launch_cfg32<4, 1, 2, 4>(p, s);
-        case 48: return launch_cfg32<4, 1, 2, 3>(p, s);
-        case 32: return launch_cfg32<4, 1, 2, 2>(p, s);
-        case 16: return launch_cfg32<4, 1, 2, 1>(p, s);
+        case 192: return launch_cfg32<2, 2, 4, 6>(p, s, exact);
+        case 128: return launch_cfg32<2, 2, 4, 4>(p, s, exact);
+        case 96: return launch_cfg32<4, 1, 2, 6>(p, s, exact);
+        case 64: return launch_cfg32<4, 1, 2, 4>(p, s, exact);
+        case 48: return launch_cfg32<4, 1, 2, 3>(p, s, exact);
+        case 32: return launch_cfg32<4, 1, 2, 2>(p, s, exact);
+        case 16: return launch_cfg32<4, 1, 2, 1>(p, s, exact);
         default: return hipErrorInvalidValue;
     }
 }

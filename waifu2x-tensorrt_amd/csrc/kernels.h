@@ -160,7 +160,7 @@ hipError_t launch_conv48_stem(const GemmParams& p, const GemmParams& ps, hipStre
 int conv3_tiles(const GemmParams& p);                           // workgroups (= pooling partials) per image of launch_conv3
 hipError_t launch_attn(const AttnParams& p, hipStream_t s);
 // k_f32.hip: the fp32 engine's kernels (Plan::elt == 4): general GEMM / convolution and the window attention core on fp32 rows
-hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s);
+hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s, bool exact);      // exact: fp32 products (Precision::FP32); else three bf16 products per k-step (Precision::TF32)
 hipError_t launch_attn_f32(const AttnParams& p, hipStream_t s);
 hipError_t launch_mlp(const MlpParams& p, hipStream_t s);
 hipError_t launch_swin_attn(const SwinAttnParams& p, hipStream_t s);

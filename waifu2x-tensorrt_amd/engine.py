@@ -19,8 +19,9 @@ class W2xError(RuntimeError):
 
 
 class Precision(enum.IntEnum):      # config.h:7-10
-    TF32 = 0
+    TF32 = 0                        # fp32 maps, split-bf16 products (include/w2x/config.h)
     FP16 = 1
+    FP32 = 2                        # not in the reference: the same engine with exact fp32 products
 
 
 class Severity(enum.IntEnum):       # logger.h:11-18
