@@ -564,7 +564,7 @@ def test_shape_specialised_kernels_agree_with_the_general_kernel(pkg, onnx_model
 
 
 FP32_NET_MAX_ABS = 2e-6   # Precision::FP32 against the fp32 oracle (outputs in [0, 1]): summation order only; measured <= 6.6e-7 (profiles/r2_final/parity.jsonl)
-TF32_NET_MAX_ABS = 3e-5   # Precision::TF32 (split-bf16 products, 16 significant bits per operand): measured <= 8.8e-6, mean 1.4e-6 (profiles/r5_final/split_precision.txt);
+TF32_NET_MAX_ABS = 3e-5   # Precision::TF32 (split-bf16 products, 16 significant bits per operand): measured <= 8.9e-6, mean 1.4e-6 (profiles/r5_final/split_precision.txt);
                           # products on 11 significant bits - what TF32 keeps - would sit near 1e-3
 
 

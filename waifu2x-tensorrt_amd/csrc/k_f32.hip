@@ -6,7 +6,7 @@
 //   Precision::TF32  TF32-CLASS products.  Both operands are split when they are staged into LDS, x = hi + lo with hi = bf16(x),
 //                    lo = bf16(x - hi) (16 significant bits, fp32's exponent range), and a k-step of 32 is three
 //                    v_mfma_f32_16x16x32_bf16: lo*hi + hi*lo + hi*hi (the dropped lo*lo is 2^-18 of the product).  Against the fp32 oracle
-//                    8.8e-6 at most (mean 1.4e-6) on outputs in [0, 1]; eleven-bit operands - what TF32 keeps - would give about 1e-3.
+//                    8.9e-6 at most (mean 1.4e-6) on outputs in [0, 1]; eleven-bit operands - what TF32 keeps - would give about 1e-3.
 //   Precision::FP32  exact fp32 products on v_mfma_f32_16x16x4_f32 (an addition to the reference's enum): 6.6e-7 at most, summation order.
 // Two kernels cover the plan:
 //   gemm32_kernel : gemm_kernel (k_gemm.hip) restated for fp32 maps - same implicit-GEMM A operand (rows / window gather / kh x kw
@@ -15,9 +15,10 @@
 //                   (kGemmBM), LDS-staged operands with register prefetch of the next k-chunk.
 //   attn32_kernel : one wave per (window, head), lane = query row, everything in that lane's registers (k_attn.hip attn_kernel
 //                   with fp32 rows).
-// Config 3 (1080p frame, round 5): 51.7 ms with TF32, 64.7 ms with FP32 (7.4 ms on the fp16 engine).  Until round 5 both were one 70 ms
+// Config 3 (1080p frame, round 5): 49.8 ms with TF32, 64.7 ms with FP32 (7.4 ms on the fp16 engine).  Until round 5 both were one 70 ms
 // path; what moved it: the split products (-10 ms) and an epilogue whose piece geometry is a compile-time fact when the launch is
-// not a pixel shuffle (its index arithmetic was a third of the kernel's vector instructions: -5 ms / -8 ms).  What is left is the
+// not a pixel shuffle (its index arithmetic was a third of the kernel's vector instructions: -5 ms / -8 ms), and with TF32 GELU as a
+// polynomial around v_exp_f32 instead of erff() (-2 ms).  What is left is the
 // fp32 traffic of an un-fused plan (2 - 3 TB/s per launch) and the lane-per-query attention core (10.8 ms).
 #include "kernels.h"
 #include <cmath>
@@ -52,6 +53,18 @@ __device__ __forceinline__ float act_fn(float v, int act, float alpha) {
         case 4: return 1.f / (1.f + expf(-v));
         default: return v;
     }
+}
+
+// GELU for the split-product (TF32) path: max(x, 0) - 0.5 u 2^-q(u), u = min(|x|, 6.5), six coefficients (tools/fit_gelu.py: |err| < 3.1e-7, a thirtieth of what the
+// split products leave) - 10 instructions where erff() takes about 35; a full-resolution fc1 launch of config 3 is 0.5 G values.
+__device__ __forceinline__ float gelu_poly(float x) {
+    const float u = fminf(fabsf(x), 6.5f);
+    float q = fmaf(-2.992485764e-05f, u, 7.398797018e-04f);
+    q = fmaf(q, u, -7.977479093e-03f);
+    q = fmaf(q, u, 5.323820859e-02f);
+    q = fmaf(q, u, 4.589156733e-01f);
+    q = fmaf(q, u, 1.151147085e+00f);
+    return fmaf(-0.5f * u, __builtin_amdgcn_exp2f(-(q * u)), fmaxf(x, 0.f));
 }
 
 #ifndef W2X_G32_WPC
@@ -267,7 +280,7 @@ __global__ __launch_bounds__(256, SPLIT && WM * WN > 16 ? 2 : W2X_G32_WPC) void 
                         float v = acc[i][j][e];
                         if (p.ln) v = s_rstd[row] * (v - s_mean[row] * cs);
                         v += bias;
-                        Cs[lrow * LDC + col] = act_fn(v, ACT < 0 ? p.act : ACT, p.alpha);
+                        Cs[lrow * LDC + col] = SPLIT && ACT == 2 ? gelu_poly(v) : act_fn(v, ACT < 0 ? p.act : ACT, p.alpha);
                     }
             }
         };
