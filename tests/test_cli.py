@@ -260,6 +260,15 @@ def test_cli_two_devices_render_a_still_as_strips_and_a_tf32_engine(pkg, tmp_pat
     assert r.returncode == 0, r.stderr
     got32 = np.array(Image.open(out / "in(cunet_art)(noise1)(scale2).png")).astype(np.int32)
     assert np.abs(got32 - outs["one"].astype(np.int32)).max() <= 2       # fp16 against fp32 engine: a couple of LSBs at most
+    # --precision fp32 (not in the reference: exact products on the same engine) builds its own engine file and renders within rounding ties of the tf32 frame
+    r = cli("--precision", "fp32", "build")
+    assert r.returncode == 0, r.stderr
+    assert len([f for f in os.listdir(os.path.dirname(path)) if f.endswith(".w2x")]) >= 3, os.listdir(os.path.dirname(path))
+    out = tmp_path / "fp32"; out.mkdir()
+    r = cli("--precision", "fp32", "render", "-i", str(tmp_path / "in.png"), "-o", str(out))
+    assert r.returncode == 0, r.stderr
+    gotx = np.array(Image.open(out / "in(cunet_art)(noise1)(scale2).png")).astype(np.int32)
+    assert np.abs(gotx - got32).max() <= 1 and (gotx != got32).mean() < 5e-3
 
 
 FAKE_FFPROBE = """#!/usr/bin/env python3
