@@ -157,10 +157,7 @@ constexpr int LDX = C + 8;                 // 104 halves
 constexpr int XS = RPX * LDX, OS = RP * LDX;
 constexpr int NPAD = G * 12;                // slab rows between the left-over tokens (kept at zero)
 constexpr int BQ_OFF = (XS + OS) * 2 + (RP + NPAD) * 8 + 16;   // q / k / v bias [3 * C] fp32 (W2X_A96_BQ_LDS)
-#ifndef W2X_A96_LDS_PAD
-#define W2X_A96_LDS_PAD 0                  // occupancy experiment (tools/ab/attn96_variants.sh "-DW2X_A96_LDS_PAD=17000"): unused LDS bytes per workgroup, so that three / two fit a CU instead of four
-#endif
-constexpr int SMEM96 = BQ_OFF + 3 * C * 4 + W2X_A96_LDS_PAD;
+constexpr int SMEM96 = BQ_OFF + 3 * C * 4;
 constexpr int DUMMY = XS * 2;              // byte offset of a row nobody reads at that point (first row of Os): target of the stores of lanes / rows without data
 constexpr int LPR = 16, PPR = C / 8, RPP = NTHR / LPR, NPASS = RP / RPP;   // row passes: 16 lanes per row (12 carry data), 16 rows per pass, 5 passes
 static_assert(NPASS == 5, "the row sums are reduced as 3 + 2 passes");
