@@ -576,26 +576,33 @@ def main():
             elif key[0] == "mlp":
                 nbytes = 2.0 * int(re.search(r"M=(\d+)", rest).group(1)) * live * key[1] * 2
             g = groups.setdefault(key, [0.0, 0, 0.0, 0.0]); g[0] += t; g[1] += 1; g[2] += flops; g[3] += nbytes
-        dom = max(groups, key=lambda k: groups[k][0])
-        dom_ms, dom_n, dom_flop, dom_bytes = groups[dom]
-        tflops = dom_flop / (dom_ms * 1e-3) / 1e12
-        gbs = dom_bytes / (dom_ms * 1e-3) / 1e9
-        t_mfma, t_hbm = dom_flop / (MFMA_F16_PEAK_TFLOPS * 1e12), dom_bytes / (HBM_PEAK_GBS * 1e9)
-        hbm_bound = t_hbm > t_mfma               # the roofline that binds this kernel = the larger of the two floor times
-        roof = {"bound": "hbm" if hbm_bound else "mfma",
-                "achieved": round(gbs if hbm_bound else tflops, 2), "peak": HBM_PEAK_GBS if hbm_bound else MFMA_F16_PEAK_TFLOPS,
-                "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tflops / MFMA_F16_PEAK_TFLOPS), 5), "traffic": None,
-                "kernel": symbols.get(dom, ("conv3_kernel" if isinstance(dom[1], str) and dom[1].startswith("conv3x3s1") and int(dom[1].split()[1].split("->")[0]) % 32 == 0 else
-                                            "gemm_kernel / pixgemm kernels") if dom[0] == "gemm" else dom[0]),
-                "plan_ops": dom[1] if isinstance(dom[1], str) else None,
-                "launches_per_frame": dom_n, "avg_launch_us": round(dom_ms * 1e3 / dom_n, 2),
-                "launch_note": "HIP events around each launch with every pass in one piece on one stream (the engine's profiling pass, = W2X_GROUPS=1: a launch covers all live tiles); the timed region of `value` runs each pass as two tile groups on two streams",
-                "algorithmic_gflop_per_launch": round(dom_flop / dom_n / 1e9, 3),
-                "algorithmic_mbyte_per_launch": round(dom_bytes / dom_n / 1e6, 3),
-                "other_roof": {"unit": "TFLOP/s" if hbm_bound else "GB/s", "achieved": round(tflops if hbm_bound else gbs, 2),
-                               "frac": round((tflops / MFMA_F16_PEAK_TFLOPS) if hbm_bound else (gbs / HBM_PEAK_GBS), 5)},
-                "kernels_ms_per_frame": {symbols.get(k, k[0] if not isinstance(k[1], str) else k[0] + " " + k[1]): round(v[0], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])}}
+        def kernel_roof(key):                    # the roofline figures of one kernel group
+            k_ms, k_n, k_flop, k_bytes = groups[key]
+            tflops = k_flop / (k_ms * 1e-3) / 1e12
+            gbs = k_bytes / (k_ms * 1e-3) / 1e9
+            t_mfma, t_hbm = k_flop / (MFMA_F16_PEAK_TFLOPS * 1e12), k_bytes / (HBM_PEAK_GBS * 1e9)
+            hbm_bound = t_hbm > t_mfma           # the roofline that binds this kernel = the larger of the two floor times
+            return {"bound": "hbm" if hbm_bound else "mfma",
+                    "achieved": round(gbs if hbm_bound else tflops, 2), "peak": HBM_PEAK_GBS if hbm_bound else MFMA_F16_PEAK_TFLOPS,
+                    "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                    "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tflops / MFMA_F16_PEAK_TFLOPS), 5), "traffic": None,
+                    "kernel": symbols.get(key, ("conv3_kernel" if isinstance(key[1], str) and key[1].startswith("conv3x3s1") and int(key[1].split()[1].split("->")[0]) % 32 == 0 else
+                                                "gemm_kernel / pixgemm kernels") if key[0] == "gemm" else key[0]),
+                    "plan_ops": key[1] if isinstance(key[1], str) else None,
+                    "launches_per_frame": k_n, "avg_launch_us": round(k_ms * 1e3 / k_n, 2),
+                    "algorithmic_gflop_per_launch": round(k_flop / k_n / 1e9, 3),
+                    "algorithmic_mbyte_per_launch": round(k_bytes / k_n / 1e6, 3),
+                    "other_roof": {"unit": "TFLOP/s" if hbm_bound else "GB/s", "achieved": round(tflops if hbm_bound else gbs, 2),
+                                   "frac": round((tflops / MFMA_F16_PEAK_TFLOPS) if hbm_bound else (gbs / HBM_PEAK_GBS), 5)}}
+        ranked = sorted(groups, key=lambda k: -groups[k][0])
+        dom = ranked[0]
+        roof = kernel_roof(dom)
+        roof["launch_note"] = ("HIP events around each launch with every pass in one piece on one stream (the engine's profiling pass, = W2X_GROUPS=1: a launch covers all live tiles); "
+                               "the timed region of `value` runs each pass as two tile groups on two streams")
+        roof["kernels_ms_per_frame"] = {symbols.get(k, k[0] if not isinstance(k[1], str) else k[0] + " " + k[1]): round(v[0], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])}
+        # config 3's two attention kernels take 2.0 ms per frame each and swap places from box to box: a kernel within a tenth of the dominant one is shown beside it
+        if len(ranked) > 1 and groups[ranked[1]][0] >= 0.9 * groups[dom][0]:
+            roof["runner_up"] = kernel_roof(ranked[1])
         notes = []
         if folded:
             notes.append("mlp96q_kernel's figure includes the image head (Linear 96 -> 64, Clip, DepthToSpace), which the engine folds into the last C = 96 MLP launch; that plan op has no launch and reports 0 ms")
@@ -606,12 +613,14 @@ def main():
         tr = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/profile_round.sh)
         if os.path.exists(tr) and CONFIG_NAME == "configs[2]":
             try:
-                t = json.load(open(tr)).get(roof["kernel"])
-                now = kernel_source_sha(roof["kernel"])
-                if t and t.get("source_sha") and t["source_sha"] == now:
-                    roof["traffic"] = t["bytes_per_launch"]; roof["traffic_source"] = t["source"]; roof["traffic_kernel_source_sha"] = now
-                elif t:          # the counters were taken on another revision of this kernel: not quoted
-                    roof["traffic_note"] = f"profiles/pmc_traffic.json holds {t['bytes_per_launch']} bytes per launch measured on kernel source {t.get('source_sha', 'unrecorded')}; the kernel now built is {now}: not quoted"
+                table = json.load(open(tr))
+                for r in [roof] + ([roof["runner_up"]] if "runner_up" in roof else []):
+                    t = table.get(r["kernel"])
+                    now = kernel_source_sha(r["kernel"])
+                    if t and t.get("source_sha") and t["source_sha"] == now:
+                        r["traffic"] = t["bytes_per_launch"]; r["traffic_source"] = t["source"]; r["traffic_kernel_source_sha"] = now
+                    elif t:          # the counters were taken on another revision of this kernel: not quoted
+                        r["traffic_note"] = f"profiles/pmc_traffic.json holds {t['bytes_per_launch']} bytes per launch measured on kernel source {t.get('source_sha', 'unrecorded')}; the kernel now built is {now}: not quoted"
             except Exception:
                 pass
         line = {
