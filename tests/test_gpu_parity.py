@@ -422,6 +422,51 @@ def test_rewritten_graphs_render_the_bytes_of_the_original(pkg, onnx_model, tmp_
         assert np.array_equal(got, want), (seed, v.applied)
 
 
+@pytest.mark.parametrize("model,scale", [("swin_unet/art", 4), ("cunet/art", 2)])
+def test_mutated_graphs_follow_the_oracle(pkg, onnx_model, tmp_path, model, scale):
+    """Ten SEMANTIC mutants per family (tools/onnx_mutate.py: another LeakyRelu slope, Clip bounds, LayerNorm epsilon, attention scale, a transposed weight, another
+    roll distance, a dropped residual or bias, a transposed bias table ... one change at one site each; the CPU side is tests/test_loader_mutations.py): whatever the
+    loader does not refuse is built, run through w2x_infer and compared with the oracle executing the MUTANT, within the bounds of the unmutated graphs - and it must be
+    far closer to the mutant than the mutant is to the original.  A lowering that fills in the value it expects instead of the one the file holds fails here."""
+    import onnx_mutate as om
+    import onnx_rewrite as rw
+    from oracle import onnx_reader
+    batch, tile = 2, 64
+    path = onnx_model(model, scale, batch, tile, noise=1)
+    g, shapes = onnx_reader.load(path), rw.runtime_shapes(path, batch, tile)
+    rng = np.random.default_rng(5)
+    x = rng.random((batch, 3, tile, tile), dtype=np.float32).astype(np.float16).astype(np.float32)
+    y_orig = onnx_exec.Executor(path).run(x)
+    ran, refused, kinds = 0, 0, []
+    for seed in range(40):
+        if ran >= 10:
+            break
+        v = om.mutate(g, shapes, seed)
+        if v.applied[0] in kinds and len(kinds) < 6:          # one mutant per kind first
+            continue
+        vdir = tmp_path / f"m{seed}"; vdir.mkdir()
+        vpath = str(vdir / os.path.basename(path))
+        rw.dump(v, vpath, packed=bool(seed & 1))
+        eng = pkg.Img2Img()
+        if not eng.build(vpath, pkg.BuildConfig.fixed(batch, tile)):
+            assert "cannot lower node" in eng.last_error() or "graph:" in eng.last_error() or "fold:" in eng.last_error(), (seed, v.applied, eng.last_error())
+            refused += 1
+            eng.close()
+            continue
+        assert eng.load(vpath, pkg.RenderConfig(batchSize=batch, height=tile, width=tile, scaling=scale)), eng.last_error()
+        y = eng.infer(x)
+        eng.close()
+        ref32, ref16 = onnx_exec.Executor(vpath).run(x), oracle16(vpath)(x)
+        moved = float(np.abs(ref32 - y_orig).max())
+        r = network_report(f"mutant {model} s{scale} seed {seed}: {v.applied[0]} at {v.site}", y, ref16, ref32)
+        assert r["max_ulp16"] <= NET_MAX_ULP16 and r["max_ulp16_vs_fp32_oracle"] <= NET_MAX_ULP16_VS_FP32 and r["mean_abs"] <= NET_MEAN_ABS, (seed, v.applied, v.site, r)
+        if moved > 20 * ULP16:                                 # the mutation moved the output by far more than the engine's error: the engine is on the mutant's side
+            assert float(np.abs(y - y_orig).max()) > 0.5 * moved, (seed, v.applied, v.site, moved)
+        kinds.append(v.applied[0]); ran += 1
+    print(f"{model}: {ran} mutants run ({sorted(set(kinds))}), {refused} refused")
+    assert ran >= (10 if model.startswith("swin") else 6)
+
+
 @pytest.mark.parametrize("pinned,small", [(False, True), (True, True), (True, False)])
 def test_frame_sequence_with_overlapped_copies_matches_render(pkg, onnx_model, pinned, small):
     """renderSequence: upload / compute / download of consecutive frames overlap on three streams (two device buffers, events);

@@ -8,7 +8,7 @@ CXX="/opt/rocm/bin/hipcc -std=c++17 -O3 --offload-arch=gfx950 -I $ROOT/waifu2x-t
 TMP=$(mktemp -d)
 i=0; objs=""; hflags=""
 for arg in "$@"; do
-  src=$ROOT/waifu2x-tensorrt_amd/tools/ab/k_swinattn192_r3.hip (round 3, two workgroups per CU) or csrc/k_swinattn192u.hip via SRC=; fl="$arg"
+  src=$ROOT/tools/ab/k_swinattn192_r3.hip; fl="$arg"
   case "$arg" in SRC=*) src=${arg%% *}; src=${src#SRC=}; fl=${arg#SRC=$src}; ;; esac
   case "$fl" in STAMPS*) fl="${fl#STAMPS} -DW2X_A192_STAMPS"; hflags="-DW2X_A192_STAMPS";; esac
   $CXX $fl -Dlaunch_swin_attn192=launch_swin_attn96_v$i -Dlaunch_swin_attn192w=launch_swin_attn96_v$i -c "$src" -o $TMP/v$i.o      # (the wide-workgroup file names its launcher ...192w)

@@ -10,13 +10,13 @@ set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT/waifu2x-tensorrt_amd"
 CXX="/opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable"
-extra() { case "$1" in k_mlp2.hip) echo "-mllvm -amdgpu-sched-strategy=max-ilp";; k_mlp96q.hip) echo "-mllvm -amdgpu-sched-strategy=max-ilp -fno-honor-nans";; *) echo "";; esac; }
+extra() { case "$1" in k_mlp2.hip) echo "-mllvm -amdgpu-sched-strategy=max-ilp -fno-honor-nans";; k_mlp96q.hip) echo "-mllvm -amdgpu-sched-strategy=max-ilp -fno-honor-nans";; *) echo "";; esac; }
 # build <object's file> <flags> [<alternative source, relative to the repository root>]
 build() { $CXX $(extra "$1") $2 -I csrc -c "${3:-csrc/$1}" -o "build/${1%.hip}.o" 2>/dev/null && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libw2x.so build/*.o; }
 run() { (cd "$ROOT"; python bench.py --no-cpu-baseline --steps ${STEPS:-20} ${BENCH_ARGS:-} 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-print('$1', '| ms/frame', d['ms_per_step'], '| full path', d['config']['full_path_ms_per_frame'], '|', d['roofline']['kernels_ms_per_frame'], '| compose', d['config']['families_ms_per_frame']['compose'])"); }
+print('$1', '| ms/frame', d['ms_per_step'], d.get('ms_per_step_samples'), '| full path', d['config']['full_path_ms_per_frame'], '|', d['roofline']['kernels_ms_per_frame'], '| compose', d['config']['families_ms_per_frame']['compose'])"); }
 last=""
 for arg in "$@"; do
   if [ -n "$last" ]; then build "$last" ""; last=""; fi

@@ -758,6 +758,12 @@ struct Img2Img::Impl {
     }
     // after the last frame of a rolling sequence: the first stream waits for the second, so that whatever follows on it sees the sequence done
     void end_rolling() { hipAssert(hipEventRecord(ev_join[0], gstream[0])); hipAssert(hipStreamWaitEvent(stream, ev_join[0], 0)); }
+    // The error exits of renderPart() and renderSequence(): every stream that may still touch the caller's buffers, the slabs or d_out drains before the
+    // function returns false (errors here are ignored, the first one is what gets reported); the next call starts outside a rolling sequence.
+    void drain_after_error() {
+        rolling = false;
+        for (hipStream_t st : {s_up, s_dn, gstream[0], stream}) if (st && hipStreamSynchronize(st) != hipSuccess) (void)hipGetLastError();
+    }
 
     // the network passes of `tile_count` tiles (slots d_slots[slots_off ..]); their outputs go to slab slots slab_slot0, slab_slot0 + 1, ...
     // fresh: the first passes of a frame (W2X_POISON wipes the arena and the slab here, not between the parts of a pipelined frame)
@@ -1274,8 +1280,7 @@ bool Img2Img::renderPart(const Image& src, Image& dst, int part, int parts, cons
 } catch (const std::exception& e) {
     // a frame in parts copies to and from the caller's buffers on the side streams and may have left the second group's stream un-joined: let everything
     // drain before the caller gets its buffers back (errors here are ignored, the first one is what gets reported)
-    impl->rolling = false;
-    for (hipStream_t st : {impl->s_up, impl->s_dn, impl->gstream[0], impl->stream}) if (st && hipStreamSynchronize(st) != hipSuccess) (void)hipGetLastError();
+    impl->drain_after_error();
     W2X_LOG_AS(who, error, "Render failed unexpectedly: " + std::string(e.what()) + ".");
     return false;
 }
@@ -1606,9 +1611,9 @@ bool Img2Img::renderSequence(const Image* srcs, Image* dsts, int count) try {
     impl->last_rows = rows; impl->last_cols = cols; impl->last_grid = grid; impl->last_strip = sp;
     return true;
 } catch (const std::exception& e) {
-    // copies on the side streams may still be reading or writing the caller's buffers: let them drain before the caller
-    // gets its buffers back (errors here are ignored, the first one is what gets reported)
-    for (hipStream_t st : {impl->s_up, impl->stream, impl->s_dn}) if (st && hipStreamSynchronize(st) != hipSuccess) (void)hipGetLastError();
+    // copies on the side streams may still be reading or writing the caller's buffers, and a rolling sequence composes on the second group's stream
+    // (end_rolling() has not run when an exception fires): let all four drain before the caller gets its buffers back
+    impl->drain_after_error();
     W2X_LOG(error, "Render failed unexpectedly: " + std::string(e.what()) + ".");
     return false;
 }

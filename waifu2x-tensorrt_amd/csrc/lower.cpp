@@ -574,7 +574,8 @@ struct Lowerer {
         // by sqrt(scale); all of them end up in one factor on the scores
         auto absorb_scale = [&](std::string& name) {
             const Node* m = only_user(name);
-            if (m && (m->op == "Mul" || m->op == "Div") && split_binary(m, dyn, c) && dyn == name && c->numel() == 1 && c->is_float()) {
+            // (a Div only with the constant as the divisor: c / name is not a scale of name and leaves the pattern unmatched -> refusal)
+            if (m && (m->op == "Mul" || (m->op == "Div" && m->in[0] == name)) && split_binary(m, dyn, c) && dyn == name && c->numel() == 1 && c->is_float()) {
                 scale *= m->op == "Mul" ? c->f[0] : 1.f / c->f[0]; done.insert(m); name = m->out[0];
             }
         };

@@ -180,7 +180,18 @@ struct Simplifier {
         if (!(mm && mm->op == "MatMul" && mm->in[0] == n->out[0] && g.is_const(mm->in[1]) && g.cst(mm->in[1]).rank() == 2)) return false;
         Node* last = mm;
         Node* add = only_consumer(mm->out[0]);
-        if (add && add->op == "Add" && ((add->in[0] == mm->out[0] && g.is_const(add->in[1])) || (add->in[1] == mm->out[0] && g.is_const(add->in[0])))) last = add; else add = nullptr;
+        if (add && add->op == "Add" && ((add->in[0] == mm->out[0] && g.is_const(add->in[1])) || (add->in[1] == mm->out[0] && g.is_const(add->in[0])))) {
+            // the Add joins the sandwich only when its constant means the same on [M, N] and on [lead.., N]: a scalar, or one value per column
+            // ([N] / [1, N]).  An [M, N] or [M, 1] table is legal in the 2-D form and broadcasts differently (or not at all) once the rows
+            // have their leading dimensions back: the sandwich then stays as the file wrote it.
+            const HTensor& c = g.cst(add->in[0] == mm->out[0] ? add->in[1] : add->in[0]);
+            const int64_t N = g.cst(mm->in[1]).shape[1];
+            bool lead1 = true;
+            for (size_t k = 0; k + 1 < c.shape.size(); ++k) lead1 = lead1 && c.shape[k] == 1;
+            const bool per_column = c.numel() == 1 || (!c.shape.empty() && c.shape.back() == N && lead1);
+            if (!per_column) return false;
+            last = add;
+        } else add = nullptr;
         if (last->out[0] == g.output) return false;
         auto us = consumers.find(last->out[0]);
         if (us == consumers.end() || us->second.empty()) return false;
