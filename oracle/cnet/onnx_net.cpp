@@ -478,6 +478,11 @@ TP run_node(const Node& n, const std::vector<TP>& a, double& flops) {
     if (op == "Relu") return unary_f(in(0), [](float x) { return x > 0.f ? x : 0.f; });
     if (op == "Sigmoid") return unary_f(in(0), [](float x) { return 1.f / (1.f + std::exp(-x)); });
     if (op == "Erf") return unary_f(in(0), [](float x) { return std::erf(x); });
+    if (op == "Gelu") {      // opset 20: 0.5 x (1 + erf(x / sqrt 2)), or its tanh approximation
+        const Attr* ap = attr(n, "approximate");
+        if (ap && ap->s == "tanh") return unary_f(in(0), [](float x) { return 0.5f * x * (1.f + std::tanh(0.7978845608028654f * (x + 0.044715f * x * x * x))); });
+        return unary_f(in(0), [](float x) { return 0.5f * x * (1.f + std::erf(x * 0.7071067811865476f)); });
+    }
     if (op == "Sqrt") return unary_f(in(0), [](float x) { return std::sqrt(x); });
     if (op == "Exp") return unary_f(in(0), [](float x) { return std::exp(x); });
     if (op == "Tanh") return unary_f(in(0), [](float x) { return std::tanh(x); });

@@ -163,6 +163,8 @@ class Executor:
             return torch.sigmoid(a[0])
         if op == "Erf":
             return torch.erf(a[0])
+        if op == "Gelu":                                  # opset 20; approximate = "none" (erf) | "tanh"
+            return F.gelu(a[0], approximate=at.get("approximate", "none"))
         if op == "Sqrt":
             return torch.sqrt(a[0])
         if op == "Exp":

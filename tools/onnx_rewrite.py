@@ -28,6 +28,7 @@ rounded to fp16 - the precision an fp16 engine gives them anyway):
     split_qkv       q, k, v = qkv[0], qkv[1], qkv[2] (three Gathers)  ->  qkv.unbind(0) (one Split + three Squeezes)
     ln_decompose    a LayerNormalization node  ->  the ReduceMean / Sub / Pow|Mul / ReduceMean / Add / Sqrt / Div / Mul / Add chain exporters write below opset 17
     sdpa_scale      q * s  ->  (q * sqrt(s)) @ (k^T * sqrt(s)), the way a decomposed scaled_dot_product_attention scales (not bit-exact: sqrt(s)^2 != s in fp32)
+    gelu_op         the erf chain Div(sqrt 2) -> Erf -> Add(1) -> Mul(x) -> Mul(0.5)  ->  one Gelu node, as the exporter writes it from opset 20 on (the file's opset becomes 20)
     dead            a node nothing reads (a Shape or a Relu of some runtime tensor)
 """
 from __future__ import annotations
@@ -561,10 +562,50 @@ def rw_ln_decompose(g, shapes, rng):
     return True
 
 
+def rw_gelu_op(g, shapes, rng):
+    prod = {n.outputs[0]: n for n in g.nodes}
+    sites = []
+    for e in g.nodes:
+        if e.op != "Erf":
+            continue
+        d = prod.get(e.inputs[0])
+        if d is None or d.op != "Div" or d.inputs[0] not in shapes:
+            continue
+        c = _const_value(g, d.inputs[1])
+        ua = _consumers(g, e.outputs[0])
+        if c is None or c.size != 1 or abs(float(c.reshape(-1)[0]) - 2 ** 0.5) > 1e-6 or len(ua) != 1 or ua[0][1].op != "Add" or len(_consumers(g, d.outputs[0])) != 1:
+            continue
+        a = ua[0][1]
+        one = [_const_value(g, i) for i in a.inputs if i != e.outputs[0]]
+        um = _consumers(g, a.outputs[0])
+        if len(one) != 1 or one[0] is None or one[0].size != 1 or float(one[0].reshape(-1)[0]) != 1.0 or len(um) != 1 or um[0][1].op != "Mul" or d.inputs[0] not in um[0][1].inputs:
+            continue
+        m = um[0][1]
+        uh = _consumers(g, m.outputs[0])
+        if len(uh) != 1 or uh[0][1].op != "Mul":
+            continue
+        hm = uh[0][1]
+        half = [_const_value(g, i) for i in hm.inputs if i != m.outputs[0]]
+        if len(half) != 1 or half[0] is None or half[0].size != 1 or float(half[0].reshape(-1)[0]) != 0.5:
+            continue
+        if sorted(k for k, n in _consumers(g, d.inputs[0])) != sorted([g.nodes.index(d), g.nodes.index(m)]):
+            continue
+        sites.append((d, e, a, m, hm))
+    if not sites:
+        return False
+    d, e, a, m, hm = sites[rng.integers(len(sites))]
+    k = g.nodes.index(d)
+    node = Node("Gelu", [d.inputs[0]], [hm.outputs[0]], {"approximate": "none"} if rng.integers(2) else {}, hm.name or _fresh(g, "Gelu"))
+    g.nodes = [n for n in g.nodes if n not in (d, e, a, m, hm)]
+    g.nodes.insert(k, node)
+    g.opset = max(g.opset, 20)
+    return True
+
+
 REWRITES = {"gemm": rw_gemm, "identity": rw_identity, "dropout": rw_dropout, "cast": rw_cast, "transpose2": rw_transpose2, "squeeze": rw_squeeze,
             "const_node": rw_const_node, "fp16_init": rw_fp16_init, "reshape_0_m1": rw_reshape_0_m1, "bias_unsqueeze": rw_bias_unsqueeze,
             "ln_axis": rw_ln_axis, "permute": rw_permute, "commute": rw_commute, "dead": rw_dead, "split_qkv": rw_split_qkv, "ln_decompose": rw_ln_decompose,
-            "sdpa_scale": rw_sdpa_scale}
+            "sdpa_scale": rw_sdpa_scale, "gelu_op": rw_gelu_op}
 INEXACT = ("fp16_init", "sdpa_scale")                      # weights rounded to fp16 / sqrt(s)^2 for s: the plan keeps its text, not its bytes
 EXACT = [k for k in REWRITES if k not in INEXACT]          # rewrites under which the engine file must not change by a byte
 

@@ -13,12 +13,10 @@ import sys
 import time
 
 
-def hwmon(card):
+def hwmons(card):
+    """hwmon directories with a power reading: of one card, or of every card (the box shows all GPUs of its host; the one that works is the one that draws)"""
     cands = sorted(glob.glob(f"/sys/class/drm/card{card}/device/hwmon/hwmon*")) if card is not None else sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
-    for h in cands:
-        if any(os.path.exists(os.path.join(h, f)) for f in ("power1_average", "power1_input")):
-            return h
-    return None
+    return [h for h in cands if any(os.path.exists(os.path.join(h, f)) for f in ("power1_average", "power1_input"))]
 
 
 def read_int(path):
@@ -36,19 +34,22 @@ def main():
         card = int(argv[1]); argv = argv[2:]
     if argv and argv[0] == "--":
         argv = argv[1:]
-    h = hwmon(card)
+    hs = hwmons(card)
+    h = hs[0] if hs else None
     child = subprocess.Popen(argv)
-    samples = []                                           # (t, watts, sclk MHz, temp C)
+    samples = []                                           # (t, watts, sclk MHz, temp C) of the card picked below
+    per_card = {x: [] for x in hs}
     t0 = time.time()
     smi_every = 1.0
     last_smi = 0.0
     while child.poll() is None:
         now = time.time() - t0
         if h:
-            p = read_int(os.path.join(h, "power1_average")) or read_int(os.path.join(h, "power1_input"))
-            f = read_int(os.path.join(h, "freq1_input"))
-            t = read_int(os.path.join(h, "temp1_input"))
-            samples.append((now, None if p is None else p / 1e6, None if f is None else f / 1e6, None if t is None else t / 1e3))
+            for x in hs:
+                p = read_int(os.path.join(x, "power1_average")) or read_int(os.path.join(x, "power1_input"))
+                f = read_int(os.path.join(x, "freq1_input"))
+                t = read_int(os.path.join(x, "temp1_input")) or read_int(os.path.join(x, "temp2_input"))
+                per_card[x].append((now, None if p is None else p / 1e6, None if f is None else f / 1e6, None if t is None else t / 1e3))
             time.sleep(0.02)
         else:
             if now - last_smi >= smi_every:
@@ -63,9 +64,12 @@ def main():
                 except Exception:
                     pass
             time.sleep(0.1)
+    if per_card:                                           # the card with the highest peak draw is the one the command ran on
+        h = max(per_card, key=lambda x: max([s_[1] for s_ in per_card[x] if s_[1] is not None] or [0.0]))
+        samples = per_card[h]
     cap = read_int(os.path.join(h, "power1_cap")) if h else None
     watts = [s[1] for s in samples if s[1] is not None]
-    out = {"hwmon": h, "samples": len(samples), "power_cap_w": None if cap is None else cap / 1e6, "exit_code": child.returncode}
+    out = {"hwmon": h, "cards_sampled": len(per_card), "samples": len(samples), "power_cap_w": None if cap is None else cap / 1e6, "exit_code": child.returncode}
     if watts:
         peak = max(watts)
         busy = [s for s in samples if s[1] is not None and s[1] > 0.5 * peak]

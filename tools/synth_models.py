@@ -404,9 +404,11 @@ def _init(net: nn.Module, seed: int):
 
 
 def export_onnx(net: nn.Module, path: str, batch: int, tile: int, opset: int = 17,
-                dynamic: bool = False) -> str:
+                dynamic: bool = False, script: bool = False, **exporter_kw) -> str:
     """TorchScript exporter; the onnx python package is absent, so its no-op
-    post-processing hook is bypassed."""
+    post-processing hook is bypassed.  exporter_kw: the exporter's own switches as torch.onnx.export takes them
+    (do_constant_folding, keep_initializers_as_inputs, training, dynamic_axes ...); script: export torch.jit.script(net) instead of tracing it
+    (tests/test_loader_exporter_switches.py)."""
     import torch.onnx._internal.torchscript_exporter.onnx_proto_utils as opu
     opu._add_onnxscript_fn = lambda model_bytes, custom_opsets: model_bytes
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
@@ -420,10 +422,12 @@ def export_onnx(net: nn.Module, path: str, batch: int, tile: int, opset: int = 1
     for prm in net.parameters():
         prm.requires_grad_(False)
     import warnings
+    kw.update(exporter_kw)
+    kw.setdefault("do_constant_folding", True)
     with warnings.catch_warnings(), torch.no_grad():
         warnings.simplefilter("ignore")
-        torch.onnx.export(net, (x,), path, dynamo=False, opset_version=opset,
-                          input_names=["x"], output_names=["y"], do_constant_folding=True, **kw)
+        torch.onnx.export(torch.jit.script(net) if script else net, (x,), path, dynamo=False, opset_version=opset,
+                          input_names=["x"], output_names=["y"], **kw)
     return path
 
 

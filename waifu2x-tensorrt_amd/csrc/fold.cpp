@@ -446,7 +446,7 @@ FoldedGraph fold_graph(const Model& m, const std::vector<int64_t>& input_shape) 
                 set_dyn({s0[0], w[1] * n.ai("group", 1), oh, ow}, dt0);
             }
         } else if (op == "LeakyRelu" || op == "Relu" || op == "Sigmoid" || op == "Erf" || op == "Tanh" || op == "Sqrt" || op == "Exp" || op == "Neg" ||
-                   op == "Clip" || op == "Softmax" || op == "LayerNormalization" || op == "Identity" || op == "Dropout" || op == "Abs" || op == "Reciprocal") {
+                   op == "Clip" || op == "Softmax" || op == "LayerNormalization" || op == "Identity" || op == "Dropout" || op == "Abs" || op == "Reciprocal" || op == "Gelu") {
             set_dyn(s0, dt0);
         } else if (op == "Cast") {
             set_dyn(s0, (int)n.ai("to", DT_F32));

@@ -192,6 +192,12 @@ struct Lowerer {
         if (u && u->op == "LeakyRelu" && p.op.act == ACT_NONE) { p.op.act = ACT_LEAKY; p.op.alpha = u->af("alpha", 0.01f); done.insert(u); p.cur = u->out[0]; return; }
         if (u && u->op == "Relu" && p.op.act == ACT_NONE) { p.op.act = ACT_RELU; done.insert(u); p.cur = u->out[0]; return; }
         if (u && u->op == "Sigmoid" && p.op.act == ACT_NONE) { p.op.act = ACT_SIGMOID; done.insert(u); p.cur = u->out[0]; return; }
+        // opset 20 has the operator itself: Gelu(approximate = "none") is the erf form the kernels compute; the tanh approximation is another function
+        if (u && u->op == "Gelu" && p.op.act == ACT_NONE) {
+            auto ap = u->attr.find("approximate");
+            if (ap != u->attr.end() && ap->second.s != "none") fail(u, "only Gelu approximate=none (the erf form) is supported, the file asks for \"" + ap->second.s + "\"");
+            p.op.act = ACT_GELU; done.insert(u); p.cur = u->out[0]; return;
+        }
         // GELU(erf): t -> {Div(sqrt2) | Mul(1/sqrt2)} -> Erf -> Add(1) -> Mul(t, .) -> Mul(0.5)
         auto us = users(p.cur);
         if (us.size() == 2 && p.op.act == ACT_NONE && p.cur != g.output) {
