@@ -295,3 +295,39 @@ def test_frame_sharded_bench_line_certifies_where_it_ran(tmp_path):
     assert h and h["ms_per_frame"] > 0 and h["per_rank_ms_per_frame"]["min"] <= h["per_rank_ms_per_frame"]["max"] <= h["ms_per_frame"] + 1e-3
     assert d["value"] > 0 and d["config"]["per_rank_resident_ms_per_step"]["max"] <= d["ms_per_step"] + 1e-3
     assert d["roofline"]["bound"] in ("hbm", "mfma") and "cpu_baseline" not in d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["frames", "shards"])
+def test_five_engines_in_five_processes_on_one_card(tmp_path, mode):
+    """The launch contract's shape at the size this pool allows: one process per rank, each with its own engine, rendezvous over gloo, page-locked frame rings
+    and (shards) hipIpc slab handles of every rank opened by its successors - FIVE ranks on the box's one GPU (W2X_DEVICE_MAP=0,0,0,0,0).  Why five and not the
+    node's eight: the pool's process guard ends a run that has more than six processes on the card, and the test runner is one of them (it holds the engine
+    library of the tests before this one).  What it shows that the two-rank tests do not: five contexts, five sets of four streams, five page-locked rings and
+    (shards) up to four opened peer slabs per rank coexist; every rank's frames are the bytes of render() (bench.py raises otherwise), the shared frame of the
+    shards mode equals rank 0's render(), and the line says REHEARSAL (5 ranks on 1 GPU).  Reference: one device per process (src/main.cpp:70-74)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = 5
+    env = dict(os.environ, W2X_DEVICE_MAP=",".join(["0"] * n), W2X_BENCH_WORK=str(tmp_path / "w"))
+    args = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--repeats", "1", "--config", "0", "--no-cpu-baseline"]
+    if mode == "shards":
+        args += ["--mode", "shards"]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    p = d["placement"]
+    assert d["n_ranks"] == n and d["n_gpus"] == 1 and d["metric"].startswith(f"REHEARSAL ({n} ranks on 1 GPU)")
+    assert p["distinct_gpus"] == 1 and not p["one_gpu_per_rank"] and len({x["pid"] for x in p["ranks"]}) == n and len({x["pci_bus_id"] for x in p["ranks"]}) == 1
+    assert d["value"] > 0
+    if mode == "shards":
+        assert d["config"]["bytes_equal_render"] is True and sum(d["config"]["tiles_per_rank"]) == 63 and min(d["config"]["tiles_per_rank"]) > 0
+        assert d["config"]["peer_device_ordinals_seen_by_rank0"] == [0] * n
+    else:
+        h = d["host_to_host"]
+        assert h and h["ms_per_frame"] > 0 and h["per_rank_ms_per_frame"]["min"] <= h["per_rank_ms_per_frame"]["max"]
+        assert d["config"]["frames_per_rank"] == 2 and d["scaling"] == "weak"

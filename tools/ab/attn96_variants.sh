@@ -1,7 +1,8 @@
 #!/bin/bash
 # Builds tools/ab/attn96_variants (here or on the GPU box) from variants of the C = 96 attention kernel:
 #   tools/ab/attn96_variants.sh "<src or -> [flags] v0" "<flags v1>" ...   each argument: optional "SRC=<file> " prefix, then compiler flags
-# e.g.  tools/ab/attn96_variants.sh "SRC=/tmp/k_swinattn96_head.hip" "-DW2X_A96_PV32=1 -DW2X_A96_BUF=0" "-DW2X_A96_PV32=1 -DW2X_A96_BUF=1"
+# e.g.  tools/ab/attn96_variants.sh "" "SRC=/tmp/k_swinattn96_other.hip"      (the build switches of rounds 3 - 5 - W2X_A96_PV32 / BUF / BQ_LDS / XRES_EARLY / WPS / PRIO - are resolved
+#        in the shipped file since round 6; the file that still has them: git show 9576837:waifu2x-tensorrt_amd/csrc/k_swinattn96.hip)
 # A baseline from an earlier revision: git show 38f61ee:waifu2x-tensorrt_amd/csrc/<kernel>.hip > tools/ab/<kernel>_r2.hip, then "SRC=$PWD/tools/ab/<kernel>_r2.hip".
 set -eu
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)

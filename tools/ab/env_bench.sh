@@ -7,6 +7,6 @@ for r in $(seq 1 "$rounds"); do
   for setting in "$@"; do
     env $setting python bench.py --steps ${STEPS:-20} --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.readlines()[-1]); print('[$setting]', 'resident', d['ms_per_step'], '| sequence', d['config']['full_path_ms_per_frame'], '| render()', d['config']['render_call_ms_pageable'])"
+d=json.loads(sys.stdin.readlines()[-1]); print('[$setting]', 'resident', d['ms_per_step'], d.get('ms_per_step_samples'), '| sequence', d['config']['full_path_ms_per_frame'], '| render()', d['config']['render_call_ms_pageable'])"
   done
 done

@@ -65,9 +65,6 @@ static float frand() { return (float)rand() / RAND_MAX * 2.f - 1.f; }
 #ifndef CW
 #define CW 96        // 192: variants of csrc/k_mlp2.hip (tools/ab/mlp192_variants.sh), weights in the 16x16x32 fragment order
 #endif
-#ifdef W2X_MLP2Q_STAMPS
-extern "C" void w2x_mlp2q_stamps(unsigned long long* out);
-#endif
 int main(int argc, char** argv) {
     const int C = CW;
     const long M = argc > 1 ? atol(argv[1]) : (C == 96 ? 2592000L : 648000L);
@@ -118,18 +115,5 @@ int main(int argc, char** argv) {
     printf("TIMING %ld rows, ms per launch (mean of %d rounds / min):", M, rounds - 1);
     for (int v = 0; v < NVAR; ++v) printf("  v%d %.4f / %.4f", v, sum[v] / (rounds - 1), best[v]);
     printf("\n");
-#ifdef W2X_MLP2Q_STAMPS
-    {   // the LAST variant is the stamped build (tools/ab/mlp192_variants.sh "STAMPS <flags>"): wave ticks per phase, averaged over the waves of one launch
-        unsigned long long st[8];
-        w2x_mlp2q_stamps(st);
-        params_of(NVAR - 1).y = yv[NVAR - 1]; CK(variants[NVAR - 1](params_of(NVAR - 1), 0)); CK(hipDeviceSynchronize());
-        w2x_mlp2q_stamps(st);
-        static const char* names[7] = {"rows in + LayerNorm", "first chunk staged + barrier", "staging requests + first-layer products", "GELU", "second-layer products", "staged-chunk wait + barrier", "rows out"};
-        double tot = 0; for (int k = 0; k < 7; ++k) tot += (double)st[k];
-        printf("STAMPS (s_memtime ticks per wave, %llu waves):", st[7]);
-        for (int k = 0; k < 7; ++k) printf("  %s %.0f (%.0f %%)", names[k], (double)st[k] / st[7], 100.0 * st[k] / tot);
-        printf("  | total %.0f\n", tot / st[7]);
-    }
-#endif
     return 0;
 }

@@ -10,7 +10,7 @@ namespace w2x {
 hipError_t launch_mlp2(const MlpParams& p, hipStream_t s);                // k_mlp2.hip
 hipError_t launch_swin_attn96(const SwinAttnParams& p, hipStream_t s);    // k_swinattn96.hip
 hipError_t launch_swin_attn192u(const SwinAttnParams& p, hipStream_t s);  // k_swinattn192u.hip: three workgroups per CU, one (window, head) unit at a time (round 4; round 3's
-                                                                          // two-per-CU kernel, 0.3 % slower at frame level in 4 of 4 alternating pairs, lives on as tools/ab/k_swinattn192_r3.hip)
+                                                                          // two-per-CU kernel, 0.3 % slower at frame level in 4 of 4 alternating pairs, retired: git 9576837:tools/ab/k_swinattn192_r3.hip)
 
 hipError_t launch_swin_attn(const SwinAttnParams& p, hipStream_t s) {
     if (!p.wqkv_frag || !p.wproj_frag) return hipErrorInvalidValue;       // the kernels read fragment-major weights only

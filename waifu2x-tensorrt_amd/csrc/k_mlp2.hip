@@ -376,12 +376,6 @@ __device__ __forceinline__ void halves_sum2(float& a0, float& a1) {   // sums ov
         : "+v"(a0), "+v"(a1), "=&v"(b0), "=&v"(b1));
 }
 
-#ifdef W2X_MLP2Q_STAMPS   // diagnostic build (tools/ab/mlp192_variants.sh "STAMPS"): s_memtime ticks per phase, summed over the waves of a launch
-__device__ unsigned long long g_mlp2q_stamps[8];
-#define W2X_STAMP(K) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); st_acc[K] += t_ - st_last; st_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define W2X_STAMP(K) do {} while (0)
-#endif
 template <int C, int NW>
 __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpParams p) {
     using K = Mlp2Cfg<C, 2, NW>;
@@ -393,10 +387,6 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r32 = lane & 31, h = lane >> 5;
-#ifdef W2X_MLP2Q_STAMPS
-    unsigned long long st_acc[8] = {}, st_last = __builtin_amdgcn_s_memtime();
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-#endif
     _Float16* Xw = (_Float16*)(smem + wv * K::SLAB);          // [RW][LDX]
     // two weight buffers of NF fragments [64 lanes][8]: odd chunks in the slab area (the rows are in registers by then), even chunks behind it (EARLY0) or there as well
     constexpr int BUF0 = W2X_MLP2Q_EARLY0 ? K::NWV * K::SLAB : 0, BUF1 = W2X_MLP2Q_EARLY0 ? 0 : K::WBUF;
@@ -453,7 +443,6 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xreg[ks] = norm8(raw[ks], rstd, nm);
     }
-    W2X_STAMP(0);                              // rows in, LayerNorm
 #if W2X_MLP2Q_PIPE
     // ---- software-pipelined chunk loop (round 4).  Per chunk a wave issues 24 matrix instructions (12 first-layer, 12 second-layer) and ~130 vector
     // instructions (the GELU of 16 values per lane), and as written above they come in separate runs: a 32 x 32 product lets about four vector
@@ -571,7 +560,6 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
     __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): this wave's share of chunk 0 has landed
     __syncthreads();
 #endif
-    W2X_STAMP(1);                              // first chunk staged
 
     half8 wr[RING];
 #pragma unroll
@@ -618,7 +606,6 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
 #if W2X_MLP2Q_SPLITACC
         acc1 += acc1b;
 #endif
-        W2X_STAMP(2);                          // staging requests + first-layer products issued
         if (ch == NCH - 1) {   // the residual rows, requested as soon as the normalised copies have served their last product
 #pragma unroll
             for (int k = 0; k < NP; ++k) xres[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(XB, vl + k * 1024u, 0, 0));
@@ -640,10 +627,6 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
 #if defined(W2X_MLP2Q_PRIO) && W2X_MLP2Q_PRIO == 3
         __builtin_amdgcn_s_setprio(0);
 #endif
-#ifdef W2X_MLP2Q_STAMPS
-        asm volatile("" :: "v"(a2[0]), "v"(a2[1]));
-#endif
-        W2X_STAMP(3);                          // GELU
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {     // fragment KS + i = (output tile i >> 1, k-step i & 1)
             const int j = KS + i;
@@ -651,10 +634,8 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
             else acc2[i >> 1][i % 16] += (float)wr[j % RING][0] + (float)a2[i & 1][0];
             if (j + RING < NF) { wr[j % RING] = lds_frag(ch, j + RING); W2X_RING_FENCE(); }
         }
-        W2X_STAMP(4);                          // second-layer products issued
         if (ch + 1 < NCH && !(W2X_MLP2Q_EXP & 2)) __builtin_amdgcn_s_waitcnt(0x0F70);
         if (!(W2X_MLP2Q_EXP & 1)) __syncthreads();
-        W2X_STAMP(5);                          // wait for the staged chunk + barrier
         if (ch + 1 < NCH) {
 #pragma unroll
             for (int i = 0; i < RING; ++i) wr[i] = lds_frag(ch + 1, i);
@@ -691,10 +672,6 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
         p.stats_out[2 * (row0 + lane)] = mean;
         p.stats_out[2 * (row0 + lane) + 1] = __builtin_amdgcn_rsqf(fmaxf(q * (1.f / C) - mean * mean, 0.f) + p.eps_out);
     }
-#ifdef W2X_MLP2Q_STAMPS
-    W2X_STAMP(6);                              // accumulators -> rows, residual, stores issued
-    if (lane == 0) { for (int k = 0; k < 7; ++k) atomicAdd(&g_mlp2q_stamps[k], st_acc[k]); atomicAdd(&g_mlp2q_stamps[7], 1ull); }
-#endif
 }
 
 template <int C, int NW>
@@ -756,10 +733,3 @@ hipError_t launch_mlp2(const MlpParams& p, hipStream_t s) {
 
 }  // namespace w2x
 
-#ifdef W2X_MLP2Q_STAMPS
-extern "C" void w2x_mlp2q_stamps(unsigned long long* out) {   // returns and clears the sums
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(w2x::g_mlp2q_stamps), sizeof(unsigned long long) * 8);
-    unsigned long long z[8] = {};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(w2x::g_mlp2q_stamps), z, sizeof z);
-}
-#endif

@@ -1,6 +1,6 @@
-// Fused Swin attention branch, C = 192 / 6 heads of 32 / window 6x6 - the THREE-WORKGROUPS-PER-CU variant of tools/ab/k_swinattn192_r3.hip (round 4).
+// Fused Swin attention branch, C = 192 / 6 heads of 32 / window 6x6 - the THREE-WORKGROUPS-PER-CU variant of git 9576837:tools/ab/k_swinattn192_r3.hip (round 4).
 //     y = x + proj( W-MSA( LayerNorm(x) ) )
-// Same math, same instruction-level recipe per (window, head) unit and the same bytes as tools/ab/k_swinattn192_r3.hip; what changes is what a wave
+// Same math, same instruction-level recipe per (window, head) unit and the same bytes as git 9576837:tools/ab/k_swinattn192_r3.hip; what changes is what a wave
 // keeps alive.  The round-2/3 kernel lets wave v multiply head v's weights against BOTH windows at once (every weight fragment feeds six
 // products) and parks the head outputs in a second LDS tile: 230+ registers and 70 KB of LDS per workgroup = two workgroups (two waves per
 // SIMD) per CU, where the kernel waits more than it issues (SQ_WAIT_INST_ANY + SQ_WAIT_ANY = 63 % of its wave cycles, profiles/r3_late).
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, W2X_A192U_WPC) void swin_attn192u_kernel(const
     const half8 zero8 = {};
 
     // this wave's three (window, head) units, in the order they run: head hA on window 0, head hA on window 1, head hC on window wC
-    // (tools/ab/k_swinattn192_r3.hip's assignment, so that the two kernels agree bit for bit unit by unit)
+    // (git 9576837:tools/ab/k_swinattn192_r3.hip's assignment, so that the two kernels agree bit for bit unit by unit)
     const int hA = wv, hC = 4 + (wv >> 1), wC = wv & 1;
     const int amask0 = wok0 ? p.maskid[wl0] : 0, amask1 = wok1 ? p.maskid[wl1] : 0;
 
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256, W2X_A192U_WPC) void swin_attn192u_kernel(const
         W2X_LOAD_BIAS()
 #endif
 #undef W2X_LOAD_BIAS
-        // ---- S^T = K Q^T on top of the bias, softmax over the keys (lane-local + two row swaps), O^T = V^T P^T scaled by 1/l (tools/ab/k_swinattn192_r3.hip's
+        // ---- S^T = K Q^T on top of the bias, softmax over the keys (lane-local + two row swaps), O^T = V^T P^T scaled by 1/l (git 9576837:tools/ab/k_swinattn192_r3.hip's
         //      attend(), instruction for instruction); the result stays in registers
 #pragma unroll
         for (int qi = 0; qi < 3; ++qi)
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256, W2X_A192U_WPC) void swin_attn192u_kernel(const
     // windows that do not exist (the last workgroup of a run) leave their rows of the tile as the slabs were: finite values, never stored
     __syncthreads();
 
-    // The residual rows (the same pixels again, for y = x + ...) are requested here, in front of the projection (tools/ab/k_swinattn192_r3.hip): the
+    // The residual rows (the same pixels again, for y = x + ...) are requested here, in front of the projection (git 9576837:tools/ab/k_swinattn192_r3.hip): the
     // fetch travels under its 90 products.
     const int li_r = tid & (LPR - 1), rsub_r = tid / LPR;
     half8 xres[NPASS];
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256, W2X_A192U_WPC) void swin_attn192u_kernel(const
 
 }  // namespace
 
-// same contract as launch_swin_attn192 (tools/ab/k_swinattn192_r3.hip)
+// same contract as launch_swin_attn192 (git 9576837:tools/ab/k_swinattn192_r3.hip)
 hipError_t launch_swin_attn192u(const SwinAttnParams& p, hipStream_t s) {
     auto kern = swin_attn192u_kernel;
     static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds

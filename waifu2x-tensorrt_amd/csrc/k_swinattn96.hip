@@ -28,31 +28,24 @@
 
 #include <algorithm>
 
-// Build switches (tools/ab/attn96_variants.sh times them against each other):
-//   W2X_A96_PV32  O^T = V^T P^T over the 32 keys of the two full key tiles as ONE v_mfma_f32_16x16x32_f16 (the accumulator tiles of
-//                 S^T and v pair up into its operands with the k order permuted identically on both sides) + one 16x16x16 for the
-//                 left-over keys, instead of three 16x16x16 - which cost the matrix pipe as much as a 16x16x32 each
-//                 (tools/issue_model.hip): 9 matrix instructions less per wave; 2 = the softmax denominators too (16 less).
-//                 The two shapes NEVER share an accumulator: a 16x16x16 whose SrcC is the vDst of the 16x16x32 right in front of it
-//                 gets no wait states from hipcc (it treats the pair like two instructions of one opcode, which the hardware forwards),
-//                 and the second product then reads a half-written accumulator - outputs off by up to 0.8 and different from run to run
-//                 in three of the four builds that had such a pair (profiles/r5_kernels/a96_mixed_chain.txt; tools/isa_mfma_chain.py
-//                 finds the pairs in the ISA, tests/test_isa_hazards.py keeps them out of the library).  Each shape accumulates into
-//                 its own registers and the two sums meet in the epilogue's fused multiply-adds.
-//   W2X_A96_BUF   weight fragments, bias tables and the rel-pos bias through buffer loads (lane offset in a VGPR once, everything else
-//                 in the scalar offset) instead of flat loads with 64-bit per-lane addresses.
-#ifndef W2X_A96_PV32
-#define W2X_A96_PV32 1     // round 5, with BQ_LDS = 1 and XRES_EARLY = 1 (126 registers, no spill): 0.510 -> 0.496 ms per launch in the harness (profiles/r5_kernels/a96_pv32_split.txt);
-#endif                     // 2 measured the same (0.498); at __launch_bounds__(256, 3) - 148 registers, three waves per SIMD - 0.533
-#ifndef W2X_A96_BUF
-#define W2X_A96_BUF 1
-#endif
-#ifndef W2X_A96_BQ_LDS
-#define W2X_A96_BQ_LDS 1       // 1: the q / k / v bias vectors are copied to LDS when the workgroup starts and read from there (tools/ab/k_swinattn192_r3.hip gains 3 % from it).
-#endif                         // (round 3, without PV32: 0.516 against 0.502 ms, three spilled registers; with PV32 the allocation fits and the bias loads leave the vector-memory queue)
-#ifndef W2X_A96_XRES_EARLY
-#define W2X_A96_XRES_EARLY 1   // where the residual rows are requested: 0 in front of the projection (round 2), 1 after the last unit's q / k / v products,
-#endif                         // 2 after its score products.  Round 3 (no PV32): 0.524 / 0.534 (two spills) / 0.518 ms; round 5 with PV32 + BQ_LDS: 1 = 0.496, 2 = 0.502
+// Choices that were build switches while they were being measured (round 3 - 5; the variants are in git history at 9576837, the records under
+// profiles/r5_kernels/a96_*.txt, profiles/r3_kernels/attn96_*.txt):
+//   * O^T = V^T P^T over the 32 keys of the two full key tiles as ONE v_mfma_f32_16x16x32_f16 (the accumulator tiles of S^T and v pair up into its
+//     operands with the k order permuted identically on both sides) + one 16x16x16 for the left-over keys, instead of three 16x16x16 - which cost the
+//     matrix pipe as much as a 16x16x32 each (tools/issue_model.hip): 9 matrix instructions less per wave (0.510 -> 0.496 ms per launch).  The softmax
+//     denominators the same way measured level (0.498) and keep their three 16x16x16.
+//     The two shapes NEVER share an accumulator: a 16x16x16 whose SrcC is the vDst of the 16x16x32 right in front of it gets no wait states from hipcc
+//     (it treats the pair like two instructions of one opcode, which the hardware forwards), and the second product then reads a half-written
+//     accumulator - outputs off by up to 0.8 and different from run to run in three of the four builds that had such a pair
+//     (profiles/r5_kernels/a96_mixed_chain.txt; tools/isa_mfma_chain.py finds the pairs in the ISA, tests/test_isa_hazards.py keeps them out of the
+//     library).  Each shape accumulates into its own registers and the two sums meet in the epilogue's fused multiply-adds.
+//   * weight fragments, bias tables and the rel-pos bias through buffer loads (lane offset in a VGPR once, everything else in the scalar offset)
+//     instead of flat loads with 64-bit per-lane addresses.
+//   * the q / k / v bias vectors are copied to LDS when the workgroup starts and read from there (with the 16x16x32 PV the allocation fits 126
+//     registers and the bias loads leave the vector-memory queue).
+//   * the residual rows are requested after the last unit's q / k / v products (in front of the projection: 0.524 ms in round 3; after the unit's score
+//     products 0.502 against 0.496).
+//   * s_setprio by phase (head loop at 1, or rising with progress): +15 % - off.
 
 namespace w2x {
 namespace {
@@ -156,7 +149,7 @@ constexpr int SLAB = 48, RPX = G * SLAB;   // slab rows per window (tokens 0..31
 constexpr int LDX = C + 8;                 // 104 halves
 constexpr int XS = RPX * LDX, OS = RP * LDX;
 constexpr int NPAD = G * 12;                // slab rows between the left-over tokens (kept at zero)
-constexpr int BQ_OFF = (XS + OS) * 2 + (RP + NPAD) * 8 + 16;   // q / k / v bias [3 * C] fp32 (W2X_A96_BQ_LDS)
+constexpr int BQ_OFF = (XS + OS) * 2 + (RP + NPAD) * 8 + 16;   // q / k / v bias [3 * C] fp32, copied in when the workgroup starts
 constexpr int SMEM96 = BQ_OFF + 3 * C * 4;
 constexpr int DUMMY = XS * 2;              // byte offset of a row nobody reads at that point (first row of Os): target of the stores of lanes / rows without data
 constexpr int LPR = 16, PPR = C / 8, RPP = NTHR / LPR, NPASS = RP / RPP;   // row passes: 16 lanes per row (12 carry data), 16 rows per pass, 5 passes
@@ -176,54 +169,36 @@ __device__ __forceinline__ void probs(const float4v s0, const float4v s1, float 
 }
 __device__ __forceinline__ half4 lo4(const half8 v) { return (half4){v[0], v[1], v[2], v[3]}; }
 __device__ __forceinline__ half4 hi4(const half8 v) { return (half4){v[4], v[5], v[6], v[7]}; }
-// product over the 36 keys: operands (a01 | a2) x (p01 | p2), added to `acc`.  W2X_A96_PV32: .a = the 32 keys of the full tiles (16x16x32), .b = the
-// left-over keys (16x16x16) - one accumulator per instruction shape (header); otherwise everything is in .a
+// product over the 36 keys: operands (a01 | a2) x (p01 | p2), added to `acc`: .a = the 32 keys of the full tiles (16x16x32), .b = the left-over keys
+// (16x16x16) - one accumulator per instruction shape (header)
 struct KeysAcc { float4v a, b; };
 __device__ __forceinline__ KeysAcc keys_product(const half8 a01, const half4 a2, const half8 p01, const half4 p2, const KeysAcc acc) {
     KeysAcc o;
-#if W2X_A96_PV32
     o.a = __builtin_amdgcn_mfma_f32_16x16x32_f16(a01, p01, acc.a, 0, 0, 0);
     o.b = __builtin_amdgcn_mfma_f32_16x16x16f16(a2, p2, acc.b, 0, 0, 0);
-#else
-    o.a = __builtin_amdgcn_mfma_f32_16x16x16f16(lo4(a01), lo4(p01), acc.a, 0, 0, 0);
-    o.a = __builtin_amdgcn_mfma_f32_16x16x16f16(hi4(a01), hi4(p01), o.a, 0, 0, 0);
-    o.a = __builtin_amdgcn_mfma_f32_16x16x16f16(a2, p2, o.a, 0, 0, 0);
-    o.b = acc.b;
-#endif
     return o;
 }
-// (o.a [+ o.b]) * inv + bv as the four fp16 values a lane stores
+// (o.a + o.b) * inv + bv as the four fp16 values a lane stores
 __device__ __forceinline__ half4 scaled_output(const KeysAcc o, float inv, const float4v bv) {
     const float2v i2 = {inv, inv};
     float2v o0 = __builtin_elementwise_fma((float2v){o.a[0], o.a[1]}, i2, (float2v){bv[0], bv[1]});
     float2v o1 = __builtin_elementwise_fma((float2v){o.a[2], o.a[3]}, i2, (float2v){bv[2], bv[3]});
-#if W2X_A96_PV32
     o0 = __builtin_elementwise_fma((float2v){o.b[0], o.b[1]}, i2, o0);
     o1 = __builtin_elementwise_fma((float2v){o.b[2], o.b[3]}, i2, o1);
-#endif
     return (half4){(_Float16)o0[0], (_Float16)o0[1], (_Float16)o1[0], (_Float16)o1[1]};
 }
-// column sums of P (the softmax denominators) off the matrix pipe: a ones matrix in place of V^T.  W2X_A96_PV32 == 2 spends four
-// registers on a ones operand for the 16x16x32 form, otherwise three 16x16x16 products share a two-register one
+// column sums of P (the softmax denominators) off the matrix pipe: a ones matrix in place of V^T; three 16x16x16 products share a two-register ones operand
 __device__ __forceinline__ float keys_sum(const half8 p01, const half4 p2) {
     const float4v zero4 = {0.f, 0.f, 0.f, 0.f};
-#if W2X_A96_PV32 == 2
-    const half8 ones8 = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
-    const float4v l32 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, p01, zero4, 0, 0, 0);      // (two shapes, two accumulators: header)
-    const float4v l16 = __builtin_amdgcn_mfma_f32_16x16x16f16(lo4(ones8), p2, zero4, 0, 0, 0);
-    return l32[0] + l16[0];
-#else
     const half4 ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
     float4v l = __builtin_amdgcn_mfma_f32_16x16x16f16(ones, lo4(p01), zero4, 0, 0, 0);
     l = __builtin_amdgcn_mfma_f32_16x16x16f16(ones, hi4(p01), l, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_16x16x16f16(ones, p2, l, 0, 0, 0)[0];
-#endif
 }
 
-#ifndef W2X_A96_WPS
-#define W2X_A96_WPS 4          // waves per SIMD the register allocation is held to (= workgroups per CU).  3 (up to 168 registers) measured 4.5 - 10 % slower in every
-#endif                         // combination of the switches above (profiles/r5_kernels/a96_*.txt): the kernel lives on its fourth wave per SIMD
-__global__ __launch_bounds__(NTHR, W2X_A96_WPS) void swin_attn96_kernel(const SwinAttnParams p) {
+// four waves per SIMD (= four workgroups per CU): at three (up to 168 registers) every combination of the choices in the header measured 4.5 - 10 % slower
+// (profiles/r5_kernels/a96_*.txt, a96_occupancy.txt) - the kernel lives on its fourth wave per SIMD
+__global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* Xs = (_Float16*)smem;              // [RPX][LDX] normalised x slabs; later the output tile [RP][LDX] (token order)
     _Float16* Os = Xs + XS;                      // [RP][LDX]  attention output, all heads, token order
@@ -249,23 +224,13 @@ __global__ __launch_bounds__(NTHR, W2X_A96_WPS) void swin_attn96_kernel(const Sw
     // weight fragments of a head (q, k, v rows h*16 + fr; 3 k-steps): lane holds [row][ks*32 + 8g .. +7]; stored
     // fragment-major, so each load is one contiguous KiB
     half8 wq[3], wk[3], wv_[3];
-#if W2X_A96_BUF
     // every table goes through a buffer resource: the lane part of the address is one VGPR for all loads, the rest is scalar
     const __amdgpu_buffer_rsrc_t WQ = make_rsrc(Wqkv, 3u * C * C * 2u), WP = make_rsrc(Wproj, (unsigned)C * C * 2u);
-    const __amdgpu_buffer_rsrc_t BQ = make_rsrc(p.bqkv, 3u * C * 4u), BP = make_rsrc(p.bproj, (unsigned)C * 4u), RB = make_rsrc(p.bias32, 0x7FFFFFF0u);
+    const __amdgpu_buffer_rsrc_t BP = make_rsrc(p.bproj, (unsigned)C * 4u), RB = make_rsrc(p.bias32, 0x7FFFFFF0u);
     const unsigned l16 = lane * 16u, l4 = lane * 4u, g16 = (lane >> 4) * 16u;
 #define W2X_WFRAG(SEL, H, KS) __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(WQ, l16, (unsigned)(((SEL) * NH + (H)) * 3 + (KS)) * 1024u, 0))
-#define W2X_BQKV(OFF) __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(BQ, g16, (unsigned)(OFF) * 4u, 0))
-#else
-    const _Float16* wlane = Wqkv + lane * 8;
-#define W2X_WFRAG(SEL, H, KS) (*(const half8*)(wlane + (size_t)(((SEL) * NH + (H)) * 3 + (KS)) * 512))
-#define W2X_BQKV(OFF) (*(const float4v*)(p.bqkv + (OFF) + g * 4))
-#endif
-#if W2X_A96_BQ_LDS
-#undef W2X_BQKV
 #define W2X_BQKV(OFF) (*(const float4v*)((const float*)(smem + BQ_OFF) + (OFF) + g * 4))
     if (tid < 3 * C / 4) *(float4v*)(smem + BQ_OFF + tid * 16) = *(const float4v*)(p.bqkv + tid * 4);   // (first use is two barriers away)
-#endif
 #define W2X_LOAD_W(H)                                                                           \
     _Pragma("unroll") for (int ks = 0; ks < 3; ++ks) {                                          \
         wq[ks] = W2X_WFRAG(0, H, ks);                                                           \
@@ -338,9 +303,6 @@ __global__ __launch_bounds__(NTHR, W2X_A96_WPS) void swin_attn96_kernel(const Sw
     }
     __syncthreads();
 
-#ifdef W2X_A96_PRIO     // s_setprio by phase (tools/ab/k_swinattn192_r3.hip): 1 = head loop at priority 1, row phases at 0; 2 = rising with progress
-    __builtin_amdgcn_s_setprio(1);
-#endif
     const float qscale = p.scale * 1.44269504088896341f;   // log2(e) folded into q: softmax uses exp2
     const float2v qs2 = {qscale, qscale};
     const half4 zeroh4 = {};
@@ -402,7 +364,6 @@ __global__ __launch_bounds__(NTHR, W2X_A96_WPS) void swin_attn96_kernel(const Sw
         const int cls = __builtin_amdgcn_readfirstlane(Cls[w]);
         float4v s[2][3];
         float b2[2];
-#if W2X_A96_BUF
         const unsigned boff = (unsigned)(cls * NH + h) * (3u * 576u * 4u);
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
@@ -411,16 +372,6 @@ __global__ __launch_bounds__(NTHR, W2X_A96_WPS) void swin_attn96_kernel(const Sw
             s[qi][2] = zero4;
             b2[qi] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(RB, l4, boff + (unsigned)(qi * 576 + 512) * 4u, 0));   // key tile 2 holds one key per lane: added after the product
         }
-#else
-        const float* bias = p.bias32 + ((size_t)cls * NH + h) * (3 * 576);
-#pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
-            s[qi][0] = *(const float4v*)(bias + qi * 576 + lane * 4);
-            s[qi][1] = *(const float4v*)(bias + qi * 576 + 256 + lane * 4);
-            s[qi][2] = zero4;
-            b2[qi] = bias[qi * 576 + 512 + lane];         // key tile 2 holds one key per lane: added after the product
-        }
-#endif
         // ---- q^T, k^T (rows = features: A = weights, B = x) and v (rows = slab rows: A = x, B = weights)
         float4v aq[2] = {bq, bq}, ak[3] = {zero4, zero4, zero4}, av[3] = {zero4, zero4, zero4};
 #pragma unroll
@@ -435,9 +386,7 @@ __global__ __launch_bounds__(NTHR, W2X_A96_WPS) void swin_attn96_kernel(const Sw
         }
         if (u == 1) { W2X_LOAD_W(hC) }   // the second head's fragments take over the registers (reloading each register right after its
                                          // last use inside the loop above measured no faster and cost a spill)
-#if W2X_A96_XRES_EARLY == 1
         if (u == NU - 1) W2X_FETCH_XRES()
-#endif
         half4 qf[2], kf[3];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
@@ -459,9 +408,6 @@ __global__ __launch_bounds__(NTHR, W2X_A96_WPS) void swin_attn96_kernel(const Sw
             s[1][kt] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf[kt], qf[1], s[1][kt], 0, 0, 0);
             sl[kt] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf[kt], qz, sl[kt], 0, 0, 0);
         }
-#if W2X_A96_XRES_EARLY == 2
-        if (u == NU - 1) W2X_FETCH_XRES()
-#endif
         // ---- softmax over the keys (column = query): lane-local maximum of 9, then the 4 lanes of the column
         const float t0 = s[0][2][0] + b2[0], t1 = s[1][2][0] + b2[1];
         float mx0 = max9(s[0][0], s[0][1], t0), mx1 = max9(s[1][0], s[1][1], t1);
@@ -498,16 +444,8 @@ __global__ __launch_bounds__(NTHR, W2X_A96_WPS) void swin_attn96_kernel(const Sw
         const float4v bv = *(const float4v*)(p.bqkv + 2 * C + hl_ * HD + g * 4);   // (hl_ differs per lane)
         if (ul < NU) *(half4*)(Os + (wl_ * NTOK + 32 + ql) * LDX + hl_ * HD + g * 4) = scaled_output(o, inv, bv);
     }
-#if defined(W2X_A96_PRIO) && W2X_A96_PRIO == 1
-    __builtin_amdgcn_s_setprio(0);
-#elif defined(W2X_A96_PRIO)
-    __builtin_amdgcn_s_setprio(2);
-#endif
     __syncthreads();      // every head's outputs are in Os; nobody reads the slabs any more
 
-#if !W2X_A96_XRES_EARLY
-    W2X_FETCH_XRES()      // the residual rows are fetched under the projection
-#endif
 #undef W2X_FETCH_XRES
     // ---- proj, transposed: out^T = Wproj Os^T + b (rows = output channels, columns = tokens), so a lane ends with 4 consecutive
     // channels of one token.  10 units of (16-token tile, 3 channel tiles); weights as fragments from L2, bias as the initial
@@ -520,13 +458,8 @@ __global__ __launch_bounds__(NTHR, W2X_A96_WPS) void swin_attn96_kernel(const Sw
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
 #pragma unroll
-#if W2X_A96_BUF
             for (int ks = 0; ks < 3; ++ks) wf[t][ks] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(WP, l16, (unsigned)((n3 + t) * 3 + ks) * 1024u, 0));
             acc[t] = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(BP, g16, (unsigned)(n3 + t) * 64u, 0));
-#else
-            for (int ks = 0; ks < 3; ++ks) wf[t][ks] = *(const half8*)(Wproj + (size_t)(((n3 + t) * 3 + ks) * 64 + lane) * 8);
-            acc[t] = *(const float4v*)(p.bproj + (n3 + t) * 16 + g * 4);
-#endif
         }
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
@@ -538,9 +471,6 @@ __global__ __launch_bounds__(NTHR, W2X_A96_WPS) void swin_attn96_kernel(const Sw
         for (int t = 0; t < 3; ++t)
             *(half4*)(Xs + (mt * 16 + fr) * LDX + (n3 + t) * 16 + g * 4) = (half4){(_Float16)acc[t][0], (_Float16)acc[t][1], (_Float16)acc[t][2], (_Float16)acc[t][3]};
     }
-#if defined(W2X_A96_PRIO) && W2X_A96_PRIO == 2
-    __builtin_amdgcn_s_setprio(3);
-#endif
     __syncthreads();
 
     // ---- row pieces: + residual x, scatter store, LayerNorm statistics for the next op
