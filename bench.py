@@ -564,7 +564,7 @@ def main():
         # dominant kernel of the frame: plan ops grouped by the kernel that serves them, by summed HIP-event time
         # (measured on the compute stream by w2x_profile_frame / w2x_op_times)
         symbols = {("swinattn", 96): "swin_attn96_kernel", ("swinattn", 192): "swin_attn192u_kernel",
-                   ("mlp", 96): "mlp96q_kernel", ("mlp", 192): "mlp2q_kernel<192,4>"}
+                   ("mlp", 96): "mlp96q_kernel", ("mlp", 192): "mlp2_kernel<192,2>"}     # (names as tools/pmc_traffic.py keys them)
         groups = {}
         for line, t in zip(desc, op_ms):
             m = re.match(r"\s*\d+ (\w+) (.*?)flops=(\d+)", line)
@@ -629,6 +629,8 @@ def main():
                     now = kernel_source_sha(r["kernel"])
                     if t and t.get("source_sha") and t["source_sha"] == now:
                         r["traffic"] = t["bytes_per_launch"]; r["traffic_source"] = t["source"]; r["traffic_kernel_source_sha"] = now
+                        for k_ in ("issue", "mfma_busy", "coexec"):      # SQ counters of the same round's passes (tools/pmc_traffic.py), same source-hash rule
+                            if k_ in t: r[k_] = t[k_]
                     elif t:          # the counters were taken on another revision of this kernel: not quoted
                         r["traffic_note"] = f"profiles/pmc_traffic.json holds {t['bytes_per_launch']} bytes per launch measured on kernel source {t.get('source_sha', 'unrecorded')}; the kernel now built is {now}: not quoted"
             except Exception:

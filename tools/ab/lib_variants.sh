@@ -12,7 +12,9 @@ cd "$ROOT/waifu2x-tensorrt_amd"
 CXX="/opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable"
 extra() { case "$1" in k_mlp2.hip) echo "-mllvm -amdgpu-sched-strategy=max-ilp -fno-honor-nans";; k_mlp96q.hip) echo "-mllvm -amdgpu-sched-strategy=max-ilp -fno-honor-nans";; *) echo "";; esac; }
 # build <object's file> <flags> [<alternative source, relative to the repository root>]
-build() { $CXX $(extra "$1") $2 -I csrc -c "${3:-csrc/$1}" -o "build/${1%.hip}.o" 2>/dev/null && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libw2x.so build/*.o; }
+# (a host file of the library - "engine.cpp:-DW2X_EXP_..." - is compiled the way the Makefile does it: -x hip, object build/<stem>.o)
+build() { local obj="build/${1%.*}.o" lang=""; case "$1" in *.cpp) lang="-x hip";; esac
+          $CXX $(extra "$1") $2 -I csrc $lang -c "${3:-csrc/$1}" -o "$obj" 2>/dev/null && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libw2x.so build/*.o; }
 run() { (cd "$ROOT"; python bench.py --no-cpu-baseline --steps ${STEPS:-20} ${BENCH_ARGS:-} 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())

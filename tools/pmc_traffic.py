@@ -1,6 +1,11 @@
 """HBM bytes per launch from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), corrected as
 MI355X_MICROARCH.md prescribes for gfx950:  bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (both counters are in KiB;
 FETCH_SIZE reports half of a wide streaming read on gfx950; Infinity-Cache hits are counted).
+Round 6: where the same round's SQ passes lie beside them (pmc_sq/, pmc_mfma/, pmc_coexec/: tools/profile_round.sh) each kernel's entry also carries
+  issue        SQ_ACTIVE_INST_ANY / SQ_BUSY_CU_CYCLES   (wave-instruction issue per SIMD-cycle: quad-cycles x 4 over CU-cycles x 4 SIMDs)
+  mfma_busy    SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)
+  coexec       SQ_VALU_MFMA_COEXEC_CYCLES / SQ_VALU_MFMA_BUSY_CYCLES   (share of the matrix pipe's busy cycles in which a vector instruction executes too)
+bench.py quotes all of them under the same rule as the bytes: only while the kernel source + build recipe they were measured on is the one that runs.
 usage: pmc_traffic.py <dir with pmc_fetch/ and pmc_write/> <out.json> <source tag>"""
 import collections, csv, glob, json, os, re, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,7 +21,7 @@ def per_kernel(d, counter):
 def symbol(name):
     m = re.search(r"(swin_attn96_kernel|swin_attn192u?_kernel|mlp96q_kernel|mlp96p_kernel|conv48_kernel|compose_kernel|gather_kernel|toimage_kernel)", name)
     if m: return m.group(1)
-    m = re.search(r"(mlp2q?_kernel)<(\d+), (\d+)[^>]*>", name)
+    m = re.search(r"(mlp2q?_kernel)<(\d+), (\d+)[^>]*>", name)      # mlp2q_kernel<192, 4> -> "mlp2q_kernel<192,4>", mlp2_kernel<192, 2, 4> -> "mlp2_kernel<192,2>"
     if m: return f"{m.group(1)}<{m.group(2)},{m.group(3)}>"
     m = re.search(r"(pixgemm_kernel<[^>]*>|merge_kernel<[^>]*>|stem_kernel<[^>]*>|conv3_kernel<[^>]*>|gemm_kernel<[^>]*>|mlp_kernel<[^>]*>|swin_attn_kernel<[^>]*>)", name)
     return m.group(1) if m else None
@@ -34,5 +39,18 @@ for k in fetch:
     f, w = fetch[k][0] / fetch[k][1], write[k][0] / write[k][1]
     res[s] = {"bytes_per_launch": round((2 * f + w) * 1024), "fetch_kib_raw": round(f, 1), "write_kib": round(w, 1),
               "launches_sampled": fetch[k][1], "source": tag, "source_sha": kernel_source_sha(s)}
+def ratio(num_dir, num, den_dir, den, scale=1.0):
+    a, b = per_kernel(root + "/" + num_dir, num), per_kernel(root + "/" + den_dir, den)
+    out_ = {}
+    for k in a:
+        s_ = symbol(k)
+        if s_ and k in b and b[k][0] > 0: out_[s_] = round(a[k][0] / a[k][1] / (b[k][0] / b[k][1]) * scale, 4)
+    return out_
+for key, args in (("issue", ("pmc_sq", "SQ_ACTIVE_INST_ANY", "pmc_mfma", "SQ_BUSY_CU_CYCLES")), ("mfma_busy", ("pmc_mfma", "SQ_VALU_MFMA_BUSY_CYCLES", "pmc_mfma", "SQ_BUSY_CU_CYCLES", 0.25)),
+                  ("coexec", ("pmc_coexec", "SQ_VALU_MFMA_COEXEC_CYCLES", "pmc_coexec", "SQ_VALU_MFMA_BUSY_CYCLES"))):
+    if os.path.isdir(root + "/" + args[0]) and os.path.isdir(root + "/" + args[2]):
+        for s_, v in ratio(*args).items():
+            if s_ in res: res[s_][key] = v
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
-for k, v in sorted(res.items(), key=lambda kv: -kv[1]["bytes_per_launch"]): print(f"{k:40s} {v['bytes_per_launch'] / 1e6:10.1f} MB/launch")
+for k, v in sorted(res.items(), key=lambda kv: -kv[1]["bytes_per_launch"]):
+    print(f"{k:40s} {v['bytes_per_launch'] / 1e6:10.1f} MB/launch" + "".join(f"  {x} {v[x]:.3f}" for x in ("issue", "mfma_busy", "coexec") if x in v))

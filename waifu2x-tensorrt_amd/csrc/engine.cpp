@@ -507,10 +507,17 @@ struct Img2Img::Impl {
             }
         for (const Op& op : plan.ops)
             if (plan.elt == 2 && op.kind == OP_MLP && mlp_supported(op.m.C)) {
-                // both MLP kernels run on 32x32x16 fragments (k_mlp96q.hip, mlp2q_kernel in k_mlp2.hip)
                 const int Cm = op.m.C;
                 const auto& w1 = plan.blobs[op.m.w1].data; const auto& w2 = plan.blobs[op.m.w2].data;
                 if (w1.size() != (size_t)2 * Cm * Cm * 2 || w2.size() != w1.size()) throw std::runtime_error("plan: MLP weight size");
+                // C = 96: 32x32x16 fragments (k_mlp96q.hip).  C = 192: 16x16x32 fragments (mlp2_kernel<192,2,4> in k_mlp2.hip) since round 6 - the 32x32x16 kernel of
+                // rounds 3-5 (mlp2q_kernel, -DW2X_MLP192_TILE32 here) takes the same time per launch but more energy per product, and the frame runs at the
+                // board's power cap: 7.272 / 7.274 against 7.306 / 7.312 / 7.307 ms per frame in alternating pairs (profiles/r6_kernels/lib_mlp192_tile16_frame_level.txt)
+                if (!mlp_frag32(Cm)) {
+                    if (!frag_blobs[op.m.w1]) upload_frag(op.m.w1, frag_major((const uint16_t*)w1.data(), 2 * Cm, Cm));
+                    if (!frag_blobs[op.m.w2]) upload_frag(op.m.w2, frag_w2((const uint16_t*)w2.data(), Cm));
+                    continue;
+                }
                 if (!frag_blobs[op.m.w1]) upload_frag(op.m.w1, frag32_major((const uint16_t*)w1.data(), 2 * Cm, Cm));
                 if (!frag_blobs[op.m.w2]) upload_frag(op.m.w2, frag32_w2((const uint16_t*)w2.data(), Cm));
             }
@@ -667,7 +674,7 @@ struct Img2Img::Impl {
                     MlpParams p;
                     p.x = tp(m.x); p.y = tp(m.y); p.M = (long)live * d.H * d.W; p.C = m.C;
                     p.w1 = blobs[m.w1]; p.b1 = (const float*)blobs[m.b1]; p.w2 = blobs[m.w2]; p.b2 = (const float*)blobs[m.b2];
-                    p.w1_frag = frag_blobs[m.w1]; p.w2_frag = frag_blobs[m.w2]; p.frag32 = true;
+                    p.w1_frag = frag_blobs[m.w1]; p.w2_frag = frag_blobs[m.w2]; p.frag32 = mlp_frag32(m.C);
                     p.eps = m.eps; p.stats_out = (float*)tp(m.stats_out); p.eps_out = m.eps_out;
                     if (d.C != m.C || plan.tensors[m.y].C != m.C) throw std::runtime_error("plan: MLP width mismatch");
                     double flops = op.flops;

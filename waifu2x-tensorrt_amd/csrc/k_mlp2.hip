@@ -161,7 +161,7 @@ struct Mlp2Cfg {
     // KEEP (C = 96): the weight buffers sit behind the slabs (50.6 KB per workgroup, still 3 workgroups per CU), so the raw x rows stay
     // in the slab and serve the residual add - x is read from HBM once.  Otherwise the buffers alias the slabs (x lives in
     // registers by then) and the residual rows are fetched a second time.
-    static constexpr bool KEEP = C == 96 || W2X_MLP192_KEEP;
+    static constexpr bool KEEP = C == 96 || (W2X_MLP192_KEEP && NW != 4);   // (the 32x32x16 kernel below is the <192, 2, 4> geometry and aliases its buffers)
     static constexpr int WORK = KEEP ? NWV * SLAB + 2 * WBUF : (NWV * SLAB > 2 * WBUF ? NWV * SLAB : 2 * WBUF);
     // b1 [2C] | b2 [C] as fp32 behind the work area: the per-chunk bias reads are LDS reads.  As global loads they shared the vector
     // memory counter with the LDS-DMA staging of the NEXT chunk, and the wait for a chunk's two bias vectors (s_waitcnt vmcnt(0), in

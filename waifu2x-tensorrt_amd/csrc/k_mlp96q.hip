@@ -156,7 +156,13 @@ constexpr int NF = KS;                       // fragments per chunk and matrix =
 static_assert(NF == NT * 2, "one ring serves both products");
 constexpr int WBYTES = (W1F + W2F) * 1024;
 constexpr int BIAS_OFF = WBYTES + NWV * SLAB;   // b1 [2C] | b2 [C] as fp32: read per chunk / tile through LDS (no vector-memory counter involved)
-constexpr int SMEM96Q = BIAS_OFF + 3 * C * 4;
+#ifndef W2X_MLP96_DYN
+#define W2X_MLP96_DYN 1      // 1: a workgroup's waves take their tiles from a counter in LDS instead of every twelfth one (round 6: -3.4 % per launch, frame 7.356 / 7.361 / 7.363
+                             // against 7.373 / 7.381 / 7.388 / 7.387 ms in alternating runs, profiles/r6_kernels/lib_mlp96_dyn_frame_level.txt; 0: tools/ab/lib_variants.sh "k_mlp96q.hip:-DW2X_MLP96_DYN=0").
+                             // The launch that carries the image head keeps the fixed stride: with the counter it spills two registers at 168.
+#endif
+constexpr int CTR_OFF = BIAS_OFF + 3 * C * 4;   // (W2X_MLP96_DYN) the workgroup's tile counter
+constexpr int SMEM96Q = CTR_OFF + 16;
 static_assert(RW * PPR % 64 == 0, "flat piece count");
 static_assert(SMEM96Q <= 160 * 1024, "LDS budget");
 
@@ -181,6 +187,7 @@ __global__ __launch_bounds__(NTHR, 3) void mlp96q_kernel(const MlpParams p, int 
             dst[i] = i < N1 ? w1[i] : w2[i - N1];
         }
         if (tid < 3 * C) ((float*)(smem + BIAS_OFF))[tid] = tid < 2 * C ? p.b1[tid] : p.b2[tid - 2 * C];
+        if (tid == 0) *(int*)(smem + CTR_OFF) = 0;
     }
 #if W2X_MLP_STAGGER
     // The three waves of a SIMD (wv, wv + 4, wv + 8) leave the barrier together and run the same program: left alone they stay in
@@ -205,7 +212,22 @@ __global__ __launch_bounds__(NTHR, 3) void mlp96q_kernel(const MlpParams p, int 
     half8 xr[NP];                                // this tile's rows as flat 16-byte pieces (piece k * 64 + lane)
 #define W2X_FETCH(TILE) { const unsigned vo = (unsigned)((W2X_MLP_EXP & 1) ? ((TILE) & 63) : (TILE)) * TILE_BYTES + lane * 16u;   \
         _Pragma("unroll") for (int k = 0; k < NP; ++k) xr[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(XB, vo + k * 1024u, 0, 0)); }
-    if (gw < ntiles) W2X_FETCH(gw)
+    // The workgroup's tiles are the ones its waves would walk with the fixed stride - {(blockIdx.x + j * gridDim.x) * NWV + w} - taken in that order by
+    // whichever wave is free: the t-th grab (one ds_add_rtn by lane 0) is tile (blockIdx.x + (t / NWV) * gridDim.x) * NWV + t % NWV, increasing in t, so the
+    // first grab past the end ends a wave.  The waves of a SIMD do not progress alike (three share its issue slots); with fixed strides the slowest wave's
+    // last tiles run beside empty slots (10.0 of 12 waves resident on average, profiles/r5_final/pmc_sq.summary.txt).  Which wave computes a tile does not
+    // change a bit of it.
+    constexpr bool DYN = W2X_MLP96_DYN && !TOIMG;
+    auto grab = [&]() -> int {
+        int t = 0;
+        if (lane == 0) t = atomicAdd((int*)(smem + CTR_OFF), 1);
+        t = __builtin_amdgcn_readfirstlane(t);
+        const int tl = (blockIdx.x + (t / NWV) * (int)gridDim.x) * NWV + t % NWV;
+        return tl < ntiles ? tl : ntiles;            // (ntiles: one tile past the end - its rows read zeros, its stores are dropped, the loop ends)
+    };
+    int tile = gw, next_tile = ntiles;
+    if constexpr (DYN) tile = grab();
+    if (tile < ntiles) W2X_FETCH(tile)
 #if W2X_MLP_PREFETCH
     // NP stores that the hardware drops (offset past the end), so that the first pass through the loop sees the same queue as every
     // later one - the tile's loads followed by NP stores - and the compiler's wait at the top of the loop is "all but the NP youngest"
@@ -214,7 +236,7 @@ __global__ __launch_bounds__(NTHR, 3) void mlp96q_kernel(const MlpParams p, int 
     for (int k = 0; k < NP; ++k) __builtin_amdgcn_raw_buffer_store_b128(uint4v{}, YB, 0xFFFFF000u + k * 16u, 0, 0);   // (distinct offsets: identical stores would be merged)
 #endif
 #pragma unroll 1
-    for (int tile = gw; tile < ntiles; tile += nw) {
+    for (; tile < ntiles; tile = DYN ? next_tile : tile + nw) {
         const long row0 = (long)((W2X_MLP_EXP & 1) ? (tile & 63) : tile) * RW;
         const long nrows = p.M - row0 < RW ? p.M - row0 : RW;
         // ---- x rows: flat coalesced pieces -> slab (the raw rows stay there for the residual add)
@@ -280,7 +302,10 @@ __global__ __launch_bounds__(NTHR, 3) void mlp96q_kernel(const MlpParams p, int 
                 W2X_RING_FENCE();
             }
 #if W2X_MLP_PREFETCH
-            if (ch == W2X_MLP_PFCH) { W2X_FETCH(tile + nw) W2X_RING_FENCE(); }   // the next tile's rows (past the last tile: zeros)
+            if (ch == W2X_MLP_PFCH) {                                           // the next tile's rows (past the last tile: zeros)
+                if constexpr (DYN) { next_tile = grab(); W2X_FETCH(next_tile) } else { W2X_FETCH(tile + nw) }
+                W2X_RING_FENCE();
+            }
 #endif
             // GELU in place; registers 8s .. 8s+7 of a lane are hidden rows 16s + 8(j >> 2) + 4h + (j & 3) of its token column ->
             // B fragment of k-step s of GEMM2 in the k order W2 is stored in (fragorder.h frag32_w2)
