@@ -401,7 +401,7 @@ struct Img2Img::Impl {
             // An image head that rides on the MLP launch in front of it (fuse_head, decided below) writes its output WHILE that MLP still reads its input:
             // the output must be alive from the MLP on, or it would be given the memory of the MLP's input, which dies at the MLP in the un-fused order.
             fuse_head.assign(nops, 0);
-            if (plan.elt == 2 && !switches().no_fuse_head)
+            if (plan.elt == 2 && !switches().no_fuse_head && mlp_frag32(96))      // (the head rides on k_mlp96q.hip's launch only)
                 for (int i = 0; i + 1 < nops; ++i) {
                     const Op& a = plan.ops[i]; const Op& b = plan.ops[i + 1];
                     if (a.kind == OP_MLP && b.kind == OP_GEMM && a.m.C == 96 && a.m.stats_out < 0 && b.g.a.t == a.m.y && last[a.m.y] == i + 1 && b.g.amode == A_ROWS && b.g.K == 96 && b.g.N == 64 &&
