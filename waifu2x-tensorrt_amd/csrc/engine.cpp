@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -236,6 +237,10 @@ struct Img2Img::Impl {
     std::vector<int> tensor_last;      // last op that touches each tensor (upload_plan)
     std::vector<char> fuse_stem;       // op i is the stem convolution whose 48-channel map only feeds the patch convolution that follows: op i + 1's launch computes it in its halo stage (k_conv48.hip), op i is skipped
     std::vector<char> fuse_head;       // op i is a C = 96 MLP whose rows only feed the image head that follows: one launch (k_mlp96q.hip), op i + 1 is skipped
+    // fp32 plans: op i (LayerNorm + fc1 + GELU) and op i + 1 (fc2 + residual) are one mlp32_kernel launch when the engine runs Precision::TF32 (k_f32.hip); the hidden
+    // map between them is neither written nor read.  mlp32_w[i] = the bf16 hi / lo planes of both matrices in fragment-major order (device memory, freed by release())
+    std::vector<char> fuse_mlp32;
+    std::vector<std::array<void*, 4>> mlp32_w;
 
     // frame-level buffers (grown on demand, reused across frames like the reference's input/output GpuMats, img2img.h:37-38)
     bool deep = false;                   // the frame in d_frame / d_out has 16-bit samples (Image::depth == 16)
@@ -342,6 +347,8 @@ struct Img2Img::Impl {
         frag_blobs.clear();
         for (void* p : perm_blobs) if (p) (void)hipFree(p);
         perm_blobs.clear();
+        for (auto& w : mlp32_w) for (void* p : w) if (p) (void)hipFree(p);
+        mlp32_w.clear(); fuse_mlp32.clear();
         tensors.clear(); blobs.clear(); gemm.clear(); pool_tensors.clear();
         for (void* h : pinned) if (hipHostUnregister(h) != hipSuccess) (void)hipGetLastError();
         pinned.clear();
@@ -556,6 +563,50 @@ struct Img2Img::Impl {
             if (p.a.Cs != 4 && (p.a.Cs % 8)) throw std::runtime_error("plan: unaligned input channels");
         }
         if (final_op < 0) throw std::runtime_error("plan: the output tensor is not produced by a fused op");
+        // fp32 plans: the fc1 / fc2 pairs that mlp32_kernel serves (decided here, used only while cfg.precision == TF32; lower.cpp's fuse_mlp() states the same pattern for
+        // the fp16 plan).  The plan itself stays un-fused - one engine file serves TF32 and FP32 lowering alike, Precision::FP32 runs the two launches.
+        fuse_mlp32.assign(plan.ops.size(), 0);
+        mlp32_w.assign(plan.ops.size(), std::array<void*, 4>{{nullptr, nullptr, nullptr, nullptr}});
+        if (plan.elt == 4 && !switches().no_fuse)
+            for (size_t i = 0; i + 1 < plan.ops.size(); ++i) {
+                if (plan.ops[i].kind != OP_GEMM || plan.ops[i + 1].kind != OP_GEMM) continue;
+                const GemmOp& g1 = plan.ops[i].g; const GemmOp& g2 = plan.ops[i + 1].g;
+                const int Cm = g1.K;
+                auto whole = [&](const View& v) { const TensorDesc& t = plan.tensors[v.t]; return v.y0 == 0 && v.x0 == 0 && v.H == t.H && v.W == t.W; };
+                if (!(mlp32_supported(Cm) && g1.amode == A_ROWS && g1.ln && g1.stats_in >= 0 && g1.act == ACT_GELU && g1.omode == O_ROWS && g1.res.t < 0 && g1.res2.t < 0 && !g1.has_clip &&
+                      g1.N == 2 * Cm && g1.stats_out < 0 && g1.pool_out < 0 && g1.se_scale < 0 && whole(g1.a) && whole(g1.out) && plan.tensors[g1.a.t].C == Cm && plan.tensors[g1.out.t].C == 2 * Cm &&
+                      g1.Mrows == plan.tensors[g1.a.t].H * plan.tensors[g1.a.t].W &&
+                      g2.amode == A_ROWS && !g2.ln && g2.act == ACT_NONE && g2.omode == O_ROWS && g2.a.t == g1.out.t && g2.K == 2 * Cm && g2.N == Cm && g2.res.t == g1.a.t && g2.res2.t < 0 &&
+                      !g2.has_clip && g2.pool_out < 0 && g2.se_scale < 0 && g2.res_scale < 0 && whole(g2.a) && whole(g2.res) && whole(g2.out) && plan.tensors[g2.out.t].C == Cm && g2.Mrows == g1.Mrows &&
+                      g1.out.t != plan.out_tensor)) continue;
+                int hidden_users = 0;
+                for (const Op& o : plan.ops) {
+                    if (o.kind == OP_GEMM && (o.g.a.t == g1.out.t || o.g.res.t == g1.out.t || o.g.res2.t == g1.out.t)) ++hidden_users;
+                    if (o.kind == OP_ATTN && o.at.qkv == g1.out.t) ++hidden_users;
+                }
+                if (hidden_users != 1) continue;
+                const auto& w1 = plan.blobs[g1.w].data; const auto& w2 = plan.blobs[g2.w].data;
+                if (w1.size() != (size_t)2 * Cm * Cm * 4 || w2.size() != w1.size()) continue;      // fp32 [2C][C] and [C][2C], rows unpadded (K is a multiple of 8)
+                auto planes = [&](const std::vector<uint8_t>& w, int N, int K, void*& dh, void*& dl) {
+                    std::vector<uint16_t> hi((size_t)N * K), lo((size_t)N * K);
+                    const float* f = (const float*)w.data();
+                    for (size_t k = 0; k < hi.size(); ++k) {      // split4 of k_f32.hip on the host: hi = bf16(x), lo = bf16(x - hi), round to nearest even
+                        auto bf = [](float x) { uint32_t u; memcpy(&u, &x, 4); return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); };
+                        const uint16_t h = bf(f[k]);
+                        uint32_t hu = (uint32_t)h << 16; float hf; memcpy(&hf, &hu, 4);
+                        hi[k] = h; lo[k] = bf(f[k] - hf);
+                    }
+                    for (int pl = 0; pl < 2; ++pl) {
+                        const std::vector<uint16_t> fr = frag_major(pl ? lo.data() : hi.data(), N, K);
+                        void*& d = pl ? dl : dh;
+                        hipAssert(hipMalloc(&d, fr.size() * 2 + 256));
+                        hipAssert(hipMemcpy(d, fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
+                    }
+                };
+                planes(w1, 2 * Cm, Cm, mlp32_w[i][0], mlp32_w[i][1]);
+                planes(w2, Cm, 2 * Cm, mlp32_w[i][2], mlp32_w[i][3]);
+                fuse_mlp32[i] = 1;
+            }
         // The image head (Linear 96 -> 4x4 sub-pixels x 4 channels, Clip) behind the last MLP: its input rows have no other reader, so the MLP launch
         // runs the head on every tile it produces and neither stores nor re-reads the 96-channel map (switches.h no_fuse_head keeps the two launches).
         for (size_t i = 0; i + 1 < plan.ops.size(); ++i)       // the candidates of the arena pass above, now with the prepared launch parameters
@@ -610,6 +661,19 @@ struct Img2Img::Impl {
                         p.a_scale = (const float*)shift(p.a_scale, g.se_scale); p.res_scale = (const float*)shift(p.res_scale, g.res_scale);
                     }
                     if ((int)i == final_op && out_override) p.out.p = out_override;
+                    if (fuse_mlp32[i] && cfg.precision == Precision::TF32) {      // fc1 + GELU + fc2 + residual on fp32 rows in one launch; op i + 1 is skipped
+                        GemmParams q = gemm[i + 1];
+                        if (b0) { const GemmOp& g2 = plan.ops[i + 1].g; q.out.p = shift(q.out.p, g2.out.t); q.stats_out = (float*)shift(q.stats_out, g2.stats_out); }
+                        Mlp32Params m;
+                        m.x = (const float*)p.a.p; m.y = (float*)q.out.p; m.M = (long)live * p.Mrows; m.C = p.K; m.stats_in = p.stats_in;
+                        m.w1h = mlp32_w[i][0]; m.w1l = mlp32_w[i][1]; m.w2h = mlp32_w[i][2]; m.w2l = mlp32_w[i][3];
+                        m.b1 = p.bias; m.b2 = q.bias; m.stats_out = q.stats_out; m.eps_out = q.ln_eps;
+                        stamp_begin(0, op.flops + plan.ops[i + 1].flops);
+                        hipAssert(launch_mlp32(m, s));
+                        stamp_end();
+                        skip_next = true;
+                        break;
+                    }
                     if (fuse_stem[i] && !check_general) { stem_p = p; stem_held = true; stem_flops = op.flops; break; }    // computed by the next op's launch
                     if (stem_held) {
                         stem_held = false;

@@ -447,7 +447,202 @@ __global__ __launch_bounds__(256) void attn32_kernel(const AttnParams p) {
     }
 }
 
+// ---- fused transformer MLP branch on fp32 rows, Precision::TF32 (round 6) ---------------------------------------------------------------
+//     y = x + W2 gelu(W1 LayerNorm(x) + b1) + b2          rows [M][C] fp32, C = 96 / 192, hidden 2C
+// The un-fused fp32 plan runs this as two gemm32 launches with the hidden map [M][2C] in HBM between them: 2.1 GB written and read again per full-resolution
+// block of config 3, more than x and y together (1.06 GB each) - fc1 + fc2 were 19.5 of the frame's 49.8 ms.  Here a workgroup of six waves owns 64 rows:
+//   * the rows are normalised with the producer's statistics (mean, rstd per row: the plan's stats tensor), split x = hi + lo into two bf16 planes (split4)
+//     and stay in LDS for the first product;
+//   * the hidden units go by in chunks of 96: wave w computes units 16 w .. 16 w + 15 of the chunk for all 64 rows - transposed (rows = hidden units,
+//     columns = tokens), three v_mfma_f32_16x16x32_bf16 per k-step as in gemm32_kernel (lo hi + hi lo + hi hi) - adds b1, applies GELU (gelu_poly) and writes
+//     the result, split again, as 8-byte pieces into the chunk's hidden tile in LDS (a lane holds four consecutive units of one token);
+//   * the second product accumulates out^T (rows = output channels, columns = tokens) over the chunks, wave w owning C / 6 output channels; a lane ends with
+//     four consecutive channels of a token: + b2 + x (read again, a cache hit), 16-byte stores;
+//   * weights never enter LDS: the host keeps both matrices as bf16 hi / lo planes in fragment-major order (fragorder.h frag_major), a fragment is one
+//     coalesced KiB per wave, requested a whole chunk ahead;
+//   * LayerNorm statistics of the produced rows (for an un-fused consumer): two passes like gemm32_kernel's epilogue (mean, then the squared distances),
+//     per-wave partial sums through LDS added in wave order - the same bits on every run.
+// Precision::FP32 (exact products) keeps the two launches.
+template <int C>
+__global__ __launch_bounds__(384, 3) void mlp32_kernel(const Mlp32Params p) {
+    constexpr int BM = 64, TT = BM / 16, HC = 96, NCH = 2 * C / HC, KS1 = C / 32, KS2 = HC / 32, NT2 = C / HC;
+    constexpr int LDX = C + 8, LDHH = HC + 8;                        // bf16 per row: 16-byte aligned rows that rotate over the banks
+    static_assert(C % HC == 0 && (2 * C) % HC == 0, "widths in chunks of 96");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned short* XH = (unsigned short*)smem;
+    unsigned short* XL = XH + BM * LDX;
+    unsigned short* HH = XL + BM * LDX;
+    unsigned short* HL = HH + BM * LDHH;
+    float* red = (float*)smem;                                        // [6 waves][BM] partial row sums; over the x planes, which are done with by then
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fk = lane >> 4;
+    const long row0 = (long)blockIdx.x * BM;
+
+    // ---- rows in: normalise, split, two planes in LDS (rows past the end: zeros)
+    for (int idx = tid; idx < BM * (C / 4); idx += 384) {
+        const int row = idx / (C / 4), c4 = idx - row * (C / 4);
+        const long r = row0 + row;
+        float4v v = {0.f, 0.f, 0.f, 0.f};
+        float mean = 0.f, rstd = 0.f;
+        if (r < p.M) { v = *(const float4v*)(p.x + r * C + c4 * 4); mean = p.stats_in[2 * r]; rstd = p.stats_in[2 * r + 1]; }
+        uint2v hi, lo;
+        split4((float4v){(v[0] - mean) * rstd, (v[1] - mean) * rstd, (v[2] - mean) * rstd, (v[3] - mean) * rstd}, hi, lo);
+        *(uint2v*)(XH + row * LDX + c4 * 4) = hi;
+        *(uint2v*)(XL + row * LDX + c4 * 4) = lo;
+    }
+    const bf16x8* W1H = (const bf16x8*)p.w1h + lane;                  // [2C / 16 row tiles][KS1][64 lanes][8]
+    const bf16x8* W1L = (const bf16x8*)p.w1l + lane;
+    const bf16x8* W2H = (const bf16x8*)p.w2h + lane;                  // [C / 16 row tiles][2C / 32 k-steps][64 lanes][8]
+    const bf16x8* W2L = (const bf16x8*)p.w2l + lane;
+    float4v acc2[NT2][TT];
+#pragma unroll
+    for (int n = 0; n < NT2; ++n)
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) acc2[n][tt] = (float4v){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+#pragma unroll 1
+    for (int hc = 0; hc < NCH; ++hc) {
+        // ---- first product, this wave's 16 hidden units of the chunk: weights requested for the whole chunk at once
+        const int ht = hc * (HC / 16) + wv;                           // hidden row tile
+        bf16x8 wh[KS1], wl[KS1];
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) { wh[ks] = W1H[(size_t)(ht * KS1 + ks) * 64]; wl[ks] = W1L[(size_t)(ht * KS1 + ks) * 64]; }
+        // (the second product's fragments of this chunk too: they travel under the first product and the GELU)
+        bf16x8 vh[NT2][KS2], vl[NT2][KS2];
+#pragma unroll
+        for (int n = 0; n < NT2; ++n)
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) {
+                const size_t f = (size_t)((wv * NT2 + n) * (2 * C / 32) + hc * KS2 + ks) * 64;
+                vh[n][ks] = W2H[f]; vl[n][ks] = W2L[f];
+            }
+        float4v acc1[TT];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) acc1[tt] = (float4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+                const bf16x8 xh = *(const bf16x8*)(XH + (tt * 16 + frow) * LDX + ks * 32 + fk * 8);
+                const bf16x8 xl = *(const bf16x8*)(XL + (tt * 16 + frow) * LDX + ks * 32 + fk * 8);
+                acc1[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks], xh, acc1[tt], 0, 0, 0);
+                acc1[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], xl, acc1[tt], 0, 0, 0);
+                acc1[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], xh, acc1[tt], 0, 0, 0);
+            }
+        // ---- + b1, GELU, split: a lane holds hidden units 16 ht + 4 fk .. + 3 of token 16 tt + frow
+        const float4v b1v = *(const float4v*)(p.b1 + ht * 16 + fk * 4);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            float4v h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = gelu_poly(acc1[tt][e] + b1v[e]);
+            uint2v hi, lo;
+            split4(h, hi, lo);
+            *(uint2v*)(HH + (tt * 16 + frow) * LDHH + wv * 16 + fk * 4) = hi;
+            *(uint2v*)(HL + (tt * 16 + frow) * LDHH + wv * 16 + fk * 4) = lo;
+        }
+        __syncthreads();
+        // ---- second product over the chunk's 96 hidden units: this wave's output channels
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks)
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+                const bf16x8 hh = *(const bf16x8*)(HH + (tt * 16 + frow) * LDHH + ks * 32 + fk * 8);
+                const bf16x8 hl = *(const bf16x8*)(HL + (tt * 16 + frow) * LDHH + ks * 32 + fk * 8);
+#pragma unroll
+                for (int n = 0; n < NT2; ++n) {
+                    acc2[n][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl[n][ks], hh, acc2[n][tt], 0, 0, 0);
+                    acc2[n][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[n][ks], hl, acc2[n][tt], 0, 0, 0);
+                    acc2[n][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[n][ks], hh, acc2[n][tt], 0, 0, 0);
+                }
+            }
+        __syncthreads();                                              // the next chunk's hidden tile goes over this one (after the last chunk: the planes are free)
+    }
+
+    // ---- + b2 + x, stores: a lane holds output channels 16 (wv NT2 + n) + 4 fk .. + 3 of token 16 tt + frow
+    float rsum[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) rsum[tt] = 0.f;
+#pragma unroll
+    for (int n = 0; n < NT2; ++n) {
+        const int ch = (wv * NT2 + n) * 16 + fk * 4;
+        const float4v b2v = *(const float4v*)(p.b2 + ch);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            const long r = row0 + tt * 16 + frow;
+            float4v v = acc2[n][tt] + b2v;
+            if (r < p.M) {
+                v += *(const float4v*)(p.x + r * C + ch);
+                *(float4v*)(p.y + r * C + ch) = v;
+            } else v = (float4v){0.f, 0.f, 0.f, 0.f};
+            acc2[n][tt] = v;
+            rsum[tt] += v[0] + v[1] + v[2] + v[3];
+        }
+    }
+    if (p.stats_out) {                                                // uniform
+        auto reduce_rows = [&](float (&part)[TT], float (&total)[TT]) {   // sums over the four lane groups, then over the six waves in wave order
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+                float v = part[tt];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (fk == 0) red[wv * BM + tt * 16 + frow] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < 6; ++w) t += red[w * BM + tt * 16 + frow];
+                total[tt] = t;
+            }
+            __syncthreads();
+        };
+        float tot[TT], mean[TT], sq[TT];
+        reduce_rows(rsum, tot);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            mean[tt] = tot[tt] / (float)C;
+            float q = 0.f;
+#pragma unroll
+            for (int n = 0; n < NT2; ++n)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = acc2[n][tt][e] - mean[tt]; q += d * d; }
+            sq[tt] = q;
+        }
+        reduce_rows(sq, tot);
+        if (wv == 0 && fk == 0) {
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+                const long r = row0 + tt * 16 + frow;
+                if (r < p.M) { p.stats_out[2 * r] = mean[tt]; p.stats_out[2 * r + 1] = rsqrtf(tot[tt] / (float)C + p.eps_out); }
+            }
+        }
+    }
+}
+
+template <int C>
+hipError_t launch_mlp32_c(const Mlp32Params& p, hipStream_t s) {
+    constexpr int SMEM = 64 * (C + 8) * 2 * 2 + 64 * (96 + 8) * 2 * 2;
+    static_assert(SMEM >= 6 * 64 * 4, "the statistics' partial sums fit the x planes");
+    static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
+    if (hipError_t e = ensure_dynamic_lds((const void*)mlp32_kernel<C>, SMEM, lds_ok); e != hipSuccess) return e;
+    hipLaunchKernelGGL(mlp32_kernel<C>, dim3((unsigned)((p.M + 63) / 64)), dim3(384), SMEM, s, p);
+    return hipGetLastError();
+}
+
 }  // namespace
+
+bool mlp32_supported(int C) { return C == 96 || C == 192; }
+hipError_t launch_mlp32(const Mlp32Params& p, hipStream_t s) {
+    if (p.M <= 0 || !p.x || !p.y || !p.stats_in || !p.w1h || !p.w1l || !p.w2h || !p.w2l || !p.b1 || !p.b2) return hipErrorInvalidValue;
+    if (p.C == 96) return launch_mlp32_c<96>(p, s);
+    if (p.C == 192) return launch_mlp32_c<192>(p, s);
+    return hipErrorInvalidValue;
+}
 
 // Tile selection as in launch_gemm (k_gemm.hip): the tile width follows N; pixel-shuffle outputs take whole output pixels.
 hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s, bool exact) {

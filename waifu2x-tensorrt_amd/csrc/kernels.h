@@ -162,6 +162,19 @@ hipError_t launch_attn(const AttnParams& p, hipStream_t s);
 // k_f32.hip: the fp32 engine's kernels (Plan::elt == 4): general GEMM / convolution and the window attention core on fp32 rows
 hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s, bool exact);      // exact: fp32 products (Precision::FP32); else three bf16 products per k-step (Precision::TF32)
 hipError_t launch_attn_f32(const AttnParams& p, hipStream_t s);
+// Fused MLP branch on fp32 rows with split-bf16 products (Precision::TF32; k_f32.hip mlp32_kernel): y = x + W2 gelu(W1 ((x - mean) rstd) + b1) + b2, the row statistics
+// from the producer's stats tensor.  w1h / w1l, w2h / w2l: the bf16 hi / lo planes of W1 [2C][C] (LayerNorm gamma folded) and W2 [C][2C] in fragment-major order
+// (fragorder.h frag_major of each plane).  The engine launches it in place of an fc1 / fc2 pair of gemm32 launches.
+struct Mlp32Params {
+    const float* x = nullptr; float* y = nullptr;
+    long M = 0; int C = 0;
+    const float* stats_in = nullptr;     // [M][2]: mean, rstd
+    const void *w1h = nullptr, *w1l = nullptr, *w2h = nullptr, *w2l = nullptr;
+    const float *b1 = nullptr, *b2 = nullptr;
+    float* stats_out = nullptr; float eps_out = 1e-5f;
+};
+bool mlp32_supported(int C);
+hipError_t launch_mlp32(const Mlp32Params& p, hipStream_t s);
 hipError_t launch_mlp(const MlpParams& p, hipStream_t s);
 hipError_t launch_swin_attn(const SwinAttnParams& p, hipStream_t s);
 // swin_attn_supported / mlp_supported / gemm_row_stats_supported / attn_supported: support.h
