@@ -241,6 +241,10 @@ struct Img2Img::Impl {
     // map between them is neither written nor read.  mlp32_w[i] = the bf16 hi / lo planes of both matrices in fragment-major order (device memory, freed by release())
     std::vector<char> fuse_mlp32;
     std::vector<std::array<void*, 4>> mlp32_w;
+    // ... and op i (LayerNorm + window gather + qkv), op i + 1 (attention core), op i + 2 (proj + window scatter + residual) are one swinattn32_kernel launch;
+    // attn32_w[i] = the planes of Wqkv and Wproj
+    std::vector<char> fuse_attn32;
+    std::vector<std::array<void*, 4>> attn32_w;
 
     // frame-level buffers (grown on demand, reused across frames like the reference's input/output GpuMats, img2img.h:37-38)
     bool deep = false;                   // the frame in d_frame / d_out has 16-bit samples (Image::depth == 16)
@@ -349,6 +353,8 @@ struct Img2Img::Impl {
         perm_blobs.clear();
         for (auto& w : mlp32_w) for (void* p : w) if (p) (void)hipFree(p);
         mlp32_w.clear(); fuse_mlp32.clear();
+        for (auto& w : attn32_w) for (void* p : w) if (p) (void)hipFree(p);
+        attn32_w.clear(); fuse_attn32.clear();
         tensors.clear(); blobs.clear(); gemm.clear(); pool_tensors.clear();
         for (void* h : pinned) if (hipHostUnregister(h) != hipSuccess) (void)hipGetLastError();
         pinned.clear();
@@ -383,6 +389,62 @@ struct Img2Img::Impl {
         return t;
     }
 
+    // fp32 plans, Precision::TF32: which runs of un-fused ops one fused launch of k_f32.hip serves.  Facts of the plan alone (lower.cpp's fuse_mlp() / fuse_attn() state
+    // the same patterns for the fp16 plan); the plan itself stays un-fused - one lowering serves TF32 and FP32, and Precision::FP32 runs every launch.
+    bool whole_view(const View& v) const { if (v.t < 0) return false; const TensorDesc& t = plan.tensors[v.t]; return v.y0 == 0 && v.x0 == 0 && v.H == t.H && v.W == t.W; }
+    int readers_of(int t) const {
+        int n = 0;
+        for (const Op& o : plan.ops) {
+            if (o.kind == OP_GEMM && (o.g.a.t == t || o.g.res.t == t || o.g.res2.t == t)) ++n;
+            if (o.kind == OP_ATTN && o.at.qkv == t) ++n;
+        }
+        return n;
+    }
+    bool mlp32_pair(size_t i) const {
+        if (plan.elt != 4 || switches().no_fuse || i + 1 >= plan.ops.size() || plan.ops[i].kind != OP_GEMM || plan.ops[i + 1].kind != OP_GEMM) return false;
+        const GemmOp& g1 = plan.ops[i].g; const GemmOp& g2 = plan.ops[i + 1].g;
+        const int Cm = g1.K;
+        return mlp32_supported(Cm) && g1.amode == A_ROWS && g1.ln && g1.stats_in >= 0 && g1.act == ACT_GELU && g1.omode == O_ROWS && g1.res.t < 0 && g1.res2.t < 0 && !g1.has_clip &&
+               g1.N == 2 * Cm && g1.stats_out < 0 && g1.pool_out < 0 && g1.se_scale < 0 && whole_view(g1.a) && whole_view(g1.out) && plan.tensors[g1.a.t].C == Cm && plan.tensors[g1.out.t].C == 2 * Cm &&
+               g1.Mrows == plan.tensors[g1.a.t].H * plan.tensors[g1.a.t].W &&
+               g2.amode == A_ROWS && !g2.ln && g2.act == ACT_NONE && g2.omode == O_ROWS && g2.a.t == g1.out.t && g2.K == 2 * Cm && g2.N == Cm && g2.res.t == g1.a.t && g2.res2.t < 0 &&
+               !g2.has_clip && g2.pool_out < 0 && g2.se_scale < 0 && g2.res_scale < 0 && whole_view(g2.a) && whole_view(g2.res) && whole_view(g2.out) && plan.tensors[g2.out.t].C == Cm && g2.Mrows == g1.Mrows &&
+               g1.out.t != plan.out_tensor && readers_of(g1.out.t) == 1 &&
+               plan.blobs[g1.w].data.size() == (size_t)2 * Cm * Cm * 4 && plan.blobs[g2.w].data.size() == (size_t)2 * Cm * Cm * 4;      // fp32 [2C][C] and [C][2C], rows unpadded
+    }
+    bool attn32_triple(size_t i) const {
+        if (plan.elt != 4 || switches().no_fuse || switches().no_fuse_attn || i + 2 >= plan.ops.size() || plan.ops[i].kind != OP_GEMM || plan.ops[i + 1].kind != OP_ATTN || plan.ops[i + 2].kind != OP_GEMM) return false;
+        const GemmOp& g1 = plan.ops[i].g; const AttnOp& a = plan.ops[i + 1].at; const GemmOp& g2 = plan.ops[i + 2].g;
+        const int Cm = g1.K;
+        return swinattn32_supported(Cm, a.heads, a.hd, a.ws * a.ws) && a.heads * a.hd == Cm &&
+               g1.amode == A_WIN && g1.win_table >= 0 && g1.ln && g1.stats_in >= 0 && g1.act == ACT_NONE && g1.omode == O_ROWS && g1.res.t < 0 && g1.res2.t < 0 && !g1.has_clip && g1.N == 3 * Cm &&
+               g1.stats_out < 0 && g1.pool_out < 0 && g1.se_scale < 0 && whole_view(g1.a) && whole_view(g1.out) && plan.tensors[g1.a.t].C == Cm && plan.tensors[g1.out.t].C == 3 * Cm &&
+               g1.Mrows == a.nwin * a.ws * a.ws && g1.Mrows == plan.tensors[g1.a.t].H * plan.tensors[g1.a.t].W &&
+               a.qkv == g1.out.t && a.bias >= 0 && a.maskid >= 0 &&
+               g2.amode == A_ROWS && g2.a.t == a.out && !g2.ln && g2.act == ACT_NONE && g2.omode == O_WIN && g2.win_table >= 0 && g2.K == Cm && g2.N == Cm && g2.res.t == g1.a.t && g2.res2.t < 0 &&
+               !g2.has_clip && g2.pool_out < 0 && g2.se_scale < 0 && g2.res_scale < 0 && whole_view(g2.a) && whole_view(g2.res) && whole_view(g2.out) && plan.tensors[g2.out.t].C == Cm &&
+               plan.tensors[g2.out.t].H * plan.tensors[g2.out.t].W == g1.Mrows && g2.Mrows == g1.Mrows &&
+               g1.out.t != plan.out_tensor && a.out != plan.out_tensor && readers_of(g1.out.t) == 1 && readers_of(a.out) == 1 &&
+               plan.blobs[g1.w].data.size() == (size_t)3 * Cm * Cm * 4 && plan.blobs[g2.w].data.size() == (size_t)Cm * Cm * 4;
+    }
+    // the bf16 hi / lo planes of an fp32 matrix [N][K] in fragment-major order (split4 of k_f32.hip on the host: hi = bf16(x), lo = bf16(x - hi), round to nearest even)
+    void upload_planes(const std::vector<uint8_t>& w, int N, int K, void*& dh, void*& dl) {
+        std::vector<uint16_t> hi((size_t)N * K), lo((size_t)N * K);
+        const float* f = (const float*)w.data();
+        auto bf = [](float x) { uint32_t u; memcpy(&u, &x, 4); return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); };
+        for (size_t k = 0; k < hi.size(); ++k) {
+            const uint16_t h = bf(f[k]);
+            const uint32_t hu = (uint32_t)h << 16; float hf; memcpy(&hf, &hu, 4);
+            hi[k] = h; lo[k] = bf(f[k] - hf);
+        }
+        for (int pl = 0; pl < 2; ++pl) {
+            const std::vector<uint16_t> fr = frag_major(pl ? lo.data() : hi.data(), N, K);
+            void*& d = pl ? dl : dh;
+            hipAssert(hipMalloc(&d, fr.size() * 2 + 256));
+            hipAssert(hipMemcpy(d, fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
+        }
+    }
+
     void upload_plan() {
         // Activation arena: tensors whose lifetimes (first writer .. last reader, in op order) do not overlap share
         // memory.  An op's outputs are placed before its inputs are released, so no op reads and writes one address.
@@ -407,6 +469,18 @@ struct Img2Img::Impl {
             last[plan.out_tensor] = nops;                     // read after the last op (infer) / replaced by the frame slab
             // An image head that rides on the MLP launch in front of it (fuse_head, decided below) writes its output WHILE that MLP still reads its input:
             // the output must be alive from the MLP on, or it would be given the memory of the MLP's input, which dies at the MLP in the un-fused order.
+            // fp32 plans: a fused launch (mlp32_kernel / swinattn32_kernel) writes the LAST op's outputs while it still reads the first op's inputs - the row statistics among
+            // them, which die at the first op in the un-fused order: the outputs are alive from the first op on
+            fuse_mlp32.assign(nops, 0); fuse_attn32.assign(nops, 0);
+            for (int i = 0; i < nops; ++i) {
+                const int span = attn32_triple((size_t)i) ? 2 : mlp32_pair((size_t)i) ? 1 : 0;
+                if (!span) continue;
+                (span == 2 ? fuse_attn32 : fuse_mlp32)[i] = 1;
+                const GemmOp& gl = plan.ops[i + span].g;
+                first[gl.out.t] = std::min(first[gl.out.t], i);
+                if (gl.stats_out >= 0) first[gl.stats_out] = std::min(first[gl.stats_out], i);
+                i += span;
+            }
             fuse_head.assign(nops, 0);
             if (plan.elt == 2 && !switches().no_fuse_head && mlp_frag32(96))      // (the head rides on k_mlp96q.hip's launch only)
                 for (int i = 0; i + 1 < nops; ++i) {
@@ -563,50 +637,21 @@ struct Img2Img::Impl {
             if (p.a.Cs != 4 && (p.a.Cs % 8)) throw std::runtime_error("plan: unaligned input channels");
         }
         if (final_op < 0) throw std::runtime_error("plan: the output tensor is not produced by a fused op");
-        // fp32 plans: the fc1 / fc2 pairs that mlp32_kernel serves (decided here, used only while cfg.precision == TF32; lower.cpp's fuse_mlp() states the same pattern for
-        // the fp16 plan).  The plan itself stays un-fused - one engine file serves TF32 and FP32 lowering alike, Precision::FP32 runs the two launches.
-        fuse_mlp32.assign(plan.ops.size(), 0);
+        // fp32 plans: the weights of the fused launches decided above (used only while cfg.precision == TF32)
         mlp32_w.assign(plan.ops.size(), std::array<void*, 4>{{nullptr, nullptr, nullptr, nullptr}});
-        if (plan.elt == 4 && !switches().no_fuse)
-            for (size_t i = 0; i + 1 < plan.ops.size(); ++i) {
-                if (plan.ops[i].kind != OP_GEMM || plan.ops[i + 1].kind != OP_GEMM) continue;
+        attn32_w.assign(plan.ops.size(), std::array<void*, 4>{{nullptr, nullptr, nullptr, nullptr}});
+        for (size_t i = 0; i < plan.ops.size(); ++i) {
+            if (fuse_mlp32[i]) {
                 const GemmOp& g1 = plan.ops[i].g; const GemmOp& g2 = plan.ops[i + 1].g;
-                const int Cm = g1.K;
-                auto whole = [&](const View& v) { const TensorDesc& t = plan.tensors[v.t]; return v.y0 == 0 && v.x0 == 0 && v.H == t.H && v.W == t.W; };
-                if (!(mlp32_supported(Cm) && g1.amode == A_ROWS && g1.ln && g1.stats_in >= 0 && g1.act == ACT_GELU && g1.omode == O_ROWS && g1.res.t < 0 && g1.res2.t < 0 && !g1.has_clip &&
-                      g1.N == 2 * Cm && g1.stats_out < 0 && g1.pool_out < 0 && g1.se_scale < 0 && whole(g1.a) && whole(g1.out) && plan.tensors[g1.a.t].C == Cm && plan.tensors[g1.out.t].C == 2 * Cm &&
-                      g1.Mrows == plan.tensors[g1.a.t].H * plan.tensors[g1.a.t].W &&
-                      g2.amode == A_ROWS && !g2.ln && g2.act == ACT_NONE && g2.omode == O_ROWS && g2.a.t == g1.out.t && g2.K == 2 * Cm && g2.N == Cm && g2.res.t == g1.a.t && g2.res2.t < 0 &&
-                      !g2.has_clip && g2.pool_out < 0 && g2.se_scale < 0 && g2.res_scale < 0 && whole(g2.a) && whole(g2.res) && whole(g2.out) && plan.tensors[g2.out.t].C == Cm && g2.Mrows == g1.Mrows &&
-                      g1.out.t != plan.out_tensor)) continue;
-                int hidden_users = 0;
-                for (const Op& o : plan.ops) {
-                    if (o.kind == OP_GEMM && (o.g.a.t == g1.out.t || o.g.res.t == g1.out.t || o.g.res2.t == g1.out.t)) ++hidden_users;
-                    if (o.kind == OP_ATTN && o.at.qkv == g1.out.t) ++hidden_users;
-                }
-                if (hidden_users != 1) continue;
-                const auto& w1 = plan.blobs[g1.w].data; const auto& w2 = plan.blobs[g2.w].data;
-                if (w1.size() != (size_t)2 * Cm * Cm * 4 || w2.size() != w1.size()) continue;      // fp32 [2C][C] and [C][2C], rows unpadded (K is a multiple of 8)
-                auto planes = [&](const std::vector<uint8_t>& w, int N, int K, void*& dh, void*& dl) {
-                    std::vector<uint16_t> hi((size_t)N * K), lo((size_t)N * K);
-                    const float* f = (const float*)w.data();
-                    for (size_t k = 0; k < hi.size(); ++k) {      // split4 of k_f32.hip on the host: hi = bf16(x), lo = bf16(x - hi), round to nearest even
-                        auto bf = [](float x) { uint32_t u; memcpy(&u, &x, 4); return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); };
-                        const uint16_t h = bf(f[k]);
-                        uint32_t hu = (uint32_t)h << 16; float hf; memcpy(&hf, &hu, 4);
-                        hi[k] = h; lo[k] = bf(f[k] - hf);
-                    }
-                    for (int pl = 0; pl < 2; ++pl) {
-                        const std::vector<uint16_t> fr = frag_major(pl ? lo.data() : hi.data(), N, K);
-                        void*& d = pl ? dl : dh;
-                        hipAssert(hipMalloc(&d, fr.size() * 2 + 256));
-                        hipAssert(hipMemcpy(d, fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
-                    }
-                };
-                planes(w1, 2 * Cm, Cm, mlp32_w[i][0], mlp32_w[i][1]);
-                planes(w2, Cm, 2 * Cm, mlp32_w[i][2], mlp32_w[i][3]);
-                fuse_mlp32[i] = 1;
+                upload_planes(plan.blobs[g1.w].data, 2 * g1.K, g1.K, mlp32_w[i][0], mlp32_w[i][1]);
+                upload_planes(plan.blobs[g2.w].data, g1.K, 2 * g1.K, mlp32_w[i][2], mlp32_w[i][3]);
             }
+            if (fuse_attn32[i]) {
+                const GemmOp& g1 = plan.ops[i].g; const GemmOp& g2 = plan.ops[i + 2].g;
+                upload_planes(plan.blobs[g1.w].data, 3 * g1.K, g1.K, attn32_w[i][0], attn32_w[i][1]);
+                upload_planes(plan.blobs[g2.w].data, g1.K, g1.K, attn32_w[i][2], attn32_w[i][3]);
+            }
+        }
         // The image head (Linear 96 -> 4x4 sub-pixels x 4 channels, Clip) behind the last MLP: its input rows have no other reader, so the MLP launch
         // runs the head on every tile it produces and neither stores nor re-reads the 96-channel map (switches.h no_fuse_head keeps the two launches).
         for (size_t i = 0; i + 1 < plan.ops.size(); ++i)       // the candidates of the arena pass above, now with the prepared launch parameters
@@ -642,7 +687,8 @@ struct Img2Img::Impl {
         auto tp = [&](int t) -> uint8_t* { return t < 0 ? nullptr : grp < 0 ? (uint8_t*)tensors[t] : group_ptr(tensors[t], grp); };
         auto shift = [&](const void* ptr, int) -> void* { return group_ptr(ptr, grp); };
         const int b0 = grp < 0 ? 0 : 1;   // (non-zero: re-address the prepared parameters)
-        bool skip_next = false;           // the op was folded into the previous launch (fuse_head)
+        bool skip_next = false;           // the op was folded into the previous launch (fuse_head, mlp32)
+        int skip_attn32 = 0;              // ops still to skip behind a swinattn32 launch
         GemmParams stem_p; bool stem_held = false; double stem_flops = 0;   // the op is folded into the NEXT launch (fuse_stem): its re-addressed parameters wait here
         for (size_t i = 0; i < plan.ops.size(); ++i) try {
             const Op& op = plan.ops[i];
@@ -652,6 +698,7 @@ struct Img2Img::Impl {
             switch (op.kind) {
                 case OP_GEMM: {
                     if (skip_next) { skip_next = false; break; }
+                    if (skip_attn32) { --skip_attn32; break; }
                     GemmParams p = gemm[i];
                     p.B = live;
                     if (b0) {
@@ -661,6 +708,22 @@ struct Img2Img::Impl {
                         p.a_scale = (const float*)shift(p.a_scale, g.se_scale); p.res_scale = (const float*)shift(p.res_scale, g.res_scale);
                     }
                     if ((int)i == final_op && out_override) p.out.p = out_override;
+                    if (fuse_attn32[i] && cfg.precision == Precision::TF32) {     // LayerNorm + window gather + qkv, attention core, proj + scatter + residual in one launch
+                        const AttnOp& a = plan.ops[i + 1].at;
+                        GemmParams q = gemm[i + 2];
+                        if (b0) { const GemmOp& g2 = plan.ops[i + 2].g; q.out.p = shift(q.out.p, g2.out.t); q.res.p = shift(q.res.p, g2.res.t); q.stats_out = (float*)shift(q.stats_out, g2.stats_out); }
+                        SwinAttn32Params m;
+                        m.x = (const float*)p.a.p; m.y = (float*)q.out.p; m.res = (const float*)q.res.p; m.B = live; m.nwin = a.nwin; m.C = p.K; m.pix_per_item = p.Mrows;
+                        m.table_in = p.win_table; m.table_out = q.win_table; m.stats_in = p.stats_in;
+                        m.wqkv_h = attn32_w[i][0]; m.wqkv_l = attn32_w[i][1]; m.wproj_h = attn32_w[i][2]; m.wproj_l = attn32_w[i][3];
+                        m.bqkv = p.bias; m.bproj = q.bias; m.scale = a.scale; m.bias = (const float*)blobs[a.bias]; m.maskid = (const int*)blobs[a.maskid];
+                        m.stats_out = q.stats_out; m.eps_out = q.ln_eps;
+                        stamp_begin(1, op.flops + plan.ops[i + 1].flops + plan.ops[i + 2].flops);
+                        hipAssert(launch_swinattn32(m, s));
+                        stamp_end();
+                        skip_attn32 = 1;          // (the attention op skips itself below, then the proj op here)
+                        break;
+                    }
                     if (fuse_mlp32[i] && cfg.precision == Precision::TF32) {      // fc1 + GELU + fc2 + residual on fp32 rows in one launch; op i + 1 is skipped
                         GemmParams q = gemm[i + 1];
                         if (b0) { const GemmOp& g2 = plan.ops[i + 1].g; q.out.p = shift(q.out.p, g2.out.t); q.stats_out = (float*)shift(q.stats_out, g2.stats_out); }
@@ -708,6 +771,7 @@ struct Img2Img::Impl {
                     break;
                 }
                 case OP_ATTN: {
+                    if (i > 0 && fuse_attn32[i - 1] && cfg.precision == Precision::TF32) break;      // computed by the launch of the op in front
                     const AttnOp& a = op.at;
                     AttnParams p;
                     p.qkv = tp(a.qkv); p.out = tp(a.out); p.B = live; p.nwin = a.nwin; p.heads = a.heads; p.hd = a.hd;

@@ -634,6 +634,331 @@ hipError_t launch_mlp32_c(const Mlp32Params& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---- fused Swin attention branch on fp32 rows, Precision::TF32 (round 6) -------------------------------------------------------------
+//     y = x + proj( W-MSA( LayerNorm(x) ) )          windows of 6 x 6 tokens, six heads of 16 (C = 96) or 32 (C = 192)
+// The un-fused fp32 plan runs this as gemm32 (LayerNorm + window gather + qkv) -> attn32 (lane-per-query core) -> gemm32 (proj + window scatter + residual) with the
+// qkv map [M][3C] and the head outputs [M][C] in HBM between them: 8.5 GB of traffic per full-resolution block of config 3 for 2.1 GB of rows in and out.  Here a
+// workgroup of six waves (wave = head) owns two windows; k_swinattn192u.hip's recipe per (window, head) unit with every product as three bf16 products
+// (lo hi + hi lo + hi hi, split4):
+//   * the windows' rows are gathered (the qkv op's window table), normalised with the producer's statistics, split and kept in LDS as two bf16 planes of 48 rows
+//     per window (rows 36 .. 47 zero);
+//   * q^T and k^T are computed transposed (rows = features: A = weights, B = x), v plain (A = x, B = weights): their accumulators are, as they stand, the operands of
+//     S^T = K Q^T (k order = the features as a lane holds them) and of O^T = V^T P^T (k order = the keys as the S^T accumulators hold them); q bias = initial
+//     accumulator, k bias dropped (constant per query), v bias added after the normalisation;
+//   * scores start from the relative-position bias (+ shift mask) table, softmax over the keys is lane-local plus two lane swaps, padded keys are -inf;
+//   * the head outputs go back to LDS - over the rows of the window they were computed from, behind a barrier - as the two planes the projection reads;
+//   * proj transposed (rows = output channels, wave w owns C / 6 of them), + bias + residual, scattered through the proj op's window table; LayerNorm statistics of
+//     the produced rows like mlp32_kernel.
+// Weights: bf16 hi / lo planes in fragment-major order, streamed from L2 per window.
+struct Bf2 { bf16x8 h, l; };
+__device__ __forceinline__ Bf2 split8(const float4v a, const float4v b) {
+    uint2v ah, al, bh, bl;
+    split4(a, ah, al); split4(b, bh, bl);
+    typedef unsigned uint4v_ __attribute__((ext_vector_type(4)));
+    Bf2 r;
+    r.h = __builtin_bit_cast(bf16x8, (uint4v_){ah[0], ah[1], bh[0], bh[1]});
+    r.l = __builtin_bit_cast(bf16x8, (uint4v_){al[0], al[1], bl[0], bl[1]});
+    return r;
+}
+__device__ __forceinline__ float4v mfma3(const Bf2& a, const Bf2& b, float4v acc) {   // a b ~ al bh + ah bl + ah bh, smallest terms first
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, acc, 0, 0, 0);
+}
+
+template <int C, int HD>
+__global__ __launch_bounds__(384, 2) void swinattn32_kernel(const SwinAttn32Params p) {
+    constexpr int NW = 2, NTOK = 36, SLAB = 48, ROWS = NW * SLAB, RT = ROWS / 16, LDX = C + 8, KS = C / 32, DT = HD / 16, NH = 6, NT2 = C / 96;
+    static_assert(C == NH * HD && (HD == 16 || HD == 32), "six heads of 16 or 32");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned short* XH = (unsigned short*)smem;                       // [ROWS][LDX]; a window's rows become its head outputs once every head has its q, k, v
+    unsigned short* XL = XH + ROWS * LDX;
+    int* pixi = (int*)(XL + ROWS * LDX);                              // [ROWS] pixel of the row on the input side (-1: none)
+    int* pixo = pixi + ROWS;                                          // [ROWS] pixel the row is stored to
+    float* red = (float*)(pixo + ROWS);                               // [6][ROWS] partial row sums of the statistics
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int h = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave = head (and, in the projection, a sixth of the output channels)
+    const int frow = lane & 15, fk = lane >> 4;
+    const long W0 = (long)blockIdx.x * NW, total = (long)p.B * p.nwin;
+    const float4v zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    for (int r = tid; r < ROWS; r += 384) {
+        const int wi = r / SLAB, t = r - wi * SLAB;
+        const long gw = W0 + wi;
+        int pin = -1, pout = -1;
+        if (t < NTOK && gw < total) {
+            const long b = gw / p.nwin; const int wl = (int)(gw - b * p.nwin);
+            pin = (int)(b * p.pix_per_item + p.table_in[wl * NTOK + t]);
+            pout = (int)(b * p.pix_per_item + p.table_out[wl * NTOK + t]);
+        }
+        pixi[r] = pin; pixo[r] = pout;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < ROWS * (C / 4); idx += 384) {
+        const int row = idx / (C / 4), c4 = idx - row * (C / 4);
+        const int pin = pixi[row];
+        float4v v = zero4;
+        float mean = 0.f, rstd = 0.f;
+        if (pin >= 0) { v = *(const float4v*)(p.x + (size_t)pin * C + c4 * 4); mean = p.stats_in[2 * (size_t)pin]; rstd = p.stats_in[2 * (size_t)pin + 1]; }
+        uint2v hi, lo;
+        split4((float4v){(v[0] - mean) * rstd, (v[1] - mean) * rstd, (v[2] - mean) * rstd, (v[3] - mean) * rstd}, hi, lo);
+        *(uint2v*)(XH + row * LDX + c4 * 4) = hi;
+        *(uint2v*)(XL + row * LDX + c4 * 4) = lo;
+    }
+    __syncthreads();
+
+    // weight planes through buffer resources: the lane's 16 bytes in one VGPR for every request, the fragment's KiB in the scalar offset (64-bit per-lane addresses
+    // cost two registers per request in flight)
+    const __amdgpu_buffer_rsrc_t WQH = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wqkv_h), 0, 3u * C * C * 2u, 0x00020000);   // [3C / 16 row tiles][KS][64 lanes][8]
+    const __amdgpu_buffer_rsrc_t WQL = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wqkv_l), 0, 3u * C * C * 2u, 0x00020000);
+    const unsigned l16 = lane * 16u;
+    typedef unsigned uint4w __attribute__((ext_vector_type(4)));
+    auto wfrag = [&](int sel, int dt, int ks) {                       // fragment of matrix sel (0 q, 1 k, 2 v), feature tile dt of this head, k-step ks
+        const unsigned f = (unsigned)(((sel * C + h * HD) / 16 + dt) * KS + ks) * 1024u;
+        Bf2 w;
+        w.h = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(WQH, l16, f, 0));
+        w.l = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(WQL, l16, f, 0));
+        return w;
+    };
+    const float qs = p.scale;
+
+#pragma unroll 1
+    for (int wi = 0; wi < NW; ++wi) {
+        const long gw = W0 + wi;
+        const bool wok = gw < total;
+        const int wl = wok ? (int)(gw % p.nwin) : 0;
+        const unsigned short* xh = XH + wi * SLAB * LDX;
+        const unsigned short* xl = XL + wi * SLAB * LDX;
+        // ---- q^T, k^T (rows = features, columns = tokens), then v (rows = tokens, columns = features).  Weight fragments are requested one k-step ahead and the
+        //      requests are pinned where they are written (left alone the compiler asks for every k-step of every matrix first: 50 spilled registers at C = 192)
+        float4v aq[DT][3], ak[DT][3], av[3][DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const float4v bq = *(const float4v*)(p.bqkv + h * HD + dt * 16 + fk * 4);
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt) { aq[dt][tt] = bq; ak[dt][tt] = zero4; }
+        }
+        auto xfrags = [&](int ks, Bf2 (&x)[3]) {
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt) {
+                x[tt].h = *(const bf16x8*)(xh + (tt * 16 + frow) * LDX + ks * 32 + fk * 8);
+                x[tt].l = *(const bf16x8*)(xl + (tt * 16 + frow) * LDX + ks * 32 + fk * 8);
+            }
+        };
+        {
+            Bf2 wq[2][DT], wk[2][DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) { wq[0][dt] = wfrag(0, dt, 0); wk[0][dt] = wfrag(1, dt, 0); }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 1 < KS) {
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) { wq[(ks + 1) & 1][dt] = wfrag(0, dt, ks + 1); wk[(ks + 1) & 1][dt] = wfrag(1, dt, ks + 1); }
+                }
+                asm volatile("" ::: "memory");
+                Bf2 x[3];
+                xfrags(ks, x);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int tt = 0; tt < 3; ++tt) {
+                        aq[dt][tt] = mfma3(wq[ks & 1][dt], x[tt], aq[dt][tt]);
+                        ak[dt][tt] = mfma3(wk[ks & 1][dt], x[tt], ak[dt][tt]);
+                    }
+            }
+        }
+        {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt) av[tt][dt] = zero4;
+            Bf2 wv[2][DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) wv[0][dt] = wfrag(2, dt, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 1 < KS) {
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) wv[(ks + 1) & 1][dt] = wfrag(2, dt, ks + 1);
+                }
+                asm volatile("" ::: "memory");
+                Bf2 x[3];
+                xfrags(ks, x);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int tt = 0; tt < 3; ++tt) av[tt][dt] = mfma3(x[tt], wv[ks & 1][dt], av[tt][dt]);
+            }
+        }
+        // the accumulators as operands: q / k tile tt = [features of tile 0 | features of tile 1] of 16 tokens; v: keys of tiles 0 | 1, and of tile 2 | nothing
+        Bf2 qf[3], kf[3], vf0[DT], vf1[DT];
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+            qf[tt] = split8(aq[0][tt] * qs, DT > 1 ? aq[DT - 1][tt] * qs : zero4);
+            kf[tt] = split8(ak[0][tt], DT > 1 ? ak[DT - 1][tt] : zero4);
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { vf0[dt] = split8(av[0][dt], av[1][dt]); vf1[dt] = split8(av[2][dt], zero4); }
+        __syncthreads();                                              // every head has read this window's rows: the head outputs may go over them
+
+        // ---- per query tile: S^T = K Q^T on top of the bias (a lane holds keys 16 kt + 4 fk + e of query 16 qi + frow), softmax over the keys, O^T = V^T P^T
+        //      normalised + v bias (a lane holds features 16 dt + 4 fk + e of the query) -> the window's rows in LDS, split again.  One query tile at a time:
+        //      scores and probabilities of all three at once cost 56 more registers (47 spilled at C = 192)
+        const float* bias = p.bias + ((size_t)(wok ? p.maskid[wl] : 0) * NH + h) * (NTOK * NTOK);
+        float4v bv[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) bv[dt] = *(const float4v*)(p.bqkv + 2 * C + h * HD + dt * 16 + fk * 4);
+#pragma unroll
+        for (int qi = 0; qi < 3; ++qi) {
+            const int q = qi * 16 + frow;
+            float4v sc[3];
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) {
+                const int k0 = kt * 16 + fk * 4;
+                float4v b = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                if (k0 < NTOK) b = q < NTOK ? *(const float4v*)(bias + q * NTOK + k0) : zero4;
+                sc[kt] = mfma3(kf[kt], qf[qi], b);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mx = fmaxf(mx, sc[kt][e]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float v = __expf(sc[kt][e] - mx); sc[kt][e] = v; sum += v; }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.f / sum;
+            const Bf2 pf0 = split8(sc[0], sc[1]), pf1 = split8(sc[2], zero4);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                float4v o = mfma3(vf0[dt], pf0, zero4);
+                o = mfma3(vf1[dt], pf1, o);
+                uint2v hi, lo;
+                split4(o * inv + bv[dt], hi, lo);
+                const int row = wi * SLAB + qi * 16 + frow, col = h * HD + dt * 16 + fk * 4;
+                *(uint2v*)(XH + row * LDX + col) = hi;
+                *(uint2v*)(XL + row * LDX + col) = lo;
+            }
+            asm volatile("" ::: "memory");                            // (one query tile after the other)
+        }
+    }
+    __syncthreads();
+
+    // ---- proj, transposed: this wave's output channels for every row tile
+    const __amdgpu_buffer_rsrc_t WPH = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wproj_h), 0, (unsigned)C * C * 2u, 0x00020000);   // [C / 16 row tiles][KS][64 lanes][8]
+    const __amdgpu_buffer_rsrc_t WPL = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wproj_l), 0, (unsigned)C * C * 2u, 0x00020000);
+    float4v acc[NT2][RT];
+#pragma unroll
+    for (int n = 0; n < NT2; ++n) {
+        const float4v bp = *(const float4v*)(p.bproj + (h * NT2 + n) * 16 + fk * 4);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[n][rt] = bp;
+    }
+    auto pfrag = [&](int n, int ks) {
+        const unsigned f = (unsigned)((h * NT2 + n) * KS + ks) * 1024u;
+        Bf2 w;
+        w.h = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(WPH, l16, f, 0));
+        w.l = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(WPL, l16, f, 0));
+        return w;
+    };
+    Bf2 wpb[2][NT2];
+#pragma unroll
+    for (int n = 0; n < NT2; ++n) wpb[0][n] = pfrag(n, 0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) {
+#pragma unroll
+            for (int n = 0; n < NT2; ++n) wpb[(ks + 1) & 1][n] = pfrag(n, ks + 1);
+        }
+        asm volatile("" ::: "memory");
+        const Bf2 (&wp)[NT2] = wpb[ks & 1];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            Bf2 o;
+            o.h = *(const bf16x8*)(XH + (rt * 16 + frow) * LDX + ks * 32 + fk * 8);
+            o.l = *(const bf16x8*)(XL + (rt * 16 + frow) * LDX + ks * 32 + fk * 8);
+#pragma unroll
+            for (int n = 0; n < NT2; ++n) acc[n][rt] = mfma3(wp[n], o, acc[n][rt]);
+        }
+    }
+    // ---- + residual, scatter store: a lane holds output channels 16 (h NT2 + n) + 4 fk + e of row 16 rt + frow
+    float rsum[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) rsum[rt] = 0.f;
+#pragma unroll
+    for (int n = 0; n < NT2; ++n) {
+        const int ch = (h * NT2 + n) * 16 + fk * 4;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int pout = pixo[rt * 16 + frow];
+            float4v v = acc[n][rt];
+            if (pout >= 0) {
+                v += *(const float4v*)(p.res + (size_t)pout * C + ch);
+                *(float4v*)(p.y + (size_t)pout * C + ch) = v;
+            } else v = zero4;
+            acc[n][rt] = v;
+            rsum[rt] += v[0] + v[1] + v[2] + v[3];
+        }
+    }
+    if (p.stats_out) {                                                // uniform
+        auto reduce_rows = [&](float (&part)[RT], float (&total_)[RT]) {   // sums over the four lane groups, then over the six waves in wave order
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                float v = part[rt];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (fk == 0) red[h * ROWS + rt * 16 + frow] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < 6; ++w) t += red[w * ROWS + rt * 16 + frow];
+                total_[rt] = t;
+            }
+            __syncthreads();
+        };
+        float tot[RT], mean[RT], sq[RT];
+        reduce_rows(rsum, tot);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            mean[rt] = tot[rt] / (float)C;
+            float q = 0.f;
+#pragma unroll
+            for (int n = 0; n < NT2; ++n)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = acc[n][rt][e] - mean[rt]; q += d * d; }
+            sq[rt] = pixo[rt * 16 + frow] >= 0 ? q : 0.f;
+        }
+        reduce_rows(sq, tot);
+        if (h == 0 && fk == 0) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int pout = pixo[rt * 16 + frow];
+                if (pout >= 0) { p.stats_out[2 * (size_t)pout] = mean[rt]; p.stats_out[2 * (size_t)pout + 1] = rsqrtf(tot[rt] / (float)C + p.eps_out); }
+            }
+        }
+    }
+}
+
+template <int C, int HD>
+hipError_t launch_swinattn32_c(const SwinAttn32Params& p, hipStream_t s) {
+    constexpr int ROWS = 96, SMEM = ROWS * (C + 8) * 2 * 2 + ROWS * 4 * 2 + 6 * ROWS * 4;
+    static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
+    if (hipError_t e = ensure_dynamic_lds((const void*)swinattn32_kernel<C, HD>, SMEM, lds_ok); e != hipSuccess) return e;
+    const long total = (long)p.B * p.nwin;
+    hipLaunchKernelGGL((swinattn32_kernel<C, HD>), dim3((unsigned)((total + 1) / 2)), dim3(384), SMEM, s, p);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 bool mlp32_supported(int C) { return C == 96 || C == 192; }
@@ -641,6 +966,16 @@ hipError_t launch_mlp32(const Mlp32Params& p, hipStream_t s) {
     if (p.M <= 0 || !p.x || !p.y || !p.stats_in || !p.w1h || !p.w1l || !p.w2h || !p.w2l || !p.b1 || !p.b2) return hipErrorInvalidValue;
     if (p.C == 96) return launch_mlp32_c<96>(p, s);
     if (p.C == 192) return launch_mlp32_c<192>(p, s);
+    return hipErrorInvalidValue;
+}
+
+bool swinattn32_supported(int C, int heads, int hd, int ntok) { return heads == 6 && ntok == 36 && ((C == 96 && hd == 16) || (C == 192 && hd == 32)); }
+hipError_t launch_swinattn32(const SwinAttn32Params& p, hipStream_t s) {
+    if (p.B <= 0 || p.nwin <= 0 || !p.x || !p.y || !p.res || !p.stats_in || !p.table_in || !p.table_out || !p.wqkv_h || !p.wqkv_l || !p.wproj_h || !p.wproj_l ||
+        !p.bqkv || !p.bproj || !p.bias || !p.maskid) return hipErrorInvalidValue;
+    if ((long)p.B * p.pix_per_item > 0x7FFFFFFFl) return hipErrorInvalidValue;        // pixel indices are ints in the kernel's tables
+    if (p.C == 96) return launch_swinattn32_c<96, 16>(p, s);
+    if (p.C == 192) return launch_swinattn32_c<192, 32>(p, s);
     return hipErrorInvalidValue;
 }
 

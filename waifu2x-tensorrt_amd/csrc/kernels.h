@@ -175,6 +175,23 @@ struct Mlp32Params {
 };
 bool mlp32_supported(int C);
 hipError_t launch_mlp32(const Mlp32Params& p, hipStream_t s);
+// Fused Swin attention branch on fp32 rows with split-bf16 products (Precision::TF32; k_f32.hip swinattn32_kernel): y = res + proj(W-MSA((x - mean) rstd)), in place of the
+// un-fused plan's qkv gemm -> attention core -> proj gemm.  Rows are pixels of plain [pixels][C] maps; table_in / table_out: window-order row -> pixel inside a batch item
+// (the qkv op's gather table and the proj op's scatter table); weights as bf16 hi / lo planes, fragment-major (frag_major of each plane of W [3C][C] / [C][C]).
+struct SwinAttn32Params {
+    const float* x = nullptr; float* y = nullptr; const float* res = nullptr;
+    int B = 0, nwin = 0, C = 0;
+    long pix_per_item = 0;
+    const int* table_in = nullptr; const int* table_out = nullptr;
+    const float* stats_in = nullptr;
+    const void *wqkv_h = nullptr, *wqkv_l = nullptr, *wproj_h = nullptr, *wproj_l = nullptr;
+    const float *bqkv = nullptr, *bproj = nullptr;
+    float scale = 1.f;
+    const float* bias = nullptr; const int* maskid = nullptr;      // fp32 [nmask][6][36][36], [nwin]
+    float* stats_out = nullptr; float eps_out = 1e-5f;
+};
+bool swinattn32_supported(int C, int heads, int hd, int ntok);
+hipError_t launch_swinattn32(const SwinAttn32Params& p, hipStream_t s);
 hipError_t launch_mlp(const MlpParams& p, hipStream_t s);
 hipError_t launch_swin_attn(const SwinAttnParams& p, hipStream_t s);
 // swin_attn_supported / mlp_supported / gemm_row_stats_supported / attn_supported: support.h
