@@ -655,6 +655,40 @@ def test_fp32_engine_matches_the_fp32_oracle(pkg, onnx_model, model, scale, batc
         eng.close()
 
 
+@pytest.mark.parametrize("model,scale,batch,tile", [("swin_unet/art", 4, 2, 64), ("swin_unet/photo", 2, 1, 88)])
+def test_tf32_fused_launches_agree_with_the_unfused_plan(pkg, onnx_model, model, scale, batch, tile):
+    """Precision::TF32 runs the fp32 plan's transformer blocks as two fused launches each (k_f32.hip: swinattn32_kernel for qkv gemm -> attention -> proj gemm,
+    mlp32_kernel for fc1 -> fc2; round 6), Precision::FP32 and the debug switch no_fuse keep the un-fused launches.  Same split-bf16 products either way: the two
+    TF32 engines agree to summation order (<= 2e-5 on outputs in [0, 1]; measured 1e-5), both stay inside the TF32 bound against the fp32 oracle, frames of a
+    ragged size come out within one rounding tie of each other, and the fused engine reproduces itself bit for bit across batch groupings (two tile groups /
+    one: the statistics' partial sums are added in a fixed order)."""
+    path = onnx_model(model, scale, batch, tile, noise=1)
+    prec = pkg.Precision.TF32
+    x = np.random.default_rng(33).random((batch, 3, tile, tile), dtype=np.float32)
+    ref = onnx_exec.Executor(path).run(x)
+    frame = smooth_frame(tile + 51, 2 * tile + 13, 8)
+    outs = []
+    for nofuse in (0, 1):
+        with pkg.debug_switches(no_fuse=nofuse):
+            eng = pkg.Img2Img()
+            assert eng.build(path, pkg.BuildConfig.fixed(batch, tile, precision=prec)), eng.last_error()
+            assert eng.load(path, pkg.RenderConfig(precision=prec, batchSize=batch, height=tile, width=tile, scaling=scale, overlap=(0.0625, 0.0625))), eng.last_error()
+            y = eng.infer(x)
+            f1 = eng.render(frame)
+            f2 = eng.render(frame)
+            assert np.array_equal(f1, f2)
+            outs.append((y, f1))
+            eng.close()
+    (y_f, fr_f), (y_u, fr_u) = outs
+    from parity_util import _record
+    d_fu = float(np.abs(y_f.astype(np.float64) - y_u).max())
+    _record({"test": f"tf32 fused vs un-fused [{model} s{scale} B{batch} T{tile}]", "kind": "network_tf32_fusion", "max_abs_fused_vs_unfused": d_fu,
+             "max_abs_fused_vs_oracle": float(np.abs(y_f - ref).max()), "max_abs_unfused_vs_oracle": float(np.abs(y_u - ref).max())})
+    assert d_fu <= 2e-5 and np.abs(y_f - ref).max() <= TF32_NET_MAX_ABS and np.abs(y_u - ref).max() <= TF32_NET_MAX_ABS
+    dfr = np.abs(fr_f.astype(np.int32) - fr_u.astype(np.int32))
+    assert dfr.max() <= 1 and (dfr > 0).mean() < 5e-3
+
+
 def test_folded_squeeze_excite_gates_equal_the_in_place_pass(pkg, onnx_model, monkeypatch):
     """cunet's squeeze-excite gates are folded into their consumers (the 1x1 / 2x2 (transposed) convolutions scale their operand
     on load, the skip add scales its residual: lower.cpp pending_gate) with the rounding of the separate in-place pass they

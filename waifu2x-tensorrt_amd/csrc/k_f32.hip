@@ -638,7 +638,7 @@ hipError_t launch_mlp32_c(const Mlp32Params& p, hipStream_t s) {
 //     y = x + proj( W-MSA( LayerNorm(x) ) )          windows of 6 x 6 tokens, six heads of 16 (C = 96) or 32 (C = 192)
 // The un-fused fp32 plan runs this as gemm32 (LayerNorm + window gather + qkv) -> attn32 (lane-per-query core) -> gemm32 (proj + window scatter + residual) with the
 // qkv map [M][3C] and the head outputs [M][C] in HBM between them: 8.5 GB of traffic per full-resolution block of config 3 for 2.1 GB of rows in and out.  Here a
-// workgroup of six waves (wave = head) owns two windows; k_swinattn192u.hip's recipe per (window, head) unit with every product as three bf16 products
+// workgroup of six waves (wave = head) owns two or three windows; k_swinattn192u.hip's recipe per (window, head) unit with every product as three bf16 products
 // (lo hi + hi lo + hi hi, split4):
 //   * the windows' rows are gathered (the qkv op's window table), normalised with the producer's statistics, split and kept in LDS as two bf16 planes of 48 rows
 //     per window (rows 36 .. 47 zero);
@@ -666,9 +666,12 @@ __device__ __forceinline__ float4v mfma3(const Bf2& a, const Bf2& b, float4v acc
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, acc, 0, 0, 0);
 }
 
-template <int C, int HD>
+#ifndef W2X_A32_NW96
+#define W2X_A32_NW96 3       // windows per workgroup at C = 96 (tools/ab/lib_variants.sh "k_f32.hip:-DW2X_A32_NW96=2")
+#endif
+template <int C, int HD, int NW>
 __global__ __launch_bounds__(384, 2) void swinattn32_kernel(const SwinAttn32Params p) {
-    constexpr int NW = 2, NTOK = 36, SLAB = 48, ROWS = NW * SLAB, RT = ROWS / 16, LDX = C + 8, KS = C / 32, DT = HD / 16, NH = 6, NT2 = C / 96;
+    constexpr int NTOK = 36, SLAB = 48, ROWS = NW * SLAB, RT = ROWS / 16, LDX = C + 8, KS = C / 32, DT = HD / 16, NH = 6, NT2 = C / 96;
     static_assert(C == NH * HD && (HD == 16 || HD == 32), "six heads of 16 or 32");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned short* XH = (unsigned short*)smem;                       // [ROWS][LDX]; a window's rows become its head outputs once every head has its q, k, v
@@ -949,13 +952,13 @@ __global__ __launch_bounds__(384, 2) void swinattn32_kernel(const SwinAttn32Para
     }
 }
 
-template <int C, int HD>
+template <int C, int HD, int NW>
 hipError_t launch_swinattn32_c(const SwinAttn32Params& p, hipStream_t s) {
-    constexpr int ROWS = 96, SMEM = ROWS * (C + 8) * 2 * 2 + ROWS * 4 * 2 + 6 * ROWS * 4;
+    constexpr int ROWS = NW * 48, SMEM = ROWS * (C + 8) * 2 * 2 + ROWS * 4 * 2 + 6 * ROWS * 4;
     static unsigned lds_ok = 0;   // per-device bit: kernels.h ensure_dynamic_lds
-    if (hipError_t e = ensure_dynamic_lds((const void*)swinattn32_kernel<C, HD>, SMEM, lds_ok); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)swinattn32_kernel<C, HD, NW>, SMEM, lds_ok); e != hipSuccess) return e;
     const long total = (long)p.B * p.nwin;
-    hipLaunchKernelGGL((swinattn32_kernel<C, HD>), dim3((unsigned)((total + 1) / 2)), dim3(384), SMEM, s, p);
+    hipLaunchKernelGGL((swinattn32_kernel<C, HD, NW>), dim3((unsigned)((total + NW - 1) / NW)), dim3(384), SMEM, s, p);
     return hipGetLastError();
 }
 
@@ -974,8 +977,9 @@ hipError_t launch_swinattn32(const SwinAttn32Params& p, hipStream_t s) {
     if (p.B <= 0 || p.nwin <= 0 || !p.x || !p.y || !p.res || !p.stats_in || !p.table_in || !p.table_out || !p.wqkv_h || !p.wqkv_l || !p.wproj_h || !p.wproj_l ||
         !p.bqkv || !p.bproj || !p.bias || !p.maskid) return hipErrorInvalidValue;
     if ((long)p.B * p.pix_per_item > 0x7FFFFFFFl) return hipErrorInvalidValue;        // pixel indices are ints in the kernel's tables
-    if (p.C == 96) return launch_swinattn32_c<96, 16>(p, s);
-    if (p.C == 192) return launch_swinattn32_c<192, 32>(p, s);
+    // windows per workgroup: three at C = 96 (60 KB of row planes: two workgroups per CU), two at C = 192 (77 KB)
+    if (p.C == 96) return launch_swinattn32_c<96, 16, W2X_A32_NW96>(p, s);
+    if (p.C == 192) return launch_swinattn32_c<192, 32, 2>(p, s);
     return hipErrorInvalidValue;
 }
 
