@@ -725,6 +725,15 @@ __global__ __launch_bounds__(384, 2) void swinattn32_kernel(const SwinAttn32Para
         return w;
     };
     const float qs = p.scale;
+    // AHEAD (C = 96, where the register budget of three waves per SIMD has room): the first fragments of every phase are requested a phase early - q / k of the next
+    // window under this window's v products and softmax (a head's first k-step is the same for every window), v under the last q / k step, proj before the windows -
+    // instead of at the top of the loop that needs them (five exposed L2 round trips per workgroup)
+    constexpr bool AHEAD = C == 96;
+    Bf2 wq0[DT], wk0[DT], wv0[DT];
+    if constexpr (AHEAD) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { wq0[dt] = wfrag(0, dt, 0); wk0[dt] = wfrag(1, dt, 0); }
+    }
 
 #pragma unroll 1
     for (int wi = 0; wi < NW; ++wi) {
@@ -752,12 +761,17 @@ __global__ __launch_bounds__(384, 2) void swinattn32_kernel(const SwinAttn32Para
         {
             Bf2 wq[2][DT], wk[2][DT];
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) { wq[0][dt] = wfrag(0, dt, 0); wk[0][dt] = wfrag(1, dt, 0); }
+            for (int dt = 0; dt < DT; ++dt) {
+                if constexpr (AHEAD) { wq[0][dt] = wq0[dt]; wk[0][dt] = wk0[dt]; } else { wq[0][dt] = wfrag(0, dt, 0); wk[0][dt] = wfrag(1, dt, 0); }
+            }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (ks + 1 < KS) {
 #pragma unroll
                     for (int dt = 0; dt < DT; ++dt) { wq[(ks + 1) & 1][dt] = wfrag(0, dt, ks + 1); wk[(ks + 1) & 1][dt] = wfrag(1, dt, ks + 1); }
+                } else if constexpr (AHEAD) {
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) wv0[dt] = wfrag(2, dt, 0);
                 }
                 asm volatile("" ::: "memory");
                 Bf2 x[3];
@@ -778,12 +792,15 @@ __global__ __launch_bounds__(384, 2) void swinattn32_kernel(const SwinAttn32Para
                 for (int tt = 0; tt < 3; ++tt) av[tt][dt] = zero4;
             Bf2 wv[2][DT];
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) wv[0][dt] = wfrag(2, dt, 0);
+            for (int dt = 0; dt < DT; ++dt) { if constexpr (AHEAD) wv[0][dt] = wv0[dt]; else wv[0][dt] = wfrag(2, dt, 0); }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (ks + 1 < KS) {
 #pragma unroll
                     for (int dt = 0; dt < DT; ++dt) wv[(ks + 1) & 1][dt] = wfrag(2, dt, ks + 1);
+                } else if constexpr (AHEAD) {      // the next window's first q / k fragments (the same ones: requested again, landing under the softmax)
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) { wq0[dt] = wfrag(0, dt, 0); wk0[dt] = wfrag(1, dt, 0); }
                 }
                 asm volatile("" ::: "memory");
                 Bf2 x[3];
