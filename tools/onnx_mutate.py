@@ -15,7 +15,7 @@ tools/synth_models.py's own exports and be wrong on the first file that differs.
     transpose_weight  a square MatMul weight W -> W^T; a Conv weight with Cin == Cout -> in / out channels swapped
     roll_shift        the distance of one torch.roll (Slice + Slice + Concat) -> another distance
     drop_residual     y = a + b (two runtime tensors)  ->  y = b
-    d2s_mode          DepthToSpace CRD <-> DCR
+    d2s_mode          DepthToSpace CRD <-> DCR with the producer's columns left as they are (the loader lowers both modes: the mutant must be followed)
     conv_drop_bias    a Conv / ConvTranspose loses its bias input
     matmul_drop_bias  the Add(bias) behind a MatMul goes
     gelu_const        one of the constants of the erf GELU chain (1 / sqrt 2, the + 1, the 0.5) -> another value

@@ -28,6 +28,8 @@ rounded to fp16 - the precision an fp16 engine gives them anyway):
     split_qkv       q, k, v = qkv[0], qkv[1], qkv[2] (three Gathers)  ->  qkv.unbind(0) (one Split + three Squeezes)
     ln_decompose    a LayerNormalization node  ->  the ReduceMean / Sub / Pow|Mul / ReduceMean / Add / Sqrt / Div / Mul / Add chain exporters write below opset 17
     sdpa_scale      q * s  ->  (q * sqrt(s)) @ (k^T * sqrt(s)), the way a decomposed scaled_dot_product_attention scales (not bit-exact: sqrt(s)^2 != s in fp32)
+    d2s_dcr         DepthToSpace(mode=CRD) behind a Linear  ->  mode=DCR (or no mode attribute: DCR is the operator's default) with the Linear's output columns and bias
+                    re-ordered so that the same values land on the same sub-pixels (what an exporter that writes DCR produces for the same network)
     gelu_op         the erf chain Div(sqrt 2) -> Erf -> Add(1) -> Mul(x) -> Mul(0.5)  ->  one Gelu node, as the exporter writes it from opset 20 on (the file's opset becomes 20)
     dead            a node nothing reads (a Shape or a Relu of some runtime tensor)
 """
@@ -602,10 +604,46 @@ def rw_gelu_op(g, shapes, rng):
     return True
 
 
+def rw_d2s_dcr(g, shapes, rng):
+    prod = {n.outputs[0]: n for n in g.nodes}
+    sites = []
+    for d in g.nodes:
+        if d.op != "DepthToSpace" or d.attrs.get("mode", "DCR") != "CRD":
+            continue
+        t = prod.get(d.inputs[0])
+        a = prod.get(t.inputs[0]) if t is not None and t.op == "Transpose" and list(t.attrs.get("perm", [])) == [0, 3, 1, 2] else None
+        if a is None or a.op != "Add" or len(_consumers(g, a.outputs[0])) != 1 or len(_consumers(g, t.outputs[0])) != 1:
+            continue
+        bname = [i for i in a.inputs if i in g.initializers]
+        mm = [prod.get(i) for i in a.inputs if i not in g.initializers]
+        if len(bname) != 1 or len(mm) != 1 or mm[0] is None or mm[0].op != "MatMul" or mm[0].inputs[1] not in g.initializers or len(_consumers(g, mm[0].outputs[0])) != 1:
+            continue
+        if len(_consumers(g, mm[0].inputs[1])) != 1 or len(_consumers(g, bname[0])) != 1:
+            continue
+        sites.append((d, a, mm[0], bname[0]))
+    if not sites:
+        return False
+    d, a, mm, bname = sites[rng.integers(len(sites))]
+    r = int(d.attrs["blocksize"]); rr = r * r
+    w, b = g.initializers[mm.inputs[1]], g.initializers[bname]
+    N = w.shape[1]; oc = N // rr
+    # DCR column s * oc + c holds what CRD column c * rr + s held
+    src = np.asarray([c * rr + s_ for s_ in range(rr) for c in range(oc)])
+    wn, bn = _fresh(g, "w_dcr"), _fresh(g, "b_dcr")
+    g.initializers[wn] = np.ascontiguousarray(w[:, src]); g.initializers[bn] = np.ascontiguousarray(b[src])
+    mm.inputs[1] = wn
+    a.inputs = [bn if i == bname else i for i in a.inputs]
+    if rng.integers(2):
+        d.attrs["mode"] = "DCR"
+    else:
+        d.attrs.pop("mode")
+    return True
+
+
 REWRITES = {"gemm": rw_gemm, "identity": rw_identity, "dropout": rw_dropout, "cast": rw_cast, "transpose2": rw_transpose2, "squeeze": rw_squeeze,
             "const_node": rw_const_node, "fp16_init": rw_fp16_init, "reshape_0_m1": rw_reshape_0_m1, "bias_unsqueeze": rw_bias_unsqueeze,
             "ln_axis": rw_ln_axis, "permute": rw_permute, "commute": rw_commute, "dead": rw_dead, "split_qkv": rw_split_qkv, "ln_decompose": rw_ln_decompose,
-            "sdpa_scale": rw_sdpa_scale, "gelu_op": rw_gelu_op}
+            "sdpa_scale": rw_sdpa_scale, "gelu_op": rw_gelu_op, "d2s_dcr": rw_d2s_dcr}
 INEXACT = ("fp16_init", "sdpa_scale")                      # weights rounded to fp16 / sqrt(s)^2 for s: the plan keeps its text, not its bytes
 EXACT = [k for k in REWRITES if k not in INEXACT]          # rewrites under which the engine file must not change by a byte
 

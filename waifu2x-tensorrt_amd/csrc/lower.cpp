@@ -167,6 +167,7 @@ struct Lowerer {
         GemmOp op;
         std::string cur;       // ONNX tensor currently representing the op's value
         bool nchw = false;     // layout of the ONNX value at `cur`
+        bool d2s_dcr = false;  // O_PIXSHUF: the file's DepthToSpace is in DCR mode (ONNX column (dy r + dx) C' + c) instead of CRD (c r r + dy r + dx)
         int outH = 0, outW = 0, outC = 0;  // logical output geometry (before pixshuf)
         LVal::Kind okind = LVal::MAP;
         int ws = 0, H = 0, W = 0;          // WINROWS bookkeeping
@@ -227,8 +228,11 @@ struct Lowerer {
             // plain layout change
             done.insert(t); p.cur = t->out[0]; p.nchw = true; return;
         }
+        // CRD is what torch's pixel_shuffle exports to; DCR is the operator's default (mode absent) and what other exporters write: the two differ in which ONNX column
+        // holds sub-pixel (dy, dx) of channel c - the weight rows are re-ordered accordingly in finish(), the kernels see (dy, dx, c) either way
         auto mode = d->attr.find("mode");
-        if (mode == d->attr.end() || mode->second.s != "CRD") fail(d, "only DepthToSpace mode=CRD (pixel_shuffle) is supported");
+        if (mode != d->attr.end() && mode->second.s != "CRD" && mode->second.s != "DCR") fail(d, "DepthToSpace mode \"" + mode->second.s + "\" (CRD or DCR expected)");
+        p.d2s_dcr = mode == d->attr.end() || mode->second.s == "DCR";
         int r = (int)d->ai("blocksize", 1);
         if (p.op.N % (r * r)) fail(d, "channel count not divisible by blocksize^2");
         done.insert(t); done.insert(d);
@@ -375,13 +379,13 @@ struct Lowerer {
         o.Cout = oC;
         int ot = new_tensor(B, oH, oW, Cs);
         o.out.t = ot; o.out.H = oH; o.out.W = oW; o.out.y0 = o.out.x0 = 0;
-        // pack W^T [Npad][K] fp16.  Column order for pixel shuffle: ONNX column c*r*r + dy*r + dx  ->  (dy*r+dx)*Cs + c.
+        // pack W^T [Npad][K] fp16.  Column order for pixel shuffle: ONNX column c*r*r + dy*r + dx (CRD) or (dy*r+dx)*C' + c (DCR)  ->  (dy*r+dx)*Cs + c.
         int K = o.K, N = o.N;
         int Np = N;
         std::vector<int> colmap(N);
         if (o.omode == O_PIXSHUF) {
             int rr = o.r * o.r; Np = rr * Cs;
-            for (int c = 0; c < oC; ++c) for (int s = 0; s < rr; ++s) colmap[c * rr + s] = s * Cs + c;
+            for (int c = 0; c < oC; ++c) for (int s = 0; s < rr; ++s) colmap[p.d2s_dcr ? s * oC + c : c * rr + s] = s * Cs + c;
         } else {
             Np = Cs;
             for (int n = 0; n < N; ++n) colmap[n] = n;
