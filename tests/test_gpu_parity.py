@@ -655,6 +655,24 @@ def test_fp32_engine_matches_the_fp32_oracle(pkg, onnx_model, model, scale, batc
         eng.close()
 
 
+def test_tf32_engine_at_the_headline_tile(pkg, onnx_model):
+    """Precision::TF32 at the tile of configs[2] (T = 256, batch 2): 240 x 240 / 120 x 120 / 60 x 60 token maps, i.e. 1 600 / 400 / 100 windows per tile through
+    swinattn32_kernel (three / two windows per workgroup, the last workgroup ragged at two tiles x 100 windows) and row counts that do not fill mlp32_kernel's last
+    64-row workgroup at any level but the first.  Network only, against the fp32 oracle: measured 9.2e-6 (T = 400: 9.0e-6)."""
+    path = onnx_model("swin_unet/art", 4, 2, 256)
+    prec = pkg.Precision.TF32
+    eng = pkg.Img2Img()
+    assert eng.build(path, pkg.BuildConfig.fixed(2, 256, precision=prec)), eng.last_error()
+    assert eng.load(path, pkg.RenderConfig(precision=prec, batchSize=2, height=256, width=256, scaling=4)), eng.last_error()
+    x = np.random.default_rng(5).random((2, 3, 256, 256), dtype=np.float32)
+    y = eng.infer(x)
+    eng.close()
+    d = np.abs(y.astype(np.float64) - onnx_exec.Executor(path).run(x))
+    from parity_util import _record
+    _record({"test": "network tf32 [swin_unet/art s4 B2 T256]", "kind": "network_tf32", "max_abs": float(d.max()), "mean_abs": float(d.mean())})
+    assert d.max() <= TF32_NET_MAX_ABS, (d.max(), d.mean())
+
+
 @pytest.mark.parametrize("model,scale,batch,tile", [("swin_unet/art", 4, 2, 64), ("swin_unet/photo", 2, 1, 88)])
 def test_tf32_fused_launches_agree_with_the_unfused_plan(pkg, onnx_model, model, scale, batch, tile):
     """Precision::TF32 runs the fp32 plan's transformer blocks as two fused launches each (k_f32.hip: swinattn32_kernel for qkv gemm -> attention -> proj gemm,
