@@ -103,7 +103,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     double best[NVAR], sum[NVAR];
     for (int v = 0; v < NVAR; ++v) { best[v] = 1e9; sum[v] = 0; }
-    const int rounds = 7, reps = 5;
+    const int rounds = 7, reps = getenv("W2X_AB_REPS") ? atoi(getenv("W2X_AB_REPS")) : 5;      // (W2X_AB_REPS=600: half a second per variant and round, long enough for tools/power_trace.py to see its power)
     for (int r = 0; r < rounds; ++r) for (int v = 0; v < NVAR; ++v) {
         params_of(v).y = yv[v];
         CK(hipEventRecord(e0, 0));
