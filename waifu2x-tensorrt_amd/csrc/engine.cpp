@@ -1225,7 +1225,10 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
     W2X_LOG(info, "Loaded \"" + enginePath + "\": " + std::to_string(plan.ops.size()) + " ops, " + std::to_string(plan.B) + " tiles per pass, activation arena " +
                       std::to_string(impl->arena_bytes >> 20) + " MiB" +
                       (std::count(impl->fuse_stem.begin(), impl->fuse_stem.end(), (char)1) ? ", stem folded into the patch convolution's launch" : "") +
-                      (std::count(impl->fuse_head.begin(), impl->fuse_head.end(), (char)1) ? ", image head folded into the last MLP launch." : "."));
+                      (std::count(impl->fuse_head.begin(), impl->fuse_head.end(), (char)1) ? ", image head folded into the last MLP launch" : "") +
+                      (config.precision == Precision::TF32 && std::count(impl->fuse_attn32.begin(), impl->fuse_attn32.end(), (char)1) + std::count(impl->fuse_mlp32.begin(), impl->fuse_mlp32.end(), (char)1) > 0
+                           ? ", " + std::to_string(std::count(impl->fuse_attn32.begin(), impl->fuse_attn32.end(), (char)1)) + " attention and " +
+                                 std::to_string(std::count(impl->fuse_mlp32.begin(), impl->fuse_mlp32.end(), (char)1)) + " MLP branches as fused fp32-row launches." : "."));
     // :262-269 blend ramps
     impl->ovx = (int)std::lround(plan.T * config.scaling * config.overlapX);
     impl->ovy = (int)std::lround(plan.T * config.scaling * config.overlapY);
