@@ -161,6 +161,7 @@ constexpr int BIAS_OFF = WBYTES + NWV * SLAB;   // b1 [2C] | b2 [C] as fp32: rea
                              // against 7.373 / 7.381 / 7.388 / 7.387 ms in alternating runs, profiles/r6_kernels/lib_mlp96_dyn_frame_level.txt; 0: tools/ab/lib_variants.sh "k_mlp96q.hip:-DW2X_MLP96_DYN=0").
                              // The launch that carries the image head keeps the fixed stride: with the counter it spills two registers at 168.
 #endif
+static_assert(!W2X_MLP96_DYN || W2X_MLP_PREFETCH, "the tile counter is read where the next tile's rows are requested: without the prefetch a wave would stop after its first tile");
 constexpr int CTR_OFF = BIAS_OFF + 3 * C * 4;   // (W2X_MLP96_DYN) the workgroup's tile counter
 constexpr int SMEM96Q = CTR_OFF + 16;
 static_assert(RW * PPR % 64 == 0, "flat piece count");
