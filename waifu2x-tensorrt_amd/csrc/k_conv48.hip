@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv48_kernel(const GemmParams p, int 
         for (int k = 0; k < NPO; ++k) {
             const int idx = k * 64 + lane, px = idx / PPO, c = idx - px * PPO;
             if (oy < Ho && ox0 + mt * 16 + px < Wo)
-                *(half8*)(Og + (size_t)(mt * 16 + px) * p.out.Cs + c * 8) = *(const half8*)(Ot + px * (N + 8) + c * 8);
+                w2x_store_out((half8*)(Og + (size_t)(mt * 16 + px) * p.out.Cs + c * 8), *(const half8*)(Ot + px * (N + 8) + c * 8));
         }
         W2X_PHASE_FENCE();
     }

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(NW * 64, (C == 96 ? 3 : W2X_MLP192_WPS) * NW / 4) v
     for (int k = 0; k < NP; ++k) {
         const int idx = k * 64 + lane, r = idx / PPR, c = idx - r * PPR;
         const half8 o = *(const half8*)(Xw + r * LDX + c * 8) + xres[k];     // fp16 + fp16 rounded once == fp32 add rounded to fp16
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, o), YB, vo + k * 1024u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, o), YB, vo + k * 1024u, 0, W2X_ST_AUX);
         if (p.stats_out) *(half8*)(Xw + r * LDX + c * 8) = o;
     }
     W2X_PHASE_FENCE();

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(NTHR, 3) void mlp96q_kernel(const MlpParams p, int 
             const int idx = k * 64 + lane, r = idx / PPR, c = idx - r * PPR;
             const half8 o = *(const half8*)(Xw + r * LDX + c * 8) + xres[k];     // fp16 + fp16 rounded once == fp32 add rounded to fp16
             if (TOIMG) *(half8*)(Xw + r * LDX + c * 8) = o;                      // the rows go through the image head below instead of to y
-            else if (!(W2X_MLP_EXP & 32)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, o), YB, yo + k * 1024u, 0, 0);
+            else if (!(W2X_MLP_EXP & 32)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, o), YB, yo + k * 1024u, 0, W2X_ST_AUX);
         }
         if (TOIMG) {
             // ---- image head: Linear 96 -> 64 = 4x4 sub-pixels x 4 stored channels, Clip, DepthToSpace(4) - the sums of toimage_kernel (k_pixgemm.hip), transposed:

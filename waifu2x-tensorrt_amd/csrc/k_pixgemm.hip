@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, TT_ == 1 ? 3 : 2) void pixgemm_kernel(const Ge
                         if (C::GATES && p.res_scale && rr < nrows) rv = gate::gate8(rv, p.res_scale + (size_t)((row0 + rr) / p.Mrows) * p.res.Cs + c * 8);   // gated skip connection
                         o += rv;                                   // fp16 + fp16 rounded once == fp32 add rounded to fp16
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, o), OB, __builtin_elementwise_add_sat(Rb[2 * rr], oshift + c * 16u), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, o), OB, __builtin_elementwise_add_sat(Rb[2 * rr], oshift + c * 16u), 0, W2X_ST_AUX);
                 }
                 W2X_PHASE_FENCE();
             }
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void toimage_kernel(const GemmParams p) {
             const int b = (int)(gr / p.Mrows), ml = (int)(gr - (long)b * p.Mrows);
             const int oy = ml / p.aW, ox = ml - oy * p.aW;
             const size_t off = ((size_t)(b * p.out.Hs + oy * 4 + (c >> 1)) * p.out.Ws + ox * 4 + (c & 1) * 2) * 4;
-            *(half8*)(Og + off) = *(const half8*)(Ot + rr * LDO + c * 8);
+            w2x_store_out((half8*)(Og + off), *(const half8*)(Ot + rr * LDO + c * 8));
         }
     }
 }
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void merge_slab_kernel(const GemmParams p) 
 #pragma unroll
     for (int k = 0; k < C::NPO; ++k) {
         const int idx = k * 64 + lane, rr = idx / C::PPO, c = idx - rr * C::PPO;
-        if (idx < npieces) *(half8*)(Og + (size_t)idx * 8) = *(const half8*)(Sl + rr * LDS_ROW + c * 8);
+        if (idx < npieces) w2x_store_out((half8*)(Og + (size_t)idx * 8), *(const half8*)(Sl + rr * LDS_ROW + c * 8));
     }
 }
 
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(256, W2X_MERGE_TT == 1 ? 3 : 2) void merge_kernel(c
 #pragma unroll
     for (int k = 0; k < C::NPO; ++k) {
         const int idx = k * 64 + lane, rr = idx / C::PPO, c = idx - rr * C::PPO;
-        if (idx < npieces) *(half8*)(Og + (size_t)idx * 8) = *(const half8*)(Sl + rr * LDS_ROW + c * 8);
+        if (idx < npieces) w2x_store_out((half8*)(Og + (size_t)idx * 8), *(const half8*)(Sl + rr * LDS_ROW + c * 8));
     }
 }
 

@@ -486,7 +486,7 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
             const bool ok = my_off[ps] != kNoRow;
             // (idle lanes read the next row's first pieces - any finite or non-finite bits: their store is dropped)
             half8 o = *(const half8*)(Xs + r * LDX + li * 8) + xres[ps];
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, o), Y, my_off[ps], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, o), Y, my_off[ps], 0, W2X_ST_AUX);
             if (p.stats_out) {
                 if (!ok) o = half8{};
                 const size_t pix = my_off[ps] / (C * 2);

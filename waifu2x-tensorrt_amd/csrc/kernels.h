@@ -23,6 +23,23 @@ inline hipError_t ensure_dynamic_lds(const void* fn, int bytes, unsigned& done_m
     return e;
 }
 
+// Cache policy of the kernels' OUTPUT stores (round 6).  What a launch produces is read by the next launch, never by itself: with the nt (streaming) policy the rows
+// stay out of L2, which they would only pass through, and leave it to the weights and to the rows a launch fetches a second time.  The four transformer kernels together:
+// -0.9 % per frame in five alternating runs on two boxes (profiles/r6_kernels/lib_nt_stores_frame_level.txt).  W2X_ST_AUX = the aux operand of the buffer stores
+// (2 = nt, 0 = default policy; per file: tools/ab/lib_variants.sh "<file>:-DW2X_ST_AUX=0"); w2x_store_out() is the same choice for stores through a plain pointer.
+#ifndef W2X_ST_AUX
+#define W2X_ST_AUX 2
+#endif
+#ifdef __HIPCC__
+template <class T> __device__ __forceinline__ void w2x_store_out(T* p, const T v) {
+#if W2X_ST_AUX == 2
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+#endif
+
 struct TView {           // device view of a channel-last tensor
     void* p = nullptr;
     int Hs = 0, Ws = 0, Cs = 0;  // stored dims
