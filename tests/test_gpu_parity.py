@@ -766,22 +766,28 @@ def test_image_head_folded_into_the_last_mlp_is_bit_identical(pkg, onnx_model, m
     assert np.array_equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("tile,batch,shape,tta", [(64, 2, (150, 170), False), (64, 3, (101, 119), True), (256, 4, (300, 420), False)])
-def test_stem_folded_into_the_patch_convolution_is_bit_identical(pkg, onnx_model, monkeypatch, tile, batch, shape, tta):
+@pytest.mark.parametrize("model,scale,tile,batch,shape,tta", [("swin_unet/art", 4, 64, 2, (150, 170), False), ("swin_unet/art", 4, 64, 3, (101, 119), True), ("swin_unet/art", 4, 256, 4, (300, 420), False),
+                                                              ("cunet/art", 2, 64, 2, (150, 170), False), ("cunet/art", 2, 96, 3, (101, 119), True), ("cunet/art", 1, 64, 2, (90, 131), False),
+                                                              ("cunet/art", 2, 256, 4, (300, 420), False)])
+def test_stem_folded_into_the_patch_convolution_is_bit_identical(pkg, onnx_model, monkeypatch, model, scale, tile, batch, shape, tta):
     """swin_unet's first two ops - the stem (3x3, 4-halves-per-pixel tile -> 48 channels) and the patch convolution behind it - run as ONE launch
     (engine.cpp fuse_stem, k_conv48.hip conv48_kernel<true>): every workgroup computes the halo tile it needs from the input tile with the stem
     kernel's own instruction sequence, and the 48-channel map between the two is neither stored nor read.  The debug switch no_fuse_stem keeps the two
     launches.  Same products in the same order: infer() and render() return the same bytes, through captured graphs and two tile groups (the
-    input tile must outlive the stem by one op in the arena); the odd batch leaves a group with one tile."""
-    path = onnx_model("swin_unet/art", 4, batch, tile, noise=1)
+    input tile must outlive the stem by one op in the arena); the odd batch leaves a group with one tile.
+    Round 6: cunet's U-Nets open the same way (3x3 4 -> 32, then 3x3 32 -> 64: k_conv3.hip conv3_kernel<false, true> computes its one 32-channel chunk) - two
+    stems folded at scale 2 (the second U-Net's input is the first one's output, which the residual at the end reads as well), one at scale 1."""
+    path = onnx_model(model, scale, batch, tile, noise=1)
     frame = smooth_frame(shape[0], shape[1], 14)
     x = np.random.default_rng(37).random((batch, 3, tile, tile), dtype=np.float32)
     outs = []
     for nofuse in (True, False):
         with pkg.debug_switches(no_fuse_stem=int(nofuse)):
-            eng = make_engine(pkg, path, batch, tile, 4, tta=tta)
-        folded = any("stem folded" in m for _, m in eng.messages)
-        assert folded == (not nofuse), [m for _, m in eng.messages if "folded" in m]
+            eng = make_engine(pkg, path, batch, tile, scale, tta=tta)
+        folded = [m for _, m in eng.messages if "stem folded" in m]
+        assert bool(folded) == (not nofuse), [m for _, m in eng.messages if "folded" in m]
+        if folded:
+            assert f", {2 if model == 'cunet/art' else 1} stem folded" in folded[0], folded[0]
         ys = [eng.infer(x) for _ in range(2)]
         rs = [eng.render(frame) for _ in range(3)]
         assert np.array_equal(ys[0], ys[1]) and np.array_equal(rs[0], rs[1]) and np.array_equal(rs[0], rs[2])

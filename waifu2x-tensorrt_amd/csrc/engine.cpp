@@ -235,7 +235,7 @@ struct Img2Img::Impl {
     std::vector<int> pool_tensors;
     int final_op = -1;
     std::vector<int> tensor_last;      // last op that touches each tensor (upload_plan)
-    std::vector<char> fuse_stem;       // op i is the stem convolution whose 48-channel map only feeds the patch convolution that follows: op i + 1's launch computes it in its halo stage (k_conv48.hip), op i is skipped
+    std::vector<char> fuse_stem;       // op i is a stem convolution whose 48- / 32-channel map only feeds the 3x3 convolution that follows: op i + 1's launch computes it in its halo stage (k_conv48.hip; k_conv3.hip for cunet), op i is skipped
     std::vector<char> fuse_head;       // op i is a C = 96 MLP whose rows only feed the image head that follows: one launch (k_mlp96q.hip), op i + 1 is skipped
     // fp32 plans: op i (LayerNorm + fc1 + GELU) and op i + 1 (fc2 + residual) are one mlp32_kernel launch when the engine runs Precision::TF32 (k_f32.hip); the hidden
     // map between them is neither written nor read.  mlp32_w[i] = the bf16 hi / lo planes of both matrices in fragment-major order (device memory, freed by release())
@@ -497,7 +497,7 @@ struct Img2Img::Impl {
             if (plan.elt == 2)
                 for (int i = 0; i + 1 < nops; ++i) {
                     const Op& a = plan.ops[i]; const Op& b = plan.ops[i + 1];
-                    if (a.kind == OP_GEMM && b.kind == OP_GEMM && a.g.a.t >= 0 && plan.tensors[a.g.a.t].C == 4 && a.g.N == 48 && b.g.K == 9 * 48 && b.g.a.t == a.g.out.t && first[a.g.out.t] == i && last[a.g.out.t] == i + 1 &&
+                    if (a.kind == OP_GEMM && b.kind == OP_GEMM && a.g.a.t >= 0 && plan.tensors[a.g.a.t].C == 4 && ((a.g.N == 48 && b.g.K == 9 * 48) || (a.g.N == 32 && b.g.K == 9 * 32 && b.g.N == 64 && b.g.pool_out < 0)) && b.g.a.t == a.g.out.t && first[a.g.out.t] == i && last[a.g.out.t] == i + 1 &&
                         a.g.out.t != plan.out_tensor && a.g.stats_out < 0 && a.g.pool_out < 0) {
                         fuse_stem[i] = 1;
                         last[a.g.a.t] = std::max(last[a.g.a.t], i + 1);
@@ -662,8 +662,9 @@ struct Img2Img::Impl {
             }
         // The stem (3x3, 4 -> 48 channels) in front of the patch convolution (3x3, 48 -> 96): its output has no other reader, so the convolution computes the halo tile
         // it needs from the input tile and the 48-channel map is neither stored nor read (k_conv48.hip conv48_kernel<true>; switches.h no_fuse_stem keeps the two launches).
+        // Round 6: the same for cunet's two U-Nets, whose stems (4 -> 32) feed a 32 -> 64 convolution each (k_conv3.hip conv3_kernel<false, true>).
         for (size_t i = 0; i + 1 < plan.ops.size(); ++i)
-            if (fuse_stem[i] && !conv48_stem_supported(gemm[i + 1], gemm[i])) fuse_stem[i] = 0;
+            if (fuse_stem[i] && !conv48_stem_supported(gemm[i + 1], gemm[i]) && !conv3_stem_supported(gemm[i + 1], gemm[i])) fuse_stem[i] = 0;
         hipAssert(hipStreamSynchronize(stream));
     }
 
@@ -741,7 +742,7 @@ struct Img2Img::Impl {
                     if (stem_held) {
                         stem_held = false;
                         stamp_begin(0, op.flops + stem_flops);
-                        hipAssert(launch_conv48_stem(p, stem_p, s));
+                        hipAssert(conv48_stem_supported(p, stem_p) ? launch_conv48_stem(p, stem_p, s) : launch_conv3_stem(p, stem_p, s));
                         stamp_end();
                         break;
                     }
@@ -1224,7 +1225,7 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
     impl->cfg = config;
     W2X_LOG(info, "Loaded \"" + enginePath + "\": " + std::to_string(plan.ops.size()) + " ops, " + std::to_string(plan.B) + " tiles per pass, activation arena " +
                       std::to_string(impl->arena_bytes >> 20) + " MiB" +
-                      (std::count(impl->fuse_stem.begin(), impl->fuse_stem.end(), (char)1) ? ", stem folded into the patch convolution's launch" : "") +
+                      (std::count(impl->fuse_stem.begin(), impl->fuse_stem.end(), (char)1) ? ", " + std::to_string(std::count(impl->fuse_stem.begin(), impl->fuse_stem.end(), (char)1)) + " stem folded into the launch of the convolution behind it" : "") +
                       (std::count(impl->fuse_head.begin(), impl->fuse_head.end(), (char)1) ? ", image head folded into the last MLP launch" : "") +
                       (config.precision == Precision::TF32 && std::count(impl->fuse_attn32.begin(), impl->fuse_attn32.end(), (char)1) + std::count(impl->fuse_mlp32.begin(), impl->fuse_mlp32.end(), (char)1) > 0
                            ? ", " + std::to_string(std::count(impl->fuse_attn32.begin(), impl->fuse_attn32.end(), (char)1)) + " attention and " +

@@ -33,6 +33,7 @@ namespace w2x {
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 
@@ -49,8 +50,17 @@ struct Conv3Cfg {
 // byte offset of piece pc (8 channels) of halo pixel x inside its row
 __device__ __forceinline__ int halo_slot(int x, int pc) { return x * 64 + ((pc + 2 * ((x >> 2) & 3)) & 3) * 16; }
 
-template <bool POOL>
-__global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int Ho, int Wo, int tiles_x, int tiles_y, int nblk, int xcd_order) {
+// STEM (round 6): the launch also computes its own input.  Both U-Nets of cunet open with 3x3 (the 4-halves-per-pixel tile -> 32 channels, k_stem.hip) followed by
+// 3x3 32 -> 64; the 32-channel map between them (full resolution: the largest map of the graph per channel) is written by one launch and read by the next and by nothing
+// else.  32 channels are exactly ONE chunk of this kernel, so with ps = the stem's parameters the chunk's 10 x 66 halo tile is not fetched but COMPUTED: 42 groups of 16
+// halo pixels, the four waves take them round-robin, each group is stem_kernel<2>'s three 16x16x16 k-steps on operands read straight from the input tile (8 bytes per
+// pixel: L2-resident), bias as the initial accumulator, LeakyReLU, fp16 - the same instructions on the same operands as stem_kernel, so the tile holds the bytes that
+// kernel would have stored (bit-identical frames by test).  A lane ends with channels 8g .. 8g + 7 of one pixel = piece g of the halo layout: one 16-byte LDS store.
+// The stem's products are recomputed for the halo (x 1.29), 8 % on top of this launch's matrix work; the stem launch, its stores and this launch's halo loads go.
+// Config 2 (tools/ab/switch_bench.py, profiles/r6_kernels/cunet_stem_fold_ab.txt): stem 0.365 + convolution 0.99 ms per frame as two launches, 1.05-1.07 ms as one; frame 7.74-7.82
+// against 7.88-7.95 ms.  (With the operands requested in three rounds the launch took 1.15 ms: each round is an L2 round trip in front of the products.)
+template <bool POOL, bool STEM>
+__global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int Ho, int Wo, int tiles_x, int tiles_y, int nblk, int xcd_order, const GemmParams ps) {
     using C = Conv3Cfg;
     constexpr int HR = C::HR, HC = C::HC;
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
@@ -72,20 +82,23 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
     const int b = tidx / tpi, trem = tidx - b * tpi;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
     const int oy0 = ty * C::TH, ox0 = tx * C::TW, n0 = nb * 64;
-    const int Cin = p.a.Cs, nchunk = Cin / 32, KST = p.K / 32;
+    const int Cin = STEM ? 32 : p.a.Cs, nchunk = Cin / 32, KST = p.K / 32;      // (STEM: one chunk, known to the compiler - the stage's addresses are not loop invariants to be hoisted and spilled)
     const __amdgpu_buffer_rsrc_t A = make_rsrc((const _Float16*)p.a.p + ((size_t)(b * p.a.Hs + p.a.y0 + oy0) * p.a.Ws + p.a.x0 + ox0) * Cin, 0x7FFFFFFFu);
     const __amdgpu_buffer_rsrc_t W = make_rsrc((const _Float16*)p.wt_perm + (size_t)nb * KST * 2048, (unsigned)KST * 4096u);   // [KST][4][64][8] of this block
     const unsigned wlane = lane * 16u;
 
     float4v acc[2][4][4];                                             // [row of the pair][16-pixel group][n-tile]
+    auto acc_init = [&](const float* bias) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const float4v bv = *(const float4v*)(p.bias + n0 + 32 * (nt >> 1) + 8 * g + 4 * (nt & 1));
+        for (int nt = 0; nt < 4; ++nt) {
+            const float4v bv = *(const float4v*)(bias + n0 + 32 * (nt >> 1) + 8 * g + 4 * (nt & 1));
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+            for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[r][mt][nt] = bv;
-    }
+                for (int mt = 0; mt < 4; ++mt) acc[r][mt][nt] = bv;
+        }
+    };
+    if (!STEM) acc_init(p.bias);                                            // (STEM: after the halo stage, whose operands need the registers)
     half8 w[3][4];                                                    // ring: slot = ky
     auto wload = [&](int slot, int kc, int ky, int kx) {     // past the last chunk the k-step lies beyond the block: the fetch returns zeros, nobody reads them
         const unsigned vo = wlane + (unsigned)((ky * 3 + kx) * nchunk + kc) * 4096u;    // k-step (tap * Cin + 32 kc) / 32
@@ -124,7 +137,69 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
     for (int kx = 0; kx < 3; ++kx) xoff[kx] = halo_slot(kx + fr, g);
 #pragma unroll 1
     for (int kc = 0; kc < nchunk; ++kc) {
-        {
+        if constexpr (STEM) {
+            // ---- the chunk (all 32 channels: conv3_stem_supported) computed from the network's input tile: stem_kernel<2>'s arithmetic per group of 16 halo pixels
+            constexpr int SNT = 2, NPIX = HR * HC, NGRP = (NPIX + 15) / 16, GPW = (NGRP + 3) / 4, HALF = GPW;             // (HALF: groups of a wave per round)
+            const int Hs_o = ps.Mrows / ps.aW, Ws_o = ps.aW;                // extent of the stem's output = this convolution's input map
+            const _Float16* __restrict__ Wt = (const _Float16*)ps.wt;
+            const half4 zero4h = {};
+            half4 wf[SNT][3];
+            float4v sbias[SNT];
+#pragma unroll
+            for (int nt = 0; nt < SNT; ++nt) {
+#pragma unroll
+                for (int t3 = 0; t3 < 3; ++t3) {
+                    const int tap = 4 * t3 + g;
+                    wf[nt][t3] = tap < 9 ? *(const half4*)(Wt + (size_t)(4 * SNT * (fr >> 2) + 4 * nt + (fr & 3)) * ps.Kw + tap * 4) : zero4h;
+                }
+                sbias[nt] = *(const float4v*)(ps.bias + 4 * SNT * g + 4 * nt);   // accumulator row 4g + j of n-tile nt = channel 8 g + 4 nt + j
+            }
+            int toff[3];
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3) {
+                const int tap = 4 * t3 + g < 9 ? 4 * t3 + g : 8;
+                toff[t3] = ((tap / 3) * ps.a.Ws + tap % 3) * 8;      // bytes
+            }
+            const __amdgpu_buffer_rsrc_t In = make_rsrc((const _Float16*)ps.a.p + (size_t)b * ps.a.Hs * ps.a.Ws * 4, (unsigned)((size_t)ps.a.Hs * ps.a.Ws * 8));   // this tile's input (conv3_stem_supported: < 2 GB)
+#pragma unroll
+            for (int k0 = 0; k0 < GPW; k0 += HALF) {                        // one round: every operand of the wave's groups is requested before the first product
+                half4 xf[HALF][3];
+#pragma unroll
+                for (int k = 0; k < HALF; ++k) {
+                    const int pi = min((wv + 4 * (k0 + k)) * 16 + fr, NPIX - 1), hr = pi / HC, hc = pi - hr * HC;
+                    const int Y = min(p.a.y0 + oy0 + hr, Hs_o - 1), X = min(p.a.x0 + ox0 + hc, Ws_o - 1);   // (halo pixels beyond the map feed outputs nobody stores)
+                    const unsigned src = (unsigned)(((ps.a.y0 + Y) * ps.a.Ws + ps.a.x0 + X) * 8);
+#pragma unroll
+                    for (int t3 = 0; t3 < 3; ++t3) {
+                        const half4 v = __builtin_bit_cast(half4, __builtin_amdgcn_raw_buffer_load_b64(In, src + (unsigned)toff[t3], 0, 0));
+                        xf[k][t3] = 4 * t3 + g < 9 ? v : zero4h;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < HALF; ++k) {
+                    const int gi = wv + 4 * (k0 + k), pi = gi * 16 + fr;
+                    if (k0 + k >= GPW || gi >= NGRP) break;
+                    _Float16 hq[8];
+#pragma unroll
+                    for (int nt = 0; nt < SNT; ++nt) {
+                        float4v a4 = sbias[nt];
+#pragma unroll
+                        for (int t3 = 0; t3 < 3; ++t3) a4 = __builtin_amdgcn_mfma_f32_16x16x16f16(wf[nt][t3], xf[k][t3], a4, 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float v = a4[j];
+                            if (ps.act == 1) v = v > 0.f ? v : v * ps.alpha;
+                            hq[4 * nt + j] = (_Float16)v;
+                        }
+                    }
+                    const int hr = pi / HC, hc = pi - hr * HC;
+                    if (pi < NPIX) *(half8*)(smem + hr * C::ROWB + halo_slot(hc, g)) = (half8){hq[0], hq[1], hq[2], hq[3], hq[4], hq[5], hq[6], hq[7]};
+                }
+            }
+            const float* bias_late = p.bias;
+            asm volatile("" : "+s"(bias_late) :: "memory");                 // the accumulators are set up HERE (hoisted above the stage they cost it 39 spilled registers)
+            acc_init(bias_late);
+        } else {
             uint4v h[HR], h1;
 #pragma unroll
             for (int hr = 0; hr < HR; ++hr)
@@ -224,19 +299,34 @@ bool conv3_supported(const GemmParams& p) {
     return p.N == 64 || p.N == 128 || p.N == 256;
 }
 
-hipError_t launch_conv3(const GemmParams& p, hipStream_t s) {
+namespace {
+hipError_t launch_conv3_any(const GemmParams& p, const GemmParams* ps, hipStream_t s) {
     using C = Conv3Cfg;
     const int Ho = p.Mrows / p.aW, Wo = p.aW;
-    static unsigned lds_ok = 0, lds_ok_pool = 0;   // per-device bits: kernels.h ensure_dynamic_lds
-    if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<false>, C::SMEM, lds_ok); e != hipSuccess) return e;
-    if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<true>, C::SMEM, lds_ok_pool); e != hipSuccess) return e;
+    static unsigned lds_ok = 0, lds_ok_pool = 0, lds_ok_stem = 0;   // per-device bits: kernels.h ensure_dynamic_lds
+    if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<false, false>, C::SMEM, lds_ok); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<true, false>, C::SMEM, lds_ok_pool); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<false, true>, C::SMEM, lds_ok_stem); e != hipSuccess) return e;
     const int tiles_x = (Wo + C::TW - 1) / C::TW, tiles_y = (Ho + C::TH - 1) / C::TH, nblk = p.N / 64;
     const int xcd_order = nblk > 1 ? 1 : 0;
     const int ntiles = p.B * tiles_x * tiles_y;
     const dim3 grid((unsigned)((xcd_order ? (ntiles + 7) / 8 * 8 : ntiles) * nblk));
-    if (p.pool_out) hipLaunchKernelGGL(conv3_kernel<true>, grid, dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, nblk, xcd_order);
-    else hipLaunchKernelGGL(conv3_kernel<false>, grid, dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, nblk, xcd_order);
+    if (ps) hipLaunchKernelGGL((conv3_kernel<false, true>), grid, dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, nblk, xcd_order, *ps);
+    else if (p.pool_out) hipLaunchKernelGGL((conv3_kernel<true, false>), grid, dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, nblk, xcd_order, GemmParams{});
+    else hipLaunchKernelGGL((conv3_kernel<false, false>), grid, dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, nblk, xcd_order, GemmParams{});
     return hipGetLastError();
 }
+}  // namespace
+
+hipError_t launch_conv3(const GemmParams& p, hipStream_t s) { return launch_conv3_any(p, nullptr, s); }
+
+// the stem (ps: a launch stem_supported() takes, 32 output channels) folded into the 32 -> 64 convolution that is the only reader of its output (p.a = a view of ps.out)
+bool conv3_stem_supported(const GemmParams& p, const GemmParams& ps) {
+    if (switches().no_fuse_stem || !conv3_supported(p) || !stem_supported(ps) || p.pool_out || p.a.Cs != 32 || p.N != 64 || ps.N != 32 || ps.out.Cs != 32 || p.a.p != ps.out.p || ps.out.y0 || ps.out.x0) return false;
+    const int Hs_o = ps.Mrows / ps.aW, Ws_o = ps.aW, Ho = p.Mrows / p.aW, Wo = p.aW;
+    return p.a.Hs == ps.out.Hs && p.a.Ws == ps.out.Ws && p.a.y0 >= 0 && p.a.x0 >= 0 && p.a.y0 + Ho + 2 <= Hs_o && p.a.x0 + Wo + 2 <= Ws_o && p.B == ps.B;
+}
+
+hipError_t launch_conv3_stem(const GemmParams& p, const GemmParams& ps, hipStream_t s) { return launch_conv3_any(p, &ps, s); }
 
 }  // namespace w2x

@@ -174,6 +174,8 @@ bool conv48_supported(const GemmParams& p);                     // k_conv48.hip:
 hipError_t launch_conv48(const GemmParams& p, hipStream_t s);
 bool conv48_stem_supported(const GemmParams& p, const GemmParams& ps);   // k_conv48.hip: the stem launch ps folded into the patch convolution p that alone reads its output
 hipError_t launch_conv48_stem(const GemmParams& p, const GemmParams& ps, hipStream_t s);
+bool conv3_stem_supported(const GemmParams& p, const GemmParams& ps);    // k_conv3.hip: the same for cunet's stem (4 -> 32) in front of its 32 -> 64 convolution
+hipError_t launch_conv3_stem(const GemmParams& p, const GemmParams& ps, hipStream_t s);
 int conv3_tiles(const GemmParams& p);                           // workgroups (= pooling partials) per image of launch_conv3
 hipError_t launch_attn(const AttnParams& p, hipStream_t s);
 // k_f32.hip: the fp32 engine's kernels (Plan::elt == 4): general GEMM / convolution and the window attention core on fp32 rows
