@@ -797,6 +797,33 @@ def test_stem_folded_into_the_patch_convolution_is_bit_identical(pkg, onnx_model
     assert np.array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("scale,tile,batch,shape,tta", [(2, 64, 2, (150, 170), False), (2, 96, 3, (101, 119), True), (1, 64, 2, (90, 131), False), (2, 256, 4, (300, 420), False)])
+def test_transposed_convolution_folded_into_the_convolution_behind_it_is_bit_identical(pkg, onnx_model, scale, tile, batch, shape, tta):
+    """cunet's decoders: ConvTranspose 2x2 stride 2 on the gated map, LeakyReLU, + the cropped skip map, then 3x3 64 -> 64.  As launches: a pixel-shuffle
+    projection (k_pixgemm.hip) that writes the largest 64-channel map of the graph, and the convolution that reads it back.  engine.cpp fuse_up runs them as ONE
+    launch (k_conv3.hip conv3_kernel UP): the convolution's halo fetch brings the skip pixels, each wave computes one sub-pixel class of the projection with
+    pixgemm_kernel's products (operand roles exchanged) and adds it in LDS.  Same products, same roundings: infer() and render() return the same bytes as with
+    the debug switch no_fuse_up, through captured graphs and tile groups; the tile sizes put the halo origin on both parities and leave ragged edge tiles."""
+    path = onnx_model("cunet/art", scale, batch, tile, noise=1)
+    frame = smooth_frame(shape[0], shape[1], 15)
+    x = np.random.default_rng(41).random((batch, 3, tile, tile), dtype=np.float32)
+    outs = []
+    for nofuse in (True, False):
+        with pkg.debug_switches(no_fuse_up=int(nofuse)):
+            eng = make_engine(pkg, path, batch, tile, scale, tta=tta)
+        folded = [m for _, m in eng.messages if "transposed convolution folded" in m]
+        assert bool(folded) == (not nofuse), [m for _, m in eng.messages if "Loaded" in m]
+        if folded:
+            assert ", 2 transposed convolution folded" in folded[0], folded[0]     # the 64-channel pairs of both U-Nets (the 128-channel one keeps its launch)
+        ys = [eng.infer(x) for _ in range(2)]
+        rs = [eng.render(frame) for _ in range(3)]
+        assert np.array_equal(ys[0], ys[1]) and np.array_equal(rs[0], rs[1]) and np.array_equal(rs[0], rs[2])
+        outs.append((ys[0], rs[0]))
+        eng.close()
+    assert np.array_equal(outs[0][0], outs[1][0]), (np.abs(outs[0][0] - outs[1][0]).max(), float((outs[0][0] != outs[1][0]).mean()))
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("name,kw,tile", [
     ("window 8 (64 tokens)", dict(variant={"ws": 8}), 80),
     ("4 / 8 heads of 24 / 48", dict(variant={"heads": 4}), 64),

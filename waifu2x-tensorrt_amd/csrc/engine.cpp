@@ -235,6 +235,7 @@ struct Img2Img::Impl {
     std::vector<int> pool_tensors;
     int final_op = -1;
     std::vector<int> tensor_last;      // last op that touches each tensor (upload_plan)
+    std::vector<char> fuse_up;         // op i is a pixel-shuffle projection (cunet's ConvTranspose) whose map only feeds the 64 -> 64 3x3 convolution that follows: op i + 1's launch computes it in its halo stage (k_conv3.hip conv3_kernel UP), op i is skipped
     std::vector<char> fuse_stem;       // op i is a stem convolution whose 48- / 32-channel map only feeds the 3x3 convolution that follows: op i + 1's launch computes it in its halo stage (k_conv48.hip; k_conv3.hip for cunet), op i is skipped
     std::vector<char> fuse_head;       // op i is a C = 96 MLP whose rows only feed the image head that follows: one launch (k_mlp96q.hip), op i + 1 is skipped
     // fp32 plans: op i (LayerNorm + fc1 + GELU) and op i + 1 (fc2 + residual) are one mlp32_kernel launch when the engine runs Precision::TF32 (k_f32.hip); the hidden
@@ -503,6 +504,20 @@ struct Img2Img::Impl {
                         last[a.g.a.t] = std::max(last[a.g.a.t], i + 1);
                     }
                 }
+            // cunet's transposed convolution folded into the 3x3 convolution behind it (fuse_up, confirmed below with the prepared parameters): that launch reads the
+            // projection's rows, its skip map and its gate, which must therefore outlive the projection by one op.
+            fuse_up.assign(nops, 0);
+            if (plan.elt == 2)
+                for (int i = 0; i + 1 < nops; ++i) {
+                    const Op& a = plan.ops[i]; const Op& b = plan.ops[i + 1];
+                    if (a.kind == OP_GEMM && b.kind == OP_GEMM && a.g.omode == O_PIXSHUF && a.g.r == 2 && a.g.K == 64 && a.g.N == 256 && a.g.res.t >= 0 && a.g.res2.t < 0 && a.g.res_scale < 0 && !a.g.ln &&
+                        a.g.stats_out < 0 && a.g.pool_out < 0 && b.g.amode == A_CONV && b.g.kh == 3 && b.g.kw == 3 && b.g.stride == 1 && b.g.K == 9 * 64 && b.g.N == 64 && b.g.pool_out < 0 && b.g.a.t == a.g.out.t &&
+                        first[a.g.out.t] == i && last[a.g.out.t] == i + 1 && a.g.out.t != plan.out_tensor) {
+                        fuse_up[i] = 1;
+                        for (int t : {a.g.a.t, a.g.res.t, a.g.se_scale})
+                            if (t >= 0) last[t] = std::max(last[t], i + 1);
+                    }
+                }
             tensor_last = last;
             struct Block { size_t off, size; };
             std::vector<Block> free_list;
@@ -665,6 +680,10 @@ struct Img2Img::Impl {
         // Round 6: the same for cunet's two U-Nets, whose stems (4 -> 32) feed a 32 -> 64 convolution each (k_conv3.hip conv3_kernel<false, true>).
         for (size_t i = 0; i + 1 < plan.ops.size(); ++i)
             if (fuse_stem[i] && !conv48_stem_supported(gemm[i + 1], gemm[i]) && !conv3_stem_supported(gemm[i + 1], gemm[i])) fuse_stem[i] = 0;
+        // Round 6: cunet's ConvTranspose 2x2 stride 2 (a pixel-shuffle projection with LeakyReLU, a gate on its rows and a skip add) in front of a 64 -> 64 convolution
+        // that alone reads it: the convolution assembles its halo tile from the skip map and the projection's input rows (k_conv3.hip conv3_kernel UP; switches.h no_fuse_up).
+        for (size_t i = 0; i + 1 < plan.ops.size(); ++i)
+            if (fuse_up[i] && !conv3_up_supported(gemm[i + 1], gemm[i])) fuse_up[i] = 0;
         hipAssert(hipStreamSynchronize(stream));
     }
 
@@ -690,7 +709,7 @@ struct Img2Img::Impl {
         const int b0 = grp < 0 ? 0 : 1;   // (non-zero: re-address the prepared parameters)
         bool skip_next = false;           // the op was folded into the previous launch (fuse_head, mlp32)
         int skip_attn32 = 0;              // ops still to skip behind a swinattn32 launch
-        GemmParams stem_p; bool stem_held = false; double stem_flops = 0;   // the op is folded into the NEXT launch (fuse_stem): its re-addressed parameters wait here
+        GemmParams stem_p; bool stem_held = false, held_up = false; double stem_flops = 0;   // the op is folded into the NEXT launch (fuse_stem): its re-addressed parameters wait here
         for (size_t i = 0; i < plan.ops.size(); ++i) try {
             const Op& op = plan.ops[i];
             cur_op = (int)i;
@@ -738,11 +757,11 @@ struct Img2Img::Impl {
                         skip_next = true;
                         break;
                     }
-                    if (fuse_stem[i] && !check_general) { stem_p = p; stem_held = true; stem_flops = op.flops; break; }    // computed by the next op's launch
+                    if ((fuse_stem[i] || fuse_up[i]) && !check_general) { stem_p = p; stem_held = true; held_up = fuse_up[i] != 0; stem_flops = op.flops; break; }    // computed by the next op's launch
                     if (stem_held) {
                         stem_held = false;
                         stamp_begin(0, op.flops + stem_flops);
-                        hipAssert(conv48_stem_supported(p, stem_p) ? launch_conv48_stem(p, stem_p, s) : launch_conv3_stem(p, stem_p, s));
+                        hipAssert(held_up ? launch_conv3_up(p, stem_p, s) : conv48_stem_supported(p, stem_p) ? launch_conv48_stem(p, stem_p, s) : launch_conv3_stem(p, stem_p, s));
                         stamp_end();
                         break;
                     }
@@ -1226,6 +1245,7 @@ bool Img2Img::load(const std::string& modelPath, const RenderConfig& config) try
     W2X_LOG(info, "Loaded \"" + enginePath + "\": " + std::to_string(plan.ops.size()) + " ops, " + std::to_string(plan.B) + " tiles per pass, activation arena " +
                       std::to_string(impl->arena_bytes >> 20) + " MiB" +
                       (std::count(impl->fuse_stem.begin(), impl->fuse_stem.end(), (char)1) ? ", " + std::to_string(std::count(impl->fuse_stem.begin(), impl->fuse_stem.end(), (char)1)) + " stem folded into the launch of the convolution behind it" : "") +
+                      (std::count(impl->fuse_up.begin(), impl->fuse_up.end(), (char)1) ? ", " + std::to_string(std::count(impl->fuse_up.begin(), impl->fuse_up.end(), (char)1)) + " transposed convolution folded into the launch of the convolution behind it" : "") +
                       (std::count(impl->fuse_head.begin(), impl->fuse_head.end(), (char)1) ? ", image head folded into the last MLP launch" : "") +
                       (config.precision == Precision::TF32 && std::count(impl->fuse_attn32.begin(), impl->fuse_attn32.end(), (char)1) + std::count(impl->fuse_mlp32.begin(), impl->fuse_mlp32.end(), (char)1) > 0
                            ? ", " + std::to_string(std::count(impl->fuse_attn32.begin(), impl->fuse_attn32.end(), (char)1)) + " attention and " +

@@ -59,9 +59,20 @@ __device__ __forceinline__ int halo_slot(int x, int pc) { return x * 64 + ((pc +
 // The stem's products are recomputed for the halo (x 1.29), 8 % on top of this launch's matrix work; the stem launch, its stores and this launch's halo loads go.
 // Config 2 (tools/ab/switch_bench.py, profiles/r6_kernels/cunet_stem_fold_ab.txt): stem 0.365 + convolution 0.99 ms per frame as two launches, 1.05-1.07 ms as one; frame 7.74-7.82
 // against 7.88-7.95 ms.  (With the operands requested in three rounds the launch took 1.15 ms: each round is an L2 round trip in front of the products.)
-template <bool POOL, bool STEM>
+// UP (round 6): the launch computes its input from the transposed convolution in front of it.  cunet's decoders go  x = LeakyReLU(ConvTranspose 2x2 stride 2 (x * gate)) + skip,
+// then 3x3 64 -> 64: as launches, a pixel-shuffle projection (k_pixgemm.hip: 64 -> 4 sub-pixels x 64, gate on its input rows, skip rows added in its epilogue) that
+// writes the largest 64-channel map of the graph (1.2 GB per pass at config 2) and this convolution that reads it back.  With ps = the projection's parameters a
+// chunk's halo tile is assembled in LDS instead: (1) the halo fetch reads the SKIP map's pixels (same extent, same 64-byte pieces: ps.res in place of p.a), each lane
+// the pieces it will add to; (2) the projection's input pixels under the tile - 6 x 34 of them, gated on arrival like pixgemm_kernel's rows - are staged once per workgroup behind the halo
+// tile (29 KB, pixel stride 144 bytes); (3) wave w owns sub-pixel class (dy, dx) = (w >> 1, w & 1): its 5 x 33 halo pixels are eleven groups of 16, each two k-steps
+// of v_mfma_f32_16x16x32_f16 per 16 channels with the bias as the initial accumulator - pixgemm_kernel's products with the operands' roles exchanged (rows = channels,
+// so a lane ends with channels 8g .. 8g + 7 of one pixel = piece g of the halo layout) - LeakyReLU, fp16, and the fp16 add of the skip piece, which was requested before the products and arrives under them; one 16-byte LDS store.
+// The projection launch, its 1.2 GB of stores and this launch's 1.2 GB of halo loads go; the projection's products are recomputed for the halo (x 1.29), 14 % on top
+// of this launch's matrix work.  Bit-identical to the two launches by test (same products in the same order, same roundings).
+template <bool POOL, int MODE>
 __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int Ho, int Wo, int tiles_x, int tiles_y, int nblk, int xcd_order, const GemmParams ps) {
     using C = Conv3Cfg;
+    constexpr bool STEM = MODE == 1, UP = MODE == 2;
     constexpr int HR = C::HR, HC = C::HC;
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -83,7 +94,10 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
     const int oy0 = ty * C::TH, ox0 = tx * C::TW, n0 = nb * 64;
     const int Cin = STEM ? 32 : p.a.Cs, nchunk = Cin / 32, KST = p.K / 32;      // (STEM: one chunk, known to the compiler - the stage's addresses are not loop invariants to be hoisted and spilled)
-    const __amdgpu_buffer_rsrc_t A = make_rsrc((const _Float16*)p.a.p + ((size_t)(b * p.a.Hs + p.a.y0 + oy0) * p.a.Ws + p.a.x0 + ox0) * Cin, 0x7FFFFFFFu);
+    // the map the halo fetch reads: this convolution's input - or, UP, the skip map of the projection that would have produced it (same pixel grid, ps.res's own crop on top)
+    const TView& hsrc = UP ? ps.res : p.a;
+    const int hsy = (UP ? ps.res.y0 : 0) + p.a.y0 + oy0, hsx = (UP ? ps.res.x0 : 0) + p.a.x0 + ox0;
+    const __amdgpu_buffer_rsrc_t A = make_rsrc((const _Float16*)hsrc.p + ((size_t)(b * hsrc.Hs + hsy) * hsrc.Ws + hsx) * Cin, 0x7FFFFFFFu);
     const __amdgpu_buffer_rsrc_t W = make_rsrc((const _Float16*)p.wt_perm + (size_t)nb * KST * 2048, (unsigned)KST * 4096u);   // [KST][4][64][8] of this block
     const unsigned wlane = lane * 16u;
 
@@ -118,13 +132,15 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
         if (slot & 1) for (int i = 0; i < W2X_CONV3_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
     }
 #endif
-    wload(0, 0, 0, 0);
-    wload(1, 0, 1, 0);
+    if (!UP) {                                                        // (UP: requested inside the halo stage, once the skip pieces have begun to leave their registers)
+        wload(0, 0, 0, 0);
+        wload(1, 0, 1, 0);
+    }
 
     // halo copy: thread (pixel column tid >> 2, 16-byte piece tid & 3) takes its column of every halo row; threads 0..79 also take
     // the two extra columns (64, 65) of row tid >> 3
     const int hrows = min(HR, Ho + 2 - oy0), hcols = min(HC, Wo + 2 - ox0);
-    const unsigned rowb = (unsigned)p.a.Ws * (unsigned)Cin * 2u;
+    const unsigned rowb = (unsigned)hsrc.Ws * (unsigned)Cin * 2u;
     const int hc0 = tid >> 2, c8 = tid & 3, hr1 = tid >> 3, hc1 = 64 + ((tid >> 2) & 1);
     const unsigned go0 = hc0 < hcols ? (unsigned)(hc0 * Cin + c8 * 8) * 2u : kNoPix;
     const unsigned go1 = (tid < 80 && hr1 < hrows && hc1 < hcols) ? (unsigned)hr1 * rowb + (unsigned)(hc1 * Cin + c8 * 8) * 2u : kNoPix;
@@ -135,6 +151,35 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
     int xoff[3];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) xoff[kx] = halo_slot(kx + fr, g);
+    // UP: the projection's input pixels under the halo tile, gated, behind the halo tile in LDS ([6][34] pixels, 144 bytes apart)
+    constexpr int XR = HR / 2 + 1, XC = HC / 2 + 1, XPIX = XR * XC, XSTRIDE = 144, XIT = (XPIX * 8 + 255) / 256;
+    unsigned char* xt = smem + C::SMEM;
+    const int Y0 = p.a.y0 + oy0, X0 = p.a.x0 + ox0;                   // the halo tile's origin in the projection's output map
+    const int iy0 = Y0 >> 1, ix0 = X0 >> 1;
+    if constexpr (UP) {
+        const int Hl = ps.Mrows / ps.aW, Wl = ps.aW;
+        const __amdgpu_buffer_rsrc_t XB = make_rsrc((const _Float16*)ps.a.p + (size_t)b * ps.Mrows * 64, (unsigned)ps.Mrows * 128u);
+        uint4v xr[XIT];
+#pragma unroll
+        for (int k = 0; k < XIT; ++k) {
+            const int idx = k * 256 + tid, pix = idx >> 3, c = idx & 7, ly = pix / XC, lx = pix - ly * XC;
+            const bool in = idx < XPIX * 8 && iy0 + ly < Hl && ix0 + lx < Wl;
+            xr[k] = __builtin_amdgcn_raw_buffer_load_b128(XB, in ? (unsigned)(((iy0 + ly) * Wl + ix0 + lx) * 128 + c * 16) : kNoPix, 0, 0);
+        }
+        if (ps.a_scale) {                                              // fp16(x * s), the rounding of pixgemm_kernel's rows; a thread's pieces all hold channels 8 (tid & 7) .. + 7
+            float sc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sc[j] = ps.a_scale[(size_t)b * 64 + (tid & 7) * 8 + j];
+#pragma unroll
+            for (int k = 0; k < XIT; ++k) xr[k] = __builtin_bit_cast(uint4v, gate::gate8(__builtin_bit_cast(half8, xr[k]), sc));
+        }
+#pragma unroll
+        for (int k = 0; k < XIT; ++k) {
+            const int idx = k * 256 + tid, pix = idx >> 3, c = idx & 7;
+            if (idx < XPIX * 8) *(uint4v*)(xt + pix * XSTRIDE + c * 16) = xr[k];
+        }
+        asm volatile("" ::: "memory");
+    }
 #pragma unroll 1
     for (int kc = 0; kc < nchunk; ++kc) {
         if constexpr (STEM) {
@@ -199,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
             const float* bias_late = p.bias;
             asm volatile("" : "+s"(bias_late) :: "memory");                 // the accumulators are set up HERE (hoisted above the stage they cost it 39 spilled registers)
             acc_init(bias_late);
-        } else {
+        } else if constexpr (!UP) {
             uint4v h[HR], h1;
 #pragma unroll
             for (int hr = 0; hr < HR; ++hr)
@@ -209,6 +254,67 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
 #pragma unroll
             for (int hr = 0; hr < HR; ++hr) *(uint4v*)(lo0 + hr * C::ROWB) = h[hr];
             if (tid < 80) *(uint4v*)lo1 = h1;
+        }
+        if constexpr (UP) {
+            // ---- the chunk's halo tile = channels 32 kc .. + 31 of the projection + the skip map, assembled by sub-pixel class: wave w owns class (w >> 1, w & 1), 165 halo
+            // pixels = eleven groups of 16; lane (fr, g) ends with piece g of pixel fr of each group.  The lane's skip pieces are requested first and arrive under the products.
+            // Groups: class row r5 (halo row 2 r5 + r_off) holds 33 pixels = two groups of 16 (k = 2 r5 + j: class columns 16 j + fr) and one left over; the five left-over
+            // pixels (class column 32) are group 10, pixel fr = class row fr.  Every address is then a per-lane constant plus a compile-time / wave-uniform term.
+            constexpr int NGR = 11;
+            const int py = wv >> 1, px = wv & 1, sub = wv;
+            const int r_off = (py - Y0) & 1, c_off = (px - X0) & 1;        // first halo row / column of the class
+            int frl = fr;
+            asm volatile("" : "+v"(frl));                                   // (per-chunk addresses: as loop invariants they would be hoisted and spilled)
+            const int hc_l = 2 * frl + c_off;                               // halo column of pixel fr in group j = 0 (j = 1: + 32; left-over group: 64 + c_off)
+            const int hr_x = 2 * min(frl, HR / 2 - 1) + r_off;              // halo row of pixel fr in the left-over group
+            const _Float16* __restrict__ Wt = (const _Float16*)ps.wt;       // [4 x 64][Kw]: row (dy * 2 + dx) * 64 + channel
+            half8 wq[2][2];
+            float4v bq[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {                                // A fragment row fr = 4 g' + j of n-tile nt = channel 8 g' + 4 nt + j of the chunk
+                const int n = sub * 64 + kc * 32 + 8 * (frl >> 2) + 4 * nt + (frl & 3);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) wq[nt][ks] = *(const half8*)(Wt + (size_t)n * ps.Kw + ks * 32 + g * 8);
+                bq[nt] = *(const float4v*)(ps.bias + sub * 64 + kc * 32 + 8 * g + 4 * nt);
+            }
+            asm volatile("" ::: "memory");                                  // weights first: memory returns in order, the products wait for these only
+            // skip pieces: piece g of the lane's pixel in every group (rows / columns beyond the map: zeros)
+            const unsigned so_l = hc_l < hcols ? (unsigned)(hc_l * Cin + g * 8) * 2u : kNoPix;                  // groups j = 0; j = 1 adds 32 pixels
+            const unsigned so_h = hc_l + 32 < hcols ? so_l + 32u * (unsigned)Cin * 2u : kNoPix;
+            const unsigned so_x = (frl < HR / 2 && hr_x < hrows && 64 + c_off < hcols) ? (unsigned)hr_x * rowb + (unsigned)((64 + c_off) * Cin + g * 8) * 2u : kNoPix;
+            uint4v sk[NGR];
+#pragma unroll
+            for (int k = 0; k < NGR - 1; ++k) {
+                const int hr = 2 * (k >> 1) + r_off;
+                sk[k] = __builtin_amdgcn_raw_buffer_load_b128(A, hr < hrows ? ((k & 1) ? so_h : so_l) : kNoPix, (unsigned)hr * rowb + (unsigned)kc * 64u, 0);
+            }
+            sk[NGR - 1] = __builtin_amdgcn_raw_buffer_load_b128(A, so_x, (unsigned)kc * 64u, 0);
+            asm volatile("" ::: "memory");
+            __syncthreads();                                                // the previous chunk's products are done with the halo tile (first chunk: the staged input pixels are in LDS)
+            // LDS: the lane's pixel of a group in the staged input tile (B operand, 2 x 16 bytes) and in the halo tile (one 16-byte store)
+            const int xl = (((X0 + hc_l) >> 1) - ix0) * XSTRIDE + g * 16;                                     // j = 1: + 16 pixels
+            const int xx = ((((Y0 + hr_x) >> 1) - iy0) * XC + ((X0 + 64 + c_off) >> 1) - ix0) * XSTRIDE + g * 16;
+            const int hl = halo_slot(hc_l, g);                                                                // j = 1: + 32 * 64 bytes (the rotation has period 16 pixels)
+            const int hx = hr_x * C::ROWB + halo_slot(64 + c_off, g);
+#pragma unroll
+            for (int k = 0; k < NGR; ++k) {
+                const bool last = k == NGR - 1;
+                const int hr = 2 * (k >> 1) + r_off;                                                         // (groups 0 .. 9)
+                const unsigned char* xp = xt + (last ? xx : (((Y0 + hr) >> 1) - iy0) * (XC * XSTRIDE) + xl + (k & 1) * 16 * XSTRIDE);
+                unsigned char* hp = smem + (last ? hx : hr * C::ROWB + hl + (k & 1) * 32 * 64);
+                if (k == 8) { wload(0, kc, 0, 0); wload(1, kc, 1, 0); }     // the first taps of this chunk's products, into registers the skip pieces have left
+                const half8 xb0 = *(const half8*)xp, xb1 = *(const half8*)(xp + 64);
+                float4v a4[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    a4[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[nt][0], xb0, bq[nt], 0, 0, 0);
+                    a4[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[nt][1], xb1, a4[nt], 0, 0, 0);
+                    if (ps.act == 1) a4[nt] = __builtin_elementwise_max(a4[nt], a4[nt] * ps.alpha);   // LeakyReLU with a slope in [0, 1] (conv3_up_supported) = pixgemm_kernel's v > 0 ? v : v * alpha
+                }
+                half8 o = (half8){(_Float16)a4[0][0], (_Float16)a4[0][1], (_Float16)a4[0][2], (_Float16)a4[0][3], (_Float16)a4[1][0], (_Float16)a4[1][1], (_Float16)a4[1][2], (_Float16)a4[1][3]};
+                o += __builtin_bit_cast(half8, sk[k]);                      // fp16 + fp16, as pixgemm_kernel's epilogue
+                if (!last || frl < HR / 2) *(half8*)hp = o;
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -224,10 +330,10 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
             wload(2, kc, 2, kx);
             mm(0, 1, xa); mm(1, 0, xa);
             xload(2);
-            if (kx < 2) wload(0, kc, 0, kx + 1); else wload(0, kc + 1, 0, 0);
+            if (kx < 2) wload(0, kc, 0, kx + 1); else if (!UP) wload(0, kc + 1, 0, 0);
             mm(0, 2, xa); mm(1, 1, xa);
             xload(3);
-            if (kx < 2) wload(1, kc, 1, kx + 1); else wload(1, kc + 1, 1, 0);
+            if (kx < 2) wload(1, kc, 1, kx + 1); else if (!UP) wload(1, kc + 1, 1, 0);
             mm(1, 2, xa);
         }
     }
@@ -300,25 +406,28 @@ bool conv3_supported(const GemmParams& p) {
 }
 
 namespace {
-hipError_t launch_conv3_any(const GemmParams& p, const GemmParams* ps, hipStream_t s) {
+constexpr int kUpSmem = Conv3Cfg::SMEM + (Conv3Cfg::HR / 2 + 1) * (Conv3Cfg::HC / 2 + 1) * 144;   // halo tile + the projection's staged input pixels (conv3_kernel, UP)
+hipError_t launch_conv3_any(const GemmParams& p, const GemmParams* ps, int mode, hipStream_t s) {
     using C = Conv3Cfg;
     const int Ho = p.Mrows / p.aW, Wo = p.aW;
-    static unsigned lds_ok = 0, lds_ok_pool = 0, lds_ok_stem = 0;   // per-device bits: kernels.h ensure_dynamic_lds
-    if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<false, false>, C::SMEM, lds_ok); e != hipSuccess) return e;
-    if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<true, false>, C::SMEM, lds_ok_pool); e != hipSuccess) return e;
-    if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<false, true>, C::SMEM, lds_ok_stem); e != hipSuccess) return e;
+    static unsigned lds_ok = 0, lds_ok_pool = 0, lds_ok_stem = 0, lds_ok_up = 0;   // per-device bits: kernels.h ensure_dynamic_lds
+    if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<false, 0>, C::SMEM, lds_ok); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<true, 0>, C::SMEM, lds_ok_pool); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<false, 1>, C::SMEM, lds_ok_stem); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<false, 2>, kUpSmem, lds_ok_up); e != hipSuccess) return e;
     const int tiles_x = (Wo + C::TW - 1) / C::TW, tiles_y = (Ho + C::TH - 1) / C::TH, nblk = p.N / 64;
     const int xcd_order = nblk > 1 ? 1 : 0;
     const int ntiles = p.B * tiles_x * tiles_y;
     const dim3 grid((unsigned)((xcd_order ? (ntiles + 7) / 8 * 8 : ntiles) * nblk));
-    if (ps) hipLaunchKernelGGL((conv3_kernel<false, true>), grid, dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, nblk, xcd_order, *ps);
-    else if (p.pool_out) hipLaunchKernelGGL((conv3_kernel<true, false>), grid, dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, nblk, xcd_order, GemmParams{});
-    else hipLaunchKernelGGL((conv3_kernel<false, false>), grid, dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, nblk, xcd_order, GemmParams{});
+    if (mode == 1) hipLaunchKernelGGL((conv3_kernel<false, 1>), grid, dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, nblk, xcd_order, *ps);
+    else if (mode == 2) hipLaunchKernelGGL((conv3_kernel<false, 2>), grid, dim3(256), kUpSmem, s, p, Ho, Wo, tiles_x, tiles_y, nblk, xcd_order, *ps);
+    else if (p.pool_out) hipLaunchKernelGGL((conv3_kernel<true, 0>), grid, dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, nblk, xcd_order, GemmParams{});
+    else hipLaunchKernelGGL((conv3_kernel<false, 0>), grid, dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, nblk, xcd_order, GemmParams{});
     return hipGetLastError();
 }
 }  // namespace
 
-hipError_t launch_conv3(const GemmParams& p, hipStream_t s) { return launch_conv3_any(p, nullptr, s); }
+hipError_t launch_conv3(const GemmParams& p, hipStream_t s) { return launch_conv3_any(p, nullptr, 0, s); }
 
 // the stem (ps: a launch stem_supported() takes, 32 output channels) folded into the 32 -> 64 convolution that is the only reader of its output (p.a = a view of ps.out)
 bool conv3_stem_supported(const GemmParams& p, const GemmParams& ps) {
@@ -327,6 +436,21 @@ bool conv3_stem_supported(const GemmParams& p, const GemmParams& ps) {
     return p.a.Hs == ps.out.Hs && p.a.Ws == ps.out.Ws && p.a.y0 >= 0 && p.a.x0 >= 0 && p.a.y0 + Ho + 2 <= Hs_o && p.a.x0 + Wo + 2 <= Ws_o && p.B == ps.B;
 }
 
-hipError_t launch_conv3_stem(const GemmParams& p, const GemmParams& ps, hipStream_t s) { return launch_conv3_any(p, &ps, s); }
+hipError_t launch_conv3_stem(const GemmParams& p, const GemmParams& ps, hipStream_t s) { return launch_conv3_any(p, &ps, 1, s); }
+
+// the pixel-shuffle projection q (cunet's ConvTranspose 2x2 stride 2 as Linear 64 -> 4 x 64 + DepthToSpace, LeakyReLU, gate on its rows, skip add: a launch
+// pixgemm_supported() takes) folded into the 64 -> 64 convolution p that is the only reader of its output (p.a = a view of q.out)
+bool conv3_up_supported(const GemmParams& p, const GemmParams& q) {
+    if (switches().no_fuse_up || !conv3_supported(p) || !pixgemm_supported(q) || p.pool_out || p.a.Cs != 64 || p.N != 64) return false;
+    if (q.act == 1 && !(q.alpha >= 0.f && q.alpha <= 1.f)) return false;   // LeakyReLU as max(v, v * alpha)
+    if (q.omode != 2 || q.r != 2 || q.K != 64 || q.N != 256 || q.out.Cs != 64 || !q.wt || q.Kw < 64 || !q.res.p || q.res.Cs != 64 || q.res_scale || q.res2.p || q.a.Cs != 64) return false;
+    if (p.a.p != q.out.p || q.out.y0 || q.out.x0 || p.a.Hs != q.out.Hs || p.a.Ws != q.out.Ws || p.B != q.B || q.aW <= 0 || q.Mrows % q.aW) return false;
+    const int Hl = q.Mrows / q.aW, Wl = q.aW, Ho = p.Mrows / p.aW, Wo = p.aW;
+    if (p.a.y0 < 0 || p.a.x0 < 0 || p.a.y0 + Ho + 2 > 2 * Hl || p.a.x0 + Wo + 2 > 2 * Wl || q.out.Hs < 2 * Hl || q.out.Ws < 2 * Wl) return false;   // every stored output reads pixels the projection produces
+    if (q.res.y0 < 0 || q.res.x0 < 0 || q.res.y0 + p.a.y0 + Ho + 2 > q.res.Hs || q.res.x0 + p.a.x0 + Wo + 2 > q.res.Ws) return false;
+    return (size_t)(Conv3Cfg::HR + 1) * q.res.Ws * 64 * 2 <= 0x7FFFFFFFull && (size_t)q.Mrows * 128 < 0xFFFF0000ull;      // 32-bit offsets
+}
+
+hipError_t launch_conv3_up(const GemmParams& p, const GemmParams& q, hipStream_t s) { return launch_conv3_any(p, &q, 2, s); }
 
 }  // namespace w2x

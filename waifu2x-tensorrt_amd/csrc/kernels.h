@@ -176,6 +176,8 @@ bool conv48_stem_supported(const GemmParams& p, const GemmParams& ps);   // k_co
 hipError_t launch_conv48_stem(const GemmParams& p, const GemmParams& ps, hipStream_t s);
 bool conv3_stem_supported(const GemmParams& p, const GemmParams& ps);    // k_conv3.hip: the same for cunet's stem (4 -> 32) in front of its 32 -> 64 convolution
 hipError_t launch_conv3_stem(const GemmParams& p, const GemmParams& ps, hipStream_t s);
+bool conv3_up_supported(const GemmParams& p, const GemmParams& q);       // k_conv3.hip: cunet's ConvTranspose (pixel-shuffle projection q, LeakyReLU, skip add) computed in the halo stage of the 64 -> 64 convolution p behind it
+hipError_t launch_conv3_up(const GemmParams& p, const GemmParams& q, hipStream_t s);
 int conv3_tiles(const GemmParams& p);                           // workgroups (= pooling partials) per image of launch_conv3
 hipError_t launch_attn(const AttnParams& p, hipStream_t s);
 // k_f32.hip: the fp32 engine's kernels (Plan::elt == 4): general GEMM / convolution and the window attention core on fp32 rows
