@@ -544,7 +544,7 @@ def main():
     desc = pkg.describe_plan(path, eng.pass_tiles, TILE).splitlines()[2:]
     op_ms = eng.op_times()
     # an op the engine folded into a neighbour's launch has no launch of its own and reports 0 ms: the image head riding on the last C = 96 MLP
-    # (engine.cpp fuse_head; its time is inside the previous op's) and the stem computed by the patch convolution behind it (fuse_stem; inside the next op's)
+    # (engine.cpp fuse_head; its time is inside the previous op's) and the stems / transposed convolutions computed by the convolution behind them (fuse_stem, fuse_up; inside the next op's)
     folded = [i for i, (line, t) in enumerate(zip(desc, op_ms)) if t == 0.0 and i > 0 and " gemm " in f" {line} " and " mlp " in f" {desc[i - 1]} "]
     folded_fwd = [i for i, (line, t) in enumerate(zip(desc, op_ms)) if t == 0.0 and i + 1 < len(desc) and " gemm " in f" {line} " and " gemm " in f" {desc[i + 1]} " and i not in folded]
     if a.op_times and rank == 0:
@@ -617,7 +617,10 @@ def main():
         if folded:
             notes.append("mlp96q_kernel's figure includes the image head (Linear 96 -> 64, Clip, DepthToSpace), which the engine folds into the last C = 96 MLP launch; that plan op has no launch and reports 0 ms")
         if folded_fwd:
-            notes.append("the stem convolution (3x3, 4 -> 48) is computed inside the patch convolution's launch (conv48_kernel<true>) and is counted with it; that plan op has no launch and reports 0 ms")
+            names = [re.sub(r"^.*\[(.*)\]\s*$", r"\1", desc[i]) for i in folded_fwd]
+            notes.append("computed inside the NEXT op's launch and counted with it (the plan op has no launch and reports 0 ms; the launch's roofline figures price its own op only): " + ", ".join(names) +
+                         " - a stem convolution in the halo stage of the convolution behind it (conv48_kernel<true> / conv3_kernel<false, 1>), cunet's transposed convolutions in the halo stage of "
+                         "the 64 -> 64 convolutions behind them (conv3_kernel<false, 2>)")
         if notes:
             roof["kernels_note"] = "; ".join(notes)
         tr = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/profile_round.sh)

@@ -125,7 +125,7 @@ int w2x_device_pci_bus_id(int device, char* buf, size_t cap);
 void w2x_sha256_hex(const void* data, size_t len, char* out);
 const char* w2x_version(void);
 /* Test hook, process-wide: the reference paths the A/B tests compare the shipped kernels and plans with - un-fused lowering ("no_fuse", "no_fuse_attn",
- * "no_se_fold"; read by build), separate launches ("no_fuse_head", "no_fuse_stem"; read by load), the general kernel instead of a shape-specialised one
+ * "no_se_fold"; read by build), separate launches ("no_fuse_head", "no_fuse_stem", "no_fuse_up"; read by load), the general kernel instead of a shape-specialised one
  * ("no_pixgemm", "no_conv3", "no_conv3h", "no_conv48", "no_stem", "attn_valu"; read per launch).  They have no environment names.  The operational
  * switches (W2X_GROUPS, W2X_NO_GRAPH, ... - csrc/switches.h) can be set here too, by field name, but are re-read from the environment by
  * every build / load.  1 = set, 0 = no such switch. */

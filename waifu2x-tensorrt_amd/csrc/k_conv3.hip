@@ -29,6 +29,12 @@
 #include "kernels.h"
 #include <cstdlib>
 
+#ifndef W2X_UP_WL
+#define W2X_UP_WL 8
+#endif
+#ifndef W2X_UP_ABL
+#define W2X_UP_ABL 0
+#endif
 namespace w2x {
 namespace {
 
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
     const int b = tidx / tpi, trem = tidx - b * tpi;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
     const int oy0 = ty * C::TH, ox0 = tx * C::TW, n0 = nb * 64;
-    const int Cin = STEM ? 32 : p.a.Cs, nchunk = Cin / 32, KST = p.K / 32;      // (STEM: one chunk, known to the compiler - the stage's addresses are not loop invariants to be hoisted and spilled)
+    const int Cin = STEM ? 32 : UP ? 64 : p.a.Cs, nchunk = Cin / 32, KST = p.K / 32;      // (STEM: one chunk, known to the compiler - the stage's addresses are not loop invariants to be hoisted and spilled)
     // the map the halo fetch reads: this convolution's input - or, UP, the skip map of the projection that would have produced it (same pixel grid, ps.res's own crop on top)
     const TView& hsrc = UP ? ps.res : p.a;
     const int hsy = (UP ? ps.res.y0 : 0) + p.a.y0 + oy0, hsx = (UP ? ps.res.x0 : 0) + p.a.x0 + ox0;
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
                 for (int mt = 0; mt < 4; ++mt) acc[r][mt][nt] = bv;
         }
     };
-    if (!STEM) acc_init(p.bias);                                            // (STEM: after the halo stage, whose operands need the registers)
+    if (!STEM && !UP) acc_init(p.bias);                                            // (STEM: after the halo stage, whose operands need the registers)
     half8 w[3][4];                                                    // ring: slot = ky
     auto wload = [&](int slot, int kc, int ky, int kx) {     // past the last chunk the k-step lies beyond the block: the fetch returns zeros, nobody reads them
         const unsigned vo = wlane + (unsigned)((ky * 3 + kx) * nchunk + kc) * 4096u;    // k-step (tap * Cin + 32 kc) / 32
@@ -156,32 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
     unsigned char* xt = smem + C::SMEM;
     const int Y0 = p.a.y0 + oy0, X0 = p.a.x0 + ox0;                   // the halo tile's origin in the projection's output map
     const int iy0 = Y0 >> 1, ix0 = X0 >> 1;
-    if constexpr (UP) {
-        const int Hl = ps.Mrows / ps.aW, Wl = ps.aW;
-        const __amdgpu_buffer_rsrc_t XB = make_rsrc((const _Float16*)ps.a.p + (size_t)b * ps.Mrows * 64, (unsigned)ps.Mrows * 128u);
-        uint4v xr[XIT];
-#pragma unroll
-        for (int k = 0; k < XIT; ++k) {
-            const int idx = k * 256 + tid, pix = idx >> 3, c = idx & 7, ly = pix / XC, lx = pix - ly * XC;
-            const bool in = idx < XPIX * 8 && iy0 + ly < Hl && ix0 + lx < Wl;
-            xr[k] = __builtin_amdgcn_raw_buffer_load_b128(XB, in ? (unsigned)(((iy0 + ly) * Wl + ix0 + lx) * 128 + c * 16) : kNoPix, 0, 0);
-        }
-        if (ps.a_scale) {                                              // fp16(x * s), the rounding of pixgemm_kernel's rows; a thread's pieces all hold channels 8 (tid & 7) .. + 7
-            float sc[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sc[j] = ps.a_scale[(size_t)b * 64 + (tid & 7) * 8 + j];
-#pragma unroll
-            for (int k = 0; k < XIT; ++k) xr[k] = __builtin_bit_cast(uint4v, gate::gate8(__builtin_bit_cast(half8, xr[k]), sc));
-        }
-#pragma unroll
-        for (int k = 0; k < XIT; ++k) {
-            const int idx = k * 256 + tid, pix = idx >> 3, c = idx & 7;
-            if (idx < XPIX * 8) *(uint4v*)(xt + pix * XSTRIDE + c * 16) = xr[k];
-        }
-        asm volatile("" ::: "memory");
-    }
-#pragma unroll 1
-    for (int kc = 0; kc < nchunk; ++kc) {
+    auto chunk = [&](const int kc) __attribute__((always_inline)) {
         if constexpr (STEM) {
             // ---- the chunk (all 32 channels: conv3_stem_supported) computed from the network's input tile: stem_kernel<2>'s arithmetic per group of 16 halo pixels
             constexpr int SNT = 2, NPIX = HR * HC, NGRP = (NPIX + 15) / 16, GPW = (NGRP + 3) / 4, HALF = GPW;             // (HALF: groups of a wave per round)
@@ -290,19 +271,50 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
             }
             sk[NGR - 1] = __builtin_amdgcn_raw_buffer_load_b128(A, so_x, (unsigned)kc * 64u, 0);
             asm volatile("" ::: "memory");
+            if (kc == 0 && !(W2X_UP_ABL & 2)) {   // the projection's input pixels: requested behind the first chunk's skip pieces (one round trip for both), gated, to LDS behind the halo tile
+                const int Hl = ps.Mrows / ps.aW, Wl = ps.aW;
+                const __amdgpu_buffer_rsrc_t XB = make_rsrc((const _Float16*)ps.a.p + (size_t)b * ps.Mrows * 64, (unsigned)ps.Mrows * 128u);
+                float sc[8];                                                    // the gate of this thread's pieces: all of them hold channels 8 (tid & 7) .. + 7
+                if (ps.a_scale) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sc[j] = ps.a_scale[(size_t)b * 64 + (tid & 7) * 8 + j];
+                }
+                uint4v xr[XIT];
+#pragma unroll
+                for (int k = 0; k < XIT; ++k) {
+                    const int idx = k * 256 + tid, pix = idx >> 3, c = idx & 7, ly = pix / XC, lx = pix - ly * XC;
+                    const bool in = idx < XPIX * 8 && iy0 + ly < Hl && ix0 + lx < Wl;
+                    xr[k] = __builtin_amdgcn_raw_buffer_load_b128(XB, in ? (unsigned)(((iy0 + ly) * Wl + ix0 + lx) * 128 + c * 16) : kNoPix, 0, 0);
+                }
+                if (ps.a_scale) {                                              // fp16(x * s), the rounding of pixgemm_kernel's rows
+#pragma unroll
+                    for (int k = 0; k < XIT; ++k) xr[k] = __builtin_bit_cast(uint4v, gate::gate8(__builtin_bit_cast(half8, xr[k]), sc));
+                }
+#pragma unroll
+                for (int k = 0; k < XIT; ++k) {
+                    const int idx = k * 256 + tid, pix = idx >> 3, c = idx & 7;
+                    if (idx < XPIX * 8) *(uint4v*)(xt + pix * XSTRIDE + c * 16) = xr[k];
+                }
+                asm volatile("" ::: "memory");
+            }
             __syncthreads();                                                // the previous chunk's products are done with the halo tile (first chunk: the staged input pixels are in LDS)
             // LDS: the lane's pixel of a group in the staged input tile (B operand, 2 x 16 bytes) and in the halo tile (one 16-byte store)
             const int xl = (((X0 + hc_l) >> 1) - ix0) * XSTRIDE + g * 16;                                     // j = 1: + 16 pixels
             const int xx = ((((Y0 + hr_x) >> 1) - iy0) * XC + ((X0 + 64 + c_off) >> 1) - ix0) * XSTRIDE + g * 16;
             const int hl = halo_slot(hc_l, g);                                                                // j = 1: + 32 * 64 bytes (the rotation has period 16 pixels)
             const int hx = hr_x * C::ROWB + halo_slot(64 + c_off, g);
+            if (kc == 0) {
+                const float* bias_late = p.bias;
+                asm volatile("" : "+s"(bias_late) :: "memory");             // (as in the STEM stage: the accumulators are set up behind the first chunk's requests)
+                acc_init(bias_late);
+            }
 #pragma unroll
             for (int k = 0; k < NGR; ++k) {
                 const bool last = k == NGR - 1;
                 const int hr = 2 * (k >> 1) + r_off;                                                         // (groups 0 .. 9)
                 const unsigned char* xp = xt + (last ? xx : (((Y0 + hr) >> 1) - iy0) * (XC * XSTRIDE) + xl + (k & 1) * 16 * XSTRIDE);
                 unsigned char* hp = smem + (last ? hx : hr * C::ROWB + hl + (k & 1) * 32 * 64);
-                if (k == 8) { wload(0, kc, 0, 0); wload(1, kc, 1, 0); }     // the first taps of this chunk's products, into registers the skip pieces have left
+                if (k == W2X_UP_WL) { wload(0, kc, 0, 0); wload(1, kc, 1, 0); }     // the first taps of this chunk's products, into registers the skip pieces have left
                 const half8 xb0 = *(const half8*)xp, xb1 = *(const half8*)(xp + 64);
                 float4v a4[2];
 #pragma unroll
@@ -313,6 +325,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
                 }
                 half8 o = (half8){(_Float16)a4[0][0], (_Float16)a4[0][1], (_Float16)a4[0][2], (_Float16)a4[0][3], (_Float16)a4[1][0], (_Float16)a4[1][1], (_Float16)a4[1][2], (_Float16)a4[1][3]};
                 o += __builtin_bit_cast(half8, sk[k]);                      // fp16 + fp16, as pixgemm_kernel's epilogue
+                if (W2X_UP_ABL & 1) o = __builtin_bit_cast(half8, sk[k]);
                 if (!last || frl < HR / 2) *(half8*)hp = o;
             }
         }
@@ -336,6 +349,11 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
             if (kx < 2) wload(1, kc, 1, kx + 1); else if (!UP) wload(1, kc + 1, 1, 0);
             mm(1, 2, xa);
         }
+    };
+    if constexpr (UP) { chunk(0); chunk(1); }                         // (two chunks, each with its own register allocation: the first one also stages the projection's input pixels)
+    else {
+#pragma unroll 1
+        for (int kc = 0; kc < nchunk; ++kc) chunk(kc);
     }
 
     // ---- epilogue: LeakyReLU / none, fp16, 2 x 16 bytes per lane and pixel; squeeze-excite partial sums of the stored values
