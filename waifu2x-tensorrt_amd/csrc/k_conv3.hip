@@ -29,12 +29,6 @@
 #include "kernels.h"
 #include <cstdlib>
 
-#ifndef W2X_UP_WL
-#define W2X_UP_WL 8
-#endif
-#ifndef W2X_UP_ABL
-#define W2X_UP_ABL 0
-#endif
 namespace w2x {
 namespace {
 
@@ -248,17 +242,19 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
             asm volatile("" : "+v"(frl));                                   // (per-chunk addresses: as loop invariants they would be hoisted and spilled)
             const int hc_l = 2 * frl + c_off;                               // halo column of pixel fr in group j = 0 (j = 1: + 32; left-over group: 64 + c_off)
             const int hr_x = 2 * min(frl, HR / 2 - 1) + r_off;              // halo row of pixel fr in the left-over group
-            const _Float16* __restrict__ Wt = (const _Float16*)ps.wt;       // [4 x 64][Kw]: row (dy * 2 + dx) * 64 + channel
+            // weights [4 x 64][Kw] (row (dy * 2 + dx) * 64 + channel) and bias through buffer resources: as pointer loads the compiler sank them below the barrier
+            const __amdgpu_buffer_rsrc_t WQ = make_rsrc(ps.wt, 256u * (unsigned)ps.Kw * 2u), BQ = make_rsrc(ps.bias, 256u * 4u);
             half8 wq[2][2];
             float4v bq[2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {                                // A fragment row fr = 4 g' + j of n-tile nt = channel 8 g' + 4 nt + j of the chunk
                 const int n = sub * 64 + kc * 32 + 8 * (frl >> 2) + 4 * nt + (frl & 3);
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) wq[nt][ks] = *(const half8*)(Wt + (size_t)n * ps.Kw + ks * 32 + g * 8);
-                bq[nt] = *(const float4v*)(ps.bias + sub * 64 + kc * 32 + 8 * g + 4 * nt);
+                for (int ks = 0; ks < 2; ++ks) wq[nt][ks] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(WQ, (unsigned)(n * ps.Kw + ks * 32 + g * 8) * 2u, 0, 0));
+                bq[nt] = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(BQ, (unsigned)(sub * 64 + kc * 32 + 8 * g + 4 * nt) * 4u, 0, 0));
             }
             asm volatile("" ::: "memory");                                  // weights first: memory returns in order, the products wait for these only
+            const float slope = ps.act == 1 ? ps.alpha : 1.f;               // LeakyReLU with a slope in [0, 1] (conv3_up_supported) as max(v, v * slope) = pixgemm_kernel's v > 0 ? v : v * alpha; 1: none
             // skip pieces: piece g of the lane's pixel in every group (rows / columns beyond the map: zeros)
             const unsigned so_l = hc_l < hcols ? (unsigned)(hc_l * Cin + g * 8) * 2u : kNoPix;                  // groups j = 0; j = 1 adds 32 pixels
             const unsigned so_h = hc_l + 32 < hcols ? so_l + 32u * (unsigned)Cin * 2u : kNoPix;
@@ -271,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
             }
             sk[NGR - 1] = __builtin_amdgcn_raw_buffer_load_b128(A, so_x, (unsigned)kc * 64u, 0);
             asm volatile("" ::: "memory");
-            if (kc == 0 && !(W2X_UP_ABL & 2)) {   // the projection's input pixels: requested behind the first chunk's skip pieces (one round trip for both), gated, to LDS behind the halo tile
+            if (kc == 0) {   // the projection's input pixels: requested behind the first chunk's skip pieces (one round trip for both), gated, to LDS behind the halo tile
                 const int Hl = ps.Mrows / ps.aW, Wl = ps.aW;
                 const __amdgpu_buffer_rsrc_t XB = make_rsrc((const _Float16*)ps.a.p + (size_t)b * ps.Mrows * 64, (unsigned)ps.Mrows * 128u);
                 float sc[8];                                                    // the gate of this thread's pieces: all of them hold channels 8 (tid & 7) .. + 7
@@ -314,18 +310,17 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
                 const int hr = 2 * (k >> 1) + r_off;                                                         // (groups 0 .. 9)
                 const unsigned char* xp = xt + (last ? xx : (((Y0 + hr) >> 1) - iy0) * (XC * XSTRIDE) + xl + (k & 1) * 16 * XSTRIDE);
                 unsigned char* hp = smem + (last ? hx : hr * C::ROWB + hl + (k & 1) * 32 * 64);
-                if (k == W2X_UP_WL) { wload(0, kc, 0, 0); wload(1, kc, 1, 0); }     // the first taps of this chunk's products, into registers the skip pieces have left
+                if (k == 8) { wload(0, kc, 0, 0); wload(1, kc, 1, 0); }     // the first taps of this chunk's products, into registers the skip pieces have left
                 const half8 xb0 = *(const half8*)xp, xb1 = *(const half8*)(xp + 64);
                 float4v a4[2];
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     a4[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[nt][0], xb0, bq[nt], 0, 0, 0);
                     a4[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[nt][1], xb1, a4[nt], 0, 0, 0);
-                    if (ps.act == 1) a4[nt] = __builtin_elementwise_max(a4[nt], a4[nt] * ps.alpha);   // LeakyReLU with a slope in [0, 1] (conv3_up_supported) = pixgemm_kernel's v > 0 ? v : v * alpha
+                    a4[nt] = __builtin_elementwise_max(a4[nt], a4[nt] * slope);
                 }
                 half8 o = (half8){(_Float16)a4[0][0], (_Float16)a4[0][1], (_Float16)a4[0][2], (_Float16)a4[0][3], (_Float16)a4[1][0], (_Float16)a4[1][1], (_Float16)a4[1][2], (_Float16)a4[1][3]};
                 o += __builtin_bit_cast(half8, sk[k]);                      // fp16 + fp16, as pixgemm_kernel's epilogue
-                if (W2X_UP_ABL & 1) o = __builtin_bit_cast(half8, sk[k]);
                 if (!last || frl < HR / 2) *(half8*)hp = o;
             }
         }
