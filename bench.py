@@ -78,7 +78,8 @@ def kernel_source_sha(symbol: str):
     if not f:
         return None
     h = hashlib.sha256()
-    for path in (os.path.join(ROOT, "waifu2x-tensorrt_amd", "csrc", f), os.path.join(ROOT, "waifu2x-tensorrt_amd", "Makefile")):
+    # (kernels.h holds what the kernel files share: the output stores' cache policy, the gate arithmetic, the parameter blocks)
+    for path in (os.path.join(ROOT, "waifu2x-tensorrt_amd", "csrc", f), os.path.join(ROOT, "waifu2x-tensorrt_amd", "csrc", "kernels.h"), os.path.join(ROOT, "waifu2x-tensorrt_amd", "Makefile")):
         try:
             h.update(open(path, "rb").read())
         except OSError:

@@ -716,7 +716,6 @@ __global__ __launch_bounds__(384, 2) void swinattn32_kernel(const SwinAttn32Para
     const __amdgpu_buffer_rsrc_t WQH = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wqkv_h), 0, 3u * C * C * 2u, 0x00020000);   // [3C / 16 row tiles][KS][64 lanes][8]
     const __amdgpu_buffer_rsrc_t WQL = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wqkv_l), 0, 3u * C * C * 2u, 0x00020000);
     const unsigned l16 = lane * 16u;
-    typedef unsigned uint4w __attribute__((ext_vector_type(4)));
     auto wfrag = [&](int sel, int dt, int ks) {                       // fragment of matrix sel (0 q, 1 k, 2 v), feature tile dt of this head, k-step ks
         const unsigned f = (unsigned)(((sel * C + h * HD) / 16 + dt) * KS + ks) * 1024u;
         Bf2 w;
