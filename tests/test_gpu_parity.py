@@ -824,6 +824,28 @@ def test_transposed_convolution_folded_into_the_convolution_behind_it_is_bit_ide
     assert np.array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("scale,tile,batch,shape,tta", [(2, 64, 2, (150, 170), False), (2, 96, 3, (101, 119), True), (1, 64, 2, (90, 131), False), (2, 256, 4, (300, 420), False), (1, 112, 1, (200, 90), False)])
+def test_image_heads_as_a_column_walk_are_bit_identical(pkg, onnx_model, scale, tile, batch, shape, tta):
+    """cunet's two image heads (3x3 from 64 channels onto 3 channels + skip + clip, and onto 4 sub-pixels x 3 channels) are pure input streams.  k_conv3h.hip runs them as a
+    walk down 64-column strips (conv3h_walk_kernel: a ring of eight input rows in LDS, four new rows requested under the products of the previous four, every row fetched
+    once) instead of one halo tile per workgroup (conv3h_kernel, kept behind the debug switch no_conv3h_walk).  Same products in the same order, same epilogue: the same
+    bytes from infer() and render(), on tiles whose maps are not multiples of 64 columns or of the row blocks, through captured graphs and tile groups."""
+    path = onnx_model("cunet/art", scale, batch, tile, noise=1)
+    frame = smooth_frame(shape[0], shape[1], 16)
+    x = np.random.default_rng(43).random((batch, 3, tile, tile), dtype=np.float32)
+    outs = []
+    for nowalk in (True, False):
+        with pkg.debug_switches(no_conv3h_walk=int(nowalk)):
+            eng = make_engine(pkg, path, batch, tile, scale, tta=tta)
+            ys = [eng.infer(x) for _ in range(2)]
+            rs = [eng.render(frame) for _ in range(3)]
+        assert np.array_equal(ys[0], ys[1]) and np.array_equal(rs[0], rs[1]) and np.array_equal(rs[0], rs[2])
+        outs.append((ys[0], rs[0]))
+        eng.close()
+    assert np.array_equal(outs[0][0], outs[1][0]), (np.abs(outs[0][0] - outs[1][0]).max(), float((outs[0][0] != outs[1][0]).mean()))
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("name,kw,tile", [
     ("window 8 (64 tokens)", dict(variant={"ws": 8}), 80),
     ("4 / 8 heads of 24 / 48", dict(variant={"heads": 4}), 64),

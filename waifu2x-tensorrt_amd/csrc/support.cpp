@@ -40,6 +40,7 @@ const Field kFields[] = {
     {"no_fuse_head", nullptr, &Switches::no_fuse_head, nullptr, 0, 1},
     {"no_fuse_stem", nullptr, &Switches::no_fuse_stem, nullptr, 0, 1},
     {"no_fuse_up", nullptr, &Switches::no_fuse_up, nullptr, 0, 1},
+    {"no_conv3h_walk", nullptr, &Switches::no_conv3h_walk, nullptr, 0, 1},
     {"no_pixgemm", nullptr, &Switches::no_pixgemm, nullptr, 0, 1},
     {"no_conv3", nullptr, &Switches::no_conv3, nullptr, 0, 1},
     {"no_conv3h", nullptr, &Switches::no_conv3h, nullptr, 0, 1},

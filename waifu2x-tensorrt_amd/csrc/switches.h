@@ -28,6 +28,7 @@ struct Switches {
     bool no_fuse_head = false;   // engine: the image head as its own launch behind the last MLP
     bool no_fuse_stem = false;   // engine: the stem as its own launch in front of the patch convolution
     bool no_fuse_up = false;     // engine: cunet's transposed convolutions as their own launches in front of the 3x3 convolutions that read them
+    bool no_conv3h_walk = false; // k_conv3h.hip: the tile kernel instead of the column walk for the 64-channel image heads
     bool no_pixgemm = false, no_conv3 = false, no_conv3h = false, no_conv48 = false, no_stem = false;   // launchers: the general kernel instead
     bool attn_valu = false;      // launchers: the lane-per-query attention core instead of the matrix-pipe one
 };
