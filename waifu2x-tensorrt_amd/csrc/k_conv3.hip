@@ -46,6 +46,7 @@ struct Conv3Cfg {
     static constexpr int TH = 8, TW = 64, HR = TH + 2, HC = TW + 2;
     static constexpr int ROWB = HC * 64;                               // bytes per halo row (32 channels)
     static constexpr int SMEM = HR * ROWB;
+    static constexpr int WCHUNK = 9 * 4 * 1024;                         // a chunk's weights: 9 taps x 4 n-tiles of 1 KiB fragments (conv3_kernel WLDS)
 };
 // byte offset of piece pc (8 channels) of halo pixel x inside its row
 __device__ __forceinline__ int halo_slot(int x, int pc) { return x * 64 + ((pc + 2 * ((x >> 2) & 3)) & 3) * 16; }
@@ -114,11 +115,31 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
     };
     if (!STEM && !UP) acc_init(p.bias);                                            // (STEM: after the halo stage, whose operands need the registers)
     half8 w[3][4];                                                    // ring: slot = ky
-    auto wload = [&](int slot, int kc, int ky, int kx) {     // past the last chunk the k-step lies beyond the block: the fetch returns zeros, nobody reads them
-        const unsigned vo = wlane + (unsigned)((ky * 3 + kx) * nchunk + kc) * 4096u;    // k-step (tap * Cin + 32 kc) / 32
+    // WLDS (round 6): the chunk's 36 weight fragments are staged in LDS once per workgroup (behind the halo tile) and every wave reads its A operands from there.
+    // Until then each wave streamed all 36 KiB of a chunk from L2 through its own register ring - 144 KiB per workgroup and chunk on the vector-memory path beside
+    // 42 KiB of halo pixels: with the stream replaced by LDS reads of anything the frame of config 2 took 6.2 instead of 7.6 ms (profiles/r6_kernels/conv3_weights_lds.txt).
+    // UP keeps the ring: its staged input pixels take the room (three regions would leave one workgroup per CU).
+    constexpr bool WLDS = !UP;
+    unsigned char* wsm = smem + C::SMEM;                              // [9 taps][4 n-tiles][64 lanes][16 bytes]
+    auto wload = [&](int slot, int kc, int ky, int kx) {     // (ring: past the last chunk the k-step lies beyond the block: the fetch returns zeros, nobody reads them)
+        if constexpr (WLDS) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) w[slot][nt] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(W, vo + nt * 1024u, 0, 0));
-        asm volatile("" ::: "memory");                                // keeps the fetch where it is written
+            for (int nt = 0; nt < 4; ++nt) w[slot][nt] = *(const half8*)(wsm + ((ky * 3 + kx) * 4 + nt) * 1024 + wlane);
+        } else {
+            const unsigned vo = wlane + (unsigned)((ky * 3 + kx) * nchunk + kc) * 4096u;    // k-step (tap * Cin + 32 kc) / 32
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) w[slot][nt] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(W, vo + nt * 1024u, 0, 0));
+            asm volatile("" ::: "memory");                            // keeps the fetch where it is written
+        }
+    };
+    // staging: thread tid takes 16 bytes of every tap's 4 KiB run (the runs of a chunk lie nchunk x 4 KiB apart in the block's fragment-major copy)
+    auto wstage_request = [&](int kc, uint4v (&ws)[9]) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) ws[t] = __builtin_amdgcn_raw_buffer_load_b128(W, (unsigned)tid * 16u, (unsigned)(t * nchunk + kc) * 4096u, 0);
+    };
+    auto wstage_store = [&](const uint4v (&ws)[9]) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) *(uint4v*)(wsm + t * 4096 + tid * 16) = ws[t];
     };
     auto mm = [&](int r, int slot, const half8 (&xa)[4]) {
 #pragma unroll
@@ -132,10 +153,6 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
         if (slot & 1) for (int i = 0; i < W2X_CONV3_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
     }
 #endif
-    if (!UP) {                                                        // (UP: requested inside the halo stage, once the skip pieces have begun to leave their registers)
-        wload(0, 0, 0, 0);
-        wload(1, 0, 1, 0);
-    }
 
     // halo copy: thread (pixel column tid >> 2, 16-byte piece tid & 3) takes its column of every halo row; threads 0..79 also take
     // the two extra columns (64, 65) of row tid >> 3
@@ -156,8 +173,13 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
     unsigned char* xt = smem + C::SMEM;
     const int Y0 = p.a.y0 + oy0, X0 = p.a.x0 + ox0;                   // the halo tile's origin in the projection's output map
     const int iy0 = Y0 >> 1, ix0 = X0 >> 1;
+    uint4v wnext[9];                                                  // WLDS, plain mode: the weights of the chunk to come, in registers until the barrier lets them into LDS
+    if constexpr (WLDS && !STEM) wstage_request(0, wnext);
     auto chunk = [&](const int kc) __attribute__((always_inline)) {
         if constexpr (STEM) {
+            uint4v wst[9];
+            wstage_request(kc, wst);
+            asm volatile("" ::: "memory");
             // ---- the chunk (all 32 channels: conv3_stem_supported) computed from the network's input tile: stem_kernel<2>'s arithmetic per group of 16 halo pixels
             constexpr int SNT = 2, NPIX = HR * HC, NGRP = (NPIX + 15) / 16, GPW = (NGRP + 3) / 4, HALF = GPW;             // (HALF: groups of a wave per round)
             const int Hs_o = ps.Mrows / ps.aW, Ws_o = ps.aW;                // extent of the stem's output = this convolution's input map
@@ -216,6 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
                     if (pi < NPIX) *(half8*)(smem + hr * C::ROWB + halo_slot(hc, g)) = (half8){hq[0], hq[1], hq[2], hq[3], hq[4], hq[5], hq[6], hq[7]};
                 }
             }
+            wstage_store(wst);
             const float* bias_late = p.bias;
             asm volatile("" : "+s"(bias_late) :: "memory");                 // the accumulators are set up HERE (hoisted above the stage they cost it 39 spilled registers)
             acc_init(bias_late);
@@ -225,10 +248,11 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
             for (int hr = 0; hr < HR; ++hr)
                 h[hr] = __builtin_amdgcn_raw_buffer_load_b128(A, hr < hrows ? go0 : kNoPix, (unsigned)hr * rowb + (unsigned)kc * 64u, 0);
             h1 = __builtin_amdgcn_raw_buffer_load_b128(A, go1, (unsigned)kc * 64u, 0);
-            __syncthreads();                                   // the previous chunk's products are done with the halo tile
+            __syncthreads();                                   // the previous chunk's products are done with the halo tile and the weights
 #pragma unroll
             for (int hr = 0; hr < HR; ++hr) *(uint4v*)(lo0 + hr * C::ROWB) = h[hr];
             if (tid < 80) *(uint4v*)lo1 = h1;
+            wstage_store(wnext);                               // (requested under the previous chunk's products; chunk 0: in front of the loop)
         }
         if constexpr (UP) {
             // ---- the chunk's halo tile = channels 32 kc .. + 31 of the projection + the skip map, assembled by sub-pixel class: wave w owns class (w >> 1, w & 1), 165 halo
@@ -325,6 +349,11 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
             }
         }
         __syncthreads();
+        if constexpr (WLDS) { wload(0, kc, 0, 0); wload(1, kc, 1, 0); }
+        if constexpr (WLDS && !STEM) {                                  // the next chunk's weights travel under this chunk's products (past the last chunk: beyond the block, zeros without a memory access)
+            wstage_request(kc + 1, wnext);
+            asm volatile("" ::: "memory");
+        }
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             half8 xa[4];
@@ -338,10 +367,10 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
             wload(2, kc, 2, kx);
             mm(0, 1, xa); mm(1, 0, xa);
             xload(2);
-            if (kx < 2) wload(0, kc, 0, kx + 1); else if (!UP) wload(0, kc + 1, 0, 0);
+            if (kx < 2) wload(0, kc, 0, kx + 1);
             mm(0, 2, xa); mm(1, 1, xa);
             xload(3);
-            if (kx < 2) wload(1, kc, 1, kx + 1); else if (!UP) wload(1, kc + 1, 1, 0);
+            if (kx < 2) wload(1, kc, 1, kx + 1);
             mm(1, 2, xa);
         }
     };
@@ -419,23 +448,24 @@ bool conv3_supported(const GemmParams& p) {
 }
 
 namespace {
+constexpr int kWldsSmem = Conv3Cfg::SMEM + Conv3Cfg::WCHUNK;                                  // halo tile + a chunk's weights (conv3_kernel, WLDS): 79 104 bytes, two workgroups per CU
 constexpr int kUpSmem = Conv3Cfg::SMEM + (Conv3Cfg::HR / 2 + 1) * (Conv3Cfg::HC / 2 + 1) * 144;   // halo tile + the projection's staged input pixels (conv3_kernel, UP)
 hipError_t launch_conv3_any(const GemmParams& p, const GemmParams* ps, int mode, hipStream_t s) {
     using C = Conv3Cfg;
     const int Ho = p.Mrows / p.aW, Wo = p.aW;
     static unsigned lds_ok = 0, lds_ok_pool = 0, lds_ok_stem = 0, lds_ok_up = 0;   // per-device bits: kernels.h ensure_dynamic_lds
-    if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<false, 0>, C::SMEM, lds_ok); e != hipSuccess) return e;
-    if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<true, 0>, C::SMEM, lds_ok_pool); e != hipSuccess) return e;
-    if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<false, 1>, C::SMEM, lds_ok_stem); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<false, 0>, kWldsSmem, lds_ok); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<true, 0>, kWldsSmem, lds_ok_pool); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<false, 1>, kWldsSmem, lds_ok_stem); e != hipSuccess) return e;
     if (hipError_t e = ensure_dynamic_lds((const void*)conv3_kernel<false, 2>, kUpSmem, lds_ok_up); e != hipSuccess) return e;
     const int tiles_x = (Wo + C::TW - 1) / C::TW, tiles_y = (Ho + C::TH - 1) / C::TH, nblk = p.N / 64;
     const int xcd_order = nblk > 1 ? 1 : 0;
     const int ntiles = p.B * tiles_x * tiles_y;
     const dim3 grid((unsigned)((xcd_order ? (ntiles + 7) / 8 * 8 : ntiles) * nblk));
-    if (mode == 1) hipLaunchKernelGGL((conv3_kernel<false, 1>), grid, dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, nblk, xcd_order, *ps);
+    if (mode == 1) hipLaunchKernelGGL((conv3_kernel<false, 1>), grid, dim3(256), kWldsSmem, s, p, Ho, Wo, tiles_x, tiles_y, nblk, xcd_order, *ps);
     else if (mode == 2) hipLaunchKernelGGL((conv3_kernel<false, 2>), grid, dim3(256), kUpSmem, s, p, Ho, Wo, tiles_x, tiles_y, nblk, xcd_order, *ps);
-    else if (p.pool_out) hipLaunchKernelGGL((conv3_kernel<true, 0>), grid, dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, nblk, xcd_order, GemmParams{});
-    else hipLaunchKernelGGL((conv3_kernel<false, 0>), grid, dim3(256), C::SMEM, s, p, Ho, Wo, tiles_x, tiles_y, nblk, xcd_order, GemmParams{});
+    else if (p.pool_out) hipLaunchKernelGGL((conv3_kernel<true, 0>), grid, dim3(256), kWldsSmem, s, p, Ho, Wo, tiles_x, tiles_y, nblk, xcd_order, GemmParams{});
+    else hipLaunchKernelGGL((conv3_kernel<false, 0>), grid, dim3(256), kWldsSmem, s, p, Ho, Wo, tiles_x, tiles_y, nblk, xcd_order, GemmParams{});
     return hipGetLastError();
 }
 }  // namespace
