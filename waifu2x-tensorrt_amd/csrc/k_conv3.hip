@@ -20,6 +20,8 @@
 //     store instruction writes 64 contiguous bytes per pixel, straight from registers; bias is the initial accumulator, LeakyReLU
 //     max(v, v * alpha); squeeze-excite pooling partials per workgroup in a fixed order.
 // Input, weights and output go through buffer resources (32-bit offsets, rows past a ragged edge read zeros / drop stores).
+// (Round 6: the weights DO enter LDS now - WLDS below; the ring remains for the UP mode.  And the ablation figures that follow were taken with wrong data, which at the
+// board's power cap measures the clock the garbage frees, not the removed work: DESIGN section 4.)
 // Measured on config 2 (tools/op_times.py): the 3x3 layers 6.2 -> 5.4 ms per frame (550-770 TFLOP/s) against the first schedule
 // (round-2 git history, tools/ab/k_conv3_v1.hip: one tap of one chunk per barrier, both operands through LDS).  What is left is not the products:
 // without the halo fetch the layers run 30-35 % faster, without the stores 25 % - fetch, products and stores of a workgroup run one
