@@ -295,7 +295,7 @@ __global__ __launch_bounds__(NW * 64, (C == 96 ? 3 : W2X_MLP192_WPS) * NW / 4) v
         }
         if (!K::KEEP && ch == NCH - 1) {   // the residual rows, requested as soon as the normalised copies have served their last product:
 #pragma unroll                           // they travel under the last GELU and second-layer products (round 2 fetched them in the epilogue and waited)
-            for (int k = 0; k < NP; ++k) xres[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(XB, vo + k * 1024u, 0, 0));
+            for (int k = 0; k < NP; ++k) xres[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(XB, vo + k * 1024u, 0, W2X_LD_LAST_AUX));
         }
         // GELU in place; lane holds hidden rows 16ht + 4g + j of token column fr -> B fragment of GEMM2 for the
         // k order (ht 0: slots 0..3, ht 1: slots 4..7)
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
         }
         if (ch == NCH - 1) {   // the residual rows, requested as soon as the normalised copies have served their last product
 #pragma unroll
-            for (int k = 0; k < NP; ++k) xres[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(XB, vl + k * 1024u, 0, 0));
+            for (int k = 0; k < NP; ++k) xres[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(XB, vl + k * 1024u, 0, W2X_LD_LAST_AUX));
         }
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {     // second layer: fragment KS + i = (output tile i >> 1, k-step i & 1)
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(NW * 64, 2 * NW / 4) void mlp2q_kernel(const MlpPar
 #endif
         if (ch == NCH - 1) {   // the residual rows, requested as soon as the normalised copies have served their last product
 #pragma unroll
-            for (int k = 0; k < NP; ++k) xres[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(XB, vl + k * 1024u, 0, 0));
+            for (int k = 0; k < NP; ++k) xres[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(XB, vl + k * 1024u, 0, W2X_LD_LAST_AUX));
         }
         half8 a2[2];
 #if defined(W2X_MLP2Q_PRIO) && W2X_MLP2Q_PRIO == 3

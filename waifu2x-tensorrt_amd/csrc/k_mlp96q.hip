@@ -212,7 +212,7 @@ __global__ __launch_bounds__(NTHR, 3) void mlp96q_kernel(const MlpParams p, int 
     constexpr unsigned TILE_BYTES = RW * C * 2;
     half8 xr[NP];                                // this tile's rows as flat 16-byte pieces (piece k * 64 + lane)
 #define W2X_FETCH(TILE) { const unsigned vo = (unsigned)((W2X_MLP_EXP & 1) ? ((TILE) & 63) : (TILE)) * TILE_BYTES + lane * 16u;   \
-        _Pragma("unroll") for (int k = 0; k < NP; ++k) xr[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(XB, vo + k * 1024u, 0, 0)); }
+        _Pragma("unroll") for (int k = 0; k < NP; ++k) xr[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(XB, vo + k * 1024u, 0, W2X_LD_LAST_AUX)); }
     // The workgroup's tiles are the ones its waves would walk with the fixed stride - {(blockIdx.x + j * gridDim.x) * NWV + w} - taken in that order by
     // whichever wave is free: the t-th grab (one ds_add_rtn by lane 0) is tile (blockIdx.x + (t / NWV) * gridDim.x) * NWV + t % NWV, increasing in t, so the
     // first grab past the end ends a wave.  The waves of a SIMD do not progress alike (three share its issue slots); with fixed strides the slowest wave's

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256, W2X_A192U_WPC) void swin_attn192u_kernel(const
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             my_off[ps] = __builtin_elementwise_add_sat((unsigned)Pix[ps * RPP + rsub_r][0], lane_off);
-            xres[ps] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(X, my_off[ps], 0, 0));
+            xres[ps] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(X, my_off[ps], 0, W2X_LD_LAST_AUX));
         }
         asm volatile("" ::: "memory");      // keeps the requests here (the scheduler would sink them to their use behind the projection)
     }

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(NTHR, 4) void swin_attn96_kernel(const SwinAttnPara
         const int li_ = tid & (LPR - 1), rsub_ = tid / LPR;                                                         \
         const unsigned lane_off_ = li_ < PPR ? li_ * 16u : kNoRow;                                                  \
         _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps)                                                        \
-            xres[ps] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(X, __builtin_elementwise_add_sat((unsigned)Pix[ps * RPP + rsub_][0], lane_off_), 0, 0)); }
+            xres[ps] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(X, __builtin_elementwise_add_sat((unsigned)Pix[ps * RPP + rsub_][0], lane_off_), 0, W2X_LD_LAST_AUX)); }
     half8 vk01[NU]; half4 vk2[NU];   // v fragments of every unit (key tiles 0 | 1, left-over keys), also for the left-over queries' O^T at the end
     half8 pl01; half4 pl2;           // left-over queries' probabilities
 

@@ -30,6 +30,10 @@ inline hipError_t ensure_dynamic_lds(const void* fn, int bytes, unsigned& done_m
 #ifndef W2X_ST_AUX
 #define W2X_ST_AUX 2
 #endif
+// cache policy of a kernel's LAST read of its input rows (the residual fetch of the transformer kernels; the C = 96 MLP reads its rows once)
+#ifndef W2X_LD_LAST_AUX
+#define W2X_LD_LAST_AUX 2
+#endif
 #ifdef __HIPCC__
 template <class T> __device__ __forceinline__ void w2x_store_out(T* p, const T v) {
 #if W2X_ST_AUX == 2
