@@ -672,7 +672,7 @@ hipError_t launch_pixgemm(const GemmParams& p, hipStream_t s) {
     if (p.K == 192 && p.out.Cs == 96) return launch_pix<192, 96, 2>(p, s);
     if (p.K == 192 && p.out.Cs == 192) return launch_pix<192, 192, 2, W2X_PIX192_TT>(p, s);
     if (p.K == 64 && p.out.Cs == 64) return launch_pix<64, 64, 2>(p, s);
-    if (p.K == 128 && p.out.Cs == 128) return launch_pix<128, 128, 2>(p, s);
+    if (p.K == 128 && p.out.Cs == 128) return launch_pix<128, 128, 2, 1>(p, s);   // (round 6: one m-tile per wave, three workgroups per CU: 0.46 -> 0.41 ms per config-2 frame; the frame itself +-0.1 %, the launch runs under the other tile group's convolutions)
     return hipErrorInvalidValue;
 }
 
