@@ -768,7 +768,7 @@ def test_image_head_folded_into_the_last_mlp_is_bit_identical(pkg, onnx_model, m
 
 @pytest.mark.parametrize("model,scale,tile,batch,shape,tta", [("swin_unet/art", 4, 64, 2, (150, 170), False), ("swin_unet/art", 4, 64, 3, (101, 119), True), ("swin_unet/art", 4, 256, 4, (300, 420), False),
                                                               ("cunet/art", 2, 64, 2, (150, 170), False), ("cunet/art", 2, 96, 3, (101, 119), True), ("cunet/art", 1, 64, 2, (90, 131), False),
-                                                              ("cunet/art", 2, 256, 4, (300, 420), False)])
+                                                              ("cunet/art", 2, 256, 4, (300, 420), False), ("cunet/art", 2, 68, 1, (77, 131), False), ("cunet/art", 1, 100, 2, (120, 95), True)])
 def test_stem_folded_into_the_patch_convolution_is_bit_identical(pkg, onnx_model, monkeypatch, model, scale, tile, batch, shape, tta):
     """swin_unet's first two ops - the stem (3x3, 4-halves-per-pixel tile -> 48 channels) and the patch convolution behind it - run as ONE launch
     (engine.cpp fuse_stem, k_conv48.hip conv48_kernel<true>): every workgroup computes the halo tile it needs from the input tile with the stem
@@ -797,7 +797,8 @@ def test_stem_folded_into_the_patch_convolution_is_bit_identical(pkg, onnx_model
     assert np.array_equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("scale,tile,batch,shape,tta", [(2, 64, 2, (150, 170), False), (2, 96, 3, (101, 119), True), (1, 64, 2, (90, 131), False), (2, 256, 4, (300, 420), False)])
+@pytest.mark.parametrize("scale,tile,batch,shape,tta", [(2, 64, 2, (150, 170), False), (2, 96, 3, (101, 119), True), (1, 64, 2, (90, 131), False), (2, 256, 4, (300, 420), False),
+                                                       (2, 68, 1, (77, 131), False), (1, 100, 2, (120, 95), True), (2, 132, 2, (160, 260), False)])
 def test_transposed_convolution_folded_into_the_convolution_behind_it_is_bit_identical(pkg, onnx_model, scale, tile, batch, shape, tta):
     """cunet's decoders: ConvTranspose 2x2 stride 2 on the gated map, LeakyReLU, + the cropped skip map, then 3x3 64 -> 64.  As launches: a pixel-shuffle
     projection (k_pixgemm.hip) that writes the largest 64-channel map of the graph, and the convolution that reads it back.  engine.cpp fuse_up runs them as ONE
@@ -824,7 +825,8 @@ def test_transposed_convolution_folded_into_the_convolution_behind_it_is_bit_ide
     assert np.array_equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("scale,tile,batch,shape,tta", [(2, 64, 2, (150, 170), False), (2, 96, 3, (101, 119), True), (1, 64, 2, (90, 131), False), (2, 256, 4, (300, 420), False), (1, 112, 1, (200, 90), False)])
+@pytest.mark.parametrize("scale,tile,batch,shape,tta", [(2, 64, 2, (150, 170), False), (2, 96, 3, (101, 119), True), (1, 64, 2, (90, 131), False), (2, 256, 4, (300, 420), False), (1, 112, 1, (200, 90), False),
+                                                       (2, 68, 1, (77, 131), False), (1, 100, 2, (120, 95), True), (2, 132, 2, (160, 260), False)])
 def test_image_heads_as_a_column_walk_are_bit_identical(pkg, onnx_model, scale, tile, batch, shape, tta):
     """cunet's two image heads (3x3 from 64 channels onto 3 channels + skip + clip, and onto 4 sub-pixels x 3 channels) are pure input streams.  k_conv3h.hip runs them as a
     walk down 64-column strips (conv3h_walk_kernel: a ring of eight input rows in LDS, four new rows requested under the products of the previous four, every row fetched
