@@ -352,8 +352,8 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const GemmParams p, int H
         }
         __syncthreads();
         if constexpr (WLDS) { wload(0, kc, 0, 0); wload(1, kc, 1, 0); }
-        if constexpr (WLDS && !STEM) {                                  // the next chunk's weights travel under this chunk's products (past the last chunk: beyond the block, zeros without a memory access)
-            wstage_request(kc + 1, wnext);
+        if constexpr (WLDS && !STEM) {                                  // the next chunk's weights travel under this chunk's products
+            if (kc + 1 < nchunk) wstage_request(kc + 1, wnext);         // (uniform)
             asm volatile("" ::: "memory");
         }
 #pragma unroll
