@@ -576,7 +576,7 @@ __global__ __launch_bounds__(384, 3) void mlp32_kernel(const Mlp32Params p) {
             float4v v = acc2[n][tt] + b2v;
             if (r < p.M) {
                 v += *(const float4v*)(p.x + r * C + ch);
-                w2x_store_out((float4v*)(p.y + r * C + ch), v);      // streaming policy, as the fp16 kernels' output rows (kernels.h)
+                *(float4v*)(p.y + r * C + ch) = v;
             } else v = (float4v){0.f, 0.f, 0.f, 0.f};
             acc2[n][tt] = v;
             rsum[tt] += v[0] + v[1] + v[2] + v[3];
@@ -920,7 +920,7 @@ __global__ __launch_bounds__(384, 2) void swinattn32_kernel(const SwinAttn32Para
             float4v v = acc[n][rt];
             if (pout >= 0) {
                 v += *(const float4v*)(p.res + (size_t)pout * C + ch);
-                w2x_store_out((float4v*)(p.y + (size_t)pout * C + ch), v);
+                *(float4v*)(p.y + (size_t)pout * C + ch) = v;
             } else v = zero4;
             acc[n][rt] = v;
             rsum[rt] += v[0] + v[1] + v[2] + v[3];
